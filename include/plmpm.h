@@ -1,0 +1,161 @@
+/* plmpm.h -- C ABI of the MI355X-native differentiable MPM engine.
+ *
+ * Drop-in boundary.  The reference has no FFI: its
+ * "operator API" is the Python class surface of
+ *   plb.engine.mpm_simulator.MPMSimulator   (/root/reference/plb/engine/mpm_simulator.py)
+ *   plb.engine.primitive.Primitives         (/root/reference/plb/engine/primitive/primitives.py:262-320)
+ *   plb.engine.losses.Loss                  (/root/reference/plb/engine/losses/loss.py)
+ * Each entry point below names the reference method(s) it stands in for
+ * (file:line).  A host-language binding only needs this header: plain
+ * pointers and sizes, int status returns (0 = ok, <0 = error; text via
+ * plmpm_last_error), no exceptions across the boundary, no torch types.
+ *
+ * Memory: the caller owns all device memory.  plmpm_workspace_bytes reports
+ * what a simulator needs, the caller allocates it (the Python facade uses
+ * torch ROCm tensors) and hands the base pointers to plmpm_bind_workspace.
+ * All kernels are enqueued on the HIP stream given to plmpm_set_stream
+ * (default: the null stream); calls that return host data synchronise that
+ * stream.  A handle is not re-entrant.
+ */
+#ifndef PLMPM_H
+#define PLMPM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PLMPM_MAX_PRIMITIVES 8
+#define PLMPM_MAX_ACTION_DIM 7
+
+enum plmpm_dtype { PLMPM_F32 = 0, PLMPM_F64 = 1 };
+enum plmpm_shape {
+    PLMPM_SPHERE = 0, PLMPM_CAPSULE = 1, PLMPM_CYLINDER = 2, PLMPM_TORUS = 3, PLMPM_BOX = 4
+};
+
+/* Simulator constants; mirrors MPMSimulator.__init__ (mpm_simulator.py:6-51). */
+typedef struct plmpm_config {
+    int32_t dtype;            /* plmpm_dtype: arithmetic type of the hot path            */
+    int32_t n_grid;           /* :19   int(128 * quality * 0.5)                          */
+    int32_t n_particles;      /* :18                                                     */
+    int32_t max_frames;       /* :33   cfg.max_steps (+1 frames are stored)              */
+    int32_t substeps;         /* :34   int(2e-3 // dt)                                   */
+    int32_t n_primitives;     /* :13                                                     */
+    double dt;                /* :22                                                     */
+    double p_vol;             /* :23   (dx/2)^2                                          */
+    double p_mass;            /* :24                                                     */
+    double gravity[3];        /* :50   cfg.gravity                                       */
+    double ground_friction;   /* :11                                                     */
+    double svd_grad_clamp;    /* :143-151 clamp of backward_svd; 1e-6 = reference, 0 = exact derivative */
+    /* z-slab owned by this rank for multi-GPU runs: nodes z in [slab_z0, slab_z1); 0,n_grid = whole grid */
+    int32_t slab_z0, slab_z1;
+} plmpm_config;
+
+/* One rigid manipulator; mirrors Primitive.default_config + per-shape params
+ * (primive_base.py:209-224, primitives.py:30-34,56-61,185-190,215-220,253-257). */
+typedef struct plmpm_primitive {
+    int32_t shape;                        /* plmpm_shape                                              */
+    int32_t action_dim;                   /* cfg.action.dim (0 = static)                              */
+    double params[3];                     /* Sphere: radius | Capsule: h,r | Cylinder: h,r | Torus: tx,ty | Box: size */
+    double friction;                      /* primive_base.py:162                                      */
+    double action_scale[PLMPM_MAX_ACTION_DIM];
+    double lower_bound[3], upper_bound[3];/* xyz_limit, primive_base.py:160                           */
+} plmpm_primitive;
+
+/* Sizes (bytes) of the four device workspaces of one simulator. */
+typedef struct plmpm_workspace {
+    size_t state_bytes;   /* particle frames: (max_frames+1) x 24 x Npad scalars  (x,v,C,F-I; SoA)  */
+    size_t adjoint_bytes; /* two ping-pong adjoint frames + material arrays                        */
+    size_t grid_bytes;    /* grid_m/grid_v_in, grid_v_out and their adjoints, block flags, loss grids */
+    size_t misc_bytes;    /* primitive trajectories, action buffers, their adjoints, loss scalars, staging */
+} plmpm_workspace;
+
+typedef struct plmpm_sim* plmpm_handle;
+
+const char* plmpm_last_error(void);
+int plmpm_version(void);
+
+/* ---- lifetime ------------------------------------------------------------------------------ */
+/* MPMSimulator.__init__ + Primitives.__init__ (mpm_simulator.py:6-51, primitives.py:263-279) */
+int plmpm_create(const plmpm_config* cfg, const plmpm_primitive* prims, plmpm_handle* out);
+int plmpm_destroy(plmpm_handle h);
+int plmpm_workspace_bytes(plmpm_handle h, plmpm_workspace* out);
+int plmpm_bind_workspace(plmpm_handle h, void* state, void* adjoint, void* grid, void* misc);
+int plmpm_set_stream(plmpm_handle h, void* hip_stream);
+
+/* ---- state I/O (host float64 arrays in the reference's AoS layout) -------------------------- */
+/* MPMSimulator.initialize (mpm_simulator.py:53-57): per-particle mu, lam, yield_stress */
+int plmpm_set_materials(plmpm_handle h, const double* mu, const double* lam, const double* yield_stress);
+/* setframe / set_state (mpm_simulator.py:292-300,325-328).  x,v:(N,3) F,C:(N,3,3).
+ * resort != 0 recomputes the cell-sorted storage order from x (do this at episode reset). */
+int plmpm_set_frame(plmpm_handle h, int frame, const double* x, const double* v, const double* F,
+                    const double* C, int resort);
+/* readframe / get_state / get_x / get_v (mpm_simulator.py:282-290,314-323,343-363); any pointer may be NULL */
+int plmpm_get_frame(plmpm_handle h, int frame, double* x, double* v, double* F, double* C);
+/* copyframe (mpm_simulator.py:302-312) incl. primitive poses */
+int plmpm_copy_frame(plmpm_handle h, int source, int target);
+/* Primitive.set_state / get_state (primive_base.py:129-151): 7 doubles = position(3) + rotation(4) */
+int plmpm_set_primitive_state(plmpm_handle h, int prim, int frame, const double* state7);
+int plmpm_get_primitive_state(plmpm_handle h, int prim, int frame, double* state7);
+/* Primitives.set_softness (primitives.py:303-305) */
+int plmpm_set_softness(plmpm_handle h, double softness);
+
+/* ---- actions ----------------------------------------------------------------------------- */
+/* Primitives.set_action (primitives.py:289-293) -> per primitive no_grad_set_action_kernel +
+ * set_velocity (primive_base.py:166-198): clip to [-1,1], store in action_buffer[step], fill
+ * v,w for frames [step*n_substeps, (step+1)*n_substeps), and run forward_kinematics
+ * (primive_base.py:117-121) over those frames (the pose chain does not depend on particles). */
+int plmpm_set_action(plmpm_handle h, int step, int n_substeps, const double* action);
+/* Primitives.get_grad (primitives.py:295-301): out is (n_steps, sum action_dim) row major */
+int plmpm_get_action_grad(plmpm_handle h, int n_steps, double* out);
+
+/* ---- the hot path ------------------------------------------------------------------------- */
+/* MPMSimulator.substep (mpm_simulator.py:245-257): frame f -> f+1 */
+int plmpm_substep(plmpm_handle h, int frame);
+/* fused loop of MPMSimulator.step (mpm_simulator.py:372-373) */
+int plmpm_step(plmpm_handle h, int first_frame, int n_substeps);
+/* what ti.Tape.__enter__ does for this path: zero every adjoint, frame `last_frame` becomes the
+ * adjoint seed frame (solver.py:36) */
+int plmpm_grad_begin(plmpm_handle h, int last_frame);
+/* MPMSimulator.substep_grad (mpm_simulator.py:260-278): consumes adjoint of frame f+1, produces frame f */
+int plmpm_substep_grad(plmpm_handle h, int frame);
+/* reverse of plmpm_step: substep_grad for frames first+n-1 .. first, then forward_kinematics.grad and
+ * set_velocity.grad for env step `step` (primive_base.py:117-121,184-192) */
+int plmpm_step_grad(plmpm_handle h, int first_frame, int n_substeps, int step);
+/* add a host-provided cotangent to the current adjoint of `frame` (x,v:(N,3) F,C:(N,3,3), any may be NULL);
+ * used by tests and by callers that differentiate their own loss */
+int plmpm_add_frame_grad(plmpm_handle h, int frame, const double* xa, const double* va, const double* Fa,
+                         const double* Ca);
+/* read back the adjoint currently held for `frame` (x.grad[f] etc. in the reference) */
+int plmpm_get_frame_grad(plmpm_handle h, int frame, double* xa, double* va, double* Fa, double* Ca);
+/* primitive pose adjoints position.grad[f], rotation.grad[f] (7 doubles) */
+int plmpm_get_primitive_grad(plmpm_handle h, int prim, int frame, double* grad7);
+
+/* ---- loss (Loss, loss.py) ------------------------------------------------------------------ */
+/* Loss.load_target_density + update_target (loss.py:46-57,81-106): density is (n,n,n) float64, [i][j][k] */
+int plmpm_loss_set_target(plmpm_handle h, const double* density);
+/* Loss.set_weights (loss.py:68-72) */
+int plmpm_loss_set_weights(plmpm_handle h, double sdf, double density, double contact, int soft_contact);
+/* Loss.compute_loss_kernel (loss.py:186-208) at `frame`; out6 = {loss increment, sdf, density, contact,
+ * iou (loss.py:239-254), reserved}.  Does not touch adjoints. */
+int plmpm_loss_forward(plmpm_handle h, int frame, double* out6);
+/* Loss.compute_loss_kernel_grad (loss.py:210-237) with d(total)/d(loss) = 1: adds into the adjoint of
+ * `frame` (particles) and into the pose adjoints of the movable primitives */
+int plmpm_loss_backward(plmpm_handle h, int frame);
+/* compute_grid_m_kernel (mpm_simulator.py:382-392) -> host (n,n,n) float64 */
+int plmpm_get_grid_mass(plmpm_handle h, int frame, double* out);
+/* target_sdf as computed by plmpm_loss_set_target, host (n,n,n) float64 */
+int plmpm_loss_get_target_sdf(plmpm_handle h, double* out);
+
+/* ---- introspection ------------------------------------------------------------------------- */
+/* number of grid nodes with mass > 0 and number of active 4^3 blocks after the last forward substep */
+int plmpm_grid_stats(plmpm_handle h, int frame, int64_t* active_nodes, int64_t* active_blocks);
+/* storage order: perm[i] = original particle index stored at sorted slot i */
+int plmpm_get_order(plmpm_handle h, int32_t* perm);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PLMPM_H */

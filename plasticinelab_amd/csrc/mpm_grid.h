@@ -1,0 +1,470 @@
+// Grid-node arithmetic: momentum->velocity, gravity, rigid-primitive contact
+// (collide), box boundary with ground friction -- forward and hand-derived
+// adjoint -- plus the serial primitive kinematics chain.
+//
+// Follows /root/reference/plb/engine/mpm_simulator.py:189-221 (grid_op),
+// plb/engine/primitive/primive_base.py:57-121,184-192 (sdf/normal/collider_v/
+// collide/forward_kinematics/set_velocity), primitives.py:17-34 (Sphere),
+// :36-61 (Capsule), :157-183 (Cylinder), :193-213 (Torus), :223-251 (Box) and
+// primitive/utils.py:3-48 (quaternions).  Shared by the HIP kernels and by
+// tests/host_emul (see mpm_math.h).
+#pragma once
+#include "mpm_math.h"
+
+namespace plb {
+
+enum ShapeKind { SHAPE_SPHERE = 0, SHAPE_CAPSULE = 1, SHAPE_CYLINDER = 2, SHAPE_TORUS = 3, SHAPE_BOX = 4 };
+
+// One primitive as a grid node sees it during substep f: static description + pose at f and f+1.
+// Rigid-body geometry (signed distance, normal, collider velocity and the pose adjoints) is always
+// evaluated in double, also on the fp32 path: collider_v is (new_pos - grid_pos)/dt, a difference of
+// O(1) positions divided by 1e-4, which in fp32 costs ~4 digits of the contact velocity.  It only runs
+// on the few nodes touching a manipulator.
+template <class T> struct PrimT {
+    int shape;
+    int movable;             // action_dim > 0: pose adjoints are wanted
+    double par[3];           // Sphere: radius | Capsule: h, r | Cylinder: h(=radius), r(=half height) | Torus: tx, ty | Box: size
+    T friction;
+    double pos[3], rot[4];   // pose at frame f
+    double pos1[3], rot1[4]; // pose at frame f+1
+};
+
+template <class T> struct PoseAdj {
+    double pos[3], rot[4], pos1[3], rot1[4];
+    PLB_HD void zero() {
+        for (int i = 0; i < 3; ++i) pos[i] = pos1[i] = 0.0;
+        for (int i = 0; i < 4; ++i) rot[i] = rot1[i] = 0.0;
+    }
+};
+
+// ------------------------------------------------------------------ quaternions (utils.py:7-47)
+template <class T> PLB_HD void qrot(const T* q, const T* v, T* out) {
+    T uv[3], uuv[3];
+    cross3(q + 1, v, uv);
+    cross3(q + 1, uv, uuv);
+    for (int i = 0; i < 3; ++i) out[i] = v[i] + T(2) * (q[0] * uv[i] + uuv[i]);
+}
+template <class T> PLB_HD void qconj(const T* q, T* c) { c[0] = q[0]; c[1] = -q[1]; c[2] = -q[2]; c[3] = -q[3]; }
+// adjoint of qrot w.r.t. q:  qa += d<g, qrot(q,v)>/dq
+template <class T> PLB_HD void qrot_adj_q(const T* q, const T* v, const T* g, T* qa) {
+    const T* u = q + 1;
+    T uv[3], vg[3];
+    cross3(u, v, uv);
+    cross3(v, g, vg);
+    qa[0] += T(2) * dot3(uv, g);
+    T uvd = dot3(u, v), gu = dot3(g, u), gvd = dot3(g, v);
+    for (int i = 0; i < 3; ++i)
+        qa[1 + i] += T(2) * q[0] * vg[i] + T(2) * (g[i] * uvd + v[i] * gu - T(2) * u[i] * gvd);
+}
+// inv_trans (utils.py:43-47): out = qrot(normalize(conj(rot)), p - pos); iq returned for reuse
+template <class T> PLB_HD void inv_trans(const T* p, const T* pos, const T* rot, T* out, T* iq) {
+    T c[4];
+    qconj(rot, c);
+    T inv = T(1) / t_sqrt(c[0] * c[0] + c[1] * c[1] + c[2] * c[2] + c[3] * c[3]);
+    for (int i = 0; i < 4; ++i) iq[i] = c[i] * inv;
+    T d[3] = {p[0] - pos[0], p[1] - pos[1], p[2] - pos[2]};
+    qrot(iq, d, out);
+}
+// adjoint of inv_trans w.r.t. (pos, rot) given adjoint g of its output
+template <class T> PLB_HD void inv_trans_adj(const T* p, const T* pos, const T* rot, const T* iq, const T* g,
+                                             T* pos_a, T* rot_a) {
+    T d[3] = {p[0] - pos[0], p[1] - pos[1], p[2] - pos[2]};
+    T iqa[4] = {T(0), T(0), T(0), T(0)};
+    qrot_adj_q(iq, d, g, iqa);
+    T ciq[4], da[3];
+    qconj(iq, ciq);
+    qrot(ciq, g, da);
+    for (int i = 0; i < 3; ++i) pos_a[i] -= da[i];
+    T nrm = t_sqrt(rot[0] * rot[0] + rot[1] * rot[1] + rot[2] * rot[2] + rot[3] * rot[3]);
+    T dotv = iq[0] * iqa[0] + iq[1] * iqa[1] + iq[2] * iqa[2] + iq[3] * iqa[3];
+    T ca[4];
+    for (int i = 0; i < 4; ++i) ca[i] = (iqa[i] - iq[i] * dotv) / nrm;
+    rot_a[0] += ca[0]; rot_a[1] -= ca[1]; rot_a[2] -= ca[2]; rot_a[3] -= ca[3];
+}
+
+// ------------------------------------------------------------------ shape SDFs in the local frame
+template <class T> PLB_HD T len14(T a, T b) { return t_sqrt(a * a + b * b + T(1e-14)); }
+template <class T> PLB_HD T len14(T a, T b, T c) { return t_sqrt(a * a + b * b + c * c + T(1e-14)); }
+
+template <class T> PLB_HD T shape_sdf_local(int shape, const T* par, const T* p) {
+    switch (shape) {
+    case SHAPE_CAPSULE: {                                 // primitives.py:42-47
+        T y = p[1] + par[0] / T(2);
+        y -= t_min(t_max(y, T(0)), par[0]);
+        return len14(p[0], y, p[2]) - par[1];
+    }
+    case SHAPE_CYLINDER: {                                // primitives.py:163-167 (h = radius, r = half height)
+        T d0 = t_abs(len14(p[0], p[2])) - par[0], d1 = t_abs(p[1]) - par[1];
+        return t_min(t_max(d0, d1), T(0)) + len14(t_max(d0, T(0)), t_max(d1, T(0)));
+    }
+    case SHAPE_TORUS: {                                   // primitives.py:199-202
+        T q0 = len14(p[0], p[2]) - par[0];
+        return len14(q0, p[1]) - par[1];
+    }
+    case SHAPE_BOX: {                                     // primitives.py:232-238
+        T q[3] = {t_abs(p[0]) - par[0], t_abs(p[1]) - par[1], t_abs(p[2]) - par[2]};
+        T o = len14(t_max(q[0], T(0)), t_max(q[1], T(0)), t_max(q[2], T(0)));
+        return o + t_min(t_max(q[0], t_max(q[1], q[2])), T(0));
+    }
+    default: return T(0);
+    }
+}
+
+template <class T> PLB_HD void shape_normal_local(int shape, const T* par, const T* p, T* n) {
+    switch (shape) {
+    case SHAPE_CAPSULE: {                                 // primitives.py:49-54
+        T y = p[1] + par[0] / T(2);
+        y -= t_min(t_max(y, T(0)), par[0]);
+        T inv = T(1) / len14(p[0], y, p[2]);
+        n[0] = p[0] * inv; n[1] = y * inv; n[2] = p[2] * inv;
+        return;
+    }
+    case SHAPE_CYLINDER: {                                // primitives.py:169-183
+        T l = len14(p[0], p[2]);
+        T d0 = l - par[0], d1 = t_abs(p[1]) - par[1];
+        T f = d0 > d1 ? T(1) : T(0);
+        T ins = t_max(d0, d1) <= T(0) ? T(1) : T(0);
+        T n20 = t_max(d0, T(0)) + ins * f, n21 = t_max(d1, T(0)) + ins * (T(1) - f);
+        T inv2 = T(1) / len14(n20, n21);
+        n20 *= inv2; n21 *= inv2;
+        T sgn = p[1] >= T(0) ? T(1) : T(-1);
+        T a = p[0] / l * n20, b = n21 * sgn, c = p[2] / l * n20;
+        T inv = T(1) / len14(a, b, c);
+        n[0] = a * inv; n[1] = b * inv; n[2] = c * inv;
+        return;
+    }
+    case SHAPE_TORUS: {                                   // primitives.py:204-213
+        T l = len14(p[0], p[2]);
+        T q0 = l - par[0], q1 = p[1];
+        T invq = T(1) / len14(q0, q1);
+        T n0 = q0 * invq, n1 = q1 * invq;
+        T a = p[0] / l * n0, b = n1, c = p[2] / l * n0;
+        T inv = T(1) / len14(a, b, c);
+        n[0] = a * inv; n[1] = b * inv; n[2] = c * inv;
+        return;
+    }
+    case SHAPE_BOX: {                                     // primitives.py:240-251 (central differences, d = 1e-4)
+        const T d = T(1e-4);
+        T g[3];
+        for (int i = 0; i < 3; ++i) {
+            T pi[3] = {p[0], p[1], p[2]}, pd[3] = {p[0], p[1], p[2]};
+            pi[i] += d; pd[i] -= d;
+            g[i] = (T(0.5) / d) * (shape_sdf_local(shape, par, pi) - shape_sdf_local(shape, par, pd));
+        }
+        T inv = T(1) / len14(g[0], g[1], g[2]);
+        n[0] = g[0] * inv; n[1] = g[1] * inv; n[2] = g[2] * inv;
+        return;
+    }
+    default: n[0] = n[1] = n[2] = T(0);
+    }
+}
+
+// world-frame signed distance / normal (Primitive.sdf / normal; Sphere overrides ignore rotation)
+template <class T> PLB_HD double prim_sdf(const PrimT<T>& pr, const double* gp) {
+    if (pr.shape == SHAPE_SPHERE)
+        return len14(gp[0] - pr.pos[0], gp[1] - pr.pos[1], gp[2] - pr.pos[2]) - pr.par[0];
+    double loc[3], iq[4];
+    inv_trans(gp, pr.pos, pr.rot, loc, iq);
+    return shape_sdf_local(pr.shape, pr.par, loc);
+}
+template <class T> PLB_HD void prim_normal(const PrimT<T>& pr, const double* gp, double* D) {
+    if (pr.shape == SHAPE_SPHERE) {
+        double d[3] = {gp[0] - pr.pos[0], gp[1] - pr.pos[1], gp[2] - pr.pos[2]};
+        double inv = 1.0 / len14(d[0], d[1], d[2]);
+        D[0] = d[0] * inv; D[1] = d[1] * inv; D[2] = d[2] * inv;
+        return;
+    }
+    double loc[3], iq[4], nl[3];
+    inv_trans(gp, pr.pos, pr.rot, loc, iq);
+    shape_normal_local(pr.shape, pr.par, loc, nl);
+    qrot(pr.rot, nl, D);
+}
+
+// ------------------------------------------------------------------ collide (primive_base.py:82-115)
+template <class T> struct CollideTmp {
+    T infl, D[3], cv[3], iv[3], nc, gvt[3], gn, e, flag;
+    double dist, rel[3], iq[4];
+};
+
+template <class T> PLB_HD bool collide_eval(const PrimT<T>& pr, T softness, T dt, const double* gp, const T* v,
+                                            CollideTmp<T>& c, T* vnew) {
+    c.dist = prim_sdf(pr, gp);
+    T ex = t_exp((T)(-c.dist * (double)softness));
+    c.infl = ex < T(1) ? ex : T(1);
+    if (!((softness > T(0) && c.infl > T(0.1)) || c.dist <= 0.0)) return false;
+    double Dd[3], np[3];
+    prim_normal(pr, gp, Dd);
+    inv_trans(gp, pr.pos, pr.rot, c.rel, c.iq);                   // collider_v :82-89
+    qrot(pr.rot1, c.rel, np);
+    for (int i = 0; i < 3; ++i) {
+        c.D[i] = (T)Dd[i];
+        c.cv[i] = (T)((np[i] + pr.pos1[i] - gp[i]) / (double)dt);
+        c.iv[i] = v[i] - c.cv[i];
+    }
+    c.nc = dot3(c.iv, c.D);
+    T mn = c.nc < T(0) ? c.nc : T(0);
+    for (int i = 0; i < 3; ++i) c.gvt[i] = c.iv[i] - mn * c.D[i];
+    T g2 = dot3(c.gvt, c.gvt);
+    c.gn = t_sqrt(g2 + T(1e-8));
+    c.e = c.gn + c.nc * pr.friction;
+    T m = c.e < T(0) ? T(0) : c.e;                                // max(0, e)
+    c.flag = (c.nc < T(0) && t_sqrt(g2) > T(1e-30)) ? T(1) : T(0);
+    for (int i = 0; i < 3; ++i) {
+        T fr = c.gvt[i] / c.gn * m;
+        T g2v = fr * c.flag + c.gvt[i] * (T(1) - c.flag);
+        vnew[i] = c.cv[i] + c.iv[i] * (T(1) - c.infl) + g2v * c.infl;
+    }
+    return true;
+}
+
+// adjoint of one collide.  v: velocity before this collide; vn_a: adjoint of its output.
+// Writes v_a; accumulates pose adjoints into pa (only for movable Spheres -- other movable
+// shapes need d sdf/d pose, d normal/d pose, which are not derived yet).
+template <class T> PLB_HD bool collide_grad(const PrimT<T>& pr, T softness, T dt, const double* gp, const T* v,
+                                            const T* vn_a, T* v_a, PoseAdj<T>* pa) {
+    CollideTmp<T> c;
+    T vnew[3];
+    if (!collide_eval(pr, softness, dt, gp, v, c, vnew)) {
+        for (int i = 0; i < 3; ++i) v_a[i] = vn_a[i];
+        return false;
+    }
+    T m = c.e < T(0) ? T(0) : c.e;
+    T cva[3], iva[3], g2a[3], gvta[3], Da[3] = {T(0), T(0), T(0)};
+    T infla = T(0);
+    for (int i = 0; i < 3; ++i) {
+        T fr = c.gvt[i] / c.gn * m;
+        T g2v = fr * c.flag + c.gvt[i] * (T(1) - c.flag);
+        cva[i] = vn_a[i];
+        iva[i] = (T(1) - c.infl) * vn_a[i];
+        g2a[i] = c.infl * vn_a[i];
+        infla += vn_a[i] * (g2v - c.iv[i]);
+    }
+    // g2v = fric*flag + gvt*(1-flag); fric = gvt * (m / gn)
+    T fra_dot_gvt = T(0);
+    for (int i = 0; i < 3; ++i) {
+        T fra = c.flag * g2a[i];
+        gvta[i] = (T(1) - c.flag) * g2a[i] + fra * (m / c.gn);
+        fra_dot_gvt += fra * c.gvt[i];
+    }
+    T gna = -fra_dot_gvt * m / (c.gn * c.gn);
+    T ma = fra_dot_gvt / c.gn;
+    T ea = c.e < T(0) ? T(0) : ma;            // max(0, e): adjoint to e unless e < 0
+    gna += ea;
+    T nca = pr.friction * ea;
+    for (int i = 0; i < 3; ++i) gvta[i] += gna * c.gvt[i] / c.gn;
+    // gvt = iv - min(nc,0) D
+    T mn = c.nc < T(0) ? c.nc : T(0);
+    T mna = T(0);
+    for (int i = 0; i < 3; ++i) { iva[i] += gvta[i]; mna -= gvta[i] * c.D[i]; Da[i] -= mn * gvta[i]; }
+    if (c.nc < T(0)) nca += mna;
+    for (int i = 0; i < 3; ++i) { iva[i] += nca * c.D[i]; Da[i] += nca * c.iv[i]; }
+    for (int i = 0; i < 3; ++i) { v_a[i] = iva[i]; cva[i] -= iva[i]; }
+    if (!pa || !pr.movable) return true;
+    // ---- pose adjoints
+    // influence = min(exp(-dist*soft), 1): adjoint to the exp iff exp < 1
+    double dista = 0.0;
+    T ex = t_exp((T)(-c.dist * (double)softness));
+    if (ex < T(1)) dista = -(double)softness * (double)ex * (double)infla;
+    // collider velocity
+    double npa[3] = {(double)cva[0] / (double)dt, (double)cva[1] / (double)dt, (double)cva[2] / (double)dt};
+    for (int i = 0; i < 3; ++i) pa->pos1[i] += npa[i];
+    qrot_adj_q(pr.rot1, c.rel, npa, pa->rot1);
+    double cr1[4], rela[3];
+    qconj(pr.rot1, cr1);
+    qrot(cr1, npa, rela);
+    inv_trans_adj(gp, pr.pos, pr.rot, c.iq, rela, pa->pos, pa->rot);
+    if (pr.shape == SHAPE_SPHERE) {
+        // dist = len14(gp - c) - r ; D = (gp - c)/len14
+        double d[3] = {gp[0] - pr.pos[0], gp[1] - pr.pos[1], gp[2] - pr.pos[2]};
+        double L = len14(d[0], d[1], d[2]);
+        double Dd[3] = {d[0] / L, d[1] / L, d[2] / L};
+        double Dad[3] = {(double)Da[0], (double)Da[1], (double)Da[2]};
+        double dD = dot3(Dad, Dd);
+        for (int i = 0; i < 3; ++i) {
+            double da = dista * d[i] / L + (Dad[i] - Dd[i] * dD) / L;   // adjoint of d = gp - c
+            pa->pos[i] -= da;
+        }
+    }
+    return true;
+}
+
+// ------------------------------------------------------------------ box boundary (mpm_simulator.py:200-219)
+// one axis d; v updated in place.
+template <class T> PLB_HD void boundary_axis(const SimP<T>& P, const int* I, int d, T* v) {
+    if (I[d] < 3 && v[d] < T(0)) {
+        if (d != 1 || P.ground_friction == T(0)) v[d] = T(0);
+        else if (P.ground_friction < T(10)) {
+            T lin = v[1];
+            T lit = t_sqrt(v[0] * v[0] + v[2] * v[2] + T(1e-8));
+            T s = t_max(T(1) + P.ground_friction * lin / lit, T(0));
+            v[0] *= s; v[2] *= s; v[1] = T(0);
+        } else v[0] = v[1] = v[2] = T(0);
+    }
+    if (I[d] > P.n - 3 && v[d] > T(0)) v[d] = T(0);
+}
+// adjoint: vb = value before the axis stage, a = adjoint (in: of output, out: of input)
+template <class T> PLB_HD void boundary_axis_grad(const SimP<T>& P, const int* I, int d, const T* vb, T* a) {
+    T vm[3] = {vb[0], vb[1], vb[2]};
+    bool lo = I[d] < 3 && vb[d] < T(0);
+    T s = T(1), lit = T(1), e = T(1);
+    int mode = 0;
+    if (lo) {
+        if (d != 1 || P.ground_friction == T(0)) { mode = 1; vm[d] = T(0); }
+        else if (P.ground_friction < T(10)) {
+            mode = 2;
+            lit = t_sqrt(vb[0] * vb[0] + vb[2] * vb[2] + T(1e-8));
+            e = T(1) + P.ground_friction * vb[1] / lit;
+            s = t_max(e, T(0));
+            vm[0] *= s; vm[2] *= s; vm[1] = T(0);
+        } else { mode = 3; vm[0] = vm[1] = vm[2] = T(0); }
+    }
+    if (I[d] > P.n - 3 && vm[d] > T(0)) a[d] = T(0);
+    if (mode == 1) a[d] = T(0);
+    else if (mode == 3) a[0] = a[1] = a[2] = T(0);
+    else if (mode == 2) {
+        T sa = a[0] * vb[0] + a[2] * vb[2];
+        T ax = s * a[0], az = s * a[2];
+        T ea = (T(0) < e) ? sa : T(0);            // max(e, 0): adjoint to e iff 0 < e
+        T lina = P.ground_friction * ea / lit;
+        T lita = -P.ground_friction * vb[1] * ea / (lit * lit);
+        ax += lita * vb[0] / lit;
+        az += lita * vb[2] / lit;
+        a[0] = ax; a[1] = lina; a[2] = az;
+    }
+}
+
+// ------------------------------------------------------------------ grid_op for one node
+// m, mv: grid_m / grid_v_in.  Returns false (and vout = 0) when the node is empty (m <= 1e-12).
+template <class T>
+PLB_HD bool grid_node_fwd(const SimP<T>& P, const int* I, T m, const T* mv, int nprim, const PrimT<T>* prims, T* vout) {
+    if (!(m > T(1e-12))) { vout[0] = vout[1] = vout[2] = T(0); return false; }
+    T inv = T(1) / m;
+    T v[3] = {inv * mv[0] + P.grav[0], inv * mv[1] + P.grav[1], inv * mv[2] + P.grav[2]};
+    double gp[3] = {I[0] / (double)P.n, I[1] / (double)P.n, I[2] / (double)P.n};
+    for (int p = 0; p < nprim; ++p) {
+        CollideTmp<T> c;
+        T vn[3];
+        if (collide_eval(prims[p], P.softness, P.dt, gp, v, c, vn)) { v[0] = vn[0]; v[1] = vn[1]; v[2] = vn[2]; }
+    }
+    for (int d = 0; d < 3; ++d) boundary_axis(P, I, d, v);
+    vout[0] = v[0]; vout[1] = v[1]; vout[2] = v[2];
+    return true;
+}
+
+// grid_op adjoint for one node.  vout_a: adjoint of grid_v_out.  Outputs m_a, mv_a; pose adjoints
+// are handed to sink(p, PoseAdj) for every primitive this node touches.
+template <class T, class Sink>
+PLB_HD void grid_node_bwd(const SimP<T>& P, const int* I, T m, const T* mv, int nprim, const PrimT<T>* prims,
+                          const T* vout_a, T* m_a, T* mv_a, Sink&& sink) {
+    *m_a = T(0); mv_a[0] = mv_a[1] = mv_a[2] = T(0);
+    if (!(m > T(1e-12))) return;
+    T inv = T(1) / m;
+    T v0[3] = {inv * mv[0] + P.grav[0], inv * mv[1] + P.grav[1], inv * mv[2] + P.grav[2]};
+    double gp[3] = {I[0] / (double)P.n, I[1] / (double)P.n, I[2] / (double)P.n};
+    // forward to the state after all collides
+    T vc[3] = {v0[0], v0[1], v0[2]};
+    for (int p = 0; p < nprim; ++p) {
+        CollideTmp<T> c;
+        T vn[3];
+        if (collide_eval(prims[p], P.softness, P.dt, gp, vc, c, vn)) { vc[0] = vn[0]; vc[1] = vn[1]; vc[2] = vn[2]; }
+    }
+    // boundary stages
+    T vb0[3] = {vc[0], vc[1], vc[2]}, vb1[3], vb2[3];
+    T t[3] = {vc[0], vc[1], vc[2]};
+    boundary_axis(P, I, 0, t); vb1[0] = t[0]; vb1[1] = t[1]; vb1[2] = t[2];
+    boundary_axis(P, I, 1, t); vb2[0] = t[0]; vb2[1] = t[1]; vb2[2] = t[2];
+    T a[3] = {vout_a[0], vout_a[1], vout_a[2]};
+    boundary_axis_grad(P, I, 2, vb2, a);
+    boundary_axis_grad(P, I, 1, vb1, a);
+    boundary_axis_grad(P, I, 0, vb0, a);
+    // collides in reverse; the velocity entering collide p is recomputed from v0
+    for (int p = nprim - 1; p >= 0; --p) {
+        T vin[3] = {v0[0], v0[1], v0[2]};
+        for (int q = 0; q < p; ++q) {
+            CollideTmp<T> c;
+            T vn[3];
+            if (collide_eval(prims[q], P.softness, P.dt, gp, vin, c, vn)) { vin[0] = vn[0]; vin[1] = vn[1]; vin[2] = vn[2]; }
+        }
+        PoseAdj<T> pa;
+        pa.zero();
+        T va[3];
+        bool hit = collide_grad(prims[p], P.softness, P.dt, gp, vin, a, va, &pa);
+        a[0] = va[0]; a[1] = va[1]; a[2] = va[2];
+        if (hit && prims[p].movable) sink(p, pa);
+    }
+    // v0 = mv / m + g
+    for (int i = 0; i < 3; ++i) { mv_a[i] = a[i] * inv; *m_a -= a[i] * mv[i] * inv * inv; }
+}
+
+// ------------------------------------------------------------------ primitive kinematics (always double)
+// forward_kinematics (primive_base.py:117-121): pos' = clamp(pos + v), rot' = normalize(w2quat(w) (x) rot)
+PLB_HD void w2quat_d(const double* a, double* q) {          // utils.py:29-41
+    double w = sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]);
+    q[0] = 1.0; q[1] = q[2] = q[3] = 0.0;
+    if (w > 1e-9) {
+        double s = sin(w / 2) / w;
+        q[0] = cos(w / 2); q[1] = a[0] * s; q[2] = a[1] * s; q[3] = a[2] * s;
+    }
+}
+PLB_HD void qmul_raw_d(const double* q, const double* r, double* o) {   // utils.py:19-26 (Hamilton q (x) r)
+    o[0] = r[0] * q[0] - r[1] * q[1] - r[2] * q[2] - r[3] * q[3];
+    o[1] = r[0] * q[1] + r[1] * q[0] - r[2] * q[3] + r[3] * q[2];
+    o[2] = r[0] * q[2] + r[1] * q[3] + r[2] * q[0] - r[3] * q[1];
+    o[3] = r[0] * q[3] - r[1] * q[2] + r[2] * q[1] + r[3] * q[0];
+}
+PLB_HD void fk_fwd_d(const double* pos, const double* rot, const double* v, const double* w,
+                     const double* lo, const double* hi, double* pos1, double* rot1) {
+    for (int i = 0; i < 3; ++i) {
+        double y = pos[i] + v[i];
+        double mn = y < hi[i] ? y : hi[i];
+        pos1[i] = lo[i] < mn ? mn : lo[i];
+    }
+    double q[4], o[4];
+    w2quat_d(w, q);
+    qmul_raw_d(q, rot, o);
+    double inv = 1.0 / sqrt(o[0] * o[0] + o[1] * o[1] + o[2] * o[2] + o[3] * o[3]);
+    for (int i = 0; i < 4; ++i) rot1[i] = o[i] * inv;
+}
+// adjoint: pos1_a, rot1_a in; accumulates pos_a, rot_a (pose at f); writes v_a, w_a (overwrite)
+PLB_HD void fk_bwd_d(const double* pos, const double* rot, const double* v, const double* w,
+                     const double* lo, const double* hi, const double* pos1_a, const double* rot1_a,
+                     double* pos_a, double* rot_a, double* v_a, double* w_a) {
+    for (int i = 0; i < 3; ++i) {
+        double y = pos[i] + v[i];
+        double mn = y < hi[i] ? y : hi[i];
+        // max(min(y,hi),lo): to y iff y < hi and lo < min
+        double gate = (y < hi[i] && lo[i] < mn) ? 1.0 : 0.0;
+        pos_a[i] += gate * pos1_a[i];
+        v_a[i] = gate * pos1_a[i];
+    }
+    double q[4], o[4];
+    w2quat_d(w, q);
+    qmul_raw_d(q, rot, o);
+    double nrm = sqrt(o[0] * o[0] + o[1] * o[1] + o[2] * o[2] + o[3] * o[3]);
+    double on[4], dotv = 0;
+    for (int i = 0; i < 4; ++i) { on[i] = o[i] / nrm; dotv += on[i] * rot1_a[i]; }
+    double oa[4];
+    for (int i = 0; i < 4; ++i) oa[i] = (rot1_a[i] - on[i] * dotv) / nrm;
+    const double* r = rot;
+    // o = q (x) r, bilinear
+    rot_a[0] += oa[0] * q[0] + oa[1] * q[1] + oa[2] * q[2] + oa[3] * q[3];
+    rot_a[1] += -oa[0] * q[1] + oa[1] * q[0] + oa[2] * q[3] - oa[3] * q[2];
+    rot_a[2] += -oa[0] * q[2] - oa[1] * q[3] + oa[2] * q[0] + oa[3] * q[1];
+    rot_a[3] += -oa[0] * q[3] + oa[1] * q[2] - oa[2] * q[1] + oa[3] * q[0];
+    double qa[4];
+    qa[0] = oa[0] * r[0] + oa[1] * r[1] + oa[2] * r[2] + oa[3] * r[3];
+    qa[1] = -oa[0] * r[1] + oa[1] * r[0] - oa[2] * r[3] + oa[3] * r[2];
+    qa[2] = -oa[0] * r[2] + oa[1] * r[3] + oa[2] * r[0] - oa[3] * r[1];
+    qa[3] = -oa[0] * r[3] - oa[1] * r[2] + oa[2] * r[1] + oa[3] * r[0];
+    double th = sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+    w_a[0] = w_a[1] = w_a[2] = 0.0;
+    if (th > 1e-9) {
+        double n[3] = {w[0] / th, w[1] / th, w[2] / th};
+        double sh = sin(th / 2), ch = cos(th / 2);
+        double nq = n[0] * qa[1] + n[1] * qa[2] + n[2] * qa[3];
+        for (int i = 0; i < 3; ++i)
+            w_a[i] = -0.5 * sh * n[i] * qa[0] + (sh / th) * (qa[1 + i] - n[i] * nq) + 0.5 * ch * n[i] * nq;
+    }
+}
+
+}  // namespace plb

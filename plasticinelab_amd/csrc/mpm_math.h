@@ -1,0 +1,514 @@
+// Per-particle / per-node arithmetic of the differentiable MLS-MPM substep.
+//
+// Everything here is a templated inline function on a scalar type T (float on
+// the fast path, double for the parity path).  The HIP kernels in
+// mpm_kernels.hip call these from device code; tests/host_emul compiles the
+// same header with g++ to check the hand-derived adjoints against the CPU
+// oracle without a GPU (test infrastructure only -- the product never runs
+// this on the host).
+//
+// What is computed follows /root/reference/plb/engine/mpm_simulator.py and
+// plb/engine/primitive/*.py (cited per function); HOW is different:
+//   * the deformation gradient is carried as E = F - I so that small strains
+//     keep full relative precision in fp32;
+//   * the 3x3 SVD is a Jacobi eigen-solve of F^T F - I (accurate sigma - 1);
+//   * the adjoint never forms dU / dV: stress and the return-mapped F are
+//     isotropic functions of F_tmp, so the VJP is written in the singular
+//     basis with divided differences.  The reference's +-1e-6 clamp in
+//     backward_svd (mpm_simulator.py:143-151) is reproduced as a pairwise
+//     attenuation min(1, |s_j^2 - s_i^2| / clamp) so results match it.
+#pragma once
+#include <math.h>
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define PLB_HD __host__ __device__ __forceinline__
+#else
+#define PLB_HD inline
+#endif
+
+namespace plb {
+
+// ---------------------------------------------------------------- scalar helpers
+template <class T> PLB_HD T t_sqrt(T x);
+template <> PLB_HD float t_sqrt<float>(float x) { return sqrtf(x); }
+template <> PLB_HD double t_sqrt<double>(double x) { return sqrt(x); }
+template <class T> PLB_HD T t_exp(T x);
+template <> PLB_HD float t_exp<float>(float x) { return expf(x); }
+template <> PLB_HD double t_exp<double>(double x) { return exp(x); }
+template <class T> PLB_HD T t_log(T x);
+template <> PLB_HD float t_log<float>(float x) { return logf(x); }
+template <> PLB_HD double t_log<double>(double x) { return log(x); }
+template <class T> PLB_HD T t_log1p(T x);
+template <> PLB_HD float t_log1p<float>(float x) { return log1pf(x); }
+template <> PLB_HD double t_log1p<double>(double x) { return log1p(x); }
+template <class T> PLB_HD T t_expm1(T x);
+template <> PLB_HD float t_expm1<float>(float x) { return expm1f(x); }
+template <> PLB_HD double t_expm1<double>(double x) { return expm1(x); }
+template <class T> PLB_HD T t_abs(T x) { return x < T(0) ? -x : x; }
+template <class T> PLB_HD T t_max(T a, T b) { return a > b ? a : b; }
+template <class T> PLB_HD T t_min(T a, T b) { return a < b ? a : b; }
+
+template <class T> struct Tol;
+template <> struct Tol<float> { static constexpr int sweeps = 5; static PLB_HD float dd() { return 2e-2f; } };
+template <> struct Tol<double> { static constexpr int sweeps = 8; static PLB_HD double dd() { return 1e-4; } };
+
+// ---------------------------------------------------------------- 3x3 helpers (row major)
+template <class T> PLB_HD void mat_mul(const T* a, const T* b, T* c) {          // c = a b
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) c[3 * i + j] = a[3 * i] * b[j] + a[3 * i + 1] * b[3 + j] + a[3 * i + 2] * b[6 + j];
+}
+template <class T> PLB_HD void mat_mul_tn(const T* a, const T* b, T* c) {       // c = a^T b
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) c[3 * i + j] = a[i] * b[j] + a[3 + i] * b[3 + j] + a[6 + i] * b[6 + j];
+}
+template <class T> PLB_HD void mat_mul_nt(const T* a, const T* b, T* c) {       // c = a b^T
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) c[3 * i + j] = a[3 * i] * b[3 * j] + a[3 * i + 1] * b[3 * j + 1] + a[3 * i + 2] * b[3 * j + 2];
+}
+template <class T> PLB_HD T det3(const T* m) {
+    return m[0] * (m[4] * m[8] - m[5] * m[7]) - m[1] * (m[3] * m[8] - m[5] * m[6]) + m[2] * (m[3] * m[7] - m[4] * m[6]);
+}
+template <class T> PLB_HD void cross3(const T* a, const T* b, T* c) {
+    c[0] = a[1] * b[2] - a[2] * b[1]; c[1] = a[2] * b[0] - a[0] * b[2]; c[2] = a[0] * b[1] - a[1] * b[0];
+}
+template <class T> PLB_HD T dot3(const T* a, const T* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+
+// ---------------------------------------------------------------- simulation constants
+template <class T> struct SimP {
+    int n;              // n_grid                                (mpm_simulator.py:19)
+    T dx, inv_dx, dt;   //                                        (:21-22)
+    T p_mass;           // (dx/2)^2, the 2-D formula kept in 3-D  (:23-24)
+    T kappa;            // -dt * p_vol * 4 * inv_dx^2             (:173)
+    T grav[3];          // dt * gravity * 30                      (:194)
+    T x_hi;             // 1 - 3 dx                               (:242)
+    T ground_friction;  //                                        (:204-217)
+    T svd_clamp;        // 1e-6 reproduces backward_svd's clamp; 0 = exact derivative
+    T softness;         // Primitive.softness                     (primive_base.py:29)
+};
+
+// ---------------------------------------------------------------- quadratic B-spline stencil
+// base = trunc(x*inv_dx - 0.5) (Taichi cast(int) truncates); fx = x*inv_dx - base;
+// w[k][d] for offset k in {0,1,2}; dw = d w / d fx.      (mpm_simulator.py:160-163)
+// X is the position type: positions are carried in double even on the fp32 path, so that fx (and with
+// it every weight) keeps full fp32 relative precision instead of the ~4e-6 an fp32 x*inv_dx would leave.
+template <class T, class X> PLB_HD void stencil(const X* x, T inv_dx, int* base, T* fx, T (*w)[3], T (*dw)[3]) {
+    for (int d = 0; d < 3; ++d) {
+        X xs = x[d] * (X)inv_dx;
+        base[d] = (int)(xs - X(0.5));
+        T f = (T)(xs - (X)base[d]);
+        fx[d] = f;
+        w[0][d] = T(0.5) * (T(1.5) - f) * (T(1.5) - f);
+        w[1][d] = T(0.75) - (f - T(1)) * (f - T(1));
+        w[2][d] = T(0.5) * (f - T(0.5)) * (f - T(0.5));
+        if (dw) {
+            dw[0][d] = -(T(1.5) - f);
+            dw[1][d] = T(-2) * (f - T(1));
+            dw[2][d] = f - T(0.5);
+        }
+    }
+}
+
+// ---------------------------------------------------------------- SVD of I + Et
+template <class T> struct Svd3 {
+    T U[9], V[9];
+    T sig[3];   // singular values
+    T s[3];     // sig - 1, accurate for small strain
+    T lam[3];   // sig^2 - 1 (eigenvalues of F^T F - I)
+};
+
+template <class T> PLB_HD void jacobi_pair(T& app, T& aqq, T& apq, T& arp, T& arq, T* V, int p, int q) {
+    if (apq == T(0)) return;
+    T theta = (aqq - app) / (T(2) * apq);
+    T t = (theta >= T(0) ? T(1) : T(-1)) / (t_abs(theta) + t_sqrt(theta * theta + T(1)));
+    T c = T(1) / t_sqrt(t * t + T(1));
+    T s = t * c;
+    app -= t * apq;
+    aqq += t * apq;
+    apq = T(0);
+    T rp = c * arp - s * arq, rq = s * arp + c * arq;
+    arp = rp; arq = rq;
+    for (int k = 0; k < 3; ++k) {
+        T vp = V[3 * k + p], vq = V[3 * k + q];
+        V[3 * k + p] = c * vp - s * vq;
+        V[3 * k + q] = s * vp + c * vq;
+    }
+}
+
+// Et = F_tmp - I.  Standard convention: sig >= 0, V a rotation, det U = sign det F.
+// (ti.svd's own convention is third-party and unverified; results downstream are
+// invariant to it whenever det F_tmp > 0.)                 (mpm_simulator.py:87-90)
+template <class T> PLB_HD void svd_eform(const T* Et, Svd3<T>& r) {
+    // A = Et + Et^T + Et^T Et = F^T F - I
+    T a00 = T(2) * Et[0] + Et[0] * Et[0] + Et[3] * Et[3] + Et[6] * Et[6];
+    T a11 = T(2) * Et[4] + Et[1] * Et[1] + Et[4] * Et[4] + Et[7] * Et[7];
+    T a22 = T(2) * Et[8] + Et[2] * Et[2] + Et[5] * Et[5] + Et[8] * Et[8];
+    T a01 = Et[1] + Et[3] + Et[0] * Et[1] + Et[3] * Et[4] + Et[6] * Et[7];
+    T a02 = Et[2] + Et[6] + Et[0] * Et[2] + Et[3] * Et[5] + Et[6] * Et[8];
+    T a12 = Et[5] + Et[7] + Et[1] * Et[2] + Et[4] * Et[5] + Et[7] * Et[8];
+    T* V = r.V;
+    V[0] = V[4] = V[8] = T(1);
+    V[1] = V[2] = V[3] = V[5] = V[6] = V[7] = T(0);
+#if defined(__HIPCC__)
+#pragma unroll 1
+#endif
+    for (int sw = 0; sw < Tol<T>::sweeps; ++sw) {
+        jacobi_pair(a00, a11, a01, a02, a12, V, 0, 1);
+        jacobi_pair(a00, a22, a02, a01, a12, V, 0, 2);
+        jacobi_pair(a11, a22, a12, a01, a02, V, 1, 2);
+    }
+    r.lam[0] = a00; r.lam[1] = a11; r.lam[2] = a22;
+    for (int i = 0; i < 3; ++i) {
+        T sg = t_sqrt(t_max(T(1) + r.lam[i], T(0)));
+        r.sig[i] = sg;
+        r.s[i] = r.lam[i] / (T(1) + sg);
+    }
+    // U = F V Sigma^-1, F = I + Et
+    for (int i = 0; i < 3; ++i) {
+        T inv = T(1) / t_max(r.sig[i], T(1e-30));
+        for (int k = 0; k < 3; ++k)
+            r.U[3 * k + i] = (V[3 * k + i] + Et[3 * k] * V[i] + Et[3 * k + 1] * V[3 + i] + Et[3 * k + 2] * V[6 + i]) * inv;
+    }
+    // nearly singular F: rebuild the weakest column from the other two
+    int kmin = r.sig[0] < r.sig[1] ? (r.sig[0] < r.sig[2] ? 0 : 2) : (r.sig[1] < r.sig[2] ? 1 : 2);
+    if (r.sig[kmin] < T(1e-3)) {
+        T Fm[9];
+        for (int i = 0; i < 9; ++i) Fm[i] = Et[i];
+        Fm[0] += T(1); Fm[4] += T(1); Fm[8] += T(1);
+        T sgn = det3(Fm) < T(0) ? T(-1) : T(1);
+        int a = (kmin + 1) % 3, b = (kmin + 2) % 3;
+        T ua[3] = {r.U[a], r.U[3 + a], r.U[6 + a]}, ub[3] = {r.U[b], r.U[3 + b], r.U[6 + b]}, uc[3];
+        cross3(ua, ub, uc);
+        T nrm = t_sqrt(dot3(uc, uc));
+        T sc = nrm > T(0) ? sgn / nrm : T(0);
+        r.U[kmin] = uc[0] * sc; r.U[3 + kmin] = uc[1] * sc; r.U[6 + kmin] = uc[2] * sc;
+    }
+}
+
+// ---------------------------------------------------------------- constitutive model
+// compute_von_mises + stress of p2g               (mpm_simulator.py:124-141, :164-171)
+template <class T> struct Consti {
+    Svd3<T> svd;
+    bool yield;
+    T g[3];      // singular values of new_F
+    T gm1[3];    // g - 1
+    T eps[3], eh[3], epsn[3];
+    T nrm, c;    // ||dev eps|| (with the 1e-8 eps), yield_stress / (2 mu)
+    T J, Jm1;    // det(new_F), det - 1
+    T h[3];      // principal (unscaled) stress: 2 mu g (g-1) + lam J (J-1)
+    bool unc[3]; // sig > 0.05 (not clamped)
+};
+
+// Et = F_tmp - I.  Outputs: En = new_F - I (what is stored as F[f+1]), stress (unscaled).
+template <class T> PLB_HD void constitutive_fwd(const T* Et, T mu, T lam, T ys, Consti<T>& k, T* En, T* stress) {
+    svd_eform(Et, k.svd);
+    const Svd3<T>& S = k.svd;
+    T mean = T(0);
+    for (int i = 0; i < 3; ++i) {
+        k.unc[i] = T(0.05) < S.sig[i];          // ti.max(sig, 0.05): adjoint to sig iff 0.05 < sig
+        k.eps[i] = k.unc[i] ? t_log1p(S.s[i]) : t_log(T(0.05));
+        mean += k.eps[i];
+    }
+    mean *= T(1) / T(3);
+    T n2 = T(1e-8);
+    for (int i = 0; i < 3; ++i) { k.eh[i] = k.eps[i] - mean; n2 += k.eh[i] * k.eh[i]; }
+    k.nrm = t_sqrt(n2);
+    k.c = ys / (T(2) * mu);
+    k.yield = (k.nrm - k.c) > T(0);
+    T detsign = T(1);
+    if (k.yield) {
+        T f = (k.nrm - k.c) / k.nrm;
+        for (int i = 0; i < 3; ++i) {
+            k.epsn[i] = k.eps[i] - f * k.eh[i];
+            k.gm1[i] = t_expm1(k.epsn[i]);
+            k.g[i] = T(1) + k.gm1[i];
+        }
+        T US[9];
+        for (int r = 0; r < 3; ++r)
+            for (int i = 0; i < 3; ++i) US[3 * r + i] = S.U[3 * r + i] * k.g[i];
+        mat_mul_nt(US, S.V, En);
+        En[0] -= T(1); En[4] -= T(1); En[8] -= T(1);
+        detsign = det3(S.U) < T(0) ? T(-1) : T(1);     // det V = +1
+    } else {
+        for (int i = 0; i < 3; ++i) { k.g[i] = S.sig[i]; k.gm1[i] = S.s[i]; k.epsn[i] = k.eps[i]; }
+        for (int i = 0; i < 9; ++i) En[i] = Et[i];
+        // det(F_tmp) sign: only negative for inverted elements
+        T Fm[9];
+        for (int i = 0; i < 9; ++i) Fm[i] = Et[i];
+        Fm[0] += T(1); Fm[4] += T(1); Fm[8] += T(1);
+        detsign = det3(Fm) < T(0) ? T(-1) : T(1);
+    }
+    T e1 = k.gm1[0] + k.gm1[1] + k.gm1[2];
+    T e2 = k.gm1[0] * k.gm1[1] + k.gm1[0] * k.gm1[2] + k.gm1[1] * k.gm1[2];
+    T e3 = k.gm1[0] * k.gm1[1] * k.gm1[2];
+    T Jp1m = e1 + e2 + e3;                      // prod(g) - 1
+    if (detsign > T(0)) { k.Jm1 = Jp1m; k.J = T(1) + Jp1m; }
+    else { k.J = -(T(1) + Jp1m); k.Jm1 = k.J - T(1); }
+    T vol = lam * k.J * k.Jm1;
+    for (int i = 0; i < 3; ++i) k.h[i] = T(2) * mu * k.g[i] * k.gm1[i] + vol;
+    T UH[9];
+    for (int r = 0; r < 3; ++r)
+        for (int i = 0; i < 3; ++i) UH[3 * r + i] = S.U[3 * r + i] * k.h[i];
+    mat_mul_nt(UH, S.U, stress);
+}
+
+// stable divided differences
+template <class T> PLB_HD T dd_exp(T a, T b) {       // (e^a - e^b)/(a - b)
+    T d = a - b;
+    if (t_abs(d) < Tol<T>::dd()) return t_exp(b) * (T(1) + d * (T(0.5) + d * (T(1) / T(6) + d * (T(1) / T(24)))));
+    return (t_exp(a) - t_exp(b)) / d;
+}
+template <class T> PLB_HD T dd_log(T a, T b) {       // (log a - log b)/(a - b), a,b > 0
+    T t = (a - b) / b;
+    if (t_abs(t) < Tol<T>::dd()) return (T(1) - t * (T(0.5) - t * (T(1) / T(3) - t * T(0.25)))) / b;
+    return t_log1p(t) / (t * b);
+}
+
+// VJP of (new_F, stress) w.r.t. F_tmp: returns Ft_adj = d<GF,new_F>/dFt + d<GS,stress>/dFt.
+// Replaces p2g.grad's U/sig/V adjoints + svd_grad    (mpm_simulator.py:92-115, :276-277)
+template <class T> PLB_HD void constitutive_vjp(const Consti<T>& k, T mu, T lam, T svd_clamp,
+                                                const T* GS, const T* GF, T* Ft_adj) {
+    const Svd3<T>& S = k.svd;
+    T tmp[9], Gs[9], Gf[9], M[9];
+    mat_mul_tn(S.U, GS, tmp); mat_mul(tmp, S.U, Gs);            // U^T GS U
+    const T* sig = S.sig;
+    T att[3][3];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            T dl = t_abs(S.lam[j] - S.lam[i]);
+            att[i][j] = (svd_clamp > T(0) && dl < svd_clamp) ? dl / svd_clamp : T(1);
+        }
+    T J = k.J;
+    if (!k.yield) {
+        T dvol = lam * (T(2) * J - T(1));
+        for (int q = 0; q < 3; ++q) {
+            T Jq = J / sig[q];      // dJ/dsig_q
+            if (sig[q] < T(1e-20)) Jq = T(0);
+            M[4 * q] = T(2) * mu * (T(2) * sig[q] - T(1)) * Gs[4 * q] + dvol * Jq * (Gs[0] + Gs[4] + Gs[8]);
+        }
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) {
+                if (i == j) continue;
+                T ssum = sig[i] + sig[j];
+                T inv = ssum > T(1e-20) ? T(1) / ssum : T(0);
+                T kij = T(2) * mu * (ssum - T(1)) * inv;
+                M[3 * i + j] = kij * sig[j] * (Gs[3 * i + j] + Gs[3 * j + i])
+                    + (T(1) - att[i][j]) * T(2) * mu * (Gs[3 * i + j] * sig[j] - Gs[3 * j + i] * sig[i]) * inv;
+            }
+        T UM[9];
+        mat_mul(S.U, M, UM); mat_mul_nt(UM, S.V, Ft_adj);
+        for (int i = 0; i < 9; ++i) Ft_adj[i] += GF[i];
+        return;
+    }
+    mat_mul_tn(S.U, GF, tmp); mat_mul(tmp, S.V, Gf);            // U^T GF V
+    // d g_i / d sig_q
+    T dg[3][3], dJ[3];
+    T cn = k.c / k.nrm, cn3 = k.c / (k.nrm * k.nrm * k.nrm);
+    for (int q = 0; q < 3; ++q) {
+        T dsc = k.unc[q] ? T(1) / sig[q] : T(0);                // d eps_q / d sig_q
+        dJ[q] = T(0);
+        for (int i = 0; i < 3; ++i) {
+            T de = T(1) / T(3) + cn * ((i == q ? T(1) : T(0)) - T(1) / T(3)) - cn3 * k.eh[i] * k.eh[q];
+            dg[i][q] = k.g[i] * de * dsc;
+            dJ[q] += (J / k.g[i]) * dg[i][q];
+        }
+    }
+    T dvol = lam * (T(2) * J - T(1));
+    for (int q = 0; q < 3; ++q) {
+        T acc = T(0);
+        for (int i = 0; i < 3; ++i) {
+            T dh = T(2) * mu * (T(2) * k.g[i] - T(1)) * dg[i][q] + dvol * dJ[q];
+            acc += dh * Gs[4 * i] + dg[i][q] * Gf[4 * i];
+        }
+        M[4 * q] = acc;
+    }
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            if (i == j) continue;
+            T ddg;
+            if (k.unc[i] && k.unc[j]) {
+                ddg = dd_exp(k.epsn[i], k.epsn[j]) * cn * dd_log(sig[i], sig[j]);
+            } else {
+                T ds = sig[i] - sig[j];
+                ddg = ds != T(0) ? (k.g[i] - k.g[j]) / ds : T(0);
+            }
+            T ssum = sig[i] + sig[j];
+            T inv = ssum > T(1e-20) ? T(1) / ssum : T(0);
+            T sumr = (k.g[i] + k.g[j]) * inv;
+            T a = T(0.5) * (ddg + sumr), b = T(0.5) * (ddg - sumr);
+            T kk = T(2) * mu * (k.g[i] + k.g[j] - T(1)) * ddg * inv;
+            M[3 * i + j] = att[i][j] * (kk * sig[j] * (Gs[3 * i + j] + Gs[3 * j + i]) + a * Gf[3 * i + j] + b * Gf[3 * j + i]);
+        }
+    T UM[9];
+    mat_mul(S.U, M, UM); mat_mul_nt(UM, S.V, Ft_adj);
+}
+
+// ---------------------------------------------------------------- particle <-> grid
+// compute_F_tmp in E-form: Et = E + dt C + dt C E        (mpm_simulator.py:82-85)
+template <class T> PLB_HD void f_tmp_eform(const T* C, const T* E, T dt, T* Et) {
+    T CE[9];
+    mat_mul(C, E, CE);
+    for (int i = 0; i < 9; ++i) Et[i] = E[i] + dt * (C[i] + CE[i]);
+}
+
+// p2g body (mpm_simulator.py:157-184).  Emit(k0,k1,k2, mass, mom[3]) is called for the 27 offsets.
+// Returns new E (F[f+1] - I) in En.
+template <class T, class X, class Emit>
+PLB_HD void p2g_particle(const SimP<T>& P, const X* x, const T* v, const T* C, const T* E,
+                         T mu, T lam, T ys, T* En, int* base, Emit&& emit) {
+    T fx[3], w[3][3];
+    stencil<T, X>(x, P.inv_dx, base, fx, w, nullptr);
+    T Et[9], stress[9], A[9];
+    f_tmp_eform(C, E, P.dt, Et);
+    Consti<T> k;
+    constitutive_fwd(Et, mu, lam, ys, k, En, stress);
+    for (int i = 0; i < 9; ++i) A[i] = P.kappa * stress[i] + P.p_mass * C[i];
+    T mv[3] = {P.p_mass * v[0], P.p_mass * v[1], P.p_mass * v[2]};
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j)
+            for (int l = 0; l < 3; ++l) {
+                T dp[3] = {(T(i) - fx[0]) * P.dx, (T(j) - fx[1]) * P.dx, (T(l) - fx[2]) * P.dx};
+                T wt = w[i][0] * w[j][1] * w[l][2];
+                T mom[3];
+                for (int a = 0; a < 3; ++a)
+                    mom[a] = wt * (mv[a] + A[3 * a] * dp[0] + A[3 * a + 1] * dp[1] + A[3 * a + 2] * dp[2]);
+                emit(i, j, l, wt * P.p_mass, mom);
+            }
+}
+
+// g2p body (mpm_simulator.py:223-242).  Fetch(k0,k1,k2, gv[3]) reads grid_v_out.
+template <class T, class X, class Fetch>
+PLB_HD void g2p_particle(const SimP<T>& P, const X* x, X* xn, T* vn, T* Cn, Fetch&& fetch) {
+    int base[3];
+    T fx[3], w[3][3];
+    stencil<T, X>(x, P.inv_dx, base, fx, w, nullptr);
+    for (int a = 0; a < 3; ++a) vn[a] = T(0);
+    for (int a = 0; a < 9; ++a) Cn[a] = T(0);
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j)
+            for (int l = 0; l < 3; ++l) {
+                T gv[3];
+                fetch(i, j, l, gv);
+                T wt = w[i][0] * w[j][1] * w[l][2];
+                T dp[3] = {T(i) - fx[0], T(j) - fx[1], T(l) - fx[2]};
+                for (int a = 0; a < 3; ++a) {
+                    T wg = wt * gv[a];
+                    vn[a] += wg;
+                    Cn[3 * a] += wg * dp[0]; Cn[3 * a + 1] += wg * dp[1]; Cn[3 * a + 2] += wg * dp[2];
+                }
+            }
+    for (int a = 0; a < 9; ++a) Cn[a] *= T(4) * P.inv_dx;
+    for (int d = 0; d < 3; ++d) {
+        X y = x[d] + (X)P.dt * (X)vn[d];
+        X hi = X(1) - X(3) / (X)P.n;
+        xn[d] = t_max(t_min(y, hi), X(0));
+    }
+}
+
+// g2p adjoint.  Inputs: x[f], the stored v[f+1] (= new_v, needed for the clamp gate), adjoints of
+// (x,v,C)[f+1]; Fetch reads grid_v_out, Emit(k0,k1,k2, gv_adj[3]) scatters into grid_v_out.grad.
+// Output xa = contribution to x[f].grad.
+template <class T, class X, class Fetch, class Emit>
+PLB_HD void g2p_particle_grad(const SimP<T>& P, const X* x, const T* vn, const T* xn_a, const T* vn_a,
+                              const T* Cn_a, T* xa, Fetch&& fetch, Emit&& emit) {
+    int base[3];
+    T fx[3], w[3][3], dw[3][3];
+    stencil<T, X>(x, P.inv_dx, base, fx, w, dw);
+    T nva[3];
+    for (int d = 0; d < 3; ++d) {
+        X y = x[d] + (X)P.dt * (X)vn[d];
+        X hi = X(1) - X(3) / (X)P.n;
+        // max(min(y, hi), 0): adjoint reaches y iff y < hi and 0 < min(y,hi)   (Taichi min/max rule)
+        T gate = (y < hi && X(0) < t_min(y, hi)) ? T(1) : T(0);
+        xa[d] = gate * xn_a[d];
+        nva[d] = vn_a[d] + P.dt * gate * xn_a[d];
+    }
+    T c4 = T(4) * P.inv_dx;
+    T fxa[3] = {T(0), T(0), T(0)};
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j)
+            for (int l = 0; l < 3; ++l) {
+                T gv[3];
+                fetch(i, j, l, gv);
+                T wt = w[i][0] * w[j][1] * w[l][2];
+                T dp[3] = {T(i) - fx[0], T(j) - fx[1], T(l) - fx[2]};
+                T ga[3], wa = T(0);
+                for (int a = 0; a < 3; ++a) {
+                    T cd = Cn_a[3 * a] * dp[0] + Cn_a[3 * a + 1] * dp[1] + Cn_a[3 * a + 2] * dp[2];
+                    T t = nva[a] + c4 * cd;
+                    ga[a] = wt * t;
+                    wa += gv[a] * t;
+                    // d/d dp_b : c4 * wt * gv_a * Cn_a[a][b]; dp = k - fx
+                    fxa[0] -= c4 * wt * gv[a] * Cn_a[3 * a];
+                    fxa[1] -= c4 * wt * gv[a] * Cn_a[3 * a + 1];
+                    fxa[2] -= c4 * wt * gv[a] * Cn_a[3 * a + 2];
+                }
+                emit(i, j, l, ga);
+                fxa[0] += wa * dw[i][0] * w[j][1] * w[l][2];
+                fxa[1] += wa * w[i][0] * dw[j][1] * w[l][2];
+                fxa[2] += wa * w[i][0] * w[j][1] * dw[l][2];
+            }
+    for (int d = 0; d < 3; ++d) xa[d] += P.inv_dx * fxa[d];
+}
+
+// p2g adjoint + svd_grad + compute_F_tmp.grad for one particle.
+// Fetch(k0,k1,k2, g[4]) reads {grid_m.grad, grid_v_in.grad[3]}.  En_a = F[f+1].grad.
+// xa_io already holds the g2p contribution and is accumulated into; va, Ca, Ea are written.
+template <class T, class X, class Fetch>
+PLB_HD void p2g_particle_grad(const SimP<T>& P, const X* x, const T* v, const T* C, const T* E,
+                              T mu, T lam, T ys, const T* En_a, T* xa_io, T* va, T* Ca, T* Ea,
+                              Fetch&& fetch) {
+    int base[3];
+    T fx[3], w[3][3], dw[3][3];
+    stencil<T, X>(x, P.inv_dx, base, fx, w, dw);
+    T Et[9], En[9], stress[9], A[9];
+    f_tmp_eform(C, E, P.dt, Et);
+    Consti<T> k;
+    constitutive_fwd(Et, mu, lam, ys, k, En, stress);
+    for (int i = 0; i < 9; ++i) A[i] = P.kappa * stress[i] + P.p_mass * C[i];
+    T mv[3] = {P.p_mass * v[0], P.p_mass * v[1], P.p_mass * v[2]};
+    T Aa[9], fxa[3] = {T(0), T(0), T(0)};
+    for (int i = 0; i < 9; ++i) Aa[i] = T(0);
+    va[0] = va[1] = va[2] = T(0);
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j)
+            for (int l = 0; l < 3; ++l) {
+                T g[4];
+                fetch(i, j, l, g);
+                const T* gva = g + 1;
+                T wt = w[i][0] * w[j][1] * w[l][2];
+                T dp[3] = {(T(i) - fx[0]) * P.dx, (T(j) - fx[1]) * P.dx, (T(l) - fx[2]) * P.dx};
+                T wa = P.p_mass * g[0];
+                for (int a = 0; a < 3; ++a) {
+                    T mom = mv[a] + A[3 * a] * dp[0] + A[3 * a + 1] * dp[1] + A[3 * a + 2] * dp[2];
+                    wa += gva[a] * mom;
+                    va[a] += P.p_mass * wt * gva[a];
+                    Aa[3 * a] += wt * gva[a] * dp[0];
+                    Aa[3 * a + 1] += wt * gva[a] * dp[1];
+                    Aa[3 * a + 2] += wt * gva[a] * dp[2];
+                }
+                // d/d dp = wt * A^T gva ; dp = (k - fx) dx
+                for (int b = 0; b < 3; ++b)
+                    fxa[b] -= P.dx * wt * (A[b] * gva[0] + A[3 + b] * gva[1] + A[6 + b] * gva[2]);
+                fxa[0] += wa * dw[i][0] * w[j][1] * w[l][2];
+                fxa[1] += wa * w[i][0] * dw[j][1] * w[l][2];
+                fxa[2] += wa * w[i][0] * w[j][1] * dw[l][2];
+            }
+    for (int d = 0; d < 3; ++d) xa_io[d] += P.inv_dx * fxa[d];
+    T GS[9], Fta[9];
+    for (int i = 0; i < 9; ++i) { Ca[i] = P.p_mass * Aa[i]; GS[i] = P.kappa * Aa[i]; }
+    constitutive_vjp(k, mu, lam, P.svd_clamp, GS, En_a, Fta);
+    // F_tmp = (I + dt C) F :  C.grad += dt Fta F^T ;  F.grad = (I + dt C)^T Fta
+    T Fm[9];
+    for (int i = 0; i < 9; ++i) Fm[i] = E[i];
+    Fm[0] += T(1); Fm[4] += T(1); Fm[8] += T(1);
+    T t1[9];
+    mat_mul_nt(Fta, Fm, t1);
+    for (int i = 0; i < 9; ++i) Ca[i] += P.dt * t1[i];
+    mat_mul_tn(C, Fta, t1);
+    for (int i = 0; i < 9; ++i) Ea[i] = Fta[i] + P.dt * t1[i];
+}
+
+// mass-only scatter weights for the loss (mpm_simulator.py:382-392) are stencil() + products.
+
+}  // namespace plb

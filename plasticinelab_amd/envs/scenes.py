@@ -1,0 +1,124 @@
+"""Built-in scene registry for the tasks BASELINE.json names.
+
+The reference keeps one YAML per task under plb/envs/*.yml with five VARIANTS
+each (move.yml:1-80, triplemove.yml:1-89, rope.yml:1-73).  The same parameter
+values are held here as Python data in the same SIMULATOR / SHAPES /
+PRIMITIVES / ENV key layout, so ``load_scene("Move", 1)`` yields the tree that
+``PlasticineEnv.load_varaints`` (plb/envs/env.py:63-86) would.  Scene files in
+the reference's YAML format also load, via ``plasticinelab_amd.config.load``.
+"""
+from __future__ import annotations
+
+from ..config import CfgNode, get_cfg_defaults, merge_lists
+
+
+def _sphere_manip(pos):
+    return {"shape": "Sphere", "radius": 0.03, "init_pos": pos, "color": (0.7, 0.7, 0.7),
+            "friction": 0.9, "action": {"dim": 3, "scale": (0.01, 0.01, 0.01)}}
+
+
+# (ball centre, ball diameter) per Move variant; manipulators sit 0.1 left/right of the centre
+_MOVE = [
+    ((0.6757143040494873, 0.5619162002773135, 0.7515980438048129), 0.2049069760770578),
+    ((0.4800617702933018, 0.6114161266624294, 0.2150469121879661), 0.22128338675873624),
+    ((0.5953388885096601, 0.7803511669469463, 0.3652372561756634), 0.21518886629207218),
+    ((0.5608152006865512, 0.5151402950552514, 0.4707541125135959), 0.23144406058863135),
+    ((0.2958401778083163, 0.5385429137124296, 0.7461548784761765), 0.23726089169300607),
+]
+
+# manipulator x coordinates exactly as written in the reference scene (centre -/+ 0.1)
+_MOVE_MANIP_X = [
+    (0.5757143040494873, 0.7757143040494873),
+    (0.3800617702933018, 0.5800617702933018),
+    (0.4953388885096601, 0.6953388885096601),
+    (0.4608152006865512, 0.6608152006865512),
+    (0.1958401778083163, 0.3958401778083163),
+]
+
+_ROPE_OBSTACLE = [
+    (0.3919300650726247, 0.0, 0.4990770359432596),
+    (0.4827737598605798, 0.0, 0.572508568647028),
+    (0.48953026610561057, 0.0, 0.5199459480962076),
+    (0.46968068720064815, 0.0, 0.3868456769743354),
+    (0.49333308965447087, 0.0, 0.5946055392248519),
+]
+
+
+def _move(version):
+    c, diam = _MOVE[version - 1]
+    lx, rx = _MOVE_MANIP_X[version - 1]
+    left, right = (lx, c[1], c[2]), (rx, c[1], c[2])
+    return {
+        "SIMULATOR": {"E": 5000.0, "n_particles": 10000, "yield_stress": 200.0},
+        "SHAPES": [{"shape": "sphere", "radius": diam / 2, "init_pos": c, "color": 127 << 16}],
+        "PRIMITIVES": [_sphere_manip(left), _sphere_manip(right)],
+        "ENV": {"loss": {"target_path": f"envs/assets/Move3D-v{version}.npy"}},
+    }
+
+
+def _triplemove(version):
+    boxes = [{"shape": "box", "width": (0.1, 0.1, 0.1), "init_pos": (x, 0.05, 0.5), "n_particles": 3333}
+             for x in (0.3, 0.5, 0.7)]
+    prims = []
+    for x in (0.23, 0.37, 0.43, 0.57, 0.63, 0.77):
+        p = _sphere_manip((x, 0.05, 0.5))
+        p["color"] = (0.8, 0.8, 0.8)
+        prims.append(p)
+    return {
+        "SIMULATOR": {"yield_stress": 200.0},
+        "SHAPES": boxes,
+        "PRIMITIVES": prims,
+        "ENV": {"loss": {"target_path": f"envs/assets/TripleMove3D-v{version}.npy"}},
+    }
+
+
+def _rope(version):
+    prims = []
+    for x in (0.22, 0.78):
+        p = _sphere_manip((x, 0.015, 0.82))
+        p["color"] = (0.8, 0.8, 0.8)
+        prims.append(p)
+    # NB reference Cylinder: h is the radius, r the half height
+    prims.append({"shape": "Cylinder", "h": 0.1, "r": 0.2, "init_pos": _ROPE_OBSTACLE[version - 1],
+                  "color": (0.3, 0.3, 0.3), "friction": 0.9})
+    return {
+        "SIMULATOR": {"yield_stress": 50.0, "ground_friction": 0.3},
+        "SHAPES": [{"shape": "box", "width": (0.6, 0.06, 0.06), "init_pos": (0.5, 0.03, 0.73),
+                    "color": ((0 << 8) + 150) << 8}],
+        "PRIMITIVES": prims,
+        "ENV": {"loss": {"target_path": f"envs/assets/Rope3D-v{version}.npy"}},
+    }
+
+
+_BUILDERS = {"Move": _move, "TripleMove": _triplemove, "Rope": _rope}
+ENV_NAMES = tuple(_BUILDERS)
+
+
+def load_scene(name: str, version: int = 1) -> CfgNode:
+    """Return the merged config tree for ``f"{name}-v{version}"``."""
+    if name not in _BUILDERS:
+        raise KeyError(f"unknown scene {name!r}; built-in: {ENV_NAMES} "
+                       f"(other tasks: load the reference-format YAML with config.load)")
+    if not 1 <= version <= 5:
+        raise ValueError("version must be 1..5")
+    cfg = get_cfg_defaults()
+    cfg.merge(_BUILDERS[name](version), strict=True)
+    cfg["VARIANTS"] = None
+    return cfg
+
+
+def load_variant_file(cfg_path: str, version: int) -> CfgNode:
+    """PlasticineEnv.load_varaints for a reference-format YAML (env.py:63-86)."""
+    from ..config import load
+    cfg = load(cfg_path)
+    variant = cfg.VARIANTS[version - 1]
+    if "PRIMITIVES" in variant:
+        variant["PRIMITIVES"] = merge_lists(list(cfg.PRIMITIVES), [v or {} for v in variant["PRIMITIVES"]])
+    if "SHAPES" in variant:
+        variant["SHAPES"] = merge_lists(list(cfg.SHAPES), [v or {} for v in variant["SHAPES"]])
+    cfg.merge(variant, strict=True)
+    name = list(cfg.ENV.loss.target_path)
+    name[-5] = str(version)
+    cfg.ENV.loss.target_path = "".join(name)
+    cfg["VARIANTS"] = None
+    return cfg

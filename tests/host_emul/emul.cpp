@@ -1,0 +1,191 @@
+// TEST INFRASTRUCTURE ONLY -- never loaded by plasticinelab_amd.
+// Runs the *same* per-particle / per-node functions the HIP kernels call
+// (plasticinelab_amd/csrc/mpm_math.h, mpm_grid.h) in plain serial loops on the
+// host, so the hand-derived adjoints can be checked against the oracle in the
+// CPU-only test tier.  The GPU kernels' indexing, tiling and atomics are covered
+// by the -m gpu tests.
+#include <vector>
+#include <cstring>
+#include "../../plasticinelab_amd/csrc/mpm_grid.h"
+
+using namespace plb;
+
+extern "C" {
+struct emul_cfg {
+    int n_grid, use_float, n_prim;
+    double dt, p_vol, p_mass, gravity[3], ground_friction, svd_clamp, softness;
+};
+struct emul_prim {
+    int shape, movable;
+    double par[3], friction, pos[3], rot[4], pos1[3], rot1[4];
+};
+}
+
+template <class T> static SimP<T> make_simp(const emul_cfg& c) {
+    SimP<T> P;
+    P.n = c.n_grid;
+    double dx = 1.0 / c.n_grid;
+    P.dx = (T)dx; P.inv_dx = (T)c.n_grid; P.dt = (T)c.dt; P.p_mass = (T)c.p_mass;
+    P.kappa = (T)(-c.dt * c.p_vol * 4 * c.n_grid * (double)c.n_grid);
+    for (int i = 0; i < 3; ++i) P.grav[i] = (T)(c.dt * c.gravity[i] * 30);
+    P.x_hi = (T)(1.0 - 3 * dx);
+    P.ground_friction = (T)c.ground_friction; P.svd_clamp = (T)c.svd_clamp; P.softness = (T)c.softness;
+    return P;
+}
+template <class T> static std::vector<PrimT<T>> make_prims(const emul_cfg& c, const emul_prim* p) {
+    std::vector<PrimT<T>> out(c.n_prim);
+    for (int i = 0; i < c.n_prim; ++i) {
+        out[i].shape = p[i].shape; out[i].movable = p[i].movable; out[i].friction = (T)p[i].friction;
+        for (int k = 0; k < 3; ++k) { out[i].par[k] = p[i].par[k]; out[i].pos[k] = p[i].pos[k]; out[i].pos1[k] = p[i].pos1[k]; }
+        for (int k = 0; k < 4; ++k) { out[i].rot[k] = p[i].rot[k]; out[i].rot1[k] = p[i].rot1[k]; }
+    }
+    return out;
+}
+
+template <class T> struct Grid {
+    int n; std::vector<T> m, mv, vout;
+    explicit Grid(int n_) : n(n_), m((size_t)n_ * n_ * n_, T(0)), mv((size_t)n_ * n_ * n_ * 3, T(0)), vout((size_t)n_ * n_ * n_ * 3, T(0)) {}
+    size_t idx(int i, int j, int k) const { return ((size_t)i * n + j) * n + k; }
+};
+
+#ifndef EMUL_XFLOAT
+typedef double XP;   // positions stay double on the fp32 path (as in the HIP kernels)
+#define XT double
+#else
+#define XT T         // experiment: fp32 positions
+#endif
+template <class T> static void load_particle(int p, const double* x, const double* v, const double* C, const double* F,
+                                             XT* xp, T* vp, T* Cp, T* Ep) {
+    for (int d = 0; d < 3; ++d) { xp[d] = (XT)x[3 * p + d]; vp[d] = (T)v[3 * p + d]; }
+    for (int d = 0; d < 9; ++d) { Cp[d] = (T)C[9 * p + d]; Ep[d] = (T)(F[9 * p + d] - ((d % 4 == 0) ? 1.0 : 0.0)); }
+}
+
+template <class T> static void forward_grid(const SimP<T>& P, const std::vector<PrimT<T>>& prims, int N,
+                                            const double* x, const double* v, const double* C, const double* F,
+                                            const double* mu, const double* lam, const double* ys, Grid<T>& g, double* F1) {
+    for (int p = 0; p < N; ++p) {
+        XT xp[3]; T vp[3], Cp[9], Ep[9], En[9];
+        int base[3];
+        load_particle<T>(p, x, v, C, F, xp, vp, Cp, Ep);
+        p2g_particle<T, XT>(P, xp, vp, Cp, Ep, (T)mu[p], (T)lam[p], (T)ys[p], En, base,
+                        [&](int i, int j, int l, T mass, const T* mom) {
+                            size_t I = g.idx(base[0] + i, base[1] + j, base[2] + l);
+                            g.m[I] += mass;
+                            for (int a = 0; a < 3; ++a) g.mv[3 * I + a] += mom[a];
+                        });
+        if (F1) for (int d = 0; d < 9; ++d) F1[9 * p + d] = (double)En[d] + ((d % 4 == 0) ? 1.0 : 0.0);
+    }
+    int n = P.n;
+    for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) for (int k = 0; k < n; ++k) {
+        size_t I = g.idx(i, j, k);
+        int Iv[3] = {i, j, k};
+        grid_node_fwd<T>(P, Iv, g.m[I], &g.mv[3 * I], (int)prims.size(), prims.data(), &g.vout[3 * I]);
+    }
+}
+
+template <class T> static int substep_t(const emul_cfg& c, const emul_prim* pr, int N, const double* x, const double* v,
+                                        const double* C, const double* F, const double* mu, const double* lam,
+                                        const double* ys, double* x1, double* v1, double* C1, double* F1) {
+    SimP<T> P = make_simp<T>(c);
+    auto prims = make_prims<T>(c, pr);
+    Grid<T> g(c.n_grid);
+    forward_grid<T>(P, prims, N, x, v, C, F, mu, lam, ys, g, F1);
+    for (int p = 0; p < N; ++p) {
+        XT xp[3] = {(XT)x[3 * p], (XT)x[3 * p + 1], (XT)x[3 * p + 2]}, xn[3]; T vn[3], Cn[9];
+        int base[3]; T fx[3], w[3][3];
+        stencil<T, XT>(xp, P.inv_dx, base, fx, w, nullptr);
+        g2p_particle<T, XT>(P, xp, xn, vn, Cn, [&](int i, int j, int l, T* gv) {
+            size_t I = g.idx(base[0] + i, base[1] + j, base[2] + l);
+            for (int a = 0; a < 3; ++a) gv[a] = g.vout[3 * I + a];
+        });
+        for (int d = 0; d < 3; ++d) { x1[3 * p + d] = xn[d]; v1[3 * p + d] = vn[d]; }
+        for (int d = 0; d < 9; ++d) C1[9 * p + d] = Cn[d];
+    }
+    return 0;
+}
+
+template <class T> static int substep_grad_t(const emul_cfg& c, const emul_prim* pr, int N, const double* x, const double* v,
+                                             const double* C, const double* F, const double* mu, const double* lam,
+                                             const double* ys, const double* v1, const double* x1a, const double* v1a,
+                                             const double* C1a, const double* F1a, double* xa, double* va, double* Ca,
+                                             double* Fa, double* pose_adj) {
+    SimP<T> P = make_simp<T>(c);
+    auto prims = make_prims<T>(c, pr);
+    int n = c.n_grid;
+    Grid<T> g(n);
+    forward_grid<T>(P, prims, N, x, v, C, F, mu, lam, ys, g, nullptr);
+    std::vector<T> vout_a((size_t)n * n * n * 3, T(0)), in_a((size_t)n * n * n * 4, T(0));
+    std::vector<T> xa_t((size_t)N * 3);
+    // g2p.grad
+    for (int p = 0; p < N; ++p) {
+        XT xp[3]; T vn[3], xna[3], vna[3], Cna[9], xat[3];
+        for (int d = 0; d < 3; ++d) { xp[d] = (XT)x[3 * p + d]; vn[d] = (T)v1[3 * p + d]; xna[d] = (T)x1a[3 * p + d]; vna[d] = (T)v1a[3 * p + d]; }
+        for (int d = 0; d < 9; ++d) Cna[d] = (T)C1a[9 * p + d];
+        int base[3]; T fx[3], w[3][3];
+        stencil<T, XT>(xp, P.inv_dx, base, fx, w, nullptr);
+        g2p_particle_grad<T, XT>(P, xp, vn, xna, vna, Cna, xat,
+            [&](int i, int j, int l, T* gv) {
+                size_t I = g.idx(base[0] + i, base[1] + j, base[2] + l);
+                for (int a = 0; a < 3; ++a) gv[a] = g.vout[3 * I + a];
+            },
+            [&](int i, int j, int l, const T* ga) {
+                size_t I = g.idx(base[0] + i, base[1] + j, base[2] + l);
+                for (int a = 0; a < 3; ++a) vout_a[3 * I + a] += ga[a];
+            });
+        for (int d = 0; d < 3; ++d) xa_t[3 * p + d] = xat[d];
+    }
+    // grid_op.grad
+    std::vector<double> padj((size_t)c.n_prim * 14, 0.0);
+    for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) for (int k = 0; k < n; ++k) {
+        size_t I = g.idx(i, j, k);
+        int Iv[3] = {i, j, k};
+        T ma, mva[3];
+        grid_node_bwd<T>(P, Iv, g.m[I], &g.mv[3 * I], (int)prims.size(), prims.data(), &vout_a[3 * I], &ma, mva,
+            [&](int p, const PoseAdj<T>& pa) {
+                double* o = &padj[(size_t)p * 14];
+                for (int d = 0; d < 3; ++d) { o[d] += pa.pos[d]; o[7 + d] += pa.pos1[d]; }
+                for (int d = 0; d < 4; ++d) { o[3 + d] += pa.rot[d]; o[10 + d] += pa.rot1[d]; }
+            });
+        in_a[4 * I] = ma; in_a[4 * I + 1] = mva[0]; in_a[4 * I + 2] = mva[1]; in_a[4 * I + 3] = mva[2];
+    }
+    if (pose_adj) memcpy(pose_adj, padj.data(), padj.size() * sizeof(double));
+    // p2g.grad (+ svd_grad + compute_F_tmp.grad)
+    for (int p = 0; p < N; ++p) {
+        XT xp[3]; T vp[3], Cp[9], Ep[9], Ena[9], xat[3], vat[3], Cat[9], Eat[9];
+        load_particle<T>(p, x, v, C, F, xp, vp, Cp, Ep);
+        for (int d = 0; d < 9; ++d) Ena[d] = (T)F1a[9 * p + d];
+        for (int d = 0; d < 3; ++d) xat[d] = xa_t[3 * p + d];
+        int base[3]; T fx[3], w[3][3];
+        stencil<T, XT>(xp, P.inv_dx, base, fx, w, nullptr);
+        p2g_particle_grad<T, XT>(P, xp, vp, Cp, Ep, (T)mu[p], (T)lam[p], (T)ys[p], Ena, xat, vat, Cat, Eat,
+            [&](int i, int j, int l, T* gg) {
+                size_t I = g.idx(base[0] + i, base[1] + j, base[2] + l);
+                for (int a = 0; a < 4; ++a) gg[a] = in_a[4 * I + a];
+            });
+        for (int d = 0; d < 3; ++d) { xa[3 * p + d] = xat[d]; va[3 * p + d] = vat[d]; }
+        for (int d = 0; d < 9; ++d) { Ca[9 * p + d] = Cat[d]; Fa[9 * p + d] = Eat[d]; }
+    }
+    return 0;
+}
+
+extern "C" {
+int emul_substep(const emul_cfg* c, const emul_prim* pr, int N, const double* x, const double* v, const double* C,
+                 const double* F, const double* mu, const double* lam, const double* ys, double* x1, double* v1,
+                 double* C1, double* F1) {
+    return c->use_float ? substep_t<float>(*c, pr, N, x, v, C, F, mu, lam, ys, x1, v1, C1, F1)
+                        : substep_t<double>(*c, pr, N, x, v, C, F, mu, lam, ys, x1, v1, C1, F1);
+}
+int emul_substep_grad(const emul_cfg* c, const emul_prim* pr, int N, const double* x, const double* v, const double* C,
+                      const double* F, const double* mu, const double* lam, const double* ys, const double* v1,
+                      const double* x1a, const double* v1a, const double* C1a, const double* F1a, double* xa, double* va,
+                      double* Ca, double* Fa, double* pose_adj) {
+    return c->use_float
+        ? substep_grad_t<float>(*c, pr, N, x, v, C, F, mu, lam, ys, v1, x1a, v1a, C1a, F1a, xa, va, Ca, Fa, pose_adj)
+        : substep_grad_t<double>(*c, pr, N, x, v, C, F, mu, lam, ys, v1, x1a, v1a, C1a, F1a, xa, va, Ca, Fa, pose_adj);
+}
+void emul_fk_fwd(const double* pos, const double* rot, const double* v, const double* w, const double* lo,
+                 const double* hi, double* pos1, double* rot1) { fk_fwd_d(pos, rot, v, w, lo, hi, pos1, rot1); }
+void emul_fk_bwd(const double* pos, const double* rot, const double* v, const double* w, const double* lo,
+                 const double* hi, const double* pos1_a, const double* rot1_a, double* pos_a, double* rot_a,
+                 double* v_a, double* w_a) { fk_bwd_d(pos, rot, v, w, lo, hi, pos1_a, rot1_a, pos_a, rot_a, v_a, w_a); }
+}
