@@ -1,0 +1,103 @@
+"""ctypes binding of libplmpm.so (include/plmpm.h).
+
+There is no fallback: if the HIP library is missing or fails to load, importing
+the engine raises.  Build it with ``python -c "import __graft_entry__ as g; g.build()"``
+(or ``make -C plasticinelab_amd/csrc``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libplmpm.so")
+
+MAX_PRIMITIVES = 8
+MAX_ACTION_DIM = 7
+F32, F64 = 0, 1
+SHAPES = {"Sphere": 0, "Capsule": 1, "Cylinder": 2, "Torus": 3, "Box": 4}
+
+
+class Config(C.Structure):
+    _fields_ = [("dtype", C.c_int32), ("n_grid", C.c_int32), ("n_particles", C.c_int32),
+                ("max_frames", C.c_int32), ("substeps", C.c_int32), ("n_primitives", C.c_int32),
+                ("dt", C.c_double), ("p_vol", C.c_double), ("p_mass", C.c_double),
+                ("gravity", C.c_double * 3), ("ground_friction", C.c_double),
+                ("svd_grad_clamp", C.c_double), ("slab_z0", C.c_int32), ("slab_z1", C.c_int32)]
+
+
+class Primitive(C.Structure):
+    _fields_ = [("shape", C.c_int32), ("action_dim", C.c_int32), ("params", C.c_double * 3),
+                ("friction", C.c_double), ("action_scale", C.c_double * MAX_ACTION_DIM),
+                ("lower_bound", C.c_double * 3), ("upper_bound", C.c_double * 3)]
+
+
+class Workspace(C.Structure):
+    _fields_ = [("state_bytes", C.c_size_t), ("adjoint_bytes", C.c_size_t),
+                ("grid_bytes", C.c_size_t), ("misc_bytes", C.c_size_t)]
+
+
+# every symbol include/plmpm.h declares: name -> (restype, argtypes)
+_P, _I, _D = C.c_void_p, C.c_int, C.c_double
+SYMBOLS = {
+    "plmpm_last_error": (C.c_char_p, []),
+    "plmpm_version": (_I, []),
+    "plmpm_create": (_I, [C.POINTER(Config), C.POINTER(Primitive), C.POINTER(_P)]),
+    "plmpm_destroy": (_I, [_P]),
+    "plmpm_workspace_bytes": (_I, [_P, C.POINTER(Workspace)]),
+    "plmpm_bind_workspace": (_I, [_P, _P, _P, _P, _P]),
+    "plmpm_set_stream": (_I, [_P, _P]),
+    "plmpm_set_materials": (_I, [_P, _P, _P, _P]),
+    "plmpm_set_frame": (_I, [_P, _I, _P, _P, _P, _P, _I]),
+    "plmpm_get_frame": (_I, [_P, _I, _P, _P, _P, _P]),
+    "plmpm_copy_frame": (_I, [_P, _I, _I]),
+    "plmpm_set_primitive_state": (_I, [_P, _I, _I, _P]),
+    "plmpm_get_primitive_state": (_I, [_P, _I, _I, _P]),
+    "plmpm_set_softness": (_I, [_P, _D]),
+    "plmpm_set_action": (_I, [_P, _I, _I, _P]),
+    "plmpm_get_action_grad": (_I, [_P, _I, _P]),
+    "plmpm_substep": (_I, [_P, _I]),
+    "plmpm_step": (_I, [_P, _I, _I]),
+    "plmpm_grad_begin": (_I, [_P, _I]),
+    "plmpm_substep_grad": (_I, [_P, _I]),
+    "plmpm_step_grad": (_I, [_P, _I, _I, _I]),
+    "plmpm_add_frame_grad": (_I, [_P, _I, _P, _P, _P, _P]),
+    "plmpm_get_frame_grad": (_I, [_P, _I, _P, _P, _P, _P]),
+    "plmpm_get_primitive_grad": (_I, [_P, _I, _I, _P]),
+    "plmpm_loss_set_target": (_I, [_P, _P]),
+    "plmpm_loss_set_weights": (_I, [_P, _D, _D, _D, _I]),
+    "plmpm_loss_forward": (_I, [_P, _I, _P]),
+    "plmpm_loss_backward": (_I, [_P, _I]),
+    "plmpm_get_grid_mass": (_I, [_P, _I, _P]),
+    "plmpm_loss_get_target_sdf": (_I, [_P, _P]),
+    "plmpm_grid_stats": (_I, [_P, _I, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "plmpm_get_order": (_I, [_P, _P]),
+}
+
+_lib = None
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libplmpm.so; raises if it is absent (no CPU fallback exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise EngineError(
+            f"{LIB_PATH} not found: the HIP engine is not built.  Run `python -c 'import __graft_entry__ as g; "
+            f"g.build()'` at the repo root (needs hipcc).  There is no CPU implementation to fall back to.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)          # AttributeError if the library lacks a declared symbol
+        fn.restype, fn.argtypes = res, args
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        raise EngineError(load().plmpm_last_error().decode())

@@ -1,0 +1,994 @@
+// C-ABI implementation (include/plmpm.h) on top of the kernels in plmpm_kernels.h.
+// Host code here only carves workspaces, moves host<->device state and sequences launches; every
+// arithmetic step of the hot path runs in a HIP kernel.  There is no CPU fallback.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/plmpm.h"
+#include "plmpm_kernels.h"
+
+using namespace plb;
+
+static thread_local std::string g_err;
+static int fail(const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return -1;
+}
+#define HIPCHK(expr)                                                                          \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess) return fail("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+#define REQUIRE(cond, ...) do { if (!(cond)) return fail(__VA_ARGS__); } while (0)
+
+static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// loss scalar slots (doubles)
+enum { LS_DENSITY = 0, LS_SDF = 1, LS_MAXGM = 2, LS_DOT = 3, LS_SUMGM = 4, LS_MIND = 8, LS_DNORM = 16, LS_COUNT = 32 };
+
+struct plmpm_sim {
+    plmpm_config cfg;
+    plmpm_primitive prims[PLMPM_MAX_PRIMITIVES];
+    int N, Npad, n, nb, nblk, P, F, act_total;
+    int act_ofs[PLMPM_MAX_PRIMITIVES + 1];
+    size_t G, tsz, frame_bytes;
+    hipStream_t stream = nullptr;
+    bool bound = false;
+    plmpm_workspace ws;
+    // device pointers
+    char *state = nullptr, *adjw = nullptr, *gridw = nullptr, *miscw = nullptr;
+    char* adj[2];
+    char *mu, *lam, *ys;
+    int* perm_d;
+    char *grid_in, *grid_out, *grid_out_adj, *grid_in_adj;
+    int* flags;
+    char *loss_gm, *loss_td, *loss_ts;
+    double *ppos, *prot, *ppos_a, *prot_a, *pv, *pw, *pv_a, *pw_a, *act, *act_a, *lscal, *staging;
+    // host state
+    std::vector<int32_t> perm;
+    double softness = 0.0;
+    double w_sdf = 10, w_density = 10, w_contact = 1;
+    int soft_contact = 0;
+    bool have_target = false;
+    double target_max = 0, target_sum = 0;
+    int adj_frame[2] = {-1, -1};
+};
+
+// ---------------------------------------------------------------------------------------------
+template <class T> static Dev<T> make_dev(const plmpm_sim* s) {
+    Dev<T> D;
+    const plmpm_config& c = s->cfg;
+    double dx = 1.0 / c.n_grid;
+    D.P.n = c.n_grid; D.P.dx = (T)dx; D.P.inv_dx = (T)c.n_grid; D.P.dt = (T)c.dt; D.P.p_mass = (T)c.p_mass;
+    D.P.kappa = (T)(-c.dt * c.p_vol * 4.0 * (double)c.n_grid * (double)c.n_grid);
+    for (int i = 0; i < 3; ++i) D.P.grav[i] = (T)(c.dt * c.gravity[i] * 30.0);
+    D.P.x_hi = (T)(1.0 - 3.0 * dx);
+    D.P.ground_friction = (T)c.ground_friction;
+    D.P.svd_clamp = (T)c.svd_grad_clamp;
+    D.P.softness = (T)s->softness;
+    D.N = s->N; D.Npad = s->Npad; D.nb = s->nb; D.nprim = s->P;
+    D.z0 = c.slab_z0; D.z1 = c.slab_z1;
+    D.frame_bytes = s->frame_bytes;
+    D.state = s->state;
+    D.adj[0] = (T*)s->adj[0]; D.adj[1] = (T*)s->adj[1];
+    D.mu = (T*)s->mu; D.lam = (T*)s->lam; D.ys = (T*)s->ys;
+    D.grid_in = (Vec4<T>*)s->grid_in; D.grid_out = (Vec4<T>*)s->grid_out;
+    D.grid_out_adj = (Vec4<T>*)s->grid_out_adj; D.grid_in_adj = (Vec4<T>*)s->grid_in_adj;
+    D.flags = s->flags;
+    D.ppos = s->ppos; D.prot = s->prot; D.ppos_a = s->ppos_a; D.prot_a = s->prot_a;
+    for (int i = 0; i < s->P; ++i) {
+        D.prim[i].shape = s->prims[i].shape;
+        D.prim[i].movable = s->prims[i].action_dim > 0;
+        for (int k = 0; k < 3; ++k) D.prim[i].par[k] = s->prims[i].params[k];
+        D.prim[i].friction = s->prims[i].friction;
+    }
+    return D;
+}
+
+// ---------------------------------------------------------------------------------------------
+// small kernels: state I/O, primitive chains, loss
+// staging layout (double, original particle order): x[N*3] v[N*3] F[N*9] C[N*9]
+template <class T>
+__global__ void k_unpack_frame(Dev<T> D, int f, const double* st, const int* perm, int has_x, int has_v, int has_F, int has_C) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= D.Npad) return;
+    double* X = frame_x_w(D, f);
+    T* R = frame_r(D, f);
+    const int N = D.N, Np = D.Npad;
+    if (i >= N) {       // padding lanes: harmless values
+        for (int d = 0; d < 3; ++d) { X[d * Np + i] = 0.5; R[d * Np + i] = T(0); }
+        for (int d = 0; d < 18; ++d) R[(3 + d) * Np + i] = T(0);
+        return;
+    }
+    int o = perm[i];
+    const double *sx = st, *sv = st + (size_t)3 * N, *sF = st + (size_t)6 * N, *sC = st + (size_t)15 * N;
+    if (has_x) for (int d = 0; d < 3; ++d) X[d * Np + i] = sx[(size_t)3 * o + d];
+    if (has_v) for (int d = 0; d < 3; ++d) R[d * Np + i] = (T)sv[(size_t)3 * o + d];
+    if (has_C) for (int d = 0; d < 9; ++d) R[(3 + d) * Np + i] = (T)sC[(size_t)9 * o + d];
+    if (has_F) for (int d = 0; d < 9; ++d) R[(12 + d) * Np + i] = (T)(sF[(size_t)9 * o + d] - ((d % 4 == 0) ? 1.0 : 0.0));
+}
+template <class T>
+__global__ void k_pack_frame(Dev<T> D, int f, double* st, const int* perm) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= D.N) return;
+    const double* X = frame_x(D, f);
+    const T* R = frame_r(D, f);
+    const int N = D.N, Np = D.Npad;
+    int o = perm[i];
+    double *sx = st, *sv = st + (size_t)3 * N, *sF = st + (size_t)6 * N, *sC = st + (size_t)15 * N;
+    for (int d = 0; d < 3; ++d) { sx[(size_t)3 * o + d] = X[d * Np + i]; sv[(size_t)3 * o + d] = (double)R[d * Np + i]; }
+    for (int d = 0; d < 9; ++d) {
+        sC[(size_t)9 * o + d] = (double)R[(3 + d) * Np + i];
+        sF[(size_t)9 * o + d] = (double)R[(12 + d) * Np + i] + ((d % 4 == 0) ? 1.0 : 0.0);
+    }
+}
+// adjoint frame <-> staging (same staging layout: xa, va, Fa, Ca)
+template <class T>
+__global__ void k_adj_io(Dev<T> D, int which, double* st, const int* perm, int add_from_staging, int has_x, int has_v, int has_F, int has_C) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= D.N) return;
+    T* A = D.adj[which];
+    const int N = D.N, Np = D.Npad;
+    int o = perm[i];
+    double *sx = st, *sv = st + (size_t)3 * N, *sF = st + (size_t)6 * N, *sC = st + (size_t)15 * N;
+    if (add_from_staging) {
+        if (has_x) for (int d = 0; d < 3; ++d) A[d * Np + i] += (T)sx[(size_t)3 * o + d];
+        if (has_v) for (int d = 0; d < 3; ++d) A[(3 + d) * Np + i] += (T)sv[(size_t)3 * o + d];
+        if (has_C) for (int d = 0; d < 9; ++d) A[(6 + d) * Np + i] += (T)sC[(size_t)9 * o + d];
+        if (has_F) for (int d = 0; d < 9; ++d) A[(15 + d) * Np + i] += (T)sF[(size_t)9 * o + d];
+    } else {
+        for (int d = 0; d < 3; ++d) { sx[(size_t)3 * o + d] = (double)A[d * Np + i]; sv[(size_t)3 * o + d] = (double)A[(3 + d) * Np + i]; }
+        for (int d = 0; d < 9; ++d) { sC[(size_t)9 * o + d] = (double)A[(6 + d) * Np + i]; sF[(size_t)9 * o + d] = (double)A[(15 + d) * Np + i]; }
+    }
+}
+template <class T> __global__ void k_set_mats(Dev<T> D, const double* st, const int* perm) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= D.Npad) return;
+    int o = i < D.N ? perm[i] : perm[0];
+    D.mu[i] = (T)st[o]; D.lam[i] = (T)st[(size_t)D.N + o]; D.ys[i] = (T)st[(size_t)2 * D.N + o];
+}
+__global__ void k_copy_frame(char* state, size_t frame_bytes, int src, int dst) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t n16 = frame_bytes / 16;
+    const uint4* s = reinterpret_cast<const uint4*>(state + (size_t)src * frame_bytes);
+    uint4* d = reinterpret_cast<uint4*>(state + (size_t)dst * frame_bytes);
+    if (i < n16) d[i] = s[i];
+}
+
+struct PrimChainArgs {
+    int P;
+    int action_dim[kMaxPrim];
+    double scale[kMaxPrim][PLMPM_MAX_ACTION_DIM];
+    double lo[kMaxPrim][3], hi[kMaxPrim][3];
+};
+struct ActionArg { double a[kMaxPrim * PLMPM_MAX_ACTION_DIM]; };
+
+// set_action: action_buffer[step] = clipped action; v,w for the step's frames (primive_base.py:166-198)
+__global__ void k_set_action(PrimChainArgs A, ActionArg act, int step, int nsub, double* actbuf, double* pv, double* pw) {
+    int p = threadIdx.x;
+    if (p >= A.P) return;
+    double* ab = actbuf + ((size_t)step * A.P + p) * PLMPM_MAX_ACTION_DIM;
+    for (int k = 0; k < PLMPM_MAX_ACTION_DIM; ++k) ab[k] = act.a[p * PLMPM_MAX_ACTION_DIM + k];
+    if (A.action_dim[p] <= 0) return;
+    for (int j = step * nsub; j < (step + 1) * nsub; ++j) {
+        double* v = pv + ((size_t)j * A.P + p) * 3;
+        double* w = pw + ((size_t)j * A.P + p) * 3;
+        for (int k = 0; k < 3; ++k) v[k] = ab[k] * A.scale[p][k] / nsub;
+        if (A.action_dim[p] > 3) for (int k = 0; k < 3; ++k) w[k] = ab[k + 3] * A.scale[p][k + 3] / nsub;
+    }
+}
+// forward_kinematics over frames [first, first+n) (primive_base.py:117-121)
+__global__ void k_fk_chain(PrimChainArgs A, int first, int n, double* ppos, double* prot, const double* pv, const double* pw) {
+    int p = threadIdx.x;
+    if (p >= A.P) return;
+    for (int s = first; s < first + n; ++s) {
+        size_t a = (size_t)s * A.P + p, b = (size_t)(s + 1) * A.P + p;
+        fk_fwd_d(ppos + a * 3, prot + a * 4, pv + a * 3, pw + a * 3, A.lo[p], A.hi[p], ppos + b * 3, prot + b * 4);
+    }
+}
+// forward_kinematics.grad for frames first+n-1..first, then set_velocity.grad for env step `step`
+__global__ void k_fk_chain_grad(PrimChainArgs A, int first, int n, int step, const double* ppos, const double* prot,
+                                const double* pv, const double* pw, double* ppos_a, double* prot_a, double* pv_a,
+                                double* pw_a, double* act_a) {
+    int p = threadIdx.x;
+    if (p >= A.P || A.action_dim[p] <= 0) return;
+    double va_sum[3] = {0, 0, 0}, wa_sum[3] = {0, 0, 0};
+    for (int s = first + n - 1; s >= first; --s) {
+        size_t a = (size_t)s * A.P + p, b = (size_t)(s + 1) * A.P + p;
+        double va[3], wa[3];
+        fk_bwd_d(ppos + a * 3, prot + a * 4, pv + a * 3, pw + a * 3, A.lo[p], A.hi[p], ppos_a + b * 3, prot_a + b * 4,
+                 ppos_a + a * 3, prot_a + a * 4, va, wa);
+        for (int k = 0; k < 3; ++k) { pv_a[a * 3 + k] = va[k]; pw_a[a * 3 + k] = wa[k]; va_sum[k] += va[k]; wa_sum[k] += wa[k]; }
+    }
+    double* aa = act_a + ((size_t)step * A.P + p) * PLMPM_MAX_ACTION_DIM;
+    for (int k = 0; k < 3; ++k) aa[k] += va_sum[k] * A.scale[p][k] / n;
+    if (A.action_dim[p] > 3) for (int k = 0; k < 3; ++k) aa[k + 3] += wa_sum[k] * A.scale[p][k + 3] / n;
+}
+
+// ---- loss -----------------------------------------------------------------------------------
+// compute_grid_m_kernel (mpm_simulator.py:382-392)
+template <class T> __global__ void k_grid_mass(Dev<T> D, int f, T* gm) {
+    int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= D.N) return;
+    const double* X = frame_x(D, f);
+    double x[3] = {X[p], X[D.Npad + p], X[2 * D.Npad + p]};
+    int base[3];
+    T fx[3], w[3][3];
+    stencil<T, double>(x, D.P.inv_dx, base, fx, w, nullptr);
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j)
+            for (int l = 0; l < 3; ++l)
+                atomicAdd(&gm[node_index(D.nb, base[0] + i, base[1] + j, base[2] + l)], w[i][0] * w[j][1] * w[l][2] * D.P.p_mass);
+}
+__device__ __forceinline__ double block_sum(double v, double* sh) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) sh[w] = v;
+    __syncthreads();
+    double r = 0;
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) r += sh[i];
+    __syncthreads();
+    return r;
+}
+__device__ __forceinline__ double block_max(double v, double* sh) {
+    for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off));
+    int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) sh[w] = v;
+    __syncthreads();
+    double r = sh[0];
+    for (int i = 1; i < (int)(blockDim.x >> 6); ++i) r = fmax(r, sh[i]);
+    __syncthreads();
+    return r;
+}
+// density / sdf losses (loss.py:145-153) + IoU sums (loss.py:239-254)
+template <class T> __global__ void k_loss_reduce(size_t G, const T* gm, const T* td, const T* ts, double* ls) {
+    __shared__ double sh[8];
+    double dens = 0, sdf = 0, mx = 0, dot = 0, sum = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < G; i += (size_t)gridDim.x * blockDim.x) {
+        double g = (double)gm[i], t = (double)td[i];
+        dens += fabs(g - t); sdf += (double)ts[i] * g; mx = fmax(mx, g); dot += g * t; sum += g;
+    }
+    dens = block_sum(dens, sh); sdf = block_sum(sdf, sh); dot = block_sum(dot, sh); sum = block_sum(sum, sh);
+    mx = block_max(mx, sh);
+    if (threadIdx.x == 0) {
+        atomicAdd(&ls[LS_DENSITY], dens); atomicAdd(&ls[LS_SDF], sdf); atomicAdd(&ls[LS_DOT], dot); atomicAdd(&ls[LS_SUMGM], sum);
+        atomicMax(reinterpret_cast<unsigned long long*>(&ls[LS_MAXGM]), (unsigned long long)__double_as_longlong(mx));
+    }
+}
+template <class T> __device__ __forceinline__ PrimT<T> prim_at(const Dev<T>& D, int q, int f) {
+    PrimT<T> p;
+    p.shape = D.prim[q].shape; p.movable = D.prim[q].movable; p.friction = (T)D.prim[q].friction;
+    for (int i = 0; i < 3; ++i) { p.par[i] = D.prim[q].par[i]; p.pos[i] = p.pos1[i] = D.ppos[((size_t)f * D.nprim + q) * 3 + i]; }
+    for (int i = 0; i < 4; ++i) p.rot[i] = p.rot1[i] = D.prot[((size_t)f * D.nprim + q) * 4 + i];
+    return p;
+}
+// contact distance passes (loss.py:116-135).  mode 0: hard min, 1: soft normaliser, 2: soft weighted sum
+template <class T> __global__ void k_contact(Dev<T> D, int f, int mode, double* ls) {
+    __shared__ double sh[8];
+    int p = blockIdx.x * blockDim.x + threadIdx.x;
+    const double* X = frame_x(D, f);
+    double x[3] = {0, 0, 0};
+    bool valid = p < D.N;
+    if (valid) { x[0] = X[p]; x[1] = X[D.Npad + p]; x[2] = X[2 * D.Npad + p]; }
+    for (int q = 0; q < D.nprim; ++q) {
+        if (!D.prim[q].movable) continue;
+        PrimT<T> pr = prim_at(D, q, f);
+        double d = valid ? fmax(prim_sdf(pr, x), 0.0) : 0.0;
+        if (mode == 0) {
+            double m = valid ? d : 1e30;
+            for (int off = 32; off > 0; off >>= 1) m = fmin(m, __shfl_xor(m, off));
+            if ((threadIdx.x & 63) == 0)
+                atomicMin(reinterpret_cast<unsigned long long*>(&ls[LS_MIND + q]), (unsigned long long)__double_as_longlong(m));
+        } else {
+            double sw = 1.0 / (1.0 + d * d * 10000.0);
+            double v = 0.0;
+            if (valid) v = mode == 1 ? sw : d * sw / ls[LS_DNORM + q];
+            v = block_sum(v, sh);
+            if (threadIdx.x == 0) atomicAdd(&ls[(mode == 1 ? LS_DNORM : LS_MIND) + q], v);
+        }
+    }
+}
+// compute_loss_kernel_grad (loss.py:210-237) per particle: density + sdf through grid_m, contact through sdf.
+template <class T>
+__global__ void k_loss_grad(Dev<T> D, int f, int which, const T* gm, const T* td, const T* ts, const double* ls,
+                            double w_sdf, double w_density, double w_contact, int soft) {
+    __shared__ double sacc[kMaxPrim * 3];
+    if (threadIdx.x < kMaxPrim * 3) sacc[threadIdx.x] = 0.0;
+    __syncthreads();
+    int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < D.N) {
+        const double* X = frame_x(D, f);
+        double x[3] = {X[p], X[D.Npad + p], X[2 * D.Npad + p]};
+        int base[3];
+        T fx[3], w[3][3], dw[3][3];
+        stencil<T, double>(x, D.P.inv_dx, base, fx, w, dw);
+        double fxa[3] = {0, 0, 0};
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j)
+                for (int l = 0; l < 3; ++l) {
+                    int idx = node_index(D.nb, base[0] + i, base[1] + j, base[2] + l);
+                    double diff = (double)gm[idx] - (double)td[idx];
+                    double sg = diff > 0 ? 1.0 : (diff < 0 ? -1.0 : 0.0);          // d|x|/dx with sgn(0) = 0
+                    double ga = (w_density * sg + w_sdf * (double)ts[idx]) * (double)D.P.p_mass;
+                    fxa[0] += ga * (double)(dw[i][0] * w[j][1] * w[l][2]);
+                    fxa[1] += ga * (double)(w[i][0] * dw[j][1] * w[l][2]);
+                    fxa[2] += ga * (double)(w[i][0] * w[j][1] * dw[l][2]);
+                }
+        double xa[3] = {fxa[0] * (double)D.P.inv_dx, fxa[1] * (double)D.P.inv_dx, fxa[2] * (double)D.P.inv_dx};
+        for (int q = 0; q < D.nprim; ++q) {
+            if (!D.prim[q].movable) continue;
+            PrimT<T> pr = prim_at(D, q, f);
+            double sd = prim_sdf(pr, x);
+            if (!(0.0 < sd)) continue;                      // max(sdf, 0): adjoint to sdf iff 0 < sdf
+            double md = ls[LS_MIND + q];
+            double coef;
+            if (!soft) coef = w_contact * 2.0 * md;         // atomic_min differentiated as add (Taichi 0.7.x)
+            else {
+                double dn = ls[LS_DNORM + q];
+                double den = 1.0 + sd * sd * 10000.0;
+                double sw = 1.0 / den, dsw = -20000.0 * sd / (den * den);
+                coef = w_contact * 2.0 * md * (sw + sd * dsw - md * dsw) / dn;
+            }
+            // Sphere: d sdf/dx = (x - c)/len ; d sdf/dc = -that
+            double dvec[3] = {x[0] - pr.pos[0], x[1] - pr.pos[1], x[2] - pr.pos[2]};
+            double L = len14(dvec[0], dvec[1], dvec[2]);
+            for (int d = 0; d < 3; ++d) {
+                double g = coef * dvec[d] / L;
+                xa[d] += g;
+                atomicAdd(&sacc[q * 3 + d], -g);
+            }
+        }
+        T* A = D.adj[which];
+        for (int d = 0; d < 3; ++d) A[d * D.Npad + p] += (T)xa[d];
+    }
+    __syncthreads();
+    if (threadIdx.x < D.nprim * 3) {
+        double v = sacc[threadIdx.x];
+        if (v != 0.0) atomicAdd(&D.ppos_a[((size_t)f * D.nprim + threadIdx.x / 3) * 3 + threadIdx.x % 3], v);
+    }
+}
+// target SDF sweep (loss.py:81-101), double, linear [i][j][k] layout
+__global__ void k_sdf_sweep(int n, double dx, double inf, const double* dens, const double* sdf_c, const double* np_c,
+                            double* sdf, double* npn, int* changed) {
+    size_t I = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t G = (size_t)n * n * n;
+    if (I >= G) return;
+    int k = I % n, j = (I / n) % n, i = I / ((size_t)n * n);
+    double gx = i * dx, gy = j * dx, gz = k * dx;
+    double best = inf, bx = npn[3 * I], by = npn[3 * I + 1], bz = npn[3 * I + 2];
+    if (dens[I] > 1e-4) { best = 0.0; bx = gx; by = gy; bz = gz; }
+    else {
+        for (int a = -3; a < 3; ++a)
+            for (int b = -3; b < 3; ++b)
+                for (int c = -3; c < 3; ++c) {
+                    int vi = i + a, vj = j + b, vk = k + c;
+                    if (vi < 0 || vj < 0 || vk < 0 || vi >= n || vj >= n || vk >= n) continue;
+                    if (a == 0 && b == 0 && c == 0) continue;
+                    size_t V = ((size_t)vi * n + vj) * n + vk;
+                    if (sdf_c[V] < inf) {
+                        double ex = gx - np_c[3 * V], ey = gy - np_c[3 * V + 1], ez = gz - np_c[3 * V + 2];
+                        double dist = sqrt(ex * ex + ey * ey + ez * ez + 1e-8);
+                        if (dist < best) { best = dist; bx = np_c[3 * V]; by = np_c[3 * V + 1]; bz = np_c[3 * V + 2]; }
+                    }
+                }
+    }
+    if (best != sdf_c[I] || bx != np_c[3 * I] || by != np_c[3 * I + 1] || bz != np_c[3 * I + 2]) *changed = 1;
+    sdf[I] = best; npn[3 * I] = bx; npn[3 * I + 1] = by; npn[3 * I + 2] = bz;
+}
+template <class T> __global__ void k_upload_grid(int n, int nb, const double* lin, T* blocked) {
+    size_t I = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (I >= (size_t)n * n * n) return;
+    int k = I % n, j = (I / n) % n, i = I / ((size_t)n * n);
+    blocked[node_index(nb, i, j, k)] = (T)lin[I];
+}
+template <class T> __global__ void k_download_grid(int n, int nb, const T* blocked, double* lin) {
+    size_t I = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (I >= (size_t)n * n * n) return;
+    int k = I % n, j = (I / n) % n, i = I / ((size_t)n * n);
+    lin[I] = (double)blocked[node_index(nb, i, j, k)];
+}
+template <class T> __global__ void k_grid_stats(Dev<T> D, unsigned long long* out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t G = (size_t)D.nb * D.nb * D.nb * 64;
+    if (i < G && D.grid_in[i].x > T(0)) atomicAdd(&out[0], 1ULL);
+    if (i < G / 64 && D.flags[i]) atomicAdd(&out[1], 1ULL);
+}
+
+// ---------------------------------------------------------------------------------------------
+static PrimChainArgs chain_args(const plmpm_sim* s) {
+    PrimChainArgs A;
+    memset(&A, 0, sizeof A);
+    A.P = s->P;
+    for (int p = 0; p < s->P; ++p) {
+        A.action_dim[p] = s->prims[p].action_dim;
+        for (int k = 0; k < PLMPM_MAX_ACTION_DIM; ++k) A.scale[p][k] = s->prims[p].action_scale[k];
+        for (int k = 0; k < 3; ++k) { A.lo[p][k] = s->prims[p].lower_bound[k]; A.hi[p][k] = s->prims[p].upper_bound[k]; }
+    }
+    return A;
+}
+static inline int nblocks_particles(const plmpm_sim* s) { return s->Npad / kBlock; }
+static inline int nblocks_grid(const plmpm_sim* s) { return (s->nblk + (kBlock / 64) - 1) / (kBlock / 64); }
+
+template <class T> static int substep_fwd(plmpm_sim* s, int f) {
+    Dev<T> D = make_dev<T>(s);
+    hipLaunchKernelGGL((k_p2g<T, true>), dim3(nblocks_particles(s)), dim3(kBlock), 0, s->stream, D, f);
+    hipLaunchKernelGGL((k_grid_op<T, true>), dim3(nblocks_grid(s)), dim3(kBlock), 0, s->stream, D, f);
+    hipLaunchKernelGGL((k_g2p<T>), dim3(nblocks_particles(s)), dim3(kBlock), 0, s->stream, D, f);
+    return 0;
+}
+template <class T> static int substep_bwd(plmpm_sim* s, int f) {
+    Dev<T> D = make_dev<T>(s);
+    const int src = (f + 1) & 1, dst = f & 1;
+    hipLaunchKernelGGL((k_p2g<T, false>), dim3(nblocks_particles(s)), dim3(kBlock), 0, s->stream, D, f);
+    hipLaunchKernelGGL((k_grid_op<T, false>), dim3(nblocks_grid(s)), dim3(kBlock), 0, s->stream, D, f);
+    hipLaunchKernelGGL((k_g2p_grad<T>), dim3(nblocks_particles(s)), dim3(kBlock), 0, s->stream, D, f, src, dst);
+    hipLaunchKernelGGL((k_grid_op_grad<T>), dim3(nblocks_grid(s)), dim3(kBlock), 0, s->stream, D, f);
+    hipLaunchKernelGGL((k_p2g_grad<T>), dim3(nblocks_particles(s)), dim3(kBlock), 0, s->stream, D, f, src, dst);
+    hipLaunchKernelGGL((k_clear_active<T>), dim3(nblocks_grid(s)), dim3(kBlock), 0, s->stream, D);
+    s->adj_frame[dst] = f;
+    return 0;
+}
+
+#define DISPATCH(s, fn, ...) ((s)->cfg.dtype == PLMPM_F64 ? fn<double>(__VA_ARGS__) : fn<float>(__VA_ARGS__))
+
+// ---------------------------------------------------------------------------------------------
+template <class T> static int set_materials_t(plmpm_sim* s) {
+    Dev<T> D = make_dev<T>(s);
+    hipLaunchKernelGGL((k_set_mats<T>), dim3(s->Npad / 256), dim3(256), 0, s->stream, D, s->staging, s->perm_d);
+    return 0;
+}
+
+template <class T> static int unpack_t(plmpm_sim* s, int f, int hx, int hv, int hF, int hC) {
+    Dev<T> D = make_dev<T>(s);
+    hipLaunchKernelGGL((k_unpack_frame<T>), dim3(s->Npad / 256), dim3(256), 0, s->stream, D, f, s->staging, s->perm_d, hx, hv, hF, hC);
+    return 0;
+}
+
+template <class T> static int pack_t(plmpm_sim* s, int f) {
+    Dev<T> D = make_dev<T>(s);
+    hipLaunchKernelGGL((k_pack_frame<T>), dim3(s->Npad / 256), dim3(256), 0, s->stream, D, f, s->staging, s->perm_d);
+    return 0;
+}
+
+template <class T> static int adj_io_t(plmpm_sim* s, int which, int add, int hx, int hv, int hF, int hC) {
+    Dev<T> D = make_dev<T>(s);
+    hipLaunchKernelGGL((k_adj_io<T>), dim3(s->Npad / 256), dim3(256), 0, s->stream, D, which, s->staging, s->perm_d, add, hx, hv, hF, hC);
+    return 0;
+}
+
+template <class T> static int upload_grid_t(plmpm_sim* s, const double* lin_d, char* dst) {
+    hipLaunchKernelGGL((k_upload_grid<T>), dim3((unsigned)((s->G + 255) / 256)), dim3(256), 0, s->stream, s->n, s->nb, lin_d, (T*)dst);
+    return 0;
+}
+
+template <class T> static int download_grid_t(plmpm_sim* s, const char* src, double* lin_d) {
+    hipLaunchKernelGGL((k_download_grid<T>), dim3((unsigned)((s->G + 255) / 256)), dim3(256), 0, s->stream, s->n, s->nb, (const T*)src, lin_d);
+    return 0;
+}
+
+template <class T> static int loss_scatter_t(plmpm_sim* s, int f) {
+    Dev<T> D = make_dev<T>(s);
+    hipMemsetAsync(s->loss_gm, 0, s->G * s->tsz, s->stream);
+    hipLaunchKernelGGL((k_grid_mass<T>), dim3(s->Npad / 256), dim3(256), 0, s->stream, D, f, (T*)s->loss_gm);
+    return 0;
+}
+
+template <class T> static int loss_contact_t(plmpm_sim* s, int f) {
+    Dev<T> D = make_dev<T>(s);
+    std::vector<double> init(LS_COUNT, 0.0);
+    if (!s->soft_contact) for (int q = 0; q < kMaxPrim; ++q) init[LS_MIND + q] = 100000.0;      // loss.py:189-191
+    hipMemcpyAsync(s->lscal, init.data(), LS_COUNT * 8, hipMemcpyHostToDevice, s->stream);
+    hipStreamSynchronize(s->stream);
+    bool any = false;
+    for (int p = 0; p < s->P; ++p) any |= s->prims[p].action_dim > 0;
+    if (!any) return 0;
+    if (s->soft_contact) {
+        hipLaunchKernelGGL((k_contact<T>), dim3(s->Npad / 256), dim3(256), 0, s->stream, D, f, 1, s->lscal);
+        hipLaunchKernelGGL((k_contact<T>), dim3(s->Npad / 256), dim3(256), 0, s->stream, D, f, 2, s->lscal);
+    } else {
+        hipLaunchKernelGGL((k_contact<T>), dim3(s->Npad / 256), dim3(256), 0, s->stream, D, f, 0, s->lscal);
+    }
+    return 0;
+}
+
+template <class T> static int loss_reduce_t(plmpm_sim* s) {
+    hipLaunchKernelGGL((k_loss_reduce<T>), dim3(1024), dim3(256), 0, s->stream, s->G, (const T*)s->loss_gm, (const T*)s->loss_td,
+                       (const T*)s->loss_ts, s->lscal);
+    return 0;
+}
+
+template <class T> static int loss_grad_t(plmpm_sim* s, int f) {
+    Dev<T> D = make_dev<T>(s);
+    hipLaunchKernelGGL((k_loss_grad<T>), dim3(s->Npad / 256), dim3(256), 0, s->stream, D, f, f & 1, (const T*)s->loss_gm,
+                       (const T*)s->loss_td, (const T*)s->loss_ts, s->lscal, s->w_sdf, s->w_density, s->w_contact, s->soft_contact);
+    return 0;
+}
+
+template <class T> static int grid_stats_t(plmpm_sim* s, int f, unsigned long long* d_out) {
+    Dev<T> D = make_dev<T>(s);
+    // recompute the scatter of frame f without consuming it, count, then clear
+    hipLaunchKernelGGL((k_p2g<T, false>), dim3(nblocks_particles(s)), dim3(kBlock), 0, s->stream, D, f);
+    hipLaunchKernelGGL((k_grid_stats<T>), dim3((unsigned)((s->G + 255) / 256)), dim3(256), 0, s->stream, D, d_out);
+    hipLaunchKernelGGL((k_clear_active<T>), dim3(nblocks_grid(s)), dim3(kBlock), 0, s->stream, D);
+    return 0;
+}
+
+extern "C" {
+
+const char* plmpm_last_error(void) { return g_err.c_str(); }
+int plmpm_version(void) { return 1; }
+
+int plmpm_create(const plmpm_config* cfg, const plmpm_primitive* prims, plmpm_handle* out) {
+    REQUIRE(cfg && out, "null argument");
+    REQUIRE(cfg->dtype == PLMPM_F32 || cfg->dtype == PLMPM_F64, "dtype must be PLMPM_F32 or PLMPM_F64");
+    REQUIRE(cfg->n_grid >= 8 && cfg->n_grid % 4 == 0, "n_grid must be a multiple of 4 (got %d)", cfg->n_grid);
+    REQUIRE(cfg->n_particles > 0, "n_particles must be positive");
+    REQUIRE(cfg->n_primitives >= 0 && cfg->n_primitives <= PLMPM_MAX_PRIMITIVES, "at most %d primitives", PLMPM_MAX_PRIMITIVES);
+    REQUIRE(cfg->max_frames >= 1, "max_frames must be >= 1");
+    REQUIRE(cfg->n_primitives == 0 || prims, "prims is null");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail("no HIP device visible: this engine has no CPU path");
+    plmpm_sim* s = new plmpm_sim();
+    s->cfg = *cfg;
+    if (s->cfg.slab_z1 <= s->cfg.slab_z0) { s->cfg.slab_z0 = 0; s->cfg.slab_z1 = cfg->n_grid; }
+    s->P = cfg->n_primitives;
+    s->act_ofs[0] = 0;
+    for (int p = 0; p < s->P; ++p) {
+        s->prims[p] = prims[p];
+        if (prims[p].action_dim < 0 || prims[p].action_dim > PLMPM_MAX_ACTION_DIM) { delete s; return fail("bad action_dim"); }
+        if (prims[p].action_dim > 0 && prims[p].shape != PLMPM_SPHERE) {
+            delete s;
+            return fail("movable primitive %d: only Sphere has pose adjoints so far (shape %d)", p, prims[p].shape);
+        }
+        s->act_ofs[p + 1] = s->act_ofs[p] + prims[p].action_dim;
+    }
+    s->act_total = s->act_ofs[s->P];
+    s->N = cfg->n_particles;
+    s->Npad = (int)align_up(s->N, kBlock);
+    s->n = cfg->n_grid; s->nb = s->n / 4; s->nblk = s->nb * s->nb * s->nb; s->G = (size_t)s->n * s->n * s->n;
+    s->F = cfg->max_frames;
+    s->tsz = cfg->dtype == PLMPM_F64 ? 8 : 4;
+    s->frame_bytes = (size_t)s->Npad * (24 + 21 * s->tsz);
+    size_t P1 = std::max(s->P, 1);
+    s->ws.state_bytes = (size_t)(s->F + 1) * s->frame_bytes;
+    s->ws.adjoint_bytes = align_up(2 * 24 * s->Npad * s->tsz, 256) + 3 * align_up(s->Npad * s->tsz, 256) + align_up((size_t)s->Npad * 4, 256);
+    s->ws.grid_bytes = 4 * align_up(s->G * 4 * s->tsz, 256) + align_up((size_t)s->nblk * 4, 256) + 3 * align_up(s->G * s->tsz, 256);
+    s->ws.misc_bytes = 2 * align_up((size_t)(s->F + 1) * P1 * 7 * 8, 256) + 2 * align_up((size_t)(s->F + 1) * P1 * 8 * 8, 256)  // poses(+adj), padded
+                       + 4 * align_up((size_t)(s->F + 1) * P1 * 3 * 8, 256)                       // v,w (+adj)
+                       + 2 * align_up((size_t)(s->F + 1) * P1 * PLMPM_MAX_ACTION_DIM * 8, 256)    // action buffers (+adj)
+                       + align_up(LS_COUNT * 8, 256) + align_up((size_t)s->N * 24 * 8, 256);
+    s->perm.resize(s->N);
+    for (int i = 0; i < s->N; ++i) s->perm[i] = i;
+    *out = s;
+    return 0;
+}
+
+int plmpm_destroy(plmpm_handle s) {
+    delete s;
+    return 0;
+}
+
+int plmpm_workspace_bytes(plmpm_handle s, plmpm_workspace* out) {
+    REQUIRE(s && out, "null argument");
+    *out = s->ws;
+    return 0;
+}
+
+int plmpm_bind_workspace(plmpm_handle s, void* state, void* adjoint, void* grid, void* misc) {
+    REQUIRE(s && state && adjoint && grid && misc, "null argument");
+    REQUIRE(((uintptr_t)state | (uintptr_t)adjoint | (uintptr_t)grid | (uintptr_t)misc) % 256 == 0, "workspaces must be 256-byte aligned");
+    s->state = (char*)state; s->adjw = (char*)adjoint; s->gridw = (char*)grid; s->miscw = (char*)misc;
+    char* p = s->adjw;
+    auto take = [&](size_t bytes) { char* r = p; p += align_up(bytes, 256); return r; };
+    s->adj[0] = take((size_t)24 * s->Npad * s->tsz);
+    s->adj[1] = s->adj[0] + (size_t)24 * s->Npad * s->tsz;
+    p = s->adjw + align_up(2 * 24 * s->Npad * s->tsz, 256);
+    s->mu = take(s->Npad * s->tsz); s->lam = take(s->Npad * s->tsz); s->ys = take(s->Npad * s->tsz);
+    s->perm_d = (int*)take((size_t)s->Npad * 4);
+    p = s->gridw;
+    s->grid_in = take(s->G * 4 * s->tsz); s->grid_out = take(s->G * 4 * s->tsz);
+    s->grid_out_adj = take(s->G * 4 * s->tsz); s->grid_in_adj = take(s->G * 4 * s->tsz);
+    s->flags = (int*)take((size_t)s->nblk * 4);
+    s->loss_gm = take(s->G * s->tsz); s->loss_td = take(s->G * s->tsz); s->loss_ts = take(s->G * s->tsz);
+    p = s->miscw;
+    size_t P1 = std::max(s->P, 1), F1 = s->F + 1;
+    s->ppos = (double*)take(F1 * P1 * 3 * 8); s->prot = (double*)take(F1 * P1 * 4 * 8);
+    s->ppos_a = (double*)take(F1 * P1 * 3 * 8); s->prot_a = (double*)take(F1 * P1 * 4 * 8);
+    s->pv = (double*)take(F1 * P1 * 3 * 8); s->pw = (double*)take(F1 * P1 * 3 * 8);
+    s->pv_a = (double*)take(F1 * P1 * 3 * 8); s->pw_a = (double*)take(F1 * P1 * 3 * 8);
+    s->act = (double*)take(F1 * P1 * PLMPM_MAX_ACTION_DIM * 8); s->act_a = (double*)take(F1 * P1 * PLMPM_MAX_ACTION_DIM * 8);
+    s->lscal = (double*)take(LS_COUNT * 8);
+    s->staging = (double*)take((size_t)s->N * 24 * 8);
+    REQUIRE((size_t)(p - s->miscw) <= s->ws.misc_bytes, "internal: misc workspace overflow");
+    // initial contents: zero grids / adjoints / primitive buffers, identity order
+    HIPCHK(hipMemsetAsync(s->adjw, 0, s->ws.adjoint_bytes, s->stream));
+    HIPCHK(hipMemsetAsync(s->gridw, 0, s->ws.grid_bytes, s->stream));
+    HIPCHK(hipMemsetAsync(s->miscw, 0, s->ws.misc_bytes, s->stream));
+    HIPCHK(hipMemcpyAsync(s->perm_d, s->perm.data(), (size_t)s->N * 4, hipMemcpyHostToDevice, s->stream));
+    // unit quaternions everywhere so an unset primitive frame is still a valid pose
+    std::vector<double> rot(F1 * P1 * 4, 0.0);
+    for (size_t i = 0; i < F1 * P1; ++i) rot[4 * i] = 1.0;
+    HIPCHK(hipMemcpyAsync(s->prot, rot.data(), rot.size() * 8, hipMemcpyHostToDevice, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    s->bound = true;
+    return 0;
+}
+
+int plmpm_set_stream(plmpm_handle s, void* hip_stream) {
+    REQUIRE(s, "null handle");
+    s->stream = (hipStream_t)hip_stream;
+    return 0;
+}
+
+#define NEED_BOUND(s) REQUIRE((s) && (s)->bound, "workspace not bound")
+#define NEED_FRAME(s, f) REQUIRE((f) >= 0 && (f) <= (s)->F, "frame %d out of range [0,%d]", (f), (s)->F)
+
+int plmpm_set_materials(plmpm_handle s, const double* mu, const double* lam, const double* ys) {
+    NEED_BOUND(s);
+    REQUIRE(mu && lam && ys, "null argument");
+    size_t nb = (size_t)s->N * 8;
+    HIPCHK(hipMemcpyAsync(s->staging, mu, nb, hipMemcpyHostToDevice, s->stream));
+    HIPCHK(hipMemcpyAsync(s->staging + s->N, lam, nb, hipMemcpyHostToDevice, s->stream));
+    HIPCHK(hipMemcpyAsync(s->staging + 2 * (size_t)s->N, ys, nb, hipMemcpyHostToDevice, s->stream));
+    DISPATCH(s, set_materials_t, s);
+    HIPCHK(hipStreamSynchronize(s->stream));
+    return 0;
+}
+
+
+// storage order: particles sorted by the blocked index of their stencil base node (4^3 blocks, z-major)
+static void compute_order(plmpm_sim* s, const double* x) {
+    const int n = s->n, nb = s->nb;
+    std::vector<uint64_t> key(s->N);
+    for (int i = 0; i < s->N; ++i) {
+        int b[3];
+        for (int d = 0; d < 3; ++d) {
+            b[d] = (int)(x[(size_t)3 * i + d] * n - 0.5);
+            b[d] = std::min(std::max(b[d], 0), n - 1);
+        }
+        uint64_t k = ((((uint64_t)(b[2] >> 2) * nb + (b[1] >> 2)) * nb + (b[0] >> 2)) << 6) | ((b[2] & 3) << 4) | ((b[1] & 3) << 2) | (b[0] & 3);
+        key[i] = (k << 32) | (uint32_t)i;
+    }
+    std::sort(key.begin(), key.end());
+    for (int i = 0; i < s->N; ++i) s->perm[i] = (int32_t)(key[i] & 0xffffffffu);
+}
+
+int plmpm_set_frame(plmpm_handle s, int frame, const double* x, const double* v, const double* F, const double* C, int resort) {
+    NEED_BOUND(s);
+    NEED_FRAME(s, frame);
+    size_t N = s->N;
+    if (resort) {
+        REQUIRE(x && v && F && C, "resort needs the full state (all of x, v, F, C)");
+        compute_order(s, x);
+        HIPCHK(hipMemcpyAsync(s->perm_d, s->perm.data(), N * 4, hipMemcpyHostToDevice, s->stream));
+    }
+    if (x) HIPCHK(hipMemcpyAsync(s->staging, x, N * 3 * 8, hipMemcpyHostToDevice, s->stream));
+    if (v) HIPCHK(hipMemcpyAsync(s->staging + 3 * N, v, N * 3 * 8, hipMemcpyHostToDevice, s->stream));
+    if (F) HIPCHK(hipMemcpyAsync(s->staging + 6 * N, F, N * 9 * 8, hipMemcpyHostToDevice, s->stream));
+    if (C) HIPCHK(hipMemcpyAsync(s->staging + 15 * N, C, N * 9 * 8, hipMemcpyHostToDevice, s->stream));
+    DISPATCH(s, unpack_t, s, frame, x != nullptr, v != nullptr, F != nullptr, C != nullptr);
+    HIPCHK(hipStreamSynchronize(s->stream));
+    return 0;
+}
+
+int plmpm_get_frame(plmpm_handle s, int frame, double* x, double* v, double* F, double* C) {
+    NEED_BOUND(s);
+    NEED_FRAME(s, frame);
+    size_t N = s->N;
+    DISPATCH(s, pack_t, s, frame);
+    if (x) HIPCHK(hipMemcpyAsync(x, s->staging, N * 3 * 8, hipMemcpyDeviceToHost, s->stream));
+    if (v) HIPCHK(hipMemcpyAsync(v, s->staging + 3 * N, N * 3 * 8, hipMemcpyDeviceToHost, s->stream));
+    if (F) HIPCHK(hipMemcpyAsync(F, s->staging + 6 * N, N * 9 * 8, hipMemcpyDeviceToHost, s->stream));
+    if (C) HIPCHK(hipMemcpyAsync(C, s->staging + 15 * N, N * 9 * 8, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    return 0;
+}
+
+int plmpm_copy_frame(plmpm_handle s, int source, int target) {
+    NEED_BOUND(s);
+    NEED_FRAME(s, source);
+    NEED_FRAME(s, target);
+    size_t n16 = s->frame_bytes / 16;
+    hipLaunchKernelGGL(k_copy_frame, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, s->stream, s->state, s->frame_bytes, source, target);
+    if (s->P > 0) {
+        HIPCHK(hipMemcpyAsync(s->ppos + (size_t)target * s->P * 3, s->ppos + (size_t)source * s->P * 3, (size_t)s->P * 3 * 8, hipMemcpyDeviceToDevice, s->stream));
+        HIPCHK(hipMemcpyAsync(s->prot + (size_t)target * s->P * 4, s->prot + (size_t)source * s->P * 4, (size_t)s->P * 4 * 8, hipMemcpyDeviceToDevice, s->stream));
+    }
+    return 0;
+}
+
+int plmpm_set_primitive_state(plmpm_handle s, int prim, int frame, const double* st) {
+    NEED_BOUND(s);
+    NEED_FRAME(s, frame);
+    REQUIRE(prim >= 0 && prim < s->P && st, "bad primitive index");
+    HIPCHK(hipMemcpyAsync(s->ppos + ((size_t)frame * s->P + prim) * 3, st, 3 * 8, hipMemcpyHostToDevice, s->stream));
+    HIPCHK(hipMemcpyAsync(s->prot + ((size_t)frame * s->P + prim) * 4, st + 3, 4 * 8, hipMemcpyHostToDevice, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    return 0;
+}
+int plmpm_get_primitive_state(plmpm_handle s, int prim, int frame, double* st) {
+    NEED_BOUND(s);
+    NEED_FRAME(s, frame);
+    REQUIRE(prim >= 0 && prim < s->P && st, "bad primitive index");
+    HIPCHK(hipMemcpyAsync(st, s->ppos + ((size_t)frame * s->P + prim) * 3, 3 * 8, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipMemcpyAsync(st + 3, s->prot + ((size_t)frame * s->P + prim) * 4, 4 * 8, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    return 0;
+}
+int plmpm_get_primitive_grad(plmpm_handle s, int prim, int frame, double* g) {
+    NEED_BOUND(s);
+    NEED_FRAME(s, frame);
+    REQUIRE(prim >= 0 && prim < s->P && g, "bad primitive index");
+    HIPCHK(hipMemcpyAsync(g, s->ppos_a + ((size_t)frame * s->P + prim) * 3, 3 * 8, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipMemcpyAsync(g + 3, s->prot_a + ((size_t)frame * s->P + prim) * 4, 4 * 8, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    return 0;
+}
+int plmpm_set_softness(plmpm_handle s, double softness) {
+    REQUIRE(s, "null handle");
+    s->softness = softness;
+    return 0;
+}
+
+int plmpm_set_action(plmpm_handle s, int step, int n_substeps, const double* action) {
+    NEED_BOUND(s);
+    REQUIRE(n_substeps > 0 && step >= 0 && (step + 1) * n_substeps <= s->F, "set_action: frames [%d,%d) exceed max_frames %d",
+            step * n_substeps, (step + 1) * n_substeps, s->F);
+    if (s->P == 0) return 0;
+    REQUIRE(action || s->act_total == 0, "null action");
+    ActionArg a;
+    memset(&a, 0, sizeof a);
+    for (int p = 0; p < s->P; ++p)
+        for (int k = 0; k < s->prims[p].action_dim; ++k) {
+            double v = action[s->act_ofs[p] + k];
+            a.a[p * PLMPM_MAX_ACTION_DIM + k] = std::min(1.0, std::max(-1.0, v));      // primitives.py:290
+        }
+    hipLaunchKernelGGL(k_set_action, dim3(1), dim3(kMaxPrim), 0, s->stream, chain_args(s), a, step, n_substeps, s->act, s->pv, s->pw);
+    return 0;
+}
+
+int plmpm_get_action_grad(plmpm_handle s, int n_steps, double* out) {
+    NEED_BOUND(s);
+    REQUIRE(out && n_steps >= 0 && n_steps <= s->F, "bad arguments");
+    if (s->P == 0 || s->act_total == 0) return 0;
+    std::vector<double> buf((size_t)n_steps * s->P * PLMPM_MAX_ACTION_DIM);
+    HIPCHK(hipMemcpyAsync(buf.data(), s->act_a, buf.size() * 8, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    for (int i = 0; i < n_steps; ++i)
+        for (int p = 0; p < s->P; ++p)
+            for (int k = 0; k < s->prims[p].action_dim; ++k)
+                out[(size_t)i * s->act_total + s->act_ofs[p] + k] = buf[((size_t)i * s->P + p) * PLMPM_MAX_ACTION_DIM + k];
+    return 0;
+}
+
+static int launch_fk(plmpm_sim* s, int first, int n) {
+    if (s->P > 0)
+        hipLaunchKernelGGL(k_fk_chain, dim3(1), dim3(kMaxPrim), 0, s->stream, chain_args(s), first, n, s->ppos, s->prot, s->pv, s->pw);
+    return 0;
+}
+
+int plmpm_substep(plmpm_handle s, int frame) {
+    NEED_BOUND(s);
+    REQUIRE(frame >= 0 && frame < s->F, "substep: frame %d out of range", frame);
+    launch_fk(s, frame, 1);
+    DISPATCH(s, substep_fwd, s, frame);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int plmpm_step(plmpm_handle s, int first_frame, int n_substeps) {
+    NEED_BOUND(s);
+    REQUIRE(first_frame >= 0 && n_substeps > 0 && first_frame + n_substeps <= s->F, "step: frames [%d,%d] exceed max_frames %d",
+            first_frame, first_frame + n_substeps, s->F);
+    launch_fk(s, first_frame, n_substeps);
+    for (int f = first_frame; f < first_frame + n_substeps; ++f) DISPATCH(s, substep_fwd, s, f);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int plmpm_grad_begin(plmpm_handle s, int last_frame) {
+    NEED_BOUND(s);
+    NEED_FRAME(s, last_frame);
+    HIPCHK(hipMemsetAsync(s->adj[0], 0, (size_t)2 * 24 * s->Npad * s->tsz, s->stream));
+    size_t P1 = std::max(s->P, 1), F1 = s->F + 1;
+    HIPCHK(hipMemsetAsync(s->ppos_a, 0, F1 * P1 * 3 * 8, s->stream));
+    HIPCHK(hipMemsetAsync(s->prot_a, 0, F1 * P1 * 4 * 8, s->stream));
+    HIPCHK(hipMemsetAsync(s->pv_a, 0, F1 * P1 * 3 * 8, s->stream));
+    HIPCHK(hipMemsetAsync(s->pw_a, 0, F1 * P1 * 3 * 8, s->stream));
+    HIPCHK(hipMemsetAsync(s->act_a, 0, F1 * P1 * PLMPM_MAX_ACTION_DIM * 8, s->stream));
+    s->adj_frame[last_frame & 1] = last_frame;
+    s->adj_frame[(last_frame + 1) & 1] = -1;
+    return 0;
+}
+
+int plmpm_substep_grad(plmpm_handle s, int frame) {
+    NEED_BOUND(s);
+    REQUIRE(frame >= 0 && frame < s->F, "substep_grad: frame %d out of range", frame);
+    REQUIRE(s->adj_frame[(frame + 1) & 1] == frame + 1, "substep_grad(%d): adjoint of frame %d is not resident (call grad_begin / go in reverse order)", frame, frame + 1);
+    DISPATCH(s, substep_bwd, s, frame);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int plmpm_step_grad(plmpm_handle s, int first_frame, int n_substeps, int step) {
+    NEED_BOUND(s);
+    REQUIRE(first_frame >= 0 && n_substeps > 0 && first_frame + n_substeps <= s->F, "step_grad: bad frame range");
+    for (int f = first_frame + n_substeps - 1; f >= first_frame; --f) {
+        REQUIRE(s->adj_frame[(f + 1) & 1] == f + 1, "step_grad: adjoint of frame %d is not resident", f + 1);
+        DISPATCH(s, substep_bwd, s, f);
+    }
+    if (s->P > 0)
+        hipLaunchKernelGGL(k_fk_chain_grad, dim3(1), dim3(kMaxPrim), 0, s->stream, chain_args(s), first_frame, n_substeps, step,
+                           s->ppos, s->prot, s->pv, s->pw, s->ppos_a, s->prot_a, s->pv_a, s->pw_a, s->act_a);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int plmpm_add_frame_grad(plmpm_handle s, int frame, const double* xa, const double* va, const double* Fa, const double* Ca) {
+    NEED_BOUND(s);
+    NEED_FRAME(s, frame);
+    REQUIRE(s->adj_frame[frame & 1] == frame, "add_frame_grad: adjoint of frame %d is not resident", frame);
+    size_t N = s->N;
+    if (xa) HIPCHK(hipMemcpyAsync(s->staging, xa, N * 3 * 8, hipMemcpyHostToDevice, s->stream));
+    if (va) HIPCHK(hipMemcpyAsync(s->staging + 3 * N, va, N * 3 * 8, hipMemcpyHostToDevice, s->stream));
+    if (Fa) HIPCHK(hipMemcpyAsync(s->staging + 6 * N, Fa, N * 9 * 8, hipMemcpyHostToDevice, s->stream));
+    if (Ca) HIPCHK(hipMemcpyAsync(s->staging + 15 * N, Ca, N * 9 * 8, hipMemcpyHostToDevice, s->stream));
+    DISPATCH(s, adj_io_t, s, frame & 1, 1, xa != nullptr, va != nullptr, Fa != nullptr, Ca != nullptr);
+    HIPCHK(hipStreamSynchronize(s->stream));
+    return 0;
+}
+int plmpm_get_frame_grad(plmpm_handle s, int frame, double* xa, double* va, double* Fa, double* Ca) {
+    NEED_BOUND(s);
+    NEED_FRAME(s, frame);
+    REQUIRE(s->adj_frame[frame & 1] == frame, "get_frame_grad: adjoint of frame %d is not resident", frame);
+    size_t N = s->N;
+    DISPATCH(s, adj_io_t, s, frame & 1, 0, 1, 1, 1, 1);
+    if (xa) HIPCHK(hipMemcpyAsync(xa, s->staging, N * 3 * 8, hipMemcpyDeviceToHost, s->stream));
+    if (va) HIPCHK(hipMemcpyAsync(va, s->staging + 3 * N, N * 3 * 8, hipMemcpyDeviceToHost, s->stream));
+    if (Fa) HIPCHK(hipMemcpyAsync(Fa, s->staging + 6 * N, N * 9 * 8, hipMemcpyDeviceToHost, s->stream));
+    if (Ca) HIPCHK(hipMemcpyAsync(Ca, s->staging + 15 * N, N * 9 * 8, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    return 0;
+}
+
+// ---- loss -----------------------------------------------------------------------------------
+
+int plmpm_loss_set_target(plmpm_handle s, const double* density) {
+    NEED_BOUND(s);
+    REQUIRE(density, "null density");
+    const size_t G = s->G;
+    double *d_dens, *d_sdf[2], *d_np[2];
+    int* d_changed;
+    HIPCHK(hipMalloc(&d_dens, G * 8));
+    for (int i = 0; i < 2; ++i) { HIPCHK(hipMalloc(&d_sdf[i], G * 8)); HIPCHK(hipMalloc(&d_np[i], G * 24)); }
+    HIPCHK(hipMalloc(&d_changed, 4));
+    HIPCHK(hipMemcpyAsync(d_dens, density, G * 8, hipMemcpyHostToDevice, s->stream));
+    std::vector<double> inf(G, 1000.0);
+    HIPCHK(hipMemcpyAsync(d_sdf[0], inf.data(), G * 8, hipMemcpyHostToDevice, s->stream));     // target_sdf_copy.fill(inf)
+    HIPCHK(hipMemsetAsync(d_np[0], 0, G * 24, s->stream));
+    HIPCHK(hipMemsetAsync(d_np[1], 0, G * 24, s->stream));
+    int cur = 0, last = 0;
+    for (int it = 0; it < 2 * s->n; ++it) {                                                  // loss.py:103-106
+        HIPCHK(hipMemsetAsync(d_changed, 0, 4, s->stream));
+        // nearest_point persists across sweeps where nothing improves: carry the previous field over
+        HIPCHK(hipMemcpyAsync(d_np[1 - cur], d_np[cur], G * 24, hipMemcpyDeviceToDevice, s->stream));
+        hipLaunchKernelGGL(k_sdf_sweep, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, s->stream, s->n, 1.0 / s->n, 1000.0,
+                           d_dens, d_sdf[cur], d_np[cur], d_sdf[1 - cur], d_np[1 - cur], d_changed);
+        int changed = 0;
+        HIPCHK(hipMemcpyAsync(&changed, d_changed, 4, hipMemcpyDeviceToHost, s->stream));
+        HIPCHK(hipStreamSynchronize(s->stream));
+        cur = 1 - cur;
+        last = cur;
+        if (!changed) break;
+    }
+    DISPATCH(s, upload_grid_t, s, d_dens, s->loss_td);
+    DISPATCH(s, upload_grid_t, s, d_sdf[last], s->loss_ts);
+    HIPCHK(hipStreamSynchronize(s->stream));
+    hipFree(d_dens); hipFree(d_changed);
+    for (int i = 0; i < 2; ++i) { hipFree(d_sdf[i]); hipFree(d_np[i]); }
+    s->target_max = 0; s->target_sum = 0;
+    for (size_t i = 0; i < G; ++i) { s->target_max = std::max(s->target_max, density[i]); s->target_sum += density[i]; }
+    s->have_target = true;
+    return 0;
+}
+
+int plmpm_loss_set_weights(plmpm_handle s, double sdf, double density, double contact, int soft_contact) {
+    REQUIRE(s, "null handle");
+    s->w_sdf = sdf; s->w_density = density; s->w_contact = contact; s->soft_contact = soft_contact;
+    return 0;
+}
+
+
+int plmpm_loss_forward(plmpm_handle s, int frame, double* out6) {
+    NEED_BOUND(s);
+    NEED_FRAME(s, frame);
+    REQUIRE(s->have_target, "loss: no target density set");
+    REQUIRE(out6, "null output");
+    DISPATCH(s, loss_contact_t, s, frame);       // also resets the scalar block
+    DISPATCH(s, loss_scatter_t, s, frame);
+    DISPATCH(s, loss_reduce_t, s);
+    double ls[LS_COUNT];
+    HIPCHK(hipMemcpyAsync(ls, s->lscal, sizeof ls, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    double contact = 0;
+    for (int p = 0; p < s->P; ++p)
+        if (s->prims[p].action_dim > 0) contact += ls[LS_MIND + p] * ls[LS_MIND + p];          // loss.py:137-140
+    double ma = ls[LS_MAXGM], mb = s->target_max;
+    double I = ls[LS_DOT] / ma / mb, U = ls[LS_SUMGM] / ma + s->target_sum / mb;                 // loss.py:252-254
+    out6[0] = contact * s->w_contact + ls[LS_DENSITY] * s->w_density + ls[LS_SDF] * s->w_sdf;   // loss.py:158-162
+    out6[1] = ls[LS_SDF]; out6[2] = ls[LS_DENSITY]; out6[3] = contact; out6[4] = I / (U - I); out6[5] = 0;
+    return 0;
+}
+
+int plmpm_loss_backward(plmpm_handle s, int frame) {
+    NEED_BOUND(s);
+    NEED_FRAME(s, frame);
+    REQUIRE(s->have_target, "loss: no target density set");
+    REQUIRE(s->adj_frame[frame & 1] == frame, "loss_backward: adjoint of frame %d is not resident", frame);
+    DISPATCH(s, loss_contact_t, s, frame);
+    DISPATCH(s, loss_scatter_t, s, frame);
+    DISPATCH(s, loss_grad_t, s, frame);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int plmpm_get_grid_mass(plmpm_handle s, int frame, double* out) {
+    NEED_BOUND(s);
+    NEED_FRAME(s, frame);
+    REQUIRE(out, "null output");
+    double* d_lin;
+    HIPCHK(hipMalloc(&d_lin, s->G * 8));
+    DISPATCH(s, loss_scatter_t, s, frame);
+    DISPATCH(s, download_grid_t, s, s->loss_gm, d_lin);
+    HIPCHK(hipMemcpyAsync(out, d_lin, s->G * 8, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    hipFree(d_lin);
+    return 0;
+}
+int plmpm_loss_get_target_sdf(plmpm_handle s, double* out) {
+    NEED_BOUND(s);
+    REQUIRE(out && s->have_target, "no target set");
+    double* d_lin;
+    HIPCHK(hipMalloc(&d_lin, s->G * 8));
+    DISPATCH(s, download_grid_t, s, s->loss_ts, d_lin);
+    HIPCHK(hipMemcpyAsync(out, d_lin, s->G * 8, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    hipFree(d_lin);
+    return 0;
+}
+
+int plmpm_grid_stats(plmpm_handle s, int frame, int64_t* active_nodes, int64_t* active_blocks) {
+    NEED_BOUND(s);
+    NEED_FRAME(s, frame);
+    unsigned long long* d_out;
+    unsigned long long h[2] = {0, 0};
+    HIPCHK(hipMalloc(&d_out, 16));
+    HIPCHK(hipMemsetAsync(d_out, 0, 16, s->stream));
+    DISPATCH(s, grid_stats_t, s, frame, d_out);
+    HIPCHK(hipMemcpyAsync(h, d_out, 16, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    hipFree(d_out);
+    if (active_nodes) *active_nodes = (int64_t)h[0];
+    if (active_blocks) *active_blocks = (int64_t)h[1];
+    return 0;
+}
+
+int plmpm_get_order(plmpm_handle s, int32_t* perm) {
+    REQUIRE(s && perm, "null argument");
+    memcpy(perm, s->perm.data(), (size_t)s->N * 4);
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,435 @@
+// HIP kernels of the differentiable MLS-MPM substep for gfx950 (MI355X).
+//
+// Data layout in HBM (T = float on the fast path, double on the parity path):
+//   particle frame f : [x0 x1 x2 : double x Npad] [v0..2, C00..22, E00..22 : T x Npad]   (SoA, E = F - I)
+//   adjoint frame    : [xa0..2, va0..2, Ca00..22, Ea00..22 : T x Npad]                    (2 ping-pong frames)
+//   grid             : 4x4x4-node blocks, block index (bz*nb + by)*nb + bx, node (lz*16 + ly*4 + lx);
+//                      grid_in  = T4 {m, mv_x, mv_y, mv_z}, grid_out = T4 {v_x, v_y, v_z, 0},
+//                      grid_out_adj / grid_in_adj likewise; flags[block] marks blocks touched this substep.
+// Particles are stored cell-sorted (plmpm_set_frame(resort=1)), so a 256-thread workgroup's particles
+// cover a small box of cells: the scatter / gather kernels stage that box in LDS (tile path) and fall back
+// to direct global atomics when a workgroup's bounding box does not fit.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "mpm_grid.h"
+
+namespace plb {
+
+constexpr int kBlock = 256;          // threads per workgroup in particle kernels
+constexpr int kMaxPrim = 8;
+// LDS tile capacity (nodes) of the scatter/gather kernels: 32 KiB per tile for either scalar type
+template <class T> struct TileCap;
+template <> struct TileCap<float> { static constexpr int nodes = 2048; };
+template <> struct TileCap<double> { static constexpr int nodes = 1024; };
+
+template <class T> struct Vec4 { T x, y, z, w; };
+template <> struct __attribute__((aligned(16))) Vec4<float> { float x, y, z, w; };
+template <> struct __attribute__((aligned(32))) Vec4<double> { double x, y, z, w; };
+
+struct PrimStatic {
+    int shape, movable;
+    double par[3];
+    double friction;
+};
+
+// everything a kernel needs to find its data
+template <class T> struct Dev {
+    SimP<T> P;
+    int N, Npad, nb;                 // particles, padded, blocks per axis
+    int nprim;
+    int z0, z1;                      // owned z-slab (nodes)
+    size_t frame_bytes;
+    char* state;                     // particle frames
+    T* adj[2];                       // ping-pong adjoint frames
+    T *mu, *lam, *ys;
+    Vec4<T>*grid_in, *grid_out, *grid_out_adj, *grid_in_adj;
+    int* flags;
+    // primitives (double): pos[(F+1)][P][3], rot[(F+1)][P][4] and adjoints
+    const double *ppos, *prot;
+    double *ppos_a, *prot_a;
+    PrimStatic prim[kMaxPrim];
+};
+
+template <class T> __device__ __forceinline__ const double* frame_x(const Dev<T>& D, int f) {
+    return reinterpret_cast<const double*>(D.state + (size_t)f * D.frame_bytes);
+}
+template <class T> __device__ __forceinline__ double* frame_x_w(const Dev<T>& D, int f) {
+    return reinterpret_cast<double*>(D.state + (size_t)f * D.frame_bytes);
+}
+template <class T> __device__ __forceinline__ T* frame_r(const Dev<T>& D, int f) {
+    return reinterpret_cast<T*>(D.state + (size_t)f * D.frame_bytes + (size_t)3 * 8 * D.Npad);
+}
+
+__device__ __forceinline__ int node_index(int nb, int i, int j, int k) {
+    return ((((k >> 2) * nb + (j >> 2)) * nb + (i >> 2)) << 6) | ((k & 3) << 4) | ((j & 3) << 2) | (i & 3);
+}
+
+template <class T> __device__ __forceinline__ void load_prims(const Dev<T>& D, int f, PrimT<T>* sp) {
+    // called by all threads of a workgroup; sp in LDS
+    int t = threadIdx.x;
+    if (t < D.nprim) {
+        PrimT<T> p;
+        p.shape = D.prim[t].shape; p.movable = D.prim[t].movable; p.friction = (T)D.prim[t].friction;
+        for (int i = 0; i < 3; ++i) p.par[i] = D.prim[t].par[i];
+        const double* a = D.ppos + ((size_t)f * D.nprim + t) * 3;
+        const double* b = D.ppos + ((size_t)(f + 1) * D.nprim + t) * 3;
+        const double* c = D.prot + ((size_t)f * D.nprim + t) * 4;
+        const double* d = D.prot + ((size_t)(f + 1) * D.nprim + t) * 4;
+        for (int i = 0; i < 3; ++i) { p.pos[i] = a[i]; p.pos1[i] = b[i]; }
+        for (int i = 0; i < 4; ++i) { p.rot[i] = c[i]; p.rot1[i] = d[i]; }
+        sp[t] = p;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// workgroup bounding box of stencil bases -> LDS tile geometry
+struct Tile {
+    int o[3];      // origin node
+    int e[3];      // extent in nodes
+    int ok;        // fits in the LDS tile
+};
+
+__device__ __forceinline__ int wave_min(int v) {
+    for (int off = 32; off > 0; off >>= 1) v = min(v, __shfl_xor(v, off));
+    return v;
+}
+__device__ __forceinline__ int wave_max(int v) {
+    for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off));
+    return v;
+}
+
+// all threads call; valid == false for padding lanes.  sred: LDS int[6*4+8]
+__device__ __forceinline__ Tile block_tile(const int* base, bool valid, int* sred, int cap) {
+    int lo[3], hi[3];
+    for (int d = 0; d < 3; ++d) {
+        lo[d] = wave_min(valid ? base[d] : 0x7fffffff);
+        hi[d] = wave_max(valid ? base[d] : -0x7fffffff);
+    }
+    int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0)
+        for (int d = 0; d < 3; ++d) { sred[wave * 6 + d] = lo[d]; sred[wave * 6 + 3 + d] = hi[d]; }
+    __syncthreads();
+    Tile t;
+    int nodes = 1;
+    for (int d = 0; d < 3; ++d) {
+        int l = sred[d], h = sred[3 + d];
+        for (int w = 1; w < kBlock / 64; ++w) { l = min(l, sred[w * 6 + d]); h = max(h, sred[w * 6 + 3 + d]); }
+        t.o[d] = l;
+        t.e[d] = h - l + 3;
+        nodes *= t.e[d];
+    }
+    t.ok = (nodes > 0 && nodes <= cap) ? 1 : 0;
+    __syncthreads();
+    return t;
+}
+
+// ------------------------------------------------------------------------------------------------
+// p2g: compute_F_tmp + svd + von Mises + stress + APIC scatter      (mpm_simulator.py:82-90,157-184)
+// WRITE_F: store F[f+1] (forward) or not (recompute in substep_grad).
+template <class T, bool WRITE_F>
+__global__ __launch_bounds__(kBlock) void k_p2g(Dev<T> D, int f) {
+    __shared__ int sred[32];
+    __shared__ Vec4<T> tile[TileCap<T>::nodes];
+    const int p = blockIdx.x * kBlock + threadIdx.x;
+    const bool valid = p < D.N;
+    const double* X = frame_x(D, f);
+    const T* R = frame_r(D, f);
+    const int Np = D.Npad;
+    double x[3] = {0.5, 0.5, 0.5};
+    if (valid) { x[0] = X[p]; x[1] = X[Np + p]; x[2] = X[2 * Np + p]; }
+    int base[3];
+    for (int d = 0; d < 3; ++d) base[d] = (int)(x[d] * (double)D.P.inv_dx - 0.5);
+    Tile tl = block_tile(base, valid, sred, TileCap<T>::nodes);
+    const int tn = tl.e[0] * tl.e[1] * tl.e[2];
+    if (tl.ok) {
+        for (int i = threadIdx.x; i < tn; i += kBlock) tile[i] = Vec4<T>{T(0), T(0), T(0), T(0)};
+        __syncthreads();
+    }
+    if (valid) {
+        T v[3], C[9], E[9], En[9];
+        for (int d = 0; d < 3; ++d) v[d] = R[d * Np + p];
+        for (int d = 0; d < 9; ++d) { C[d] = R[(3 + d) * Np + p]; E[d] = R[(12 + d) * Np + p]; }
+        T mu = D.mu[p], lam = D.lam[p], ys = D.ys[p];
+        int b2[3];
+        if (tl.ok) {
+            const int ox = base[0] - tl.o[0], oy = base[1] - tl.o[1], oz = base[2] - tl.o[2];
+            const int ex = tl.e[0], exy = tl.e[0] * tl.e[1];
+            p2g_particle<T, double>(D.P, x, v, C, E, mu, lam, ys, En, b2, [&](int i, int j, int l, T mass, const T* mom) {
+                T* q = reinterpret_cast<T*>(&tile[(oz + l) * exy + (oy + j) * ex + (ox + i)]);
+                atomicAdd(q, mass); atomicAdd(q + 1, mom[0]); atomicAdd(q + 2, mom[1]); atomicAdd(q + 3, mom[2]);
+            });
+        } else {
+            p2g_particle<T, double>(D.P, x, v, C, E, mu, lam, ys, En, b2, [&](int i, int j, int l, T mass, const T* mom) {
+                int idx = node_index(D.nb, base[0] + i, base[1] + j, base[2] + l);
+                T* q = reinterpret_cast<T*>(&D.grid_in[idx]);
+                atomicAdd(q, mass); atomicAdd(q + 1, mom[0]); atomicAdd(q + 2, mom[1]); atomicAdd(q + 3, mom[2]);
+                D.flags[idx >> 6] = 1;
+            });
+        }
+        if (WRITE_F) {
+            T* R1 = frame_r(D, f + 1);
+            for (int d = 0; d < 9; ++d) R1[(12 + d) * Np + p] = En[d];
+        }
+    }
+    if (tl.ok) {
+        __syncthreads();
+        const int ex = tl.e[0], exy = tl.e[0] * tl.e[1];
+        for (int i = threadIdx.x; i < tn; i += kBlock) {
+            Vec4<T> a = tile[i];
+            if (a.x != T(0) || a.y != T(0) || a.z != T(0) || a.w != T(0)) {
+                int lz = i / exy, r = i - lz * exy, ly = r / ex, lx = r - ly * ex;
+                int idx = node_index(D.nb, tl.o[0] + lx, tl.o[1] + ly, tl.o[2] + lz);
+                T* q = reinterpret_cast<T*>(&D.grid_in[idx]);
+                atomicAdd(q, a.x); atomicAdd(q + 1, a.y); atomicAdd(q + 2, a.z); atomicAdd(q + 3, a.w);
+                D.flags[idx >> 6] = 1;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// grid_op (mpm_simulator.py:189-221) over active 4^3 blocks; one wave per block.
+// CLEAR: forward pass -- consume grid_in (zero it and the flag for the next substep).
+template <class T, bool CLEAR>
+__global__ __launch_bounds__(kBlock) void k_grid_op(Dev<T> D, int f) {
+    __shared__ PrimT<T> sp[kMaxPrim];
+    load_prims(D, f, sp);
+    __syncthreads();
+    const int blk = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    const int nblk = D.nb * D.nb * D.nb;
+    if (blk >= nblk || D.flags[blk] == 0) return;
+    const int lane = threadIdx.x & 63;
+    const int idx = (blk << 6) | lane;
+    const int bx = blk % D.nb, by = (blk / D.nb) % D.nb, bz = blk / (D.nb * D.nb);
+    int I[3] = {(bx << 2) | (lane & 3), (by << 2) | ((lane >> 2) & 3), (bz << 2) | (lane >> 4)};
+    Vec4<T> g = D.grid_in[idx];
+    T mv[3] = {g.y, g.z, g.w}, vo[3];
+    grid_node_fwd<T>(D.P, I, g.x, mv, D.nprim, sp, vo);
+    D.grid_out[idx] = Vec4<T>{vo[0], vo[1], vo[2], T(0)};
+    if (CLEAR) {
+        D.grid_in[idx] = Vec4<T>{T(0), T(0), T(0), T(0)};
+        if (lane == 0) D.flags[blk] = 0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// g2p (mpm_simulator.py:223-242): gather v_out through an LDS tile, write x,v,C of frame f+1
+template <class T>
+__global__ __launch_bounds__(kBlock) void k_g2p(Dev<T> D, int f) {
+    __shared__ int sred[32];
+    __shared__ Vec4<T> tile[TileCap<T>::nodes];
+    const int p = blockIdx.x * kBlock + threadIdx.x;
+    const bool valid = p < D.N;
+    const double* X = frame_x(D, f);
+    const int Np = D.Npad;
+    double x[3] = {0.5, 0.5, 0.5};
+    if (valid) { x[0] = X[p]; x[1] = X[Np + p]; x[2] = X[2 * Np + p]; }
+    int base[3];
+    for (int d = 0; d < 3; ++d) base[d] = (int)(x[d] * (double)D.P.inv_dx - 0.5);
+    Tile tl = block_tile(base, valid, sred, TileCap<T>::nodes);
+    const int ex = tl.e[0], exy = tl.e[0] * tl.e[1], tn = exy * tl.e[2];
+    if (tl.ok) {
+        for (int i = threadIdx.x; i < tn; i += kBlock) {
+            int lz = i / exy, r = i - lz * exy, ly = r / ex, lx = r - ly * ex;
+            tile[i] = D.grid_out[node_index(D.nb, tl.o[0] + lx, tl.o[1] + ly, tl.o[2] + lz)];
+        }
+        __syncthreads();
+    }
+    if (!valid) return;
+    double xn[3];
+    T vn[3], Cn[9];
+    if (tl.ok) {
+        const int ox = base[0] - tl.o[0], oy = base[1] - tl.o[1], oz = base[2] - tl.o[2];
+        g2p_particle<T, double>(D.P, x, xn, vn, Cn, [&](int i, int j, int l, T* gv) {
+            Vec4<T> a = tile[(oz + l) * exy + (oy + j) * ex + (ox + i)];
+            gv[0] = a.x; gv[1] = a.y; gv[2] = a.z;
+        });
+    } else {
+        g2p_particle<T, double>(D.P, x, xn, vn, Cn, [&](int i, int j, int l, T* gv) {
+            Vec4<T> a = D.grid_out[node_index(D.nb, base[0] + i, base[1] + j, base[2] + l)];
+            gv[0] = a.x; gv[1] = a.y; gv[2] = a.z;
+        });
+    }
+    double* X1 = frame_x_w(D, f + 1);
+    T* R1 = frame_r(D, f + 1);
+    for (int d = 0; d < 3; ++d) { X1[d * Np + p] = xn[d]; R1[d * Np + p] = vn[d]; }
+    for (int d = 0; d < 9; ++d) R1[(3 + d) * Np + p] = Cn[d];
+}
+
+// ------------------------------------------------------------------------------------------------
+// g2p.grad: scatter grid_v_out.grad, x[f].grad partial -> adjoint frame `dst`
+template <class T>
+__global__ __launch_bounds__(kBlock) void k_g2p_grad(Dev<T> D, int f, int src, int dst) {
+    __shared__ int sred[32];
+    __shared__ Vec4<T> tile[TileCap<T>::nodes];      // v_out values
+    __shared__ Vec4<T> tile_a[TileCap<T>::nodes];    // v_out adjoint accumulation
+    const int p = blockIdx.x * kBlock + threadIdx.x;
+    const bool valid = p < D.N;
+    const double* X = frame_x(D, f);
+    const int Np = D.Npad;
+    double x[3] = {0.5, 0.5, 0.5};
+    if (valid) { x[0] = X[p]; x[1] = X[Np + p]; x[2] = X[2 * Np + p]; }
+    int base[3];
+    for (int d = 0; d < 3; ++d) base[d] = (int)(x[d] * (double)D.P.inv_dx - 0.5);
+    Tile tl = block_tile(base, valid, sred, TileCap<T>::nodes);
+    const int ex = tl.e[0], exy = tl.e[0] * tl.e[1], tn = exy * tl.e[2];
+    if (tl.ok) {
+        for (int i = threadIdx.x; i < tn; i += kBlock) {
+            int lz = i / exy, r = i - lz * exy, ly = r / ex, lx = r - ly * ex;
+            tile[i] = D.grid_out[node_index(D.nb, tl.o[0] + lx, tl.o[1] + ly, tl.o[2] + lz)];
+            tile_a[i] = Vec4<T>{T(0), T(0), T(0), T(0)};
+        }
+        __syncthreads();
+    }
+    if (valid) {
+        const T* R1 = frame_r(D, f + 1);
+        const T* A1 = D.adj[src];
+        T vn[3], xna[3], vna[3], Cna[9], xa[3];
+        for (int d = 0; d < 3; ++d) { vn[d] = R1[d * Np + p]; xna[d] = A1[d * Np + p]; vna[d] = A1[(3 + d) * Np + p]; }
+        for (int d = 0; d < 9; ++d) Cna[d] = A1[(6 + d) * Np + p];
+        if (tl.ok) {
+            const int ox = base[0] - tl.o[0], oy = base[1] - tl.o[1], oz = base[2] - tl.o[2];
+            g2p_particle_grad<T, double>(D.P, x, vn, xna, vna, Cna, xa,
+                [&](int i, int j, int l, T* gv) {
+                    Vec4<T> a = tile[(oz + l) * exy + (oy + j) * ex + (ox + i)];
+                    gv[0] = a.x; gv[1] = a.y; gv[2] = a.z;
+                },
+                [&](int i, int j, int l, const T* ga) {
+                    T* q = reinterpret_cast<T*>(&tile_a[(oz + l) * exy + (oy + j) * ex + (ox + i)]);
+                    atomicAdd(q, ga[0]); atomicAdd(q + 1, ga[1]); atomicAdd(q + 2, ga[2]);
+                });
+        } else {
+            g2p_particle_grad<T, double>(D.P, x, vn, xna, vna, Cna, xa,
+                [&](int i, int j, int l, T* gv) {
+                    Vec4<T> a = D.grid_out[node_index(D.nb, base[0] + i, base[1] + j, base[2] + l)];
+                    gv[0] = a.x; gv[1] = a.y; gv[2] = a.z;
+                },
+                [&](int i, int j, int l, const T* ga) {
+                    T* q = reinterpret_cast<T*>(&D.grid_out_adj[node_index(D.nb, base[0] + i, base[1] + j, base[2] + l)]);
+                    atomicAdd(q, ga[0]); atomicAdd(q + 1, ga[1]); atomicAdd(q + 2, ga[2]);
+                });
+        }
+        T* A0 = D.adj[dst];
+        for (int d = 0; d < 3; ++d) A0[d * Np + p] = xa[d];
+    }
+    if (tl.ok) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < tn; i += kBlock) {
+            Vec4<T> a = tile_a[i];
+            if (a.x != T(0) || a.y != T(0) || a.z != T(0)) {
+                int lz = i / exy, r = i - lz * exy, ly = r / ex, lx = r - ly * ex;
+                T* q = reinterpret_cast<T*>(&D.grid_out_adj[node_index(D.nb, tl.o[0] + lx, tl.o[1] + ly, tl.o[2] + lz)]);
+                atomicAdd(q, a.x); atomicAdd(q + 1, a.y); atomicAdd(q + 2, a.z);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// grid_op.grad over active blocks: grid_out_adj -> grid_in_adj, pose adjoints; clears grid_out_adj
+template <class T>
+__global__ __launch_bounds__(kBlock) void k_grid_op_grad(Dev<T> D, int f) {
+    __shared__ PrimT<T> sp[kMaxPrim];
+    __shared__ double sacc[kMaxPrim * 14];
+    __shared__ int shit;
+    load_prims(D, f, sp);
+    if (threadIdx.x < kMaxPrim * 14) sacc[threadIdx.x] = 0.0;
+    if (threadIdx.x == 0) shit = 0;
+    __syncthreads();
+    const int blk = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    const int nblk = D.nb * D.nb * D.nb;
+    const bool active = blk < nblk && D.flags[blk] != 0;
+    if (active) {
+        const int lane = threadIdx.x & 63;
+        const int idx = (blk << 6) | lane;
+        const int bx = blk % D.nb, by = (blk / D.nb) % D.nb, bz = blk / (D.nb * D.nb);
+        int I[3] = {(bx << 2) | (lane & 3), (by << 2) | ((lane >> 2) & 3), (bz << 2) | (lane >> 4)};
+        Vec4<T> g = D.grid_in[idx];
+        Vec4<T> oa = D.grid_out_adj[idx];
+        T mv[3] = {g.y, g.z, g.w}, va[3] = {oa.x, oa.y, oa.z}, ma, mva[3];
+        grid_node_bwd<T>(D.P, I, g.x, mv, D.nprim, sp, va, &ma, mva, [&](int q, const PoseAdj<T>& pa) {
+            double* o = &sacc[q * 14];
+            for (int d = 0; d < 3; ++d) { atomicAdd(&o[d], pa.pos[d]); atomicAdd(&o[7 + d], pa.pos1[d]); }
+            for (int d = 0; d < 4; ++d) { atomicAdd(&o[3 + d], pa.rot[d]); atomicAdd(&o[10 + d], pa.rot1[d]); }
+            shit = 1;
+        });
+        D.grid_in_adj[idx] = Vec4<T>{ma, mva[0], mva[1], mva[2]};
+        D.grid_out_adj[idx] = Vec4<T>{T(0), T(0), T(0), T(0)};
+    }
+    __syncthreads();
+    if (shit && threadIdx.x < D.nprim * 14) {
+        int q = threadIdx.x / 14, c = threadIdx.x % 14;
+        double v = sacc[threadIdx.x];
+        if (v != 0.0) {
+            // c: 0-2 pos[f], 3-6 rot[f], 7-9 pos[f+1], 10-13 rot[f+1]
+            if (c < 3) atomicAdd(&D.ppos_a[((size_t)f * D.nprim + q) * 3 + c], v);
+            else if (c < 7) atomicAdd(&D.prot_a[((size_t)f * D.nprim + q) * 4 + (c - 3)], v);
+            else if (c < 10) atomicAdd(&D.ppos_a[((size_t)(f + 1) * D.nprim + q) * 3 + (c - 7)], v);
+            else atomicAdd(&D.prot_a[((size_t)(f + 1) * D.nprim + q) * 4 + (c - 10)], v);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// p2g.grad + svd_grad + compute_F_tmp.grad: gather grid_in_adj, finish adjoint frame `dst`
+template <class T>
+__global__ __launch_bounds__(kBlock) void k_p2g_grad(Dev<T> D, int f, int src, int dst) {
+    __shared__ int sred[32];
+    __shared__ Vec4<T> tile[TileCap<T>::nodes];
+    const int p = blockIdx.x * kBlock + threadIdx.x;
+    const bool valid = p < D.N;
+    const double* X = frame_x(D, f);
+    const T* R = frame_r(D, f);
+    const int Np = D.Npad;
+    double x[3] = {0.5, 0.5, 0.5};
+    if (valid) { x[0] = X[p]; x[1] = X[Np + p]; x[2] = X[2 * Np + p]; }
+    int base[3];
+    for (int d = 0; d < 3; ++d) base[d] = (int)(x[d] * (double)D.P.inv_dx - 0.5);
+    Tile tl = block_tile(base, valid, sred, TileCap<T>::nodes);
+    const int ex = tl.e[0], exy = tl.e[0] * tl.e[1], tn = exy * tl.e[2];
+    if (tl.ok) {
+        for (int i = threadIdx.x; i < tn; i += kBlock) {
+            int lz = i / exy, r = i - lz * exy, ly = r / ex, lx = r - ly * ex;
+            tile[i] = D.grid_in_adj[node_index(D.nb, tl.o[0] + lx, tl.o[1] + ly, tl.o[2] + lz)];
+        }
+        __syncthreads();
+    }
+    if (!valid) return;
+    T v[3], C[9], E[9], Ena[9], xa[3], va[3], Ca[9], Ea[9];
+    for (int d = 0; d < 3; ++d) v[d] = R[d * Np + p];
+    for (int d = 0; d < 9; ++d) { C[d] = R[(3 + d) * Np + p]; E[d] = R[(12 + d) * Np + p]; }
+    const T* A1 = D.adj[src];
+    T* A0 = D.adj[dst];
+    for (int d = 0; d < 9; ++d) Ena[d] = A1[(15 + d) * Np + p];
+    for (int d = 0; d < 3; ++d) xa[d] = A0[d * Np + p];
+    T mu = D.mu[p], lam = D.lam[p], ys = D.ys[p];
+    if (tl.ok) {
+        const int ox = base[0] - tl.o[0], oy = base[1] - tl.o[1], oz = base[2] - tl.o[2];
+        p2g_particle_grad<T, double>(D.P, x, v, C, E, mu, lam, ys, Ena, xa, va, Ca, Ea, [&](int i, int j, int l, T* g) {
+            Vec4<T> a = tile[(oz + l) * exy + (oy + j) * ex + (ox + i)];
+            g[0] = a.x; g[1] = a.y; g[2] = a.z; g[3] = a.w;
+        });
+    } else {
+        p2g_particle_grad<T, double>(D.P, x, v, C, E, mu, lam, ys, Ena, xa, va, Ca, Ea, [&](int i, int j, int l, T* g) {
+            Vec4<T> a = D.grid_in_adj[node_index(D.nb, base[0] + i, base[1] + j, base[2] + l)];
+            g[0] = a.x; g[1] = a.y; g[2] = a.z; g[3] = a.w;
+        });
+    }
+    for (int d = 0; d < 3; ++d) { A0[d * Np + p] = xa[d]; A0[(3 + d) * Np + p] = va[d]; }
+    for (int d = 0; d < 9; ++d) { A0[(6 + d) * Np + p] = Ca[d]; A0[(15 + d) * Np + p] = Ea[d]; }
+}
+
+// after substep_grad: zero grid_in / grid_in_adj / flags of the active blocks
+template <class T>
+__global__ __launch_bounds__(kBlock) void k_clear_active(Dev<T> D) {
+    const int blk = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    const int nblk = D.nb * D.nb * D.nb;
+    if (blk >= nblk || D.flags[blk] == 0) return;
+    const int lane = threadIdx.x & 63;
+    const int idx = (blk << 6) | lane;
+    D.grid_in[idx] = Vec4<T>{T(0), T(0), T(0), T(0)};
+    D.grid_in_adj[idx] = Vec4<T>{T(0), T(0), T(0), T(0)};
+    if (lane == 0) D.flags[blk] = 0;
+}
+
+}  // namespace plb

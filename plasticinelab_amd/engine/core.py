@@ -1,0 +1,210 @@
+"""Thin object wrapper over the C ABI: one ``Engine`` = one ``plmpm_handle``.
+
+Device memory comes from torch (ROCm caching allocator) and is bound into the
+engine; kernels run on torch's current HIP stream so that they order with
+``torch.distributed`` collectives.  All numerics live in libplmpm.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence
+
+import numpy as np
+import torch
+
+from .. import _lib as L
+
+
+def _ptr(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _f64(a, shape=None):
+    if a is None:
+        return None
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if shape is not None:
+        a = a.reshape(shape)
+    return a
+
+
+class Engine:
+    def __init__(self, *, n_grid: int, n_particles: int, max_frames: int, substeps: int, dt: float, p_vol: float,
+                 p_mass: float, gravity: Sequence[float], ground_friction: float, primitives: Sequence[dict] = (),
+                 dtype: str = "float32", svd_grad_clamp: float = 1e-6, device: Optional[torch.device] = None,
+                 slab: Optional[Sequence[int]] = None):
+        self.lib = L.load()
+        if not torch.cuda.is_available():
+            raise L.EngineError("no ROCm device visible: the MPM engine has no CPU path")
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        cfg = L.Config()
+        cfg.dtype = L.F64 if dtype in ("float64", "f64") else L.F32
+        cfg.n_grid, cfg.n_particles, cfg.max_frames, cfg.substeps = n_grid, n_particles, max_frames, substeps
+        cfg.n_primitives = len(primitives)
+        cfg.dt, cfg.p_vol, cfg.p_mass = dt, p_vol, p_mass
+        cfg.gravity = (C.c_double * 3)(*[float(g) for g in gravity])
+        cfg.ground_friction, cfg.svd_grad_clamp = float(ground_friction), float(svd_grad_clamp)
+        cfg.slab_z0, cfg.slab_z1 = (0, n_grid) if slab is None else (int(slab[0]), int(slab[1]))
+        parr = (L.Primitive * max(len(primitives), 1))()
+        self.action_dims = []
+        for i, p in enumerate(primitives):
+            parr[i].shape = L.SHAPES[p["shape"]]
+            parr[i].action_dim = int(p.get("action_dim", 0))
+            pr = list(p.get("params", ())) + [0.0, 0.0, 0.0]
+            parr[i].params = (C.c_double * 3)(*pr[:3])
+            parr[i].friction = float(p.get("friction", 0.9))
+            sc = list(p.get("action_scale", ())) + [0.0] * L.MAX_ACTION_DIM
+            parr[i].action_scale = (C.c_double * L.MAX_ACTION_DIM)(*sc[:L.MAX_ACTION_DIM])
+            parr[i].lower_bound = (C.c_double * 3)(*p.get("lower_bound", (0.0, 0.0, 0.0)))
+            parr[i].upper_bound = (C.c_double * 3)(*p.get("upper_bound", (1.0, 1.0, 1.0)))
+            self.action_dims.append(parr[i].action_dim)
+        self.cfg, self.n_primitives = cfg, len(primitives)
+        self.n_grid, self.n_particles, self.max_frames = n_grid, n_particles, max_frames
+        self.dtype = "float64" if cfg.dtype == L.F64 else "float32"
+        self.h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            L.check(self.lib.plmpm_create(C.byref(cfg), parr, C.byref(self.h)))
+            ws = L.Workspace()
+            L.check(self.lib.plmpm_workspace_bytes(self.h, C.byref(ws)))
+            self.workspace_bytes = {k: getattr(ws, k) for k, _ in L.Workspace._fields_}
+            # torch owns the memory; keep the tensors alive as long as the handle
+            self._bufs = [torch.empty(max(n, 256), dtype=torch.uint8, device=self.device)
+                          for n in (ws.state_bytes, ws.adjoint_bytes, ws.grid_bytes, ws.misc_bytes)]
+            self.use_current_stream()
+            L.check(self.lib.plmpm_bind_workspace(self.h, *[C.c_void_p(b.data_ptr()) for b in self._bufs]))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.plmpm_destroy(self.h)
+            self.h = None
+            self._bufs = []
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- plumbing
+    def use_current_stream(self):
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        L.check(self.lib.plmpm_set_stream(self.h, C.c_void_p(stream)))
+
+    # ---- state
+    def set_materials(self, mu, lam, ys):
+        N = self.n_particles
+        a = [np.ascontiguousarray(np.broadcast_to(np.asarray(v, np.float64), (N,))) for v in (mu, lam, ys)]
+        L.check(self.lib.plmpm_set_materials(self.h, *[_ptr(v) for v in a]))
+
+    def set_frame(self, f, x=None, v=None, F=None, C_=None, resort=False):
+        N = self.n_particles
+        x, v, F, C_ = _f64(x, (N, 3)), _f64(v, (N, 3)), _f64(F, (N, 3, 3)), _f64(C_, (N, 3, 3))
+        L.check(self.lib.plmpm_set_frame(self.h, f, _ptr(x), _ptr(v), _ptr(F), _ptr(C_), int(resort)))
+
+    def get_frame(self, f, want=("x", "v", "F", "C")):
+        N = self.n_particles
+        out = {"x": np.empty((N, 3)) if "x" in want else None, "v": np.empty((N, 3)) if "v" in want else None,
+               "F": np.empty((N, 3, 3)) if "F" in want else None, "C": np.empty((N, 3, 3)) if "C" in want else None}
+        L.check(self.lib.plmpm_get_frame(self.h, f, _ptr(out["x"]), _ptr(out["v"]), _ptr(out["F"]), _ptr(out["C"])))
+        return out
+
+    def copy_frame(self, src, dst):
+        L.check(self.lib.plmpm_copy_frame(self.h, src, dst))
+
+    def set_primitive_state(self, prim, f, state7):
+        s = _f64(state7, (7,))
+        L.check(self.lib.plmpm_set_primitive_state(self.h, prim, f, _ptr(s)))
+
+    def get_primitive_state(self, prim, f):
+        s = np.empty(7)
+        L.check(self.lib.plmpm_get_primitive_state(self.h, prim, f, _ptr(s)))
+        return s
+
+    def get_primitive_grad(self, prim, f):
+        s = np.empty(7)
+        L.check(self.lib.plmpm_get_primitive_grad(self.h, prim, f, _ptr(s)))
+        return s
+
+    def set_softness(self, softness):
+        L.check(self.lib.plmpm_set_softness(self.h, float(softness)))
+
+    # ---- actions
+    def set_action(self, step, n_substeps, action):
+        a = _f64(action).reshape(-1) if action is not None else np.zeros(0)
+        if a.size != sum(self.action_dims):
+            raise ValueError(f"action has {a.size} entries, expected {sum(self.action_dims)}")
+        L.check(self.lib.plmpm_set_action(self.h, step, n_substeps, _ptr(a) if a.size else None))
+
+    def get_action_grad(self, n_steps):
+        out = np.zeros((n_steps, sum(self.action_dims)))
+        L.check(self.lib.plmpm_get_action_grad(self.h, n_steps, _ptr(out)))
+        return out
+
+    # ---- hot path
+    def substep(self, f):
+        L.check(self.lib.plmpm_substep(self.h, f))
+
+    def step(self, first, n):
+        L.check(self.lib.plmpm_step(self.h, first, n))
+
+    def grad_begin(self, last_frame):
+        L.check(self.lib.plmpm_grad_begin(self.h, last_frame))
+
+    def substep_grad(self, f):
+        L.check(self.lib.plmpm_substep_grad(self.h, f))
+
+    def step_grad(self, first, n, step):
+        L.check(self.lib.plmpm_step_grad(self.h, first, n, step))
+
+    def add_frame_grad(self, f, xa=None, va=None, Fa=None, Ca=None):
+        N = self.n_particles
+        xa, va, Fa, Ca = _f64(xa, (N, 3)), _f64(va, (N, 3)), _f64(Fa, (N, 3, 3)), _f64(Ca, (N, 3, 3))
+        L.check(self.lib.plmpm_add_frame_grad(self.h, f, _ptr(xa), _ptr(va), _ptr(Fa), _ptr(Ca)))
+
+    def get_frame_grad(self, f):
+        N = self.n_particles
+        out = {"x": np.empty((N, 3)), "v": np.empty((N, 3)), "F": np.empty((N, 3, 3)), "C": np.empty((N, 3, 3))}
+        L.check(self.lib.plmpm_get_frame_grad(self.h, f, _ptr(out["x"]), _ptr(out["v"]), _ptr(out["F"]), _ptr(out["C"])))
+        return out
+
+    # ---- loss
+    def loss_set_target(self, density):
+        n = self.n_grid
+        d = _f64(density, (n, n, n))
+        L.check(self.lib.plmpm_loss_set_target(self.h, _ptr(d)))
+
+    def loss_set_weights(self, sdf, density, contact, soft_contact):
+        L.check(self.lib.plmpm_loss_set_weights(self.h, float(sdf), float(density), float(contact), int(bool(soft_contact))))
+
+    def loss_forward(self, f):
+        out = np.zeros(6)
+        L.check(self.lib.plmpm_loss_forward(self.h, f, _ptr(out)))
+        return dict(loss=out[0], sdf_loss=out[1], density_loss=out[2], contact_loss=out[3], iou=out[4])
+
+    def loss_backward(self, f):
+        L.check(self.lib.plmpm_loss_backward(self.h, f))
+
+    def grid_mass(self, f):
+        n = self.n_grid
+        out = np.empty((n, n, n))
+        L.check(self.lib.plmpm_get_grid_mass(self.h, f, _ptr(out)))
+        return out
+
+    def target_sdf(self):
+        n = self.n_grid
+        out = np.empty((n, n, n))
+        L.check(self.lib.plmpm_loss_get_target_sdf(self.h, _ptr(out)))
+        return out
+
+    def grid_stats(self, f):
+        a, b = C.c_int64(0), C.c_int64(0)
+        L.check(self.lib.plmpm_grid_stats(self.h, f, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def order(self):
+        p = np.empty(self.n_particles, np.int32)
+        L.check(self.lib.plmpm_get_order(self.h, _ptr(p)))
+        return p
+
+    def synchronize(self):
+        torch.cuda.current_stream(self.device).synchronize()
