@@ -1,0 +1,234 @@
+#!/usr/bin/env python
+"""Benchmark: MPM substeps/sec (forward + backward) on the BASELINE.json workload.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--dtype float32] [--no-cpu-baseline]
+
+One "step" = one env step of the hot path: `substeps` x substep forward, the loss, and -- after the K
+forward steps -- the K reverse steps (loss adjoint + `substeps` x substep_grad + primitive-chain adjoint),
+exactly the call sequence of Solver.forward (plb/optimizer/solver.py:31-44).  The timed region starts with
+the particle state already resident in HBM and covers K steps forward + K steps backward.
+
+Workload (config.workload "config3_cube128"): BASELINE.json configs[2] as synthesised in SURVEY.md 8(d):
+128^3 grid (quality 2, 39 substeps / env step), one elastoplastic cube of side 0.31 at (0.5, 0.2, 0.5)
+with 500 000 seed-0 uniform particles (~8 per cell), sigma_y = 200, two Sphere manipulators (r = 0.05)
+touching opposite faces, seeded actions, own target grid (the cube's mass grid shifted by a few cells).
+
+Prints ONE JSON line (rank 0).  N > 1: one process per GPU, each running the full workload (independent
+replicas, no data-path collective) -- the z-slab decomposition with an RCCL halo is not built yet, see
+DESIGN.md "multi-GPU"; scaling is therefore reported as "weak".
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+# algorithmic scalars per particle (cN) and per active node (cA) of each kernel; the rows sum to the
+# SURVEY.md 8(d) figure 150 N + 57 A per fwd+bwd substep (DESIGN.md "algorithmic bytes")
+ALG = {
+    "p2g": (36, 4), "grid_op": (0, 11), "g2p": (15, 3),
+    "p2g_recompute": (27, 8), "grid_op_recompute": (0, 7), "g2p_grad": (18, 9),
+    "grid_op_grad": (0, 11), "p2g_grad": (54, 4), "clear_active": (0, 0),
+}
+HBM_PEAK_GBS = 8000.0          # MI355X spec (MI355X_MICROARCH.md); measured copy peak there: 6290 GB/s
+
+
+def workload_cfg(n_particles=500_000, quality=2, max_steps=1024):
+    from plasticinelab_amd.config import get_cfg_defaults
+    cfg = get_cfg_defaults()
+    side = 0.31
+    r = 0.05
+    cfg.merge({
+        "SIMULATOR": {"quality": quality, "yield_stress": 200.0, "E": 5000.0, "nu": 0.2, "max_steps": max_steps,
+                      "n_particles": n_particles},
+        "SHAPES": [{"shape": "box", "width": (side, side, side), "init_pos": (0.5, 0.2, 0.5), "n_particles": n_particles}],
+        "PRIMITIVES": [
+            {"shape": "Sphere", "radius": r, "init_pos": (0.5 - side / 2 - r, 0.2, 0.5), "friction": 0.9,
+             "action": {"dim": 3, "scale": (0.01, 0.01, 0.01)}},
+            {"shape": "Sphere", "radius": r, "init_pos": (0.5 + side / 2 + r, 0.2, 0.5), "friction": 0.9,
+             "action": {"dim": 3, "scale": (0.01, 0.01, 0.01)}},
+        ],
+    }, strict=True)
+    cfg["VARIANTS"] = None
+    return cfg
+
+
+def mass_grid(x, n, p_mass):
+    """host copy of compute_grid_m_kernel (only used to synthesise the benchmark's own target grid)."""
+    xs = x * n
+    base = (xs - 0.5).astype(np.int64)
+    fx = xs - base
+    w = [0.5 * (1.5 - fx) ** 2, 0.75 - (fx - 1) ** 2, 0.5 * (fx - 0.5) ** 2]
+    g = np.zeros(n * n * n)
+    for i in range(3):
+        for j in range(3):
+            for k in range(3):
+                idx = ((base[:, 0] + i) * n + base[:, 1] + j) * n + base[:, 2] + k
+                np.add.at(g, idx, w[i][:, 0] * w[j][:, 1] * w[k][:, 2] * p_mass)
+    return g.reshape(n, n, n)
+
+
+def seeded_actions(K, A):
+    a = np.random.default_rng(0).uniform(-1, 1, (K, A)) * 0.2
+    a[:, 0] = 0.8          # left manipulator pushes +x into the cube
+    a[:, 3] = -0.8         # right manipulator pushes -x
+    return a
+
+
+def build_env(args, device):
+    from plasticinelab_amd.engine.taichi_env import TaichiEnv
+    sub = int(2e-3 // (0.5e-4 / (args.quality * 0.5)))
+    frames = max(args.steps, args.warmup, 1) * sub + 1
+    cfg = workload_cfg(args.particles, args.quality, max_steps=frames)
+    env = TaichiEnv(cfg, compute_dtype=args.dtype, device=device)
+    env.initialize()
+    sim = env.simulator
+    target = mass_grid(np.clip(env.init_particles + np.array([0.03, 0.0, 0.02]), 0.03, 0.97), sim.n_grid, sim.p_mass)
+    env.loss.load_target_density(grids=target)
+    env.loss.set_weights(10, 10, 1, False)
+    return env
+
+
+def rollout(env, actions):
+    """K env steps forward + the reverse sweep (Tape): the timed body."""
+    from plasticinelab_amd.engine.taichi_env import Tape
+    with Tape(env):
+        for a in actions:
+            env.step(a)
+            env.compute_loss()
+    return env.loss.loss
+
+
+def cpu_baseline(args, env):
+    """Bounded sample of the same workload on the host cores: ONE substep forward + its adjoint through the
+    float64 oracle (oracle/plb_oracle.py, torch CPU) on the workload's initial state.  kind = "port": the
+    reference's own CPU path is Taichi, which cannot be installed here."""
+    from oracle import plb_oracle as O
+    sim_g = env.simulator
+    x0 = env.init_particles
+    sim = O.SimCfg(n_particles=len(x0), quality=args.quality, yield_stress=200.0, E=5000.0, nu=0.2,
+                   ground_friction=sim_g.ground_friction, gravity=tuple(sim_g.default_gravity))
+    prims = [O.PrimCfg(shape="Sphere", radius=p.params()[0], init_pos=tuple(p.cfg.init_pos), friction=p.friction,
+                       action_dim=3, action_scale=tuple(p.cfg.action.scale)) for p in env.primitives]
+    state = tuple(t.requires_grad_(True) for t in O.init_state(x0))
+    mats, poses = O.materials(sim), O.init_poses(prims)
+    a = torch.tensor([0.8, 0, 0, -0.8, 0, 0], dtype=O.DT)
+    vel = [O.set_velocity(p, a[3 * k:3 * k + 3], sim.substeps) for k, p in enumerate(prims)]
+    nxt = [O.forward_kinematics(p, pos, rot, v, w) for p, (pos, rot), (v, w) in zip(prims, poses, vel)]
+    t0 = time.perf_counter()
+    out = O.substep(sim, prims, 666.0, state, mats, poses, nxt)
+    obj = sum((o * o).sum() for o in out)
+    torch.autograd.grad(obj, list(state))
+    dt = time.perf_counter() - t0
+    return {"value": 1.0 / dt, "unit": "substeps/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"1 substep fwd+bwd of the same {len(x0)}-particle / {sim.n_grid}^3 workload through the "
+                      f"float64 torch-CPU oracle ({dt:.1f} s); Taichi (the reference's CPU backend) is not installable here"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--dtype", default="float32")
+    ap.add_argument("--particles", type=int, default=500_000)
+    ap.add_argument("--quality", type=float, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    env = build_env(args, device)
+    sim = env.simulator
+    K, W, sub = args.steps, args.warmup, sim.substeps
+    A = env.primitives.action_dim
+    state0 = env.get_state()["state"]
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    if W > 0:
+        env.set_state(state0, 666.0, False)
+        rollout(env, seeded_actions(W, A))
+    env.set_state(state0, 666.0, False)          # inputs resident in HBM before the timed region
+    acts = seeded_actions(K, A)
+    barrier()
+    t0 = time.perf_counter()
+    loss = rollout(env, acts)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    total_substeps = K * sub * world
+    value = total_substeps / elapsed
+
+    out = {
+        "metric": "MPM substeps/sec (fwd+bwd)", "value": value, "unit": "substeps/s", "n_gpus": world,
+        "steps": K, "warmup": W, "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32" if args.dtype == "float32" else "f64", "data": "synthetic",
+        "config": {"workload": "config3_cube128", "n_grid": sim.n_grid, "n_particles": sim.n_particles,
+                   "substeps_per_step": sub, "primitives": 2, "positions": "f64", "loss": "sdf+density+hard contact",
+                   "parallelism": "single GPU" if world == 1 else f"{world} independent replicas (no collective)"},
+        "final_loss": float(loss),
+    }
+
+    if rank == 0 and not args.no_roofline:
+        # per-kernel durations, measured live with HIP events on the launch stream over the same K-step rollout
+        env.set_state(state0, 666.0, False)
+        nodes, blocks = sim.engine.grid_stats(0)
+        sim.engine.profile_enable(True)
+        rollout(env, acts)
+        prof = sim.engine.profile_read()
+        sim.engine.profile_enable(False)
+        N = sim.n_particles
+        kernels = {}
+        for name, (ms, cnt) in prof.items():
+            if cnt == 0:
+                continue
+            cN, cA = ALG[name]
+            avg = ms / cnt
+            kernels[name] = {"avg_us": 1e3 * avg, "launches": cnt, "alg_MB": 4e-6 * (cN * N + cA * nodes),
+                             "GBps": 4e-9 * (cN * N + cA * nodes) / (1e-3 * avg) if avg > 0 else 0.0}
+        dom = max(kernels, key=lambda k: kernels[k]["avg_us"] * kernels[k]["launches"])
+        alg_substep = 4.0 * (150 * N + 57 * nodes)
+        sum_us = sum(v["avg_us"] for v in kernels.values())
+        out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": kernels[dom]["GBps"], "peak": HBM_PEAK_GBS,
+                           "unit": "GB/s", "frac": kernels[dom]["GBps"] / HBM_PEAK_GBS, "traffic": None,
+                           "active_nodes": nodes, "active_blocks": blocks,
+                           "substep_alg_MB": alg_substep * 1e-6,
+                           "substep_kernel_sum_us": sum_us,
+                           "substep_frac": (alg_substep / (sum_us * 1e-6)) / (HBM_PEAK_GBS * 1e9),
+                           "kernels": kernels}
+    if rank == 0 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args, env)
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

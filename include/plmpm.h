@@ -152,6 +152,13 @@ int plmpm_loss_get_target_sdf(plmpm_handle h, double* out);
 /* ---- introspection ------------------------------------------------------------------------- */
 /* number of grid nodes with mass > 0 and number of active 4^3 blocks after the last forward substep */
 int plmpm_grid_stats(plmpm_handle h, int frame, int64_t* active_nodes, int64_t* active_blocks);
+/* per-kernel timing with HIP events recorded on the launch stream, around every hot-path kernel.
+ * enable(1) starts collecting; read() synchronises, returns summed milliseconds and launch counts for
+ * the plmpm_profile_kernel_count() kernel classes and resets the collection. */
+int plmpm_profile_enable(plmpm_handle h, int on);
+int plmpm_profile_kernel_count(void);
+const char* plmpm_profile_kernel_name(int id);
+int plmpm_profile_read(plmpm_handle h, double* total_ms, int64_t* launches);
 /* storage order: perm[i] = original particle index stored at sorted slot i */
 int plmpm_get_order(plmpm_handle h, int32_t* perm);
 

@@ -72,6 +72,10 @@ SYMBOLS = {
     "plmpm_loss_get_target_sdf": (_I, [_P, _P]),
     "plmpm_grid_stats": (_I, [_P, _I, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "plmpm_get_order": (_I, [_P, _P]),
+    "plmpm_profile_enable": (_I, [_P, _I]),
+    "plmpm_profile_kernel_count": (_I, []),
+    "plmpm_profile_kernel_name": (C.c_char_p, [_I]),
+    "plmpm_profile_read": (_I, [_P, _P, _P]),
 }
 
 _lib = None

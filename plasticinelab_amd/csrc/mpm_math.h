@@ -23,8 +23,12 @@
 
 #if defined(__HIPCC__)
 #define PLB_HD __host__ __device__ __forceinline__
+#define PLB_ROLL _Pragma("unroll 1")
+#define PLB_UNROLL _Pragma("unroll")
 #else
 #define PLB_HD inline
+#define PLB_ROLL
+#define PLB_UNROLL
 #endif
 
 namespace plb {
@@ -48,6 +52,8 @@ template <> PLB_HD double t_expm1<double>(double x) { return expm1(x); }
 template <class T> PLB_HD T t_abs(T x) { return x < T(0) ? -x : x; }
 template <class T> PLB_HD T t_max(T a, T b) { return a > b ? a : b; }
 template <class T> PLB_HD T t_min(T a, T b) { return a < b ? a : b; }
+// pick one of three by a loop index that stays a run-time value (outer stencil loop is kept rolled on the GPU)
+template <class T> PLB_HD T sel3(int i, T a, T b, T c) { return i == 0 ? a : (i == 1 ? b : c); }
 
 template <class T> struct Tol;
 template <> struct Tol<float> { static constexpr int sweeps = 5; static PLB_HD float dd() { return 2e-2f; } };
@@ -169,19 +175,27 @@ template <class T> PLB_HD void svd_eform(const T* Et, Svd3<T>& r) {
         for (int k = 0; k < 3; ++k)
             r.U[3 * k + i] = (V[3 * k + i] + Et[3 * k] * V[i] + Et[3 * k + 1] * V[3 + i] + Et[3 * k + 2] * V[6 + i]) * inv;
     }
-    // nearly singular F: rebuild the weakest column from the other two
-    int kmin = r.sig[0] < r.sig[1] ? (r.sig[0] < r.sig[2] ? 0 : 2) : (r.sig[1] < r.sig[2] ? 1 : 2);
-    if (r.sig[kmin] < T(1e-3)) {
+    // nearly singular F: rebuild the weakest column from the other two (constant indices only: a run-time
+    // index into U/sig would push the whole decomposition into scratch memory on the GPU)
+    T smin = t_min(r.sig[0], t_min(r.sig[1], r.sig[2]));
+    if (smin < T(1e-3)) {
         T Fm[9];
         for (int i = 0; i < 9; ++i) Fm[i] = Et[i];
         Fm[0] += T(1); Fm[4] += T(1); Fm[8] += T(1);
         T sgn = det3(Fm) < T(0) ? T(-1) : T(1);
-        int a = (kmin + 1) % 3, b = (kmin + 2) % 3;
-        T ua[3] = {r.U[a], r.U[3 + a], r.U[6 + a]}, ub[3] = {r.U[b], r.U[3 + b], r.U[6 + b]}, uc[3];
-        cross3(ua, ub, uc);
-        T nrm = t_sqrt(dot3(uc, uc));
-        T sc = nrm > T(0) ? sgn / nrm : T(0);
-        r.U[kmin] = uc[0] * sc; r.U[3 + kmin] = uc[1] * sc; r.U[6 + kmin] = uc[2] * sc;
+        bool done = false;
+        PLB_UNROLL
+        for (int k = 0; k < 3; ++k) {
+            if (!done && r.sig[k] == smin) {
+                const int a = (k + 1) % 3, b = (k + 2) % 3;
+                T ua[3] = {r.U[a], r.U[3 + a], r.U[6 + a]}, ub[3] = {r.U[b], r.U[3 + b], r.U[6 + b]}, uc[3];
+                cross3(ua, ub, uc);
+                T nrm = t_sqrt(dot3(uc, uc));
+                T sc = nrm > T(0) ? sgn / nrm : T(0);
+                r.U[k] = uc[0] * sc; r.U[3 + k] = uc[1] * sc; r.U[6 + k] = uc[2] * sc;
+                done = true;
+            }
+        }
     }
 }
 
@@ -364,16 +378,19 @@ PLB_HD void p2g_particle(const SimP<T>& P, const X* x, const T* v, const T* C, c
     constitutive_fwd(Et, mu, lam, ys, k, En, stress);
     for (int i = 0; i < 9; ++i) A[i] = P.kappa * stress[i] + P.p_mass * C[i];
     T mv[3] = {P.p_mass * v[0], P.p_mass * v[1], P.p_mass * v[2]};
-    for (int i = 0; i < 3; ++i)
+    PLB_ROLL
+    for (int i = 0; i < 3; ++i) {
+        const T wi = sel3(i, w[0][0], w[1][0], w[2][0]);
         for (int j = 0; j < 3; ++j)
             for (int l = 0; l < 3; ++l) {
                 T dp[3] = {(T(i) - fx[0]) * P.dx, (T(j) - fx[1]) * P.dx, (T(l) - fx[2]) * P.dx};
-                T wt = w[i][0] * w[j][1] * w[l][2];
+                T wt = wi * w[j][1] * w[l][2];
                 T mom[3];
                 for (int a = 0; a < 3; ++a)
                     mom[a] = wt * (mv[a] + A[3 * a] * dp[0] + A[3 * a + 1] * dp[1] + A[3 * a + 2] * dp[2]);
                 emit(i, j, l, wt * P.p_mass, mom);
             }
+    }
 }
 
 // g2p body (mpm_simulator.py:223-242).  Fetch(k0,k1,k2, gv[3]) reads grid_v_out.
@@ -384,12 +401,14 @@ PLB_HD void g2p_particle(const SimP<T>& P, const X* x, X* xn, T* vn, T* Cn, Fetc
     stencil<T, X>(x, P.inv_dx, base, fx, w, nullptr);
     for (int a = 0; a < 3; ++a) vn[a] = T(0);
     for (int a = 0; a < 9; ++a) Cn[a] = T(0);
-    for (int i = 0; i < 3; ++i)
+    PLB_ROLL
+    for (int i = 0; i < 3; ++i) {
+        const T wi = sel3(i, w[0][0], w[1][0], w[2][0]);
         for (int j = 0; j < 3; ++j)
             for (int l = 0; l < 3; ++l) {
                 T gv[3];
                 fetch(i, j, l, gv);
-                T wt = w[i][0] * w[j][1] * w[l][2];
+                T wt = wi * w[j][1] * w[l][2];
                 T dp[3] = {T(i) - fx[0], T(j) - fx[1], T(l) - fx[2]};
                 for (int a = 0; a < 3; ++a) {
                     T wg = wt * gv[a];
@@ -397,6 +416,7 @@ PLB_HD void g2p_particle(const SimP<T>& P, const X* x, X* xn, T* vn, T* Cn, Fetc
                     Cn[3 * a] += wg * dp[0]; Cn[3 * a + 1] += wg * dp[1]; Cn[3 * a + 2] += wg * dp[2];
                 }
             }
+    }
     for (int a = 0; a < 9; ++a) Cn[a] *= T(4) * P.inv_dx;
     for (int d = 0; d < 3; ++d) {
         X y = x[d] + (X)P.dt * (X)vn[d];
@@ -425,12 +445,18 @@ PLB_HD void g2p_particle_grad(const SimP<T>& P, const X* x, const T* vn, const T
     }
     T c4 = T(4) * P.inv_dx;
     T fxa[3] = {T(0), T(0), T(0)};
-    for (int i = 0; i < 3; ++i)
-        for (int j = 0; j < 3; ++j)
+    PLB_ROLL
+    for (int i = 0; i < 3; ++i) {
+        const T wi = sel3(i, w[0][0], w[1][0], w[2][0]);
+        const T dwi = sel3(i, dw[0][0], dw[1][0], dw[2][0]);
+        PLB_ROLL
+        for (int j = 0; j < 3; ++j) {
+            const T wj = sel3(j, w[0][1], w[1][1], w[2][1]);
+            const T dwj = sel3(j, dw[0][1], dw[1][1], dw[2][1]);
             for (int l = 0; l < 3; ++l) {
                 T gv[3];
                 fetch(i, j, l, gv);
-                T wt = w[i][0] * w[j][1] * w[l][2];
+                T wt = wi * wj * w[l][2];
                 T dp[3] = {T(i) - fx[0], T(j) - fx[1], T(l) - fx[2]};
                 T ga[3], wa = T(0);
                 for (int a = 0; a < 3; ++a) {
@@ -444,10 +470,12 @@ PLB_HD void g2p_particle_grad(const SimP<T>& P, const X* x, const T* vn, const T
                     fxa[2] -= c4 * wt * gv[a] * Cn_a[3 * a + 2];
                 }
                 emit(i, j, l, ga);
-                fxa[0] += wa * dw[i][0] * w[j][1] * w[l][2];
-                fxa[1] += wa * w[i][0] * dw[j][1] * w[l][2];
-                fxa[2] += wa * w[i][0] * w[j][1] * dw[l][2];
+                fxa[0] += wa * dwi * wj * w[l][2];
+                fxa[1] += wa * wi * dwj * w[l][2];
+                fxa[2] += wa * wi * wj * dw[l][2];
             }
+        }
+    }
     for (int d = 0; d < 3; ++d) xa[d] += P.inv_dx * fxa[d];
 }
 
@@ -461,39 +489,60 @@ PLB_HD void p2g_particle_grad(const SimP<T>& P, const X* x, const T* v, const T*
     int base[3];
     T fx[3], w[3][3], dw[3][3];
     stencil<T, X>(x, P.inv_dx, base, fx, w, dw);
+    // Gather pass first, with accumulators that do not need the affine matrix A = kappa*stress + m C:
+    //   va   = m sum_o w_o gva_o                 Aa[a][b] = sum_o w_o gva_o[a] dp_o[b]
+    //   s1[d] = sum_o (m gm_o + gva_o . m v) dw_o/dfx_d
+    //   M[a][b][d] = sum_o gva_o[a] dp_o[b] dw_o/dfx_d        (so that sum_o (gva_o^T A dp_o) dw_o = A : M)
+    // The SVD / return mapping then runs after the loop and its ~60 registers are not live across it.
+    T mv[3] = {P.p_mass * v[0], P.p_mass * v[1], P.p_mass * v[2]};
+    T Aa[9], s1[3] = {T(0), T(0), T(0)}, M[27];
+    for (int i = 0; i < 9; ++i) Aa[i] = T(0);
+    for (int i = 0; i < 27; ++i) M[i] = T(0);
+    va[0] = va[1] = va[2] = T(0);
+    PLB_ROLL
+    for (int i = 0; i < 3; ++i) {
+        const T wi = sel3(i, w[0][0], w[1][0], w[2][0]);
+        const T dwi = sel3(i, dw[0][0], dw[1][0], dw[2][0]);
+        PLB_ROLL
+        for (int j = 0; j < 3; ++j) {
+            const T wj = sel3(j, w[0][1], w[1][1], w[2][1]);
+            const T dwj = sel3(j, dw[0][1], dw[1][1], dw[2][1]);
+            for (int l = 0; l < 3; ++l) {
+                T g[4];
+                fetch(i, j, l, g);
+                const T* gva = g + 1;
+                T wt = wi * wj * w[l][2];
+                T dp[3] = {(T(i) - fx[0]) * P.dx, (T(j) - fx[1]) * P.dx, (T(l) - fx[2]) * P.dx};
+                T gw[3] = {dwi * wj * w[l][2], wi * dwj * w[l][2], wi * wj * dw[l][2]};
+                T sc = P.p_mass * g[0] + gva[0] * mv[0] + gva[1] * mv[1] + gva[2] * mv[2];
+                for (int d = 0; d < 3; ++d) s1[d] += sc * gw[d];
+                for (int a = 0; a < 3; ++a) {
+                    va[a] += P.p_mass * wt * gva[a];
+                    for (int b = 0; b < 3; ++b) {
+                        T gd = gva[a] * dp[b];
+                        Aa[3 * a + b] += wt * gd;
+                        M[9 * a + 3 * b] += gd * gw[0];
+                        M[9 * a + 3 * b + 1] += gd * gw[1];
+                        M[9 * a + 3 * b + 2] += gd * gw[2];
+                    }
+                }
+            }
+        }
+    }
     T Et[9], En[9], stress[9], A[9];
     f_tmp_eform(C, E, P.dt, Et);
     Consti<T> k;
     constitutive_fwd(Et, mu, lam, ys, k, En, stress);
     for (int i = 0; i < 9; ++i) A[i] = P.kappa * stress[i] + P.p_mass * C[i];
-    T mv[3] = {P.p_mass * v[0], P.p_mass * v[1], P.p_mass * v[2]};
-    T Aa[9], fxa[3] = {T(0), T(0), T(0)};
-    for (int i = 0; i < 9; ++i) Aa[i] = T(0);
-    va[0] = va[1] = va[2] = T(0);
-    for (int i = 0; i < 3; ++i)
-        for (int j = 0; j < 3; ++j)
-            for (int l = 0; l < 3; ++l) {
-                T g[4];
-                fetch(i, j, l, g);
-                const T* gva = g + 1;
-                T wt = w[i][0] * w[j][1] * w[l][2];
-                T dp[3] = {(T(i) - fx[0]) * P.dx, (T(j) - fx[1]) * P.dx, (T(l) - fx[2]) * P.dx};
-                T wa = P.p_mass * g[0];
-                for (int a = 0; a < 3; ++a) {
-                    T mom = mv[a] + A[3 * a] * dp[0] + A[3 * a + 1] * dp[1] + A[3 * a + 2] * dp[2];
-                    wa += gva[a] * mom;
-                    va[a] += P.p_mass * wt * gva[a];
-                    Aa[3 * a] += wt * gva[a] * dp[0];
-                    Aa[3 * a + 1] += wt * gva[a] * dp[1];
-                    Aa[3 * a + 2] += wt * gva[a] * dp[2];
-                }
-                // d/d dp = wt * A^T gva ; dp = (k - fx) dx
-                for (int b = 0; b < 3; ++b)
-                    fxa[b] -= P.dx * wt * (A[b] * gva[0] + A[3 + b] * gva[1] + A[6 + b] * gva[2]);
-                fxa[0] += wa * dw[i][0] * w[j][1] * w[l][2];
-                fxa[1] += wa * w[i][0] * dw[j][1] * w[l][2];
-                fxa[2] += wa * w[i][0] * w[j][1] * dw[l][2];
-            }
+    T fxa[3];
+    for (int d = 0; d < 3; ++d) {
+        T acc = s1[d];
+        for (int a = 0; a < 3; ++a) {
+            for (int b = 0; b < 3; ++b) acc += A[3 * a + b] * M[9 * a + 3 * b + d];
+            acc -= P.dx * A[3 * a + d] * va[a] / P.p_mass;       // d/d dp: sum_o w_o A^T gva_o, dp = (k - fx) dx
+        }
+        fxa[d] = acc;
+    }
     for (int d = 0; d < 3; ++d) xa_io[d] += P.inv_dx * fxa[d];
     T GS[9], Fta[9];
     for (int i = 0; i < 9; ++i) { Ca[i] = P.p_mass * Aa[i]; GS[i] = P.kappa * Aa[i]; }

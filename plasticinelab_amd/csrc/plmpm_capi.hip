@@ -64,7 +64,38 @@ struct plmpm_sim {
     bool have_target = false;
     double target_max = 0, target_sum = 0;
     int adj_frame[2] = {-1, -1};
+    // optional per-kernel timing with HIP events on the launch stream (plmpm_profile_*)
+    bool prof = false;
+    std::vector<hipEvent_t> ev_pool;
+    std::vector<std::pair<int, int>> ev_used;     // (kernel id, index of the start event)
+    size_t ev_next = 0;
 };
+
+enum KernelId { K_P2G = 0, K_GRID_OP, K_G2P, K_P2G_RE, K_GRID_OP_RE, K_G2P_GRAD, K_GRID_OP_GRAD, K_P2G_GRAD, K_CLEAR, K_COUNT };
+static const char* kKernelNames[K_COUNT] = {"p2g", "grid_op", "g2p", "p2g_recompute", "grid_op_recompute",
+                                            "g2p_grad", "grid_op_grad", "p2g_grad", "clear_active"};
+
+static void prof_begin(plmpm_sim* s, int id) {
+    if (!s->prof) return;
+    if (s->ev_next + 2 > s->ev_pool.size()) {
+        size_t old = s->ev_pool.size();
+        s->ev_pool.resize(old + 1024);
+        for (size_t i = old; i < s->ev_pool.size(); ++i) (void)hipEventCreate(&s->ev_pool[i]);
+    }
+    s->ev_used.push_back({id, (int)s->ev_next});
+    (void)hipEventRecord(s->ev_pool[s->ev_next], s->stream);
+    s->ev_next += 2;
+}
+static void prof_end(plmpm_sim* s) {
+    if (!s->prof) return;
+    (void)hipEventRecord(s->ev_pool[s->ev_used.back().second + 1], s->stream);
+}
+#define LAUNCH(s, id, kern, grid, ...)                                                     \
+    do {                                                                                   \
+        prof_begin(s, id);                                                                 \
+        hipLaunchKernelGGL(kern, grid, dim3(kBlock), 0, (s)->stream, __VA_ARGS__);        \
+        prof_end(s);                                                                       \
+    } while (0)
 
 // ---------------------------------------------------------------------------------------------
 template <class T> static Dev<T> make_dev(const plmpm_sim* s) {
@@ -423,20 +454,20 @@ static inline int nblocks_grid(const plmpm_sim* s) { return (s->nblk + (kBlock /
 
 template <class T> static int substep_fwd(plmpm_sim* s, int f) {
     Dev<T> D = make_dev<T>(s);
-    hipLaunchKernelGGL((k_p2g<T, true>), dim3(nblocks_particles(s)), dim3(kBlock), 0, s->stream, D, f);
-    hipLaunchKernelGGL((k_grid_op<T, true>), dim3(nblocks_grid(s)), dim3(kBlock), 0, s->stream, D, f);
-    hipLaunchKernelGGL((k_g2p<T>), dim3(nblocks_particles(s)), dim3(kBlock), 0, s->stream, D, f);
+    LAUNCH(s, K_P2G, (k_p2g<T, true>), dim3(nblocks_particles(s)), D, f);
+    LAUNCH(s, K_GRID_OP, (k_grid_op<T, true>), dim3(nblocks_grid(s)), D, f);
+    LAUNCH(s, K_G2P, (k_g2p<T>), dim3(nblocks_particles(s)), D, f);
     return 0;
 }
 template <class T> static int substep_bwd(plmpm_sim* s, int f) {
     Dev<T> D = make_dev<T>(s);
     const int src = (f + 1) & 1, dst = f & 1;
-    hipLaunchKernelGGL((k_p2g<T, false>), dim3(nblocks_particles(s)), dim3(kBlock), 0, s->stream, D, f);
-    hipLaunchKernelGGL((k_grid_op<T, false>), dim3(nblocks_grid(s)), dim3(kBlock), 0, s->stream, D, f);
-    hipLaunchKernelGGL((k_g2p_grad<T>), dim3(nblocks_particles(s)), dim3(kBlock), 0, s->stream, D, f, src, dst);
-    hipLaunchKernelGGL((k_grid_op_grad<T>), dim3(nblocks_grid(s)), dim3(kBlock), 0, s->stream, D, f);
-    hipLaunchKernelGGL((k_p2g_grad<T>), dim3(nblocks_particles(s)), dim3(kBlock), 0, s->stream, D, f, src, dst);
-    hipLaunchKernelGGL((k_clear_active<T>), dim3(nblocks_grid(s)), dim3(kBlock), 0, s->stream, D);
+    LAUNCH(s, K_P2G_RE, (k_p2g<T, false>), dim3(nblocks_particles(s)), D, f);
+    LAUNCH(s, K_GRID_OP_RE, (k_grid_op<T, false>), dim3(nblocks_grid(s)), D, f);
+    LAUNCH(s, K_G2P_GRAD, (k_g2p_grad<T>), dim3(nblocks_particles(s)), D, f, src, dst);
+    LAUNCH(s, K_GRID_OP_GRAD, (k_grid_op_grad<T>), dim3(nblocks_grid(s)), D, f);
+    LAUNCH(s, K_P2G_GRAD, (k_p2g_grad<T>), dim3(nblocks_particles(s)), D, f, src, dst);
+    LAUNCH(s, K_CLEAR, (k_clear_active<T>), dim3(nblocks_grid(s)), D);
     s->adj_frame[dst] = f;
     return 0;
 }
@@ -576,6 +607,7 @@ int plmpm_create(const plmpm_config* cfg, const plmpm_primitive* prims, plmpm_ha
 }
 
 int plmpm_destroy(plmpm_handle s) {
+    if (s) for (auto e : s->ev_pool) (void)hipEventDestroy(e);
     delete s;
     return 0;
 }
@@ -648,9 +680,20 @@ int plmpm_set_materials(plmpm_handle s, const double* mu, const double* lam, con
 }
 
 
-// storage order: particles sorted by the blocked index of their stencil base node (4^3 blocks, z-major)
+static inline uint64_t spread3(uint64_t v) {      // bits of v -> every third bit
+    v &= 0x1fffff;
+    v = (v | v << 32) & 0x1f00000000ffffULL;
+    v = (v | v << 16) & 0x1f0000ff0000ffULL;
+    v = (v | v << 8) & 0x100f00f00f00f00fULL;
+    v = (v | v << 4) & 0x10c30c30c30c30c3ULL;
+    v = (v | v << 2) & 0x1249249249249249ULL;
+    return v;
+}
+// storage order: particles sorted by the Morton code of the 4^3 block of their stencil base node, then by
+// the cell inside the block.  Consecutive 256-particle workgroups therefore cover compact boxes of cells
+// (small LDS tiles), and lanes of a wave that share a cell are adjacent (wave-level pre-reduction).
 static void compute_order(plmpm_sim* s, const double* x) {
-    const int n = s->n, nb = s->nb;
+    const int n = s->n;
     std::vector<uint64_t> key(s->N);
     for (int i = 0; i < s->N; ++i) {
         int b[3];
@@ -658,7 +701,8 @@ static void compute_order(plmpm_sim* s, const double* x) {
             b[d] = (int)(x[(size_t)3 * i + d] * n - 0.5);
             b[d] = std::min(std::max(b[d], 0), n - 1);
         }
-        uint64_t k = ((((uint64_t)(b[2] >> 2) * nb + (b[1] >> 2)) * nb + (b[0] >> 2)) << 6) | ((b[2] & 3) << 4) | ((b[1] & 3) << 2) | (b[0] & 3);
+        uint64_t m = spread3(b[0] >> 2) | (spread3(b[1] >> 2) << 1) | (spread3(b[2] >> 2) << 2);
+        uint64_t k = (m << 6) | ((b[2] & 3) << 4) | ((b[1] & 3) << 2) | (b[0] & 3);
         key[i] = (k << 32) | (uint32_t)i;
     }
     std::sort(key.begin(), key.end());
@@ -982,6 +1026,30 @@ int plmpm_grid_stats(plmpm_handle s, int frame, int64_t* active_nodes, int64_t* 
     hipFree(d_out);
     if (active_nodes) *active_nodes = (int64_t)h[0];
     if (active_blocks) *active_blocks = (int64_t)h[1];
+    return 0;
+}
+
+int plmpm_profile_enable(plmpm_handle s, int on) {
+    REQUIRE(s, "null handle");
+    s->prof = on != 0;
+    s->ev_used.clear();
+    s->ev_next = 0;
+    return 0;
+}
+int plmpm_profile_kernel_count(void) { return K_COUNT; }
+const char* plmpm_profile_kernel_name(int id) { return (id >= 0 && id < K_COUNT) ? kKernelNames[id] : ""; }
+int plmpm_profile_read(plmpm_handle s, double* total_ms, int64_t* launches) {
+    REQUIRE(s && total_ms && launches, "null argument");
+    HIPCHK(hipStreamSynchronize(s->stream));
+    for (int i = 0; i < K_COUNT; ++i) { total_ms[i] = 0; launches[i] = 0; }
+    for (auto& u : s->ev_used) {
+        float ms = 0;
+        HIPCHK(hipEventElapsedTime(&ms, s->ev_pool[u.second], s->ev_pool[u.second + 1]));
+        total_ms[u.first] += ms;
+        launches[u.first] += 1;
+    }
+    s->ev_used.clear();
+    s->ev_next = 0;
     return 0;
 }
 

@@ -17,10 +17,10 @@ namespace plb {
 
 constexpr int kBlock = 256;          // threads per workgroup in particle kernels
 constexpr int kMaxPrim = 8;
-// LDS tile capacity (nodes) of the scatter/gather kernels: 32 KiB per tile for either scalar type
+// LDS tile capacity (nodes) of the scatter/gather kernels: 16 KiB per tile for either scalar type
 template <class T> struct TileCap;
-template <> struct TileCap<float> { static constexpr int nodes = 2048; };
-template <> struct TileCap<double> { static constexpr int nodes = 1024; };
+template <> struct TileCap<float> { static constexpr int nodes = 1024; };
+template <> struct TileCap<double> { static constexpr int nodes = 512; };
 
 template <class T> struct Vec4 { T x, y, z, w; };
 template <> struct __attribute__((aligned(16))) Vec4<float> { float x, y, z, w; };
@@ -98,6 +98,47 @@ __device__ __forceinline__ int wave_max(int v) {
     return v;
 }
 
+// Wave-level segmented reduction.  Particles are stored cell-sorted, so lanes that share a stencil base
+// form runs; the 27 x 4 per-particle contributions of a run are summed with shuffles and only the run's
+// head lane touches LDS / HBM atomics (same-address atomics serialise, shuffles do not).
+// Runs are additionally cut at 16-lane DPP rows so the whole reduction is 4 row-shift steps of pure VALU.
+template <class T> struct Seg {
+    T m1, m2, m4, m8;   // 1 where the lane `d` to the right still belongs to this lane's run
+    bool head;          // first lane of a (row-clipped) run
+};
+template <class T> __device__ __forceinline__ Seg<T> wave_segments(int key) {
+    const int lane = threadIdx.x & 63;
+    int prev = __shfl_up(key, 1);
+    Seg<T> s;
+    s.head = ((lane & 15) == 0) || (key != prev);
+    unsigned long long heads = __ballot(s.head);
+    unsigned long long higher = lane == 63 ? 0ULL : (heads >> (lane + 1));
+    const int end = higher ? lane + __ffsll((long long)higher) - 1 : 63;
+    s.m1 = lane + 1 <= end ? T(1) : T(0);
+    s.m2 = lane + 2 <= end ? T(1) : T(0);
+    s.m4 = lane + 4 <= end ? T(1) : T(0);
+    s.m8 = lane + 8 <= end ? T(1) : T(0);
+    return s;
+}
+// value of the lane D to the right inside the 16-lane row (0 outside the row)
+template <int D> __device__ __forceinline__ float row_shl(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x100 + D, 0xf, 0xf, true));
+}
+template <int D> __device__ __forceinline__ double row_shl(double v) {
+    long long b = __builtin_bit_cast(long long, v);
+    int lo = (int)(b & 0xffffffffLL), hi = (int)(b >> 32);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x100 + D, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x100 + D, 0xf, 0xf, true);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+template <class T> __device__ __forceinline__ T seg_sum(T v, const Seg<T>& s) {
+    v += row_shl<1>(v) * s.m1;
+    v += row_shl<2>(v) * s.m2;
+    v += row_shl<4>(v) * s.m4;
+    v += row_shl<8>(v) * s.m8;
+    return v;
+}
+
 // all threads call; valid == false for padding lanes.  sred: LDS int[6*4+8]
 __device__ __forceinline__ Tile block_tile(const int* base, bool valid, int* sred, int cap) {
     int lo[3], hi[3];
@@ -145,28 +186,41 @@ __global__ __launch_bounds__(kBlock) void k_p2g(Dev<T> D, int f) {
         for (int i = threadIdx.x; i < tn; i += kBlock) tile[i] = Vec4<T>{T(0), T(0), T(0), T(0)};
         __syncthreads();
     }
-    if (valid) {
-        T v[3], C[9], E[9], En[9];
-        for (int d = 0; d < 3; ++d) v[d] = R[d * Np + p];
-        for (int d = 0; d < 9; ++d) { C[d] = R[(3 + d) * Np + p]; E[d] = R[(12 + d) * Np + p]; }
-        T mu = D.mu[p], lam = D.lam[p], ys = D.ys[p];
+    {
+        // every lane runs the arithmetic (padding lanes on dummy data) so the shuffles below are well defined
+        T v[3] = {T(0), T(0), T(0)}, C[9], E[9], En[9];
+        for (int d = 0; d < 9; ++d) { C[d] = T(0); E[d] = T(0); }
+        T mu = T(1), lam = T(1), ys = T(1);
+        if (valid) {
+            for (int d = 0; d < 3; ++d) v[d] = R[d * Np + p];
+            for (int d = 0; d < 9; ++d) { C[d] = R[(3 + d) * Np + p]; E[d] = R[(12 + d) * Np + p]; }
+            mu = D.mu[p]; lam = D.lam[p]; ys = D.ys[p];
+        }
+        const Seg<T> sg = wave_segments<T>(valid ? (base[2] * D.P.n + base[1]) * D.P.n + base[0] : -1);
+        const bool emitter = sg.head && valid;
         int b2[3];
         if (tl.ok) {
             const int ox = base[0] - tl.o[0], oy = base[1] - tl.o[1], oz = base[2] - tl.o[2];
             const int ex = tl.e[0], exy = tl.e[0] * tl.e[1];
             p2g_particle<T, double>(D.P, x, v, C, E, mu, lam, ys, En, b2, [&](int i, int j, int l, T mass, const T* mom) {
-                T* q = reinterpret_cast<T*>(&tile[(oz + l) * exy + (oy + j) * ex + (ox + i)]);
-                atomicAdd(q, mass); atomicAdd(q + 1, mom[0]); atomicAdd(q + 2, mom[1]); atomicAdd(q + 3, mom[2]);
+                T a0 = seg_sum(mass, sg), a1 = seg_sum(mom[0], sg), a2 = seg_sum(mom[1], sg), a3 = seg_sum(mom[2], sg);
+                if (emitter) {
+                    T* q = reinterpret_cast<T*>(&tile[(oz + l) * exy + (oy + j) * ex + (ox + i)]);
+                    atomicAdd(q, a0); atomicAdd(q + 1, a1); atomicAdd(q + 2, a2); atomicAdd(q + 3, a3);
+                }
             });
         } else {
             p2g_particle<T, double>(D.P, x, v, C, E, mu, lam, ys, En, b2, [&](int i, int j, int l, T mass, const T* mom) {
-                int idx = node_index(D.nb, base[0] + i, base[1] + j, base[2] + l);
-                T* q = reinterpret_cast<T*>(&D.grid_in[idx]);
-                atomicAdd(q, mass); atomicAdd(q + 1, mom[0]); atomicAdd(q + 2, mom[1]); atomicAdd(q + 3, mom[2]);
-                D.flags[idx >> 6] = 1;
+                T a0 = seg_sum(mass, sg), a1 = seg_sum(mom[0], sg), a2 = seg_sum(mom[1], sg), a3 = seg_sum(mom[2], sg);
+                if (emitter) {
+                    int idx = node_index(D.nb, base[0] + i, base[1] + j, base[2] + l);
+                    T* q = reinterpret_cast<T*>(&D.grid_in[idx]);
+                    atomicAdd(q, a0); atomicAdd(q + 1, a1); atomicAdd(q + 2, a2); atomicAdd(q + 3, a3);
+                    D.flags[idx >> 6] = 1;
+                }
             });
         }
-        if (WRITE_F) {
+        if (WRITE_F && valid) {
             T* R1 = frame_r(D, f + 1);
             for (int d = 0; d < 9; ++d) R1[(12 + d) * Np + p] = En[d];
         }
@@ -281,12 +335,17 @@ __global__ __launch_bounds__(kBlock) void k_g2p_grad(Dev<T> D, int f, int src, i
         }
         __syncthreads();
     }
-    if (valid) {
+    {
         const T* R1 = frame_r(D, f + 1);
         const T* A1 = D.adj[src];
-        T vn[3], xna[3], vna[3], Cna[9], xa[3];
-        for (int d = 0; d < 3; ++d) { vn[d] = R1[d * Np + p]; xna[d] = A1[d * Np + p]; vna[d] = A1[(3 + d) * Np + p]; }
-        for (int d = 0; d < 9; ++d) Cna[d] = A1[(6 + d) * Np + p];
+        T vn[3] = {T(0), T(0), T(0)}, xna[3] = {T(0), T(0), T(0)}, vna[3] = {T(0), T(0), T(0)}, Cna[9], xa[3];
+        for (int d = 0; d < 9; ++d) Cna[d] = T(0);
+        if (valid) {
+            for (int d = 0; d < 3; ++d) { vn[d] = R1[d * Np + p]; xna[d] = A1[d * Np + p]; vna[d] = A1[(3 + d) * Np + p]; }
+            for (int d = 0; d < 9; ++d) Cna[d] = A1[(6 + d) * Np + p];
+        }
+        const Seg<T> sg = wave_segments<T>(valid ? (base[2] * D.P.n + base[1]) * D.P.n + base[0] : -1);
+        const bool emitter = sg.head && valid;
         if (tl.ok) {
             const int ox = base[0] - tl.o[0], oy = base[1] - tl.o[1], oz = base[2] - tl.o[2];
             g2p_particle_grad<T, double>(D.P, x, vn, xna, vna, Cna, xa,
@@ -295,22 +354,33 @@ __global__ __launch_bounds__(kBlock) void k_g2p_grad(Dev<T> D, int f, int src, i
                     gv[0] = a.x; gv[1] = a.y; gv[2] = a.z;
                 },
                 [&](int i, int j, int l, const T* ga) {
-                    T* q = reinterpret_cast<T*>(&tile_a[(oz + l) * exy + (oy + j) * ex + (ox + i)]);
-                    atomicAdd(q, ga[0]); atomicAdd(q + 1, ga[1]); atomicAdd(q + 2, ga[2]);
+                    T a0 = seg_sum(ga[0], sg), a1 = seg_sum(ga[1], sg), a2 = seg_sum(ga[2], sg);
+                    if (emitter) {
+                        T* q = reinterpret_cast<T*>(&tile_a[(oz + l) * exy + (oy + j) * ex + (ox + i)]);
+                        atomicAdd(q, a0); atomicAdd(q + 1, a1); atomicAdd(q + 2, a2);
+                    }
                 });
         } else {
             g2p_particle_grad<T, double>(D.P, x, vn, xna, vna, Cna, xa,
                 [&](int i, int j, int l, T* gv) {
-                    Vec4<T> a = D.grid_out[node_index(D.nb, base[0] + i, base[1] + j, base[2] + l)];
-                    gv[0] = a.x; gv[1] = a.y; gv[2] = a.z;
+                    gv[0] = gv[1] = gv[2] = T(0);
+                    if (valid) {
+                        Vec4<T> a = D.grid_out[node_index(D.nb, base[0] + i, base[1] + j, base[2] + l)];
+                        gv[0] = a.x; gv[1] = a.y; gv[2] = a.z;
+                    }
                 },
                 [&](int i, int j, int l, const T* ga) {
-                    T* q = reinterpret_cast<T*>(&D.grid_out_adj[node_index(D.nb, base[0] + i, base[1] + j, base[2] + l)]);
-                    atomicAdd(q, ga[0]); atomicAdd(q + 1, ga[1]); atomicAdd(q + 2, ga[2]);
+                    T a0 = seg_sum(ga[0], sg), a1 = seg_sum(ga[1], sg), a2 = seg_sum(ga[2], sg);
+                    if (emitter) {
+                        T* q = reinterpret_cast<T*>(&D.grid_out_adj[node_index(D.nb, base[0] + i, base[1] + j, base[2] + l)]);
+                        atomicAdd(q, a0); atomicAdd(q + 1, a1); atomicAdd(q + 2, a2);
+                    }
                 });
         }
-        T* A0 = D.adj[dst];
-        for (int d = 0; d < 3; ++d) A0[d * Np + p] = xa[d];
+        if (valid) {
+            T* A0 = D.adj[dst];
+            for (int d = 0; d < 3; ++d) A0[d * Np + p] = xa[d];
+        }
     }
     if (tl.ok) {
         __syncthreads();

@@ -206,5 +206,15 @@ class Engine:
         L.check(self.lib.plmpm_get_order(self.h, _ptr(p)))
         return p
 
+    def profile_enable(self, on=True):
+        L.check(self.lib.plmpm_profile_enable(self.h, int(on)))
+
+    def profile_read(self):
+        """{kernel name: (total ms, launches)} measured with HIP events on the launch stream."""
+        k = self.lib.plmpm_profile_kernel_count()
+        ms, cnt = np.zeros(k), np.zeros(k, np.int64)
+        L.check(self.lib.plmpm_profile_read(self.h, _ptr(ms), _ptr(cnt)))
+        return {self.lib.plmpm_profile_kernel_name(i).decode(): (float(ms[i]), int(cnt[i])) for i in range(k)}
+
     def synchronize(self):
         torch.cuda.current_stream(self.device).synchronize()
