@@ -1,11 +1,11 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -5
-timeout 900 python bench.py --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/bench_r01_b.json 2> gpurun_out/bench_r01_b.err
-tail -3 gpurun_out/bench_r01_b.err
+timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -3
+timeout 900 python bench.py --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/bench_r01_d.json 2> gpurun_out/bench_r01_d.err
+tail -3 gpurun_out/bench_r01_d.err
 python - <<'PY'
 import json
-d=json.load(open('gpurun_out/bench_r01_b.json'))
-print(d['value'], d['roofline']['substep_kernel_sum_us'], d['roofline']['substep_frac'])
+d=json.load(open('gpurun_out/bench_r01_d.json'))
+print(d['value'], d['ms_per_step'], d['roofline']['substep_kernel_sum_us'], d['roofline']['substep_frac'])
 for k,v in d['roofline']['kernels'].items(): print(k, round(v['avg_us'],1), round(v['GBps'],1))
 PY

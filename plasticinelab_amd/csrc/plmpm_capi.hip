@@ -115,8 +115,9 @@ template <class T> static Dev<T> make_dev(const plmpm_sim* s) {
     D.state = s->state;
     D.adj[0] = (T*)s->adj[0]; D.adj[1] = (T*)s->adj[1];
     D.mu = (T*)s->mu; D.lam = (T*)s->lam; D.ys = (T*)s->ys;
-    D.grid_in = (Vec4<T>*)s->grid_in; D.grid_out = (Vec4<T>*)s->grid_out;
-    D.grid_out_adj = (Vec4<T>*)s->grid_out_adj; D.grid_in_adj = (Vec4<T>*)s->grid_in_adj;
+    for (int c = 0; c < 4; ++c) D.gin[c] = (T*)s->grid_in + (size_t)c * s->G;
+    for (int c = 0; c < 3; ++c) D.goa[c] = (T*)s->grid_out_adj + (size_t)c * s->G;
+    D.grid_out = (Vec4<T>*)s->grid_out; D.grid_in_adj = (Vec4<T>*)s->grid_in_adj;
     D.flags = s->flags;
     D.ppos = s->ppos; D.prot = s->prot; D.ppos_a = s->ppos_a; D.prot_a = s->prot_a;
     for (int i = 0; i < s->P; ++i) {
@@ -249,20 +250,6 @@ __global__ void k_fk_chain_grad(PrimChainArgs A, int first, int n, int step, con
 }
 
 // ---- loss -----------------------------------------------------------------------------------
-// compute_grid_m_kernel (mpm_simulator.py:382-392)
-template <class T> __global__ void k_grid_mass(Dev<T> D, int f, T* gm) {
-    int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= D.N) return;
-    const double* X = frame_x(D, f);
-    double x[3] = {X[p], X[D.Npad + p], X[2 * D.Npad + p]};
-    int base[3];
-    T fx[3], w[3][3];
-    stencil<T, double>(x, D.P.inv_dx, base, fx, w, nullptr);
-    for (int i = 0; i < 3; ++i)
-        for (int j = 0; j < 3; ++j)
-            for (int l = 0; l < 3; ++l)
-                atomicAdd(&gm[node_index(D.nb, base[0] + i, base[1] + j, base[2] + l)], w[i][0] * w[j][1] * w[l][2] * D.P.p_mass);
-}
 __device__ __forceinline__ double block_sum(double v, double* sh) {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
     int w = threadIdx.x >> 6;
@@ -433,7 +420,7 @@ template <class T> __global__ void k_download_grid(int n, int nb, const T* block
 template <class T> __global__ void k_grid_stats(Dev<T> D, unsigned long long* out) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     size_t G = (size_t)D.nb * D.nb * D.nb * 64;
-    if (i < G && D.grid_in[i].x > T(0)) atomicAdd(&out[0], 1ULL);
+    if (i < G && D.gin[0][i] > T(0)) atomicAdd(&out[0], 1ULL);
     if (i < G / 64 && D.flags[i]) atomicAdd(&out[1], 1ULL);
 }
 
@@ -512,7 +499,7 @@ template <class T> static int download_grid_t(plmpm_sim* s, const char* src, dou
 template <class T> static int loss_scatter_t(plmpm_sim* s, int f) {
     Dev<T> D = make_dev<T>(s);
     hipMemsetAsync(s->loss_gm, 0, s->G * s->tsz, s->stream);
-    hipLaunchKernelGGL((k_grid_mass<T>), dim3(s->Npad / 256), dim3(256), 0, s->stream, D, f, (T*)s->loss_gm);
+    hipLaunchKernelGGL((k_grid_mass<T>), dim3(nblocks_particles(s)), dim3(kBlock), 0, s->stream, D, f, (T*)s->loss_gm);
     return 0;
 }
 

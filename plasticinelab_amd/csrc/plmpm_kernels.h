@@ -4,8 +4,11 @@
 //   particle frame f : [x0 x1 x2 : double x Npad] [v0..2, C00..22, E00..22 : T x Npad]   (SoA, E = F - I)
 //   adjoint frame    : [xa0..2, va0..2, Ca00..22, Ea00..22 : T x Npad]                    (2 ping-pong frames)
 //   grid             : 4x4x4-node blocks, block index (bz*nb + by)*nb + bx, node (lz*16 + ly*4 + lx);
-//                      grid_in  = T4 {m, mv_x, mv_y, mv_z}, grid_out = T4 {v_x, v_y, v_z, 0},
-//                      grid_out_adj / grid_in_adj likewise; flags[block] marks blocks touched this substep.
+//                      grid_out = T4 {v_x, v_y, v_z, 0} and grid_in_adj = T4 {m', mv'} are AoS (gathered 16 B at a
+//                      time); the two grids that are *accumulated* with atomics, grid_in {m, mv_x, mv_y, mv_z} and
+//                      grid_out_adj {v'_x, v'_y, v'_z}, are SoA: float atomics run at ~300 G/s on consecutive
+//                      addresses but ~80 G/s at a 16-byte stride (profiles/microbench/global_atomics.hip).
+//                      flags[block] marks blocks touched this substep.
 // Particles are stored cell-sorted (plmpm_set_frame(resort=1)), so a 256-thread workgroup's particles
 // cover a small box of cells: the scatter / gather kernels stage that box in LDS (tile path) and fall back
 // to direct global atomics when a workgroup's bounding box does not fit.
@@ -42,7 +45,9 @@ template <class T> struct Dev {
     char* state;                     // particle frames
     T* adj[2];                       // ping-pong adjoint frames
     T *mu, *lam, *ys;
-    Vec4<T>*grid_in, *grid_out, *grid_out_adj, *grid_in_adj;
+    T* gin[4];                       // grid_m, grid_v_in x/y/z (SoA, accumulated)
+    T* goa[3];                       // grid_v_out.grad x/y/z (SoA, accumulated)
+    Vec4<T>*grid_out, *grid_in_adj;  // AoS
     int* flags;
     // primitives (double): pos[(F+1)][P][3], rot[(F+1)][P][4] and adjoints
     const double *ppos, *prot;
@@ -170,7 +175,9 @@ __device__ __forceinline__ Tile block_tile(const int* base, bool valid, int* sre
 template <class T, bool WRITE_F>
 __global__ __launch_bounds__(kBlock) void k_p2g(Dev<T> D, int f) {
     __shared__ int sred[32];
-    __shared__ Vec4<T> tile[TileCap<T>::nodes];
+    // accumulate in double: on gfx950 ds_add_f64 is ~5x cheaper per instruction than ds_add_f32
+    // (profiles/microbench/lds_atomics.hip), and the node sums lose no precision
+    __shared__ Vec4<double> tile[TileCap<T>::nodes];
     const int p = blockIdx.x * kBlock + threadIdx.x;
     const bool valid = p < D.N;
     const double* X = frame_x(D, f);
@@ -183,7 +190,7 @@ __global__ __launch_bounds__(kBlock) void k_p2g(Dev<T> D, int f) {
     Tile tl = block_tile(base, valid, sred, TileCap<T>::nodes);
     const int tn = tl.e[0] * tl.e[1] * tl.e[2];
     if (tl.ok) {
-        for (int i = threadIdx.x; i < tn; i += kBlock) tile[i] = Vec4<T>{T(0), T(0), T(0), T(0)};
+        for (int i = threadIdx.x; i < tn; i += kBlock) tile[i] = Vec4<double>{0.0, 0.0, 0.0, 0.0};
         __syncthreads();
     }
     {
@@ -205,8 +212,8 @@ __global__ __launch_bounds__(kBlock) void k_p2g(Dev<T> D, int f) {
             p2g_particle<T, double>(D.P, x, v, C, E, mu, lam, ys, En, b2, [&](int i, int j, int l, T mass, const T* mom) {
                 T a0 = seg_sum(mass, sg), a1 = seg_sum(mom[0], sg), a2 = seg_sum(mom[1], sg), a3 = seg_sum(mom[2], sg);
                 if (emitter) {
-                    T* q = reinterpret_cast<T*>(&tile[(oz + l) * exy + (oy + j) * ex + (ox + i)]);
-                    atomicAdd(q, a0); atomicAdd(q + 1, a1); atomicAdd(q + 2, a2); atomicAdd(q + 3, a3);
+                    double* q = reinterpret_cast<double*>(&tile[(oz + l) * exy + (oy + j) * ex + (ox + i)]);
+                    atomicAdd(q, (double)a0); atomicAdd(q + 1, (double)a1); atomicAdd(q + 2, (double)a2); atomicAdd(q + 3, (double)a3);
                 }
             });
         } else {
@@ -214,8 +221,8 @@ __global__ __launch_bounds__(kBlock) void k_p2g(Dev<T> D, int f) {
                 T a0 = seg_sum(mass, sg), a1 = seg_sum(mom[0], sg), a2 = seg_sum(mom[1], sg), a3 = seg_sum(mom[2], sg);
                 if (emitter) {
                     int idx = node_index(D.nb, base[0] + i, base[1] + j, base[2] + l);
-                    T* q = reinterpret_cast<T*>(&D.grid_in[idx]);
-                    atomicAdd(q, a0); atomicAdd(q + 1, a1); atomicAdd(q + 2, a2); atomicAdd(q + 3, a3);
+                    atomicAdd(&D.gin[0][idx], a0); atomicAdd(&D.gin[1][idx], a1);
+                    atomicAdd(&D.gin[2][idx], a2); atomicAdd(&D.gin[3][idx], a3);
                     D.flags[idx >> 6] = 1;
                 }
             });
@@ -229,12 +236,12 @@ __global__ __launch_bounds__(kBlock) void k_p2g(Dev<T> D, int f) {
         __syncthreads();
         const int ex = tl.e[0], exy = tl.e[0] * tl.e[1];
         for (int i = threadIdx.x; i < tn; i += kBlock) {
-            Vec4<T> a = tile[i];
-            if (a.x != T(0) || a.y != T(0) || a.z != T(0) || a.w != T(0)) {
+            Vec4<double> a = tile[i];
+            if (a.x != 0.0 || a.y != 0.0 || a.z != 0.0 || a.w != 0.0) {
                 int lz = i / exy, r = i - lz * exy, ly = r / ex, lx = r - ly * ex;
                 int idx = node_index(D.nb, tl.o[0] + lx, tl.o[1] + ly, tl.o[2] + lz);
-                T* q = reinterpret_cast<T*>(&D.grid_in[idx]);
-                atomicAdd(q, a.x); atomicAdd(q + 1, a.y); atomicAdd(q + 2, a.z); atomicAdd(q + 3, a.w);
+                atomicAdd(&D.gin[0][idx], (T)a.x); atomicAdd(&D.gin[1][idx], (T)a.y);
+                atomicAdd(&D.gin[2][idx], (T)a.z); atomicAdd(&D.gin[3][idx], (T)a.w);
                 D.flags[idx >> 6] = 1;
             }
         }
@@ -256,12 +263,12 @@ __global__ __launch_bounds__(kBlock) void k_grid_op(Dev<T> D, int f) {
     const int idx = (blk << 6) | lane;
     const int bx = blk % D.nb, by = (blk / D.nb) % D.nb, bz = blk / (D.nb * D.nb);
     int I[3] = {(bx << 2) | (lane & 3), (by << 2) | ((lane >> 2) & 3), (bz << 2) | (lane >> 4)};
-    Vec4<T> g = D.grid_in[idx];
-    T mv[3] = {g.y, g.z, g.w}, vo[3];
-    grid_node_fwd<T>(D.P, I, g.x, mv, D.nprim, sp, vo);
+    T m = D.gin[0][idx];
+    T mv[3] = {D.gin[1][idx], D.gin[2][idx], D.gin[3][idx]}, vo[3];
+    grid_node_fwd<T>(D.P, I, m, mv, D.nprim, sp, vo);
     D.grid_out[idx] = Vec4<T>{vo[0], vo[1], vo[2], T(0)};
     if (CLEAR) {
-        D.grid_in[idx] = Vec4<T>{T(0), T(0), T(0), T(0)};
+        D.gin[0][idx] = T(0); D.gin[1][idx] = T(0); D.gin[2][idx] = T(0); D.gin[3][idx] = T(0);
         if (lane == 0) D.flags[blk] = 0;
     }
 }
@@ -316,7 +323,7 @@ template <class T>
 __global__ __launch_bounds__(kBlock) void k_g2p_grad(Dev<T> D, int f, int src, int dst) {
     __shared__ int sred[32];
     __shared__ Vec4<T> tile[TileCap<T>::nodes];      // v_out values
-    __shared__ Vec4<T> tile_a[TileCap<T>::nodes];    // v_out adjoint accumulation
+    __shared__ Vec4<double> tile_a[TileCap<T>::nodes];    // v_out adjoint accumulation (f64, see k_p2g)
     const int p = blockIdx.x * kBlock + threadIdx.x;
     const bool valid = p < D.N;
     const double* X = frame_x(D, f);
@@ -331,7 +338,7 @@ __global__ __launch_bounds__(kBlock) void k_g2p_grad(Dev<T> D, int f, int src, i
         for (int i = threadIdx.x; i < tn; i += kBlock) {
             int lz = i / exy, r = i - lz * exy, ly = r / ex, lx = r - ly * ex;
             tile[i] = D.grid_out[node_index(D.nb, tl.o[0] + lx, tl.o[1] + ly, tl.o[2] + lz)];
-            tile_a[i] = Vec4<T>{T(0), T(0), T(0), T(0)};
+            tile_a[i] = Vec4<double>{0.0, 0.0, 0.0, 0.0};
         }
         __syncthreads();
     }
@@ -356,8 +363,8 @@ __global__ __launch_bounds__(kBlock) void k_g2p_grad(Dev<T> D, int f, int src, i
                 [&](int i, int j, int l, const T* ga) {
                     T a0 = seg_sum(ga[0], sg), a1 = seg_sum(ga[1], sg), a2 = seg_sum(ga[2], sg);
                     if (emitter) {
-                        T* q = reinterpret_cast<T*>(&tile_a[(oz + l) * exy + (oy + j) * ex + (ox + i)]);
-                        atomicAdd(q, a0); atomicAdd(q + 1, a1); atomicAdd(q + 2, a2);
+                        double* q = reinterpret_cast<double*>(&tile_a[(oz + l) * exy + (oy + j) * ex + (ox + i)]);
+                        atomicAdd(q, (double)a0); atomicAdd(q + 1, (double)a1); atomicAdd(q + 2, (double)a2);
                     }
                 });
         } else {
@@ -372,8 +379,8 @@ __global__ __launch_bounds__(kBlock) void k_g2p_grad(Dev<T> D, int f, int src, i
                 [&](int i, int j, int l, const T* ga) {
                     T a0 = seg_sum(ga[0], sg), a1 = seg_sum(ga[1], sg), a2 = seg_sum(ga[2], sg);
                     if (emitter) {
-                        T* q = reinterpret_cast<T*>(&D.grid_out_adj[node_index(D.nb, base[0] + i, base[1] + j, base[2] + l)]);
-                        atomicAdd(q, a0); atomicAdd(q + 1, a1); atomicAdd(q + 2, a2);
+                        int idx = node_index(D.nb, base[0] + i, base[1] + j, base[2] + l);
+                        atomicAdd(&D.goa[0][idx], a0); atomicAdd(&D.goa[1][idx], a1); atomicAdd(&D.goa[2][idx], a2);
                     }
                 });
         }
@@ -385,11 +392,11 @@ __global__ __launch_bounds__(kBlock) void k_g2p_grad(Dev<T> D, int f, int src, i
     if (tl.ok) {
         __syncthreads();
         for (int i = threadIdx.x; i < tn; i += kBlock) {
-            Vec4<T> a = tile_a[i];
-            if (a.x != T(0) || a.y != T(0) || a.z != T(0)) {
+            Vec4<double> a = tile_a[i];
+            if (a.x != 0.0 || a.y != 0.0 || a.z != 0.0) {
                 int lz = i / exy, r = i - lz * exy, ly = r / ex, lx = r - ly * ex;
-                T* q = reinterpret_cast<T*>(&D.grid_out_adj[node_index(D.nb, tl.o[0] + lx, tl.o[1] + ly, tl.o[2] + lz)]);
-                atomicAdd(q, a.x); atomicAdd(q + 1, a.y); atomicAdd(q + 2, a.z);
+                int idx = node_index(D.nb, tl.o[0] + lx, tl.o[1] + ly, tl.o[2] + lz);
+                atomicAdd(&D.goa[0][idx], (T)a.x); atomicAdd(&D.goa[1][idx], (T)a.y); atomicAdd(&D.goa[2][idx], (T)a.z);
             }
         }
     }
@@ -414,17 +421,17 @@ __global__ __launch_bounds__(kBlock) void k_grid_op_grad(Dev<T> D, int f) {
         const int idx = (blk << 6) | lane;
         const int bx = blk % D.nb, by = (blk / D.nb) % D.nb, bz = blk / (D.nb * D.nb);
         int I[3] = {(bx << 2) | (lane & 3), (by << 2) | ((lane >> 2) & 3), (bz << 2) | (lane >> 4)};
-        Vec4<T> g = D.grid_in[idx];
-        Vec4<T> oa = D.grid_out_adj[idx];
-        T mv[3] = {g.y, g.z, g.w}, va[3] = {oa.x, oa.y, oa.z}, ma, mva[3];
-        grid_node_bwd<T>(D.P, I, g.x, mv, D.nprim, sp, va, &ma, mva, [&](int q, const PoseAdj<T>& pa) {
+        T gm = D.gin[0][idx];
+        T mv[3] = {D.gin[1][idx], D.gin[2][idx], D.gin[3][idx]};
+        T va[3] = {D.goa[0][idx], D.goa[1][idx], D.goa[2][idx]}, ma, mva[3];
+        grid_node_bwd<T>(D.P, I, gm, mv, D.nprim, sp, va, &ma, mva, [&](int q, const PoseAdj<T>& pa) {
             double* o = &sacc[q * 14];
             for (int d = 0; d < 3; ++d) { atomicAdd(&o[d], pa.pos[d]); atomicAdd(&o[7 + d], pa.pos1[d]); }
             for (int d = 0; d < 4; ++d) { atomicAdd(&o[3 + d], pa.rot[d]); atomicAdd(&o[10 + d], pa.rot1[d]); }
             shit = 1;
         });
         D.grid_in_adj[idx] = Vec4<T>{ma, mva[0], mva[1], mva[2]};
-        D.grid_out_adj[idx] = Vec4<T>{T(0), T(0), T(0), T(0)};
+        D.goa[0][idx] = T(0); D.goa[1][idx] = T(0); D.goa[2][idx] = T(0);
     }
     __syncthreads();
     if (shit && threadIdx.x < D.nprim * 14) {
@@ -489,6 +496,51 @@ __global__ __launch_bounds__(kBlock) void k_p2g_grad(Dev<T> D, int f, int src, i
     for (int d = 0; d < 9; ++d) { A0[(6 + d) * Np + p] = Ca[d]; A0[(15 + d) * Np + p] = Ea[d]; }
 }
 
+// compute_grid_m_kernel (mpm_simulator.py:382-392): mass-only scatter for the loss, same LDS-tile +
+// wave pre-reduction scheme as k_p2g.  gm is a dense blocked T grid (zeroed by the caller).
+template <class T>
+__global__ __launch_bounds__(kBlock) void k_grid_mass(Dev<T> D, int f, T* gm) {
+    __shared__ int sred[32];
+    __shared__ double tile[TileCap<T>::nodes * 4];
+    const int p = blockIdx.x * kBlock + threadIdx.x;
+    const bool valid = p < D.N;
+    const double* X = frame_x(D, f);
+    const int Np = D.Npad;
+    double x[3] = {0.5, 0.5, 0.5};
+    if (valid) { x[0] = X[p]; x[1] = X[Np + p]; x[2] = X[2 * Np + p]; }
+    int base[3];
+    T fx[3], w[3][3];
+    stencil<T, double>(x, D.P.inv_dx, base, fx, w, nullptr);
+    Tile tl = block_tile(base, valid, sred, TileCap<T>::nodes * 4);
+    const int ex = tl.e[0], exy = tl.e[0] * tl.e[1], tn = exy * tl.e[2];
+    if (tl.ok) {
+        for (int i = threadIdx.x; i < tn; i += kBlock) tile[i] = 0.0;
+        __syncthreads();
+    }
+    const Seg<T> sg = wave_segments<T>(valid ? (base[2] * D.P.n + base[1]) * D.P.n + base[0] : -1);
+    const bool emitter = sg.head && valid;
+    const int ox = base[0] - tl.o[0], oy = base[1] - tl.o[1], oz = base[2] - tl.o[2];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j)
+            for (int l = 0; l < 3; ++l) {
+                T m = seg_sum(w[i][0] * w[j][1] * w[l][2] * D.P.p_mass, sg);
+                if (emitter) {
+                    if (tl.ok) atomicAdd(&tile[(oz + l) * exy + (oy + j) * ex + (ox + i)], (double)m);
+                    else atomicAdd(&gm[node_index(D.nb, base[0] + i, base[1] + j, base[2] + l)], m);
+                }
+            }
+    if (tl.ok) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < tn; i += kBlock) {
+            double a = tile[i];
+            if (a != 0.0) {
+                int lz = i / exy, r = i - lz * exy, ly = r / ex, lx = r - ly * ex;
+                atomicAdd(&gm[node_index(D.nb, tl.o[0] + lx, tl.o[1] + ly, tl.o[2] + lz)], (T)a);
+            }
+        }
+    }
+}
+
 // after substep_grad: zero grid_in / grid_in_adj / flags of the active blocks
 template <class T>
 __global__ __launch_bounds__(kBlock) void k_clear_active(Dev<T> D) {
@@ -497,7 +549,7 @@ __global__ __launch_bounds__(kBlock) void k_clear_active(Dev<T> D) {
     if (blk >= nblk || D.flags[blk] == 0) return;
     const int lane = threadIdx.x & 63;
     const int idx = (blk << 6) | lane;
-    D.grid_in[idx] = Vec4<T>{T(0), T(0), T(0), T(0)};
+    D.gin[0][idx] = T(0); D.gin[1][idx] = T(0); D.gin[2][idx] = T(0); D.gin[3][idx] = T(0);
     D.grid_in_adj[idx] = Vec4<T>{T(0), T(0), T(0), T(0)};
     if (lane == 0) D.flags[blk] = 0;
 }
