@@ -51,6 +51,10 @@ typedef struct plmpm_config {
     double svd_grad_clamp;    /* :143-151 clamp of backward_svd; 1e-6 = reference, 0 = exact derivative */
     /* z-slab owned by this rank for multi-GPU runs: nodes z in [slab_z0, slab_z1); 0,n_grid = whole grid */
     int32_t slab_z0, slab_z1;
+    /* 1: keep grid_m / grid_v_in of every frame resident (max_frames x 16 n^3 bytes at fp32) so that
+     * substep_grad skips the p2g recompute of mpm_simulator.py:265-267 (same results, less work);
+     * 0: recompute like the reference (use this for very large grids / copy-mode-only use). */
+    int32_t store_grid;
 } plmpm_config;
 
 /* One rigid manipulator; mirrors Primitive.default_config + per-shape params

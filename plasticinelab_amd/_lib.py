@@ -23,7 +23,8 @@ class Config(C.Structure):
                 ("max_frames", C.c_int32), ("substeps", C.c_int32), ("n_primitives", C.c_int32),
                 ("dt", C.c_double), ("p_vol", C.c_double), ("p_mass", C.c_double),
                 ("gravity", C.c_double * 3), ("ground_friction", C.c_double),
-                ("svd_grad_clamp", C.c_double), ("slab_z0", C.c_int32), ("slab_z1", C.c_int32)]
+                ("svd_grad_clamp", C.c_double), ("slab_z0", C.c_int32), ("slab_z1", C.c_int32),
+                ("store_grid", C.c_int32)]
 
 
 class Primitive(C.Structure):

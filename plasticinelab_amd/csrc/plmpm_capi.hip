@@ -64,6 +64,12 @@ struct plmpm_sim {
     bool have_target = false;
     double target_max = 0, target_sum = 0;
     int adj_frame[2] = {-1, -1};
+    // per-frame grid_m / grid_v_in store (cfg.store_grid)
+    bool store = false;
+    char* gstore = nullptr;
+    int* fstore = nullptr;
+    size_t gstride = 0;
+    std::vector<char> dirty;          // frame f holds a scattered grid that has not been consumed/cleared
     // optional per-kernel timing with HIP events on the launch stream (plmpm_profile_*)
     bool prof = false;
     std::vector<hipEvent_t> ev_pool;
@@ -98,7 +104,8 @@ static void prof_end(plmpm_sim* s) {
     } while (0)
 
 // ---------------------------------------------------------------------------------------------
-template <class T> static Dev<T> make_dev(const plmpm_sim* s) {
+// frame >= 0 with the grid store on: that frame's own grid_in / flags; otherwise the shared scratch grid
+template <class T> static Dev<T> make_dev(const plmpm_sim* s, int frame = -1) {
     Dev<T> D;
     const plmpm_config& c = s->cfg;
     double dx = 1.0 / c.n_grid;
@@ -115,10 +122,12 @@ template <class T> static Dev<T> make_dev(const plmpm_sim* s) {
     D.state = s->state;
     D.adj[0] = (T*)s->adj[0]; D.adj[1] = (T*)s->adj[1];
     D.mu = (T*)s->mu; D.lam = (T*)s->lam; D.ys = (T*)s->ys;
-    for (int c = 0; c < 4; ++c) D.gin[c] = (T*)s->grid_in + (size_t)c * s->G;
+    const bool framed = s->store && frame >= 0;
+    char* gin_base = framed ? s->gstore + (size_t)frame * s->gstride : s->grid_in;
+    for (int c = 0; c < 4; ++c) D.gin[c] = (T*)gin_base + (size_t)c * s->G;
     for (int c = 0; c < 3; ++c) D.goa[c] = (T*)s->grid_out_adj + (size_t)c * s->G;
     D.grid_out = (Vec4<T>*)s->grid_out; D.grid_in_adj = (Vec4<T>*)s->grid_in_adj;
-    D.flags = s->flags;
+    D.flags = framed ? s->fstore + (size_t)frame * s->nblk : s->flags;
     D.ppos = s->ppos; D.prot = s->prot; D.ppos_a = s->ppos_a; D.prot_a = s->prot_a;
     for (int i = 0; i < s->P; ++i) {
         D.prim[i].shape = s->prims[i].shape;
@@ -440,21 +449,30 @@ static inline int nblocks_particles(const plmpm_sim* s) { return s->Npad / kBloc
 static inline int nblocks_grid(const plmpm_sim* s) { return (s->nblk + (kBlock / 64) - 1) / (kBlock / 64); }
 
 template <class T> static int substep_fwd(plmpm_sim* s, int f) {
-    Dev<T> D = make_dev<T>(s);
-    LAUNCH(s, K_P2G, (k_p2g<T, true>), dim3(nblocks_particles(s)), D, f);
-    LAUNCH(s, K_GRID_OP, (k_grid_op<T, true>), dim3(nblocks_grid(s)), D, f);
+    Dev<T> D = make_dev<T>(s, f);
+    if (s->store) {
+        if (s->dirty[f]) LAUNCH(s, K_CLEAR, (k_clear_active<T>), dim3(nblocks_grid(s)), D);   // frame reused without a backward pass
+        LAUNCH(s, K_P2G, (k_p2g<T, true>), dim3(nblocks_particles(s)), D, f);
+        LAUNCH(s, K_GRID_OP, (k_grid_op<T, false>), dim3(nblocks_grid(s)), D, f);                // keep grid_in for substep_grad
+        s->dirty[f] = 1;
+    } else {
+        LAUNCH(s, K_P2G, (k_p2g<T, true>), dim3(nblocks_particles(s)), D, f);
+        LAUNCH(s, K_GRID_OP, (k_grid_op<T, true>), dim3(nblocks_grid(s)), D, f);
+    }
     LAUNCH(s, K_G2P, (k_g2p<T>), dim3(nblocks_particles(s)), D, f);
     return 0;
 }
 template <class T> static int substep_bwd(plmpm_sim* s, int f) {
-    Dev<T> D = make_dev<T>(s);
+    Dev<T> D = make_dev<T>(s, f);
     const int src = (f + 1) & 1, dst = f & 1;
-    LAUNCH(s, K_P2G_RE, (k_p2g<T, false>), dim3(nblocks_particles(s)), D, f);
+    if (!(s->store && s->dirty[f]))          // grid_m / grid_v_in of this frame are not resident: recompute (mpm_simulator.py:265-267)
+        LAUNCH(s, K_P2G_RE, (k_p2g<T, false>), dim3(nblocks_particles(s)), D, f);
     LAUNCH(s, K_GRID_OP_RE, (k_grid_op<T, false>), dim3(nblocks_grid(s)), D, f);
     LAUNCH(s, K_G2P_GRAD, (k_g2p_grad<T>), dim3(nblocks_particles(s)), D, f, src, dst);
     LAUNCH(s, K_GRID_OP_GRAD, (k_grid_op_grad<T>), dim3(nblocks_grid(s)), D, f);
     LAUNCH(s, K_P2G_GRAD, (k_p2g_grad<T>), dim3(nblocks_particles(s)), D, f, src, dst);
     LAUNCH(s, K_CLEAR, (k_clear_active<T>), dim3(nblocks_grid(s)), D);
+    if (s->store) s->dirty[f] = 0;
     s->adj_frame[dst] = f;
     return 0;
 }
@@ -583,6 +601,10 @@ int plmpm_create(const plmpm_config* cfg, const plmpm_primitive* prims, plmpm_ha
     s->ws.state_bytes = (size_t)(s->F + 1) * s->frame_bytes;
     s->ws.adjoint_bytes = align_up(2 * 24 * s->Npad * s->tsz, 256) + 3 * align_up(s->Npad * s->tsz, 256) + align_up((size_t)s->Npad * 4, 256);
     s->ws.grid_bytes = 4 * align_up(s->G * 4 * s->tsz, 256) + align_up((size_t)s->nblk * 4, 256) + 3 * align_up(s->G * s->tsz, 256);
+    s->store = cfg->store_grid != 0;
+    s->gstride = align_up(s->G * 4 * s->tsz, 256);
+    if (s->store) s->ws.grid_bytes += (size_t)s->F * s->gstride + align_up((size_t)s->F * s->nblk * 4, 256);
+    s->dirty.assign(s->F + 1, 0);
     s->ws.misc_bytes = 2 * align_up((size_t)(s->F + 1) * P1 * 7 * 8, 256) + 2 * align_up((size_t)(s->F + 1) * P1 * 8 * 8, 256)  // poses(+adj), padded
                        + 4 * align_up((size_t)(s->F + 1) * P1 * 3 * 8, 256)                       // v,w (+adj)
                        + 2 * align_up((size_t)(s->F + 1) * P1 * PLMPM_MAX_ACTION_DIM * 8, 256)    // action buffers (+adj)
@@ -621,6 +643,11 @@ int plmpm_bind_workspace(plmpm_handle s, void* state, void* adjoint, void* grid,
     s->grid_out_adj = take(s->G * 4 * s->tsz); s->grid_in_adj = take(s->G * 4 * s->tsz);
     s->flags = (int*)take((size_t)s->nblk * 4);
     s->loss_gm = take(s->G * s->tsz); s->loss_td = take(s->G * s->tsz); s->loss_ts = take(s->G * s->tsz);
+    if (s->store) {
+        s->gstore = take((size_t)s->F * s->gstride);
+        s->fstore = (int*)take((size_t)s->F * s->nblk * 4);
+    }
+    REQUIRE((size_t)(p - s->gridw) <= s->ws.grid_bytes, "internal: grid workspace overflow");
     p = s->miscw;
     size_t P1 = std::max(s->P, 1), F1 = s->F + 1;
     s->ppos = (double*)take(F1 * P1 * 3 * 8); s->prot = (double*)take(F1 * P1 * 4 * 8);

@@ -86,6 +86,14 @@ template <class T> __device__ __forceinline__ void load_prims(const Dev<T>& D, i
     }
 }
 
+// true when at least one of the 4^3 blocks this workgroup covers was touched (workgroup-uniform)
+template <class T> __device__ __forceinline__ bool any_block_active(const Dev<T>& D) {
+    const int b0 = blockIdx.x * (kBlock / 64), nblk = D.nb * D.nb * D.nb;
+    int any = 0;
+    for (int i = 0; i < kBlock / 64; ++i) any |= (b0 + i < nblk) ? D.flags[b0 + i] : 0;
+    return any != 0;
+}
+
 // ------------------------------------------------------------------------------------------------
 // workgroup bounding box of stencil bases -> LDS tile geometry
 struct Tile {
@@ -254,6 +262,7 @@ __global__ __launch_bounds__(kBlock) void k_p2g(Dev<T> D, int f) {
 template <class T, bool CLEAR>
 __global__ __launch_bounds__(kBlock) void k_grid_op(Dev<T> D, int f) {
     __shared__ PrimT<T> sp[kMaxPrim];
+    if (!any_block_active(D)) return;
     load_prims(D, f, sp);
     __syncthreads();
     const int blk = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
@@ -409,6 +418,7 @@ __global__ __launch_bounds__(kBlock) void k_grid_op_grad(Dev<T> D, int f) {
     __shared__ PrimT<T> sp[kMaxPrim];
     __shared__ double sacc[kMaxPrim * 14];
     __shared__ int shit;
+    if (!any_block_active(D)) return;
     load_prims(D, f, sp);
     if (threadIdx.x < kMaxPrim * 14) sacc[threadIdx.x] = 0.0;
     if (threadIdx.x == 0) shit = 0;

@@ -32,7 +32,7 @@ class Engine:
     def __init__(self, *, n_grid: int, n_particles: int, max_frames: int, substeps: int, dt: float, p_vol: float,
                  p_mass: float, gravity: Sequence[float], ground_friction: float, primitives: Sequence[dict] = (),
                  dtype: str = "float32", svd_grad_clamp: float = 1e-6, device: Optional[torch.device] = None,
-                 slab: Optional[Sequence[int]] = None):
+                 slab: Optional[Sequence[int]] = None, store_grid="auto"):
         self.lib = L.load()
         if not torch.cuda.is_available():
             raise L.EngineError("no ROCm device visible: the MPM engine has no CPU path")
@@ -45,6 +45,10 @@ class Engine:
         cfg.gravity = (C.c_double * 3)(*[float(g) for g in gravity])
         cfg.ground_friction, cfg.svd_grad_clamp = float(ground_friction), float(svd_grad_clamp)
         cfg.slab_z0, cfg.slab_z1 = (0, n_grid) if slab is None else (int(slab[0]), int(slab[1]))
+        if store_grid == "auto":       # per-frame grid_m/grid_v_in: worth it while it stays a modest slice of 288 GB
+            store_grid = max_frames * 4 * (8 if cfg.dtype == L.F64 else 4) * n_grid ** 3 <= 48 * 2 ** 30
+        cfg.store_grid = int(bool(store_grid))
+        self.store_grid = bool(store_grid)
         parr = (L.Primitive * max(len(primitives), 1))()
         self.action_dims = []
         for i, p in enumerate(primitives):

@@ -52,7 +52,7 @@ class MPMSimulator:
                              substeps=self.substeps, dt=self.dt, p_vol=self.p_vol, p_mass=self.p_mass,
                              gravity=self.default_gravity, ground_friction=self.ground_friction, primitives=descr,
                              dtype=self.compute_dtype, svd_grad_clamp=float(cfg.get("svd_grad_clamp", 1e-6)),
-                             device=device, slab=slab)
+                             device=device, slab=slab, store_grid=cfg.get("store_grid", "auto"))
         if hasattr(primitives, "_bind"):
             primitives._bind(self.engine)
         self._mats = None
