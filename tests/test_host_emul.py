@@ -1,0 +1,96 @@
+"""CPU tier: the per-particle / per-node arithmetic the HIP kernels are built from (csrc/mpm_math.h,
+mpm_grid.h) compiled for the host (tests/host_emul, test infrastructure only) against the oracle:
+forward substep and the hand-derived adjoint -- including the closed-form SVD-free constitutive VJP with the
+reference's 1e-6 clamp, quaternion pose adjoints and the primitive kinematics chain."""
+import numpy as np
+import pytest
+import torch
+
+from tests import emul
+from tests.util import O, oracle_scene
+
+
+def relerr(a, b):
+    a, b = np.asarray(a, float), np.asarray(b, float)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-300))
+
+
+@pytest.fixture(scope="module")
+def case():
+    torch.manual_seed(0)
+    cfg, sim, prims, x0 = oracle_scene("Move", 1, n_particles=1500)
+    state, mats, poses = O.init_state(x0), O.materials(sim), O.init_poses(prims)
+    acts = torch.zeros(2, 6, dtype=O.DT); acts[:, 0] = 0.9; acts[:, 3] = -0.9; acts[:, 1] = 0.3
+    with torch.no_grad():
+        for a in acts:
+            state, poses = O.env_step(sim, prims, 666.0, state, mats, poses, a)
+    vel = [O.set_velocity(p, acts[0][3 * k:3 * k + 3], sim.substeps) for k, p in enumerate(prims)]
+    nxt = [O.forward_kinematics(p, pos, rot, v, w) for p, (pos, rot), (v, w) in zip(prims, poses, vel)]
+    sin = tuple(t.clone().requires_grad_(True) for t in state)
+    pin = [(p.clone().requires_grad_(True), r.clone().requires_grad_(True)) for p, r in poses]
+    nin = [(p.clone().requires_grad_(True), r.clone().requires_grad_(True)) for p, r in nxt]
+    out = O.substep(sim, prims, 666.0, sin, mats, pin, nin)
+    cot = [torch.randn_like(t) for t in out]
+    inputs = list(sin) + [t for pr in pin for t in pr] + [t for pr in nin for t in pr]
+    gs = torch.autograd.grad(sum((o * c).sum() for o, c in zip(out, cot)), inputs, allow_unused=True)
+    gs = [torch.zeros_like(t) if g is None else g for g, t in zip(gs, inputs)]
+    assert (state[3] - torch.eye(3, dtype=O.DT)).abs().max() > 0.1          # the state is really deformed / yielding
+    return sim, prims, state, mats, poses, nxt, out, cot, gs
+
+
+@pytest.mark.parametrize("use_float,tol", [(False, 1e-11), (True, 5e-6)])
+def test_substep_math_matches_oracle(case, use_float, tol):
+    sim, prims, state, mats, poses, nxt, out, cot, gs = case
+    ec = emul.make_cfg(sim, len(prims), 666.0, use_float=use_float)
+    pa = emul.make_prims(prims, [(p.numpy(), r.numpy()) for p, r in poses], [(p.numpy(), r.numpy()) for p, r in nxt])
+    st, mt = [t.numpy() for t in state], [t.numpy() for t in mats]
+    e = emul.substep(ec, pa, st, mt)
+    for a, b in zip(e, out):
+        assert relerr(a, b.detach().numpy()) < tol
+    (xa, va, Ca, Fa), pose = emul.substep_grad(ec, pa, st, mt, out[1].detach().numpy(), [c.numpy() for c in cot])
+    for a, b in zip((xa, va, Ca, Fa), gs[:4]):
+        assert relerr(a, b.numpy()) < 3 * tol
+    P = len(prims)
+    for k in range(P):
+        ref = np.concatenate([gs[4 + 2 * k].numpy(), gs[5 + 2 * k].numpy(),
+                              gs[4 + 2 * P + 2 * k].numpy(), gs[5 + 2 * P + 2 * k].numpy()])
+        assert np.abs(ref).max() > 0 and relerr(pose[k], ref) < 3 * tol
+
+
+def test_kinematics_chain_and_adjoint():
+    torch.manual_seed(3)
+    p = O.PrimCfg(shape="Sphere", lower_bound=(0.0, 0.0, 0.0), upper_bound=(0.6, 1.0, 1.0), action_dim=6,
+                  action_scale=(0.01,) * 6)
+    pos = torch.tensor([0.595, 0.3, 0.002], dtype=O.DT, requires_grad=True)
+    rot = torch.tensor([0.8, 0.2, -0.5, 0.1], dtype=O.DT); rot = (rot / rot.norm()).requires_grad_(True)
+    v = torch.tensor([0.01, -0.004, -0.005], dtype=O.DT, requires_grad=True)      # hits the upper x and lower z clamps
+    w = torch.tensor([0.02, -0.01, 0.03], dtype=O.DT, requires_grad=True)
+    pos1, rot1 = O.forward_kinematics(p, pos, rot, v, w)
+    e_pos1, e_rot1 = emul.fk_fwd(pos.detach().numpy(), rot.detach().numpy(), v.detach().numpy(), w.detach().numpy(),
+                                 p.lower_bound, p.upper_bound)
+    assert np.allclose(e_pos1, pos1.detach().numpy(), atol=1e-15) and np.allclose(e_rot1, rot1.detach().numpy(), atol=1e-15)
+    cp, cr = torch.randn(3, dtype=O.DT), torch.randn(4, dtype=O.DT)
+    gs = torch.autograd.grad((pos1 * cp).sum() + (rot1 * cr).sum(), [pos, rot, v, w])
+    got = emul.fk_bwd(pos.detach().numpy(), rot.detach().numpy(), v.detach().numpy(), w.detach().numpy(),
+                      p.lower_bound, p.upper_bound, cp.numpy(), cr.numpy())
+    for a, b in zip(got, gs):
+        assert np.allclose(a, b.numpy(), atol=1e-13)
+    assert got[2][0] == 0.0 and got[2][2] == 0.0 and got[2][1] != 0.0              # clamp gates the gradient (Q7-like)
+
+
+def test_static_cylinder_contact_forward(case):
+    """Rope's static Cylinder obstacle (h = radius, r = half height): forward parity of collide."""
+    cfg, sim, prims, x0 = oracle_scene("Rope", 1, n_particles=1500)
+    state, mats, poses = O.init_state(x0), O.materials(sim), O.init_poses(prims)
+    a = torch.tensor([0.5, 0.2, -0.9, -0.5, 0.2, -0.9], dtype=O.DT)
+    with torch.no_grad():
+        state, poses = O.env_step(sim, prims, 666.0, state, mats, poses, a)
+        vel = [O.set_velocity(p, a[3 * k:3 * k + 3], sim.substeps) if p.action_dim else (torch.zeros(3, dtype=O.DT),) * 2
+               for k, p in enumerate(prims)]
+        nxt = [O.forward_kinematics(p, pos, rot, v, w) for p, (pos, rot), (v, w) in zip(prims, poses, vel)]
+        out = O.substep(sim, prims, 666.0, state, mats, poses, nxt)
+    ec = emul.make_cfg(sim, len(prims), 666.0)
+    pa = emul.make_prims(prims, [(p.numpy(), r.numpy()) for p, r in poses], [(p.numpy(), r.numpy()) for p, r in nxt])
+    e = emul.substep(ec, pa, [t.numpy() for t in state], [t.numpy() for t in mats])
+    for x, y in zip(e, out):
+        assert relerr(x, y.numpy()) < 1e-11
