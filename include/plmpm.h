@@ -55,6 +55,10 @@ typedef struct plmpm_config {
      * substep_grad skips the p2g recompute of mpm_simulator.py:265-267 (same results, less work);
      * 0: recompute like the reference (use this for very large grids / copy-mode-only use). */
     int32_t store_grid;
+    /* node layers beyond [slab_z0, slab_z1) that this rank's particles may still reach (fixed ownership, no
+     * migration yet): a particle whose stencil leaves [slab_z0 - slab_halo, slab_z1 + slab_halo) raises
+     * PLMPM_ERR_HALO in plmpm_check_error.  0 on a single GPU. */
+    int32_t slab_halo;
 } plmpm_config;
 
 /* One rigid manipulator; mirrors Primitive.default_config + per-shape params
@@ -152,6 +156,41 @@ int plmpm_loss_backward(plmpm_handle h, int frame);
 int plmpm_get_grid_mass(plmpm_handle h, int frame, double* out);
 /* target_sdf as computed by plmpm_loss_set_target, host (n,n,n) float64 */
 int plmpm_loss_get_target_sdf(plmpm_handle h, double* out);
+
+/* ---- multi-GPU building blocks (z-slab decomposition; the host side exchanges halos with RCCL) ------------
+ * The forward substep is p2g | halo sum-exchange of grid_m,grid_v_in | grid_op + g2p, the reverse
+ * grid_op(recompute) + g2p.grad | halo sum-exchange of grid_v_out.grad | grid_op.grad + p2g.grad.  These split
+ * plmpm_substep / plmpm_substep_grad at the exchange points.  Requires store_grid = 1. */
+enum plmpm_halo_field { PLMPM_HALO_GRID_IN = 0 /* 4 comps */, PLMPM_HALO_GRID_OUT_ADJ = 1 /* 3 comps */,
+                        PLMPM_HALO_LOSS_MASS = 2 /* 1 comp */ };
+#define PLMPM_ERR_HALO 1
+int plmpm_fk(plmpm_handle h, int first_frame, int n_substeps);              /* forward_kinematics chain only */
+int plmpm_p2g(plmpm_handle h, int frame);
+int plmpm_grid_g2p(plmpm_handle h, int frame);
+int plmpm_grad_scatter(plmpm_handle h, int frame);                          /* grid_op recompute + g2p.grad */
+int plmpm_grad_gather(plmpm_handle h, int frame);                           /* grid_op.grad + p2g.grad + clear */
+int plmpm_chain_grad(plmpm_handle h, int first_frame, int n_substeps, int step);   /* fk.grad + set_velocity.grad */
+/* element size in bytes of the engine's scalar type, and the size of a halo buffer for planes [za, zb) */
+int plmpm_halo_bytes(plmpm_handle h, int field, int za, int zb, size_t* bytes);
+/* device buffers laid out [comp][z - za][y][x] in the engine's scalar type */
+int plmpm_halo_pack(plmpm_handle h, int field, int frame, int za, int zb, void* dev_buf);
+int plmpm_halo_unpack_add(plmpm_handle h, int field, int frame, int za, int zb, const void* dev_buf);
+/* block flags of `frame` (int32 per 4^3 block, z-major: planes [bz_a, bz_b) are contiguous) for OR-merging
+ * with a neighbour's, and the primitive pose adjoints (double) for the cross-rank sum */
+int plmpm_flags_region(plmpm_handle h, int frame, int bz_a, int bz_b, void** dev_ptr, size_t* count);
+int plmpm_pose_grad_region(plmpm_handle h, int first_frame, int n_frames, void** pos_adj, size_t* pos_count,
+                           void** rot_adj, size_t* rot_count);
+int plmpm_action_grad_region(plmpm_handle h, void** dev_ptr, size_t* count);
+/* loss in phases: scatter (then exchange PLMPM_HALO_LOSS_MASS), local partial sums over owned nodes /
+ * particles, set globally reduced contact scalars, local adjoint.
+ * partials (32 doubles): [0] density [1] sdf [2] max grid_m [3] sum m*target [4] sum m; [8+q] min_dist (hard: min,
+ * soft: weighted sum), [16+q] dist_norm (soft).  phase 0: hard-min or soft normaliser; phase 1: soft weighted sum */
+int plmpm_loss_scatter(plmpm_handle h, int frame);
+int plmpm_loss_partials(plmpm_handle h, int frame, int phase, double* out32);
+int plmpm_loss_set_globals(plmpm_handle h, const double* in32);
+int plmpm_loss_finish(plmpm_handle h, const double* global32, double* out6);   /* host arithmetic of loss.py:137-162,252-254 */
+int plmpm_loss_backward_local(plmpm_handle h, int frame);
+int plmpm_check_error(plmpm_handle h, int* flags);
 
 /* ---- introspection ------------------------------------------------------------------------- */
 /* number of grid nodes with mass > 0 and number of active 4^3 blocks after the last forward substep */

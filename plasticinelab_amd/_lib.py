@@ -24,7 +24,7 @@ class Config(C.Structure):
                 ("dt", C.c_double), ("p_vol", C.c_double), ("p_mass", C.c_double),
                 ("gravity", C.c_double * 3), ("ground_friction", C.c_double),
                 ("svd_grad_clamp", C.c_double), ("slab_z0", C.c_int32), ("slab_z1", C.c_int32),
-                ("store_grid", C.c_int32)]
+                ("store_grid", C.c_int32), ("slab_halo", C.c_int32)]
 
 
 class Primitive(C.Structure):
@@ -73,6 +73,24 @@ SYMBOLS = {
     "plmpm_loss_get_target_sdf": (_I, [_P, _P]),
     "plmpm_grid_stats": (_I, [_P, _I, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "plmpm_get_order": (_I, [_P, _P]),
+    "plmpm_fk": (_I, [_P, _I, _I]),
+    "plmpm_p2g": (_I, [_P, _I]),
+    "plmpm_grid_g2p": (_I, [_P, _I]),
+    "plmpm_grad_scatter": (_I, [_P, _I]),
+    "plmpm_grad_gather": (_I, [_P, _I]),
+    "plmpm_chain_grad": (_I, [_P, _I, _I, _I]),
+    "plmpm_halo_bytes": (_I, [_P, _I, _I, _I, C.POINTER(C.c_size_t)]),
+    "plmpm_halo_pack": (_I, [_P, _I, _I, _I, _I, _P]),
+    "plmpm_halo_unpack_add": (_I, [_P, _I, _I, _I, _I, _P]),
+    "plmpm_flags_region": (_I, [_P, _I, _I, _I, C.POINTER(_P), C.POINTER(C.c_size_t)]),
+    "plmpm_pose_grad_region": (_I, [_P, _I, _I, C.POINTER(_P), C.POINTER(C.c_size_t), C.POINTER(_P), C.POINTER(C.c_size_t)]),
+    "plmpm_action_grad_region": (_I, [_P, C.POINTER(_P), C.POINTER(C.c_size_t)]),
+    "plmpm_loss_scatter": (_I, [_P, _I]),
+    "plmpm_loss_partials": (_I, [_P, _I, _I, _P]),
+    "plmpm_loss_set_globals": (_I, [_P, _P]),
+    "plmpm_loss_finish": (_I, [_P, _P, _P]),
+    "plmpm_loss_backward_local": (_I, [_P, _I]),
+    "plmpm_check_error": (_I, [_P, C.POINTER(_I)]),
     "plmpm_profile_enable": (_I, [_P, _I]),
     "plmpm_profile_kernel_count": (_I, []),
     "plmpm_profile_kernel_name": (C.c_char_p, [_I]),

@@ -56,8 +56,16 @@ template <class T> PLB_HD T t_min(T a, T b) { return a < b ? a : b; }
 template <class T> PLB_HD T sel3(int i, T a, T b, T c) { return i == 0 ? a : (i == 1 ? b : c); }
 
 template <class T> struct Tol;
-template <> struct Tol<float> { static constexpr int sweeps = 5; static PLB_HD float dd() { return 2e-2f; } };
-template <> struct Tol<double> { static constexpr int sweeps = 8; static PLB_HD double dd() { return 1e-4; } };
+template <> struct Tol<float> {
+    static constexpr int sweeps = 5;
+    static PLB_HD float dd() { return 2e-2f; }
+    static PLB_HD float small_angle() { return 1e-6f; }
+};
+template <> struct Tol<double> {
+    static constexpr int sweeps = 8;
+    static PLB_HD double dd() { return 1e-4; }
+    static PLB_HD double small_angle() { return 1e-12; }
+};
 
 // ---------------------------------------------------------------- 3x3 helpers (row major)
 template <class T> PLB_HD void mat_mul(const T* a, const T* b, T* c) {          // c = a b
@@ -125,8 +133,14 @@ template <class T> struct Svd3 {
 
 template <class T> PLB_HD void jacobi_pair(T& app, T& aqq, T& apq, T& arp, T& arq, T* V, int p, int q) {
     if (apq == T(0)) return;
-    T theta = (aqq - app) / (T(2) * apq);
-    T t = (theta >= T(0) ? T(1) : T(-1)) / (t_abs(theta) + t_sqrt(theta * theta + T(1)));
+    const T d = aqq - app;
+    T t;
+    if (t_abs(apq) < Tol<T>::small_angle() * t_abs(d)) {
+        t = apq / d;                 // tan(theta) ~ apq/(aqq-app): keeps theta = d/(2 apq) from overflowing
+    } else {
+        T theta = d / (T(2) * apq);
+        t = (theta >= T(0) ? T(1) : T(-1)) / (t_abs(theta) + t_sqrt(theta * theta + T(1)));
+    }
     T c = T(1) / t_sqrt(t * t + T(1));
     T s = t * c;
     app -= t * apq;

@@ -56,6 +56,11 @@ struct plmpm_sim {
     int* flags;
     char *loss_gm, *loss_td, *loss_ts;
     double *ppos, *prot, *ppos_a, *prot_a, *pv, *pw, *pv_a, *pw_a, *act, *act_a, *lscal, *staging;
+    int* err_d = nullptr;
+    // multi-GPU: pose adjoints produced by this rank's nodes/particles accumulate in *_l, get summed over
+    // ranks by the host and are then merged into the global ppos_a/prot_a the kinematics chain reads
+    bool dist = false;
+    double *ppos_l = nullptr, *prot_l = nullptr;
     // host state
     std::vector<int32_t> perm;
     double softness = 0.0;
@@ -118,6 +123,10 @@ template <class T> static Dev<T> make_dev(const plmpm_sim* s, int frame = -1) {
     D.P.softness = (T)s->softness;
     D.N = s->N; D.Npad = s->Npad; D.nb = s->nb; D.nprim = s->P;
     D.z0 = c.slab_z0; D.z1 = c.slab_z1;
+    D.zlo = c.slab_z0 - c.slab_halo; D.zhi = c.slab_z1 + c.slab_halo;
+    if (c.slab_z0 <= 0) D.zlo = -(1 << 20);
+    if (c.slab_z1 >= c.n_grid) D.zhi = 1 << 20;
+    D.err = s->err_d;
     D.frame_bytes = s->frame_bytes;
     D.state = s->state;
     D.adj[0] = (T*)s->adj[0]; D.adj[1] = (T*)s->adj[1];
@@ -128,7 +137,9 @@ template <class T> static Dev<T> make_dev(const plmpm_sim* s, int frame = -1) {
     for (int c = 0; c < 3; ++c) D.goa[c] = (T*)s->grid_out_adj + (size_t)c * s->G;
     D.grid_out = (Vec4<T>*)s->grid_out; D.grid_in_adj = (Vec4<T>*)s->grid_in_adj;
     D.flags = framed ? s->fstore + (size_t)frame * s->nblk : s->flags;
-    D.ppos = s->ppos; D.prot = s->prot; D.ppos_a = s->ppos_a; D.prot_a = s->prot_a;
+    D.ppos = s->ppos; D.prot = s->prot;
+    D.ppos_a = s->dist ? s->ppos_l : s->ppos_a;
+    D.prot_a = s->dist ? s->prot_l : s->prot_a;
     for (int i = 0; i < s->P; ++i) {
         D.prim[i].shape = s->prims[i].shape;
         D.prim[i].movable = s->prims[i].action_dim > 0;
@@ -208,6 +219,12 @@ __global__ void k_copy_frame(char* state, size_t frame_bytes, int src, int dst) 
     if (i < n16) d[i] = s[i];
 }
 
+// global += local; local = 0   (pose adjoints after the cross-rank sum)
+__global__ void k_merge_pose_adj(double* g, double* l, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { g[i] += l[i]; l[i] = 0.0; }
+}
+
 struct PrimChainArgs {
     int P;
     int action_dim[kMaxPrim];
@@ -280,10 +297,12 @@ __device__ __forceinline__ double block_max(double v, double* sh) {
     return r;
 }
 // density / sdf losses (loss.py:145-153) + IoU sums (loss.py:239-254)
-template <class T> __global__ void k_loss_reduce(size_t G, const T* gm, const T* td, const T* ts, double* ls) {
+template <class T> __global__ void k_loss_reduce(size_t G, int nb, int z0, int z1, const T* gm, const T* td, const T* ts, double* ls) {
     __shared__ double sh[8];
     double dens = 0, sdf = 0, mx = 0, dot = 0, sum = 0;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < G; i += (size_t)gridDim.x * blockDim.x) {
+        int z = (int)((i >> 6) / ((size_t)nb * nb)) * 4 + (int)((i & 63) >> 4);
+        if (z < z0 || z >= z1) continue;                      // nodes owned by another rank
         double g = (double)gm[i], t = (double)td[i];
         dens += fabs(g - t); sdf += (double)ts[i] * g; mx = fmax(mx, g); dot += g * t; sum += g;
     }
@@ -477,6 +496,36 @@ template <class T> static int substep_bwd(plmpm_sim* s, int f) {
     return 0;
 }
 
+// phase-split variants used by the multi-GPU driver (store_grid mode only)
+template <class T> static int phase_p2g(plmpm_sim* s, int f) {
+    Dev<T> D = make_dev<T>(s, f);
+    if (s->dirty[f]) LAUNCH(s, K_CLEAR, (k_clear_active<T>), dim3(nblocks_grid(s)), D);
+    LAUNCH(s, K_P2G, (k_p2g<T, true>), dim3(nblocks_particles(s)), D, f);
+    s->dirty[f] = 1;
+    return 0;
+}
+template <class T> static int phase_grid_g2p(plmpm_sim* s, int f) {
+    Dev<T> D = make_dev<T>(s, f);
+    LAUNCH(s, K_GRID_OP, (k_grid_op<T, false>), dim3(nblocks_grid(s)), D, f);
+    LAUNCH(s, K_G2P, (k_g2p<T>), dim3(nblocks_particles(s)), D, f);
+    return 0;
+}
+template <class T> static int phase_grad_scatter(plmpm_sim* s, int f) {
+    Dev<T> D = make_dev<T>(s, f);
+    LAUNCH(s, K_GRID_OP_RE, (k_grid_op<T, false>), dim3(nblocks_grid(s)), D, f);
+    LAUNCH(s, K_G2P_GRAD, (k_g2p_grad<T>), dim3(nblocks_particles(s)), D, f, (f + 1) & 1, f & 1);
+    return 0;
+}
+template <class T> static int phase_grad_gather(plmpm_sim* s, int f) {
+    Dev<T> D = make_dev<T>(s, f);
+    LAUNCH(s, K_GRID_OP_GRAD, (k_grid_op_grad<T>), dim3(nblocks_grid(s)), D, f);
+    LAUNCH(s, K_P2G_GRAD, (k_p2g_grad<T>), dim3(nblocks_particles(s)), D, f, (f + 1) & 1, f & 1);
+    LAUNCH(s, K_CLEAR, (k_clear_active<T>), dim3(nblocks_grid(s)), D);
+    s->dirty[f] = 0;
+    s->adj_frame[f & 1] = f;
+    return 0;
+}
+
 #define DISPATCH(s, fn, ...) ((s)->cfg.dtype == PLMPM_F64 ? fn<double>(__VA_ARGS__) : fn<float>(__VA_ARGS__))
 
 // ---------------------------------------------------------------------------------------------
@@ -521,27 +570,26 @@ template <class T> static int loss_scatter_t(plmpm_sim* s, int f) {
     return 0;
 }
 
-template <class T> static int loss_contact_t(plmpm_sim* s, int f) {
+// mode 0: hard min, 1: soft normaliser, 2: soft weighted sum (needs the global normaliser in lscal)
+template <class T> static int loss_contact_pass_t(plmpm_sim* s, int f, int mode) {
     Dev<T> D = make_dev<T>(s);
-    std::vector<double> init(LS_COUNT, 0.0);
-    if (!s->soft_contact) for (int q = 0; q < kMaxPrim; ++q) init[LS_MIND + q] = 100000.0;      // loss.py:189-191
-    hipMemcpyAsync(s->lscal, init.data(), LS_COUNT * 8, hipMemcpyHostToDevice, s->stream);
-    hipStreamSynchronize(s->stream);
     bool any = false;
     for (int p = 0; p < s->P; ++p) any |= s->prims[p].action_dim > 0;
-    if (!any) return 0;
-    if (s->soft_contact) {
-        hipLaunchKernelGGL((k_contact<T>), dim3(s->Npad / 256), dim3(256), 0, s->stream, D, f, 1, s->lscal);
-        hipLaunchKernelGGL((k_contact<T>), dim3(s->Npad / 256), dim3(256), 0, s->stream, D, f, 2, s->lscal);
-    } else {
-        hipLaunchKernelGGL((k_contact<T>), dim3(s->Npad / 256), dim3(256), 0, s->stream, D, f, 0, s->lscal);
-    }
+    if (any) hipLaunchKernelGGL((k_contact<T>), dim3(s->Npad / 256), dim3(256), 0, s->stream, D, f, mode, s->lscal);
+    return 0;
+}
+static int loss_reset_scalars(plmpm_sim* s) {
+    double init[LS_COUNT];
+    for (int i = 0; i < LS_COUNT; ++i) init[i] = 0.0;
+    if (!s->soft_contact) for (int q = 0; q < kMaxPrim; ++q) init[LS_MIND + q] = 100000.0;      // loss.py:189-191
+    HIPCHK(hipMemcpyAsync(s->lscal, init, sizeof init, hipMemcpyHostToDevice, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
     return 0;
 }
 
 template <class T> static int loss_reduce_t(plmpm_sim* s) {
-    hipLaunchKernelGGL((k_loss_reduce<T>), dim3(1024), dim3(256), 0, s->stream, s->G, (const T*)s->loss_gm, (const T*)s->loss_td,
-                       (const T*)s->loss_ts, s->lscal);
+    hipLaunchKernelGGL((k_loss_reduce<T>), dim3(1024), dim3(256), 0, s->stream, s->G, s->nb, s->cfg.slab_z0, s->cfg.slab_z1,
+                       (const T*)s->loss_gm, (const T*)s->loss_td, (const T*)s->loss_ts, s->lscal);
     return 0;
 }
 
@@ -601,6 +649,8 @@ int plmpm_create(const plmpm_config* cfg, const plmpm_primitive* prims, plmpm_ha
     s->ws.state_bytes = (size_t)(s->F + 1) * s->frame_bytes;
     s->ws.adjoint_bytes = align_up(2 * 24 * s->Npad * s->tsz, 256) + 3 * align_up(s->Npad * s->tsz, 256) + align_up((size_t)s->Npad * 4, 256);
     s->ws.grid_bytes = 4 * align_up(s->G * 4 * s->tsz, 256) + align_up((size_t)s->nblk * 4, 256) + 3 * align_up(s->G * s->tsz, 256);
+    s->dist = s->cfg.slab_z0 > 0 || s->cfg.slab_z1 < cfg->n_grid || cfg->slab_halo > 0;
+    if (s->dist) s->ws.misc_bytes += 2 * align_up((size_t)(s->F + 1) * P1 * 4 * 8, 256);
     s->store = cfg->store_grid != 0;
     s->gstride = align_up(s->G * 4 * s->tsz, 256);
     if (s->store) s->ws.grid_bytes += (size_t)s->F * s->gstride + align_up((size_t)s->F * s->nblk * 4, 256);
@@ -608,7 +658,7 @@ int plmpm_create(const plmpm_config* cfg, const plmpm_primitive* prims, plmpm_ha
     s->ws.misc_bytes = 2 * align_up((size_t)(s->F + 1) * P1 * 7 * 8, 256) + 2 * align_up((size_t)(s->F + 1) * P1 * 8 * 8, 256)  // poses(+adj), padded
                        + 4 * align_up((size_t)(s->F + 1) * P1 * 3 * 8, 256)                       // v,w (+adj)
                        + 2 * align_up((size_t)(s->F + 1) * P1 * PLMPM_MAX_ACTION_DIM * 8, 256)    // action buffers (+adj)
-                       + align_up(LS_COUNT * 8, 256) + align_up((size_t)s->N * 24 * 8, 256);
+                       + align_up(LS_COUNT * 8, 256) + align_up((size_t)s->N * 24 * 8, 256) + 256;
     s->perm.resize(s->N);
     for (int i = 0; i < s->N; ++i) s->perm[i] = i;
     *out = s;
@@ -657,6 +707,8 @@ int plmpm_bind_workspace(plmpm_handle s, void* state, void* adjoint, void* grid,
     s->act = (double*)take(F1 * P1 * PLMPM_MAX_ACTION_DIM * 8); s->act_a = (double*)take(F1 * P1 * PLMPM_MAX_ACTION_DIM * 8);
     s->lscal = (double*)take(LS_COUNT * 8);
     s->staging = (double*)take((size_t)s->N * 24 * 8);
+    s->err_d = (int*)take(256);
+    if (s->dist) { s->ppos_l = (double*)take(F1 * P1 * 3 * 8); s->prot_l = (double*)take(F1 * P1 * 4 * 8); }
     REQUIRE((size_t)(p - s->miscw) <= s->ws.misc_bytes, "internal: misc workspace overflow");
     // initial contents: zero grids / adjoints / primitive buffers, identity order
     HIPCHK(hipMemsetAsync(s->adjw, 0, s->ws.adjoint_bytes, s->stream));
@@ -866,6 +918,10 @@ int plmpm_grad_begin(plmpm_handle s, int last_frame) {
     HIPCHK(hipMemsetAsync(s->pv_a, 0, F1 * P1 * 3 * 8, s->stream));
     HIPCHK(hipMemsetAsync(s->pw_a, 0, F1 * P1 * 3 * 8, s->stream));
     HIPCHK(hipMemsetAsync(s->act_a, 0, F1 * P1 * PLMPM_MAX_ACTION_DIM * 8, s->stream));
+    if (s->dist) {
+        HIPCHK(hipMemsetAsync(s->ppos_l, 0, F1 * P1 * 3 * 8, s->stream));
+        HIPCHK(hipMemsetAsync(s->prot_l, 0, F1 * P1 * 4 * 8, s->stream));
+    }
     s->adj_frame[last_frame & 1] = last_frame;
     s->adj_frame[(last_frame + 1) & 1] = -1;
     return 0;
@@ -969,17 +1025,42 @@ int plmpm_loss_set_weights(plmpm_handle s, double sdf, double density, double co
 }
 
 
-int plmpm_loss_forward(plmpm_handle s, int frame, double* out6) {
+int plmpm_loss_scatter(plmpm_handle s, int frame) {
+    NEED_BOUND(s);
+    NEED_FRAME(s, frame);
+    DISPATCH(s, loss_scatter_t, s, frame);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int plmpm_loss_partials(plmpm_handle s, int frame, int phase, double* out32) {
     NEED_BOUND(s);
     NEED_FRAME(s, frame);
     REQUIRE(s->have_target, "loss: no target density set");
-    REQUIRE(out6, "null output");
-    DISPATCH(s, loss_contact_t, s, frame);       // also resets the scalar block
-    DISPATCH(s, loss_scatter_t, s, frame);
-    DISPATCH(s, loss_reduce_t, s);
-    double ls[LS_COUNT];
-    HIPCHK(hipMemcpyAsync(ls, s->lscal, sizeof ls, hipMemcpyDeviceToHost, s->stream));
+    REQUIRE(out32 && (phase == 0 || phase == 1), "bad arguments");
+    if (phase == 0) {
+        if (loss_reset_scalars(s)) return -1;
+        DISPATCH(s, loss_reduce_t, s);
+        DISPATCH(s, loss_contact_pass_t, s, frame, s->soft_contact ? 1 : 0);
+    } else {
+        REQUIRE(s->soft_contact, "phase 1 only exists for the soft contact loss");
+        DISPATCH(s, loss_contact_pass_t, s, frame, 2);
+    }
+    HIPCHK(hipMemcpyAsync(out32, s->lscal, LS_COUNT * 8, hipMemcpyDeviceToHost, s->stream));
     HIPCHK(hipStreamSynchronize(s->stream));
+    return 0;
+}
+
+int plmpm_loss_set_globals(plmpm_handle s, const double* in32) {
+    NEED_BOUND(s);
+    REQUIRE(in32, "null argument");
+    HIPCHK(hipMemcpyAsync(s->lscal, in32, LS_COUNT * 8, hipMemcpyHostToDevice, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    return 0;
+}
+
+int plmpm_loss_finish(plmpm_handle s, const double* ls, double* out6) {
+    REQUIRE(s && ls && out6, "null argument");
     double contact = 0;
     for (int p = 0; p < s->P; ++p)
         if (s->prims[p].action_dim > 0) contact += ls[LS_MIND + p] * ls[LS_MIND + p];          // loss.py:137-140
@@ -990,16 +1071,41 @@ int plmpm_loss_forward(plmpm_handle s, int frame, double* out6) {
     return 0;
 }
 
-int plmpm_loss_backward(plmpm_handle s, int frame) {
+int plmpm_loss_backward_local(plmpm_handle s, int frame) {
     NEED_BOUND(s);
     NEED_FRAME(s, frame);
     REQUIRE(s->have_target, "loss: no target density set");
     REQUIRE(s->adj_frame[frame & 1] == frame, "loss_backward: adjoint of frame %d is not resident", frame);
-    DISPATCH(s, loss_contact_t, s, frame);
-    DISPATCH(s, loss_scatter_t, s, frame);
     DISPATCH(s, loss_grad_t, s, frame);
     HIPCHK(hipGetLastError());
     return 0;
+}
+
+// single-rank composition of the phases above
+static int loss_globals_single(plmpm_sim* s, int frame, double* ls) {
+    if (plmpm_loss_scatter(s, frame)) return -1;
+    if (plmpm_loss_partials(s, frame, 0, ls)) return -1;
+    if (s->soft_contact) {
+        if (plmpm_loss_set_globals(s, ls)) return -1;
+        if (plmpm_loss_partials(s, frame, 1, ls)) return -1;
+    }
+    return 0;
+}
+
+int plmpm_loss_forward(plmpm_handle s, int frame, double* out6) {
+    NEED_BOUND(s);
+    REQUIRE(out6, "null output");
+    double ls[LS_COUNT];
+    if (loss_globals_single(s, frame, ls)) return -1;
+    return plmpm_loss_finish(s, ls, out6);
+}
+
+int plmpm_loss_backward(plmpm_handle s, int frame) {
+    NEED_BOUND(s);
+    double ls[LS_COUNT];
+    if (loss_globals_single(s, frame, ls)) return -1;       // recompute grid_m and the contact scalars (loss.py:210-237)
+    if (plmpm_loss_set_globals(s, ls)) return -1;
+    return plmpm_loss_backward_local(s, frame);
 }
 
 int plmpm_get_grid_mass(plmpm_handle s, int frame, double* out) {
@@ -1040,6 +1146,131 @@ int plmpm_grid_stats(plmpm_handle s, int frame, int64_t* active_nodes, int64_t* 
     hipFree(d_out);
     if (active_nodes) *active_nodes = (int64_t)h[0];
     if (active_blocks) *active_blocks = (int64_t)h[1];
+    return 0;
+}
+
+int plmpm_fk(plmpm_handle s, int first_frame, int n_substeps) {
+    NEED_BOUND(s);
+    REQUIRE(first_frame >= 0 && n_substeps > 0 && first_frame + n_substeps <= s->F, "fk: bad frame range");
+    return launch_fk(s, first_frame, n_substeps);
+}
+int plmpm_p2g(plmpm_handle s, int frame) {
+    NEED_BOUND(s);
+    REQUIRE(s->store, "the phase-split substep needs store_grid = 1");
+    REQUIRE(frame >= 0 && frame < s->F, "p2g: frame out of range");
+    DISPATCH(s, phase_p2g, s, frame);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+int plmpm_grid_g2p(plmpm_handle s, int frame) {
+    NEED_BOUND(s);
+    REQUIRE(s->store && frame >= 0 && frame < s->F, "grid_g2p: bad call");
+    DISPATCH(s, phase_grid_g2p, s, frame);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+int plmpm_grad_scatter(plmpm_handle s, int frame) {
+    NEED_BOUND(s);
+    REQUIRE(s->store && frame >= 0 && frame < s->F, "grad_scatter: bad call");
+    REQUIRE(s->dirty[frame], "grad_scatter(%d): the frame's grid is not resident (run the forward substep first)", frame);
+    REQUIRE(s->adj_frame[(frame + 1) & 1] == frame + 1, "grad_scatter(%d): adjoint of frame %d is not resident", frame, frame + 1);
+    DISPATCH(s, phase_grad_scatter, s, frame);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+int plmpm_grad_gather(plmpm_handle s, int frame) {
+    NEED_BOUND(s);
+    REQUIRE(s->store && frame >= 0 && frame < s->F, "grad_gather: bad call");
+    DISPATCH(s, phase_grad_gather, s, frame);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+int plmpm_chain_grad(plmpm_handle s, int first_frame, int n_substeps, int step) {
+    NEED_BOUND(s);
+    REQUIRE(first_frame >= 0 && n_substeps > 0 && first_frame + n_substeps <= s->F, "chain_grad: bad frame range");
+    if (s->dist && s->P > 0) {          // fold this step's (already rank-summed) local pose adjoints into the global ones
+        size_t np = (size_t)(n_substeps + 1) * s->P * 3, nr = (size_t)(n_substeps + 1) * s->P * 4;
+        hipLaunchKernelGGL(k_merge_pose_adj, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, s->stream,
+                           s->ppos_a + (size_t)first_frame * s->P * 3, s->ppos_l + (size_t)first_frame * s->P * 3, np);
+        hipLaunchKernelGGL(k_merge_pose_adj, dim3((unsigned)((nr + 255) / 256)), dim3(256), 0, s->stream,
+                           s->prot_a + (size_t)first_frame * s->P * 4, s->prot_l + (size_t)first_frame * s->P * 4, nr);
+    }
+    if (s->P > 0)
+        hipLaunchKernelGGL(k_fk_chain_grad, dim3(1), dim3(kMaxPrim), 0, s->stream, chain_args(s), first_frame, n_substeps, step,
+                           s->ppos, s->prot, s->pv, s->pw, s->ppos_a, s->prot_a, s->pv_a, s->pw_a, s->act_a);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+static int halo_field(plmpm_sim* s, int field, int frame, char** base, int* ncomp) {
+    if (field == PLMPM_HALO_GRID_IN) {
+        REQUIRE(s->store && frame >= 0 && frame < s->F, "halo: grid_in needs store_grid and a valid frame");
+        *base = s->gstore + (size_t)frame * s->gstride; *ncomp = 4;
+    } else if (field == PLMPM_HALO_GRID_OUT_ADJ) { *base = s->grid_out_adj; *ncomp = 3; }
+    else if (field == PLMPM_HALO_LOSS_MASS) { *base = s->loss_gm; *ncomp = 1; }
+    else return fail("unknown halo field %d", field);
+    return 0;
+}
+int plmpm_halo_bytes(plmpm_handle s, int field, int za, int zb, size_t* bytes) {
+    REQUIRE(s && bytes && za >= 0 && zb <= s->n && za < zb, "halo_bytes: bad plane range [%d,%d)", za, zb);
+    int nc = field == PLMPM_HALO_GRID_IN ? 4 : (field == PLMPM_HALO_GRID_OUT_ADJ ? 3 : 1);
+    *bytes = (size_t)nc * (zb - za) * s->n * s->n * s->tsz;
+    return 0;
+}
+int plmpm_halo_pack(plmpm_handle s, int field, int frame, int za, int zb, void* buf) {
+    NEED_BOUND(s);
+    REQUIRE(buf && za >= 0 && zb <= s->n && za < zb, "halo_pack: bad plane range [%d,%d)", za, zb);
+    char* base; int nc;
+    if (halo_field(s, field, frame, &base, &nc)) return -1;
+    size_t tot = (size_t)nc * (zb - za) * s->n * s->n;
+    if (s->cfg.dtype == PLMPM_F64)
+        hipLaunchKernelGGL((k_halo_pack<double>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s->stream, (const double*)base, s->G, nc, s->n, s->nb, za, zb, (double*)buf);
+    else
+        hipLaunchKernelGGL((k_halo_pack<float>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s->stream, (const float*)base, s->G, nc, s->n, s->nb, za, zb, (float*)buf);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+int plmpm_halo_unpack_add(plmpm_handle s, int field, int frame, int za, int zb, const void* buf) {
+    NEED_BOUND(s);
+    REQUIRE(buf && za >= 0 && zb <= s->n && za < zb, "halo_unpack_add: bad plane range [%d,%d)", za, zb);
+    char* base; int nc;
+    if (halo_field(s, field, frame, &base, &nc)) return -1;
+    size_t tot = (size_t)nc * (zb - za) * s->n * s->n;
+    if (s->cfg.dtype == PLMPM_F64)
+        hipLaunchKernelGGL((k_halo_unpack_add<double>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s->stream, (double*)base, s->G, nc, s->n, s->nb, za, zb, (const double*)buf);
+    else
+        hipLaunchKernelGGL((k_halo_unpack_add<float>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s->stream, (float*)base, s->G, nc, s->n, s->nb, za, zb, (const float*)buf);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+int plmpm_flags_region(plmpm_handle s, int frame, int bz_a, int bz_b, void** dev_ptr, size_t* count) {
+    NEED_BOUND(s);
+    REQUIRE(s->store && frame >= 0 && frame < s->F && dev_ptr && count, "flags_region: bad call");
+    REQUIRE(bz_a >= 0 && bz_b <= s->nb && bz_a < bz_b, "flags_region: bad block-plane range");
+    *dev_ptr = s->fstore + (size_t)frame * s->nblk + (size_t)bz_a * s->nb * s->nb;
+    *count = (size_t)(bz_b - bz_a) * s->nb * s->nb;
+    return 0;
+}
+int plmpm_pose_grad_region(plmpm_handle s, int first_frame, int n_frames, void** pos_adj, size_t* pos_count, void** rot_adj, size_t* rot_count) {
+    NEED_BOUND(s);
+    REQUIRE(first_frame >= 0 && n_frames > 0 && first_frame + n_frames <= s->F + 1, "pose_grad_region: bad frame range");
+    double* pa = s->dist ? s->ppos_l : s->ppos_a;
+    double* ra = s->dist ? s->prot_l : s->prot_a;
+    *pos_adj = pa + (size_t)first_frame * s->P * 3; *pos_count = (size_t)n_frames * s->P * 3;
+    *rot_adj = ra + (size_t)first_frame * s->P * 4; *rot_count = (size_t)n_frames * s->P * 4;
+    return 0;
+}
+int plmpm_action_grad_region(plmpm_handle s, void** dev_ptr, size_t* count) {
+    NEED_BOUND(s);
+    *dev_ptr = s->act_a; *count = (size_t)(s->F + 1) * std::max(s->P, 1) * PLMPM_MAX_ACTION_DIM;
+    return 0;
+}
+int plmpm_check_error(plmpm_handle s, int* flags) {
+    NEED_BOUND(s);
+    REQUIRE(flags, "null argument");
+    HIPCHK(hipMemcpyAsync(flags, s->err_d, 4, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    if (*flags) HIPCHK(hipMemsetAsync(s->err_d, 0, 4, s->stream));
     return 0;
 }
 

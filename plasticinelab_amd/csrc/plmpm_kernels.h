@@ -40,7 +40,9 @@ template <class T> struct Dev {
     SimP<T> P;
     int N, Npad, nb;                 // particles, padded, blocks per axis
     int nprim;
-    int z0, z1;                      // owned z-slab (nodes)
+    int z0, z1;                      // owned z-slab (nodes): pose adjoints / loss sums only count these
+    int zlo, zhi;                    // stencil bases of this rank's particles must satisfy zlo <= z, z + 2 < zhi
+    int* err;                        // device error word (bit 0: a particle left the slab + halo)
     size_t frame_bytes;
     char* state;                     // particle frames
     T* adj[2];                       // ping-pong adjoint frames
@@ -195,6 +197,7 @@ __global__ __launch_bounds__(kBlock) void k_p2g(Dev<T> D, int f) {
     if (valid) { x[0] = X[p]; x[1] = X[Np + p]; x[2] = X[2 * Np + p]; }
     int base[3];
     for (int d = 0; d < 3; ++d) base[d] = (int)(x[d] * (double)D.P.inv_dx - 0.5);
+    if (WRITE_F && valid && (base[2] < D.zlo || base[2] + 2 >= D.zhi)) atomicOr(D.err, 1);
     Tile tl = block_tile(base, valid, sred, TileCap<T>::nodes);
     const int tn = tl.e[0] * tl.e[1] * tl.e[2];
     if (tl.ok) {
@@ -434,7 +437,9 @@ __global__ __launch_bounds__(kBlock) void k_grid_op_grad(Dev<T> D, int f) {
         T gm = D.gin[0][idx];
         T mv[3] = {D.gin[1][idx], D.gin[2][idx], D.gin[3][idx]};
         T va[3] = {D.goa[0][idx], D.goa[1][idx], D.goa[2][idx]}, ma, mva[3];
+        const bool owned = I[2] >= D.z0 && I[2] < D.z1;     // halo nodes are computed on two ranks: count once
         grid_node_bwd<T>(D.P, I, gm, mv, D.nprim, sp, va, &ma, mva, [&](int q, const PoseAdj<T>& pa) {
+            if (!owned) return;
             double* o = &sacc[q * 14];
             for (int d = 0; d < 3; ++d) { atomicAdd(&o[d], pa.pos[d]); atomicAdd(&o[7 + d], pa.pos1[d]); }
             for (int d = 0; d < 4; ++d) { atomicAdd(&o[3 + d], pa.rot[d]); atomicAdd(&o[10 + d], pa.rot1[d]); }
@@ -549,6 +554,30 @@ __global__ __launch_bounds__(kBlock) void k_grid_mass(Dev<T> D, int f, T* gm) {
             }
         }
     }
+}
+
+// z-slab halo: node planes z in [za, zb) of `ncomp` SoA component arrays (stride G) <-> a dense buffer
+// laid out [comp][z - za][y][x].  Unpack adds (symmetric sum exchange).
+template <class T>
+__global__ void k_halo_pack(const T* src, size_t G, int ncomp, int n, int nb, int za, int zb, T* buf) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t per = (size_t)(zb - za) * n * n;
+    if (i >= per * ncomp) return;
+    int c = (int)(i / per);
+    size_t r = i - (size_t)c * per;
+    int x = (int)(r % n), y = (int)((r / n) % n), z = za + (int)(r / ((size_t)n * n));
+    buf[i] = src[(size_t)c * G + node_index(nb, x, y, z)];
+}
+template <class T>
+__global__ void k_halo_unpack_add(T* dst, size_t G, int ncomp, int n, int nb, int za, int zb, const T* buf) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t per = (size_t)(zb - za) * n * n;
+    if (i >= per * ncomp) return;
+    int c = (int)(i / per);
+    size_t r = i - (size_t)c * per;
+    int x = (int)(r % n), y = (int)((r / n) % n), z = za + (int)(r / ((size_t)n * n));
+    T v = buf[i];
+    if (v != T(0)) dst[(size_t)c * G + node_index(nb, x, y, z)] += v;
 }
 
 // after substep_grad: zero grid_in / grid_in_adj / flags of the active blocks

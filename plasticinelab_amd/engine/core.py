@@ -32,7 +32,7 @@ class Engine:
     def __init__(self, *, n_grid: int, n_particles: int, max_frames: int, substeps: int, dt: float, p_vol: float,
                  p_mass: float, gravity: Sequence[float], ground_friction: float, primitives: Sequence[dict] = (),
                  dtype: str = "float32", svd_grad_clamp: float = 1e-6, device: Optional[torch.device] = None,
-                 slab: Optional[Sequence[int]] = None, store_grid="auto"):
+                 slab: Optional[Sequence[int]] = None, store_grid="auto", slab_halo: int = 0):
         self.lib = L.load()
         if not torch.cuda.is_available():
             raise L.EngineError("no ROCm device visible: the MPM engine has no CPU path")
@@ -48,6 +48,7 @@ class Engine:
         if store_grid == "auto":       # per-frame grid_m/grid_v_in: worth it while it stays a modest slice of 288 GB
             store_grid = max_frames * 4 * (8 if cfg.dtype == L.F64 else 4) * n_grid ** 3 <= 48 * 2 ** 30
         cfg.store_grid = int(bool(store_grid))
+        cfg.slab_halo = int(slab_halo)
         self.store_grid = bool(store_grid)
         parr = (L.Primitive * max(len(primitives), 1))()
         self.action_dims = []
@@ -209,6 +210,90 @@ class Engine:
         p = np.empty(self.n_particles, np.int32)
         L.check(self.lib.plmpm_get_order(self.h, _ptr(p)))
         return p
+
+    # ---- multi-GPU building blocks (plasticinelab_amd.distributed drives these)
+    HALO_GRID_IN, HALO_GRID_OUT_ADJ, HALO_LOSS_MASS = 0, 1, 2
+
+    def fk(self, first, n):
+        L.check(self.lib.plmpm_fk(self.h, first, n))
+
+    def p2g(self, f):
+        L.check(self.lib.plmpm_p2g(self.h, f))
+
+    def grid_g2p(self, f):
+        L.check(self.lib.plmpm_grid_g2p(self.h, f))
+
+    def grad_scatter(self, f):
+        L.check(self.lib.plmpm_grad_scatter(self.h, f))
+
+    def grad_gather(self, f):
+        L.check(self.lib.plmpm_grad_gather(self.h, f))
+
+    def chain_grad(self, first, n, step):
+        L.check(self.lib.plmpm_chain_grad(self.h, first, n, step))
+
+    @property
+    def torch_dtype(self):
+        return torch.float64 if self.dtype == "float64" else torch.float32
+
+    def halo_pack(self, field, f, za, zb):
+        """Planes z in [za, zb) of a halo field as a dense device tensor [comp, zb-za, n, n]."""
+        nb = C.c_size_t()
+        L.check(self.lib.plmpm_halo_bytes(self.h, field, za, zb, C.byref(nb)))
+        n = self.n_grid
+        buf = torch.empty(nb.value // (8 if self.dtype == "float64" else 4), dtype=self.torch_dtype, device=self.device)
+        L.check(self.lib.plmpm_halo_pack(self.h, field, f, za, zb, C.c_void_p(buf.data_ptr())))
+        return buf.view(-1, zb - za, n, n)
+
+    def halo_unpack_add(self, field, f, za, zb, buf):
+        buf = buf.contiguous()
+        L.check(self.lib.plmpm_halo_unpack_add(self.h, field, f, za, zb, C.c_void_p(buf.data_ptr())))
+
+    def _view(self, ptr, count, dtype):
+        """torch view of engine-owned device memory (inside one of the bound workspaces)."""
+        esz = torch.empty(0, dtype=dtype).element_size()
+        for b in self._bufs:
+            off = ptr - b.data_ptr()
+            if 0 <= off and off + count * esz <= b.numel():
+                return b[off:off + count * esz].view(dtype)
+        raise L.EngineError("pointer outside the bound workspaces")
+
+    def flags_view(self, f, bz_a, bz_b):
+        p, cnt = C.c_void_p(), C.c_size_t()
+        L.check(self.lib.plmpm_flags_region(self.h, f, bz_a, bz_b, C.byref(p), C.byref(cnt)))
+        return self._view(p.value, cnt.value, torch.int32)
+
+    def pose_grad_views(self, first, n_frames):
+        pa, pc, ra, rc = C.c_void_p(), C.c_size_t(), C.c_void_p(), C.c_size_t()
+        L.check(self.lib.plmpm_pose_grad_region(self.h, first, n_frames, C.byref(pa), C.byref(pc), C.byref(ra), C.byref(rc)))
+        return self._view(pa.value, pc.value, torch.float64), self._view(ra.value, rc.value, torch.float64)
+
+    def loss_scatter(self, f):
+        L.check(self.lib.plmpm_loss_scatter(self.h, f))
+
+    def loss_partials(self, f, phase):
+        out = np.zeros(32)
+        L.check(self.lib.plmpm_loss_partials(self.h, f, phase, _ptr(out)))
+        return out
+
+    def loss_set_globals(self, g32):
+        g = _f64(g32, (32,))
+        L.check(self.lib.plmpm_loss_set_globals(self.h, _ptr(g)))
+
+    def loss_finish(self, g32):
+        g, out = _f64(g32, (32,)), np.zeros(6)
+        L.check(self.lib.plmpm_loss_finish(self.h, _ptr(g), _ptr(out)))
+        return dict(loss=out[0], sdf_loss=out[1], density_loss=out[2], contact_loss=out[3], iou=out[4])
+
+    def loss_backward_local(self, f):
+        L.check(self.lib.plmpm_loss_backward_local(self.h, f))
+
+    def check_error(self):
+        e = C.c_int(0)
+        L.check(self.lib.plmpm_check_error(self.h, C.byref(e)))
+        if e.value & 1:
+            raise L.EngineError("a particle left this rank's z-slab + halo (fixed ownership, no migration yet): "
+                                "raise slab_halo or use fewer ranks")
 
     def profile_enable(self, on=True):
         L.check(self.lib.plmpm_profile_enable(self.h, int(on)))
