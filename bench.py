@@ -13,9 +13,11 @@ Workload (config.workload "config3_cube128"): BASELINE.json configs[2] as synthe
 with 500 000 seed-0 uniform particles (~8 per cell), sigma_y = 200, two Sphere manipulators (r = 0.05)
 touching opposite faces, seeded actions, own target grid (the cube's mass grid shifted by a few cells).
 
-Prints ONE JSON line (rank 0).  N > 1: one process per GPU, each running the full workload (independent
-replicas, no data-path collective) -- the z-slab decomposition with an RCCL halo is not built yet, see
-DESIGN.md "multi-GPU"; scaling is therefore reported as "weak".
+Prints ONE JSON line (rank 0).  N > 1: one process per GPU; the SAME total workload is cut into z-slabs
+(plasticinelab_amd/distributed.py: fixed particle ownership, symmetric halo sum exchange over RCCL each substep,
+forward and adjoint) -> "scaling": "strong".  If the slab path cannot run (body too thin for N slabs, a particle
+drifting past the halo, an RCCL error) the bench falls back to N independent replicas of the workload
+("scaling": "weak") and says so in config.parallelism.
 """
 from __future__ import annotations
 
@@ -84,18 +86,28 @@ def seeded_actions(K, A):
     return a
 
 
-def build_env(args, device):
+def _target(x_all, sim):
+    return mass_grid(np.clip(x_all + np.array([0.03, 0.0, 0.02]), 0.03, 0.97), sim.n_grid, sim.p_mass)
+
+
+def build_env(args, device, rank=0, world=1, slabs=False):
     from plasticinelab_amd.engine.taichi_env import TaichiEnv
     sub = int(2e-3 // (0.5e-4 / (args.quality * 0.5)))
     frames = max(args.steps, args.warmup, 1) * sub + 1
     cfg = workload_cfg(args.particles, args.quality, max_steps=frames)
+    if slabs:
+        from plasticinelab_amd.distributed import make_slab_env
+        n = int(128 * args.quality * 0.5)
+        span = int(0.31 * n) + 3
+        halo = max(2, min(4, span // (2 * world)))
+        env, layout, _ = make_slab_env(cfg, rank, world, halo=halo, compute_dtype=args.dtype, device=device, target_fn=_target)
+        env.loss.set_weights(10, 10, 1, False)
+        return env, f"{world} z-slabs {list(layout.bounds)}, halo {halo} layers, RCCL sum exchange per substep"
     env = TaichiEnv(cfg, compute_dtype=args.dtype, device=device)
     env.initialize()
-    sim = env.simulator
-    target = mass_grid(np.clip(env.init_particles + np.array([0.03, 0.0, 0.02]), 0.03, 0.97), sim.n_grid, sim.p_mass)
-    env.loss.load_target_density(grids=target)
+    env.loss.load_target_density(grids=_target(env.init_particles, env.simulator))
     env.loss.set_weights(10, 10, 1, False)
-    return env
+    return env, ("single GPU" if world == 1 else f"{world} independent replicas (no collective)")
 
 
 def rollout(env, actions):
@@ -144,31 +156,73 @@ def main():
     ap.add_argument("--quality", type=float, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--replicas", action="store_true", help="N > 1: independent replicas instead of z-slabs")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
-    local = int(os.environ.get("LOCAL_RANK", 0))
+    local = int(os.environ.get("LOCAL_RANK", 0)) % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
-
-    env = build_env(args, device)
-    sim = env.simulator
-    K, W, sub = args.steps, args.warmup, sim.substeps
-    A = env.primitives.action_dim
-    state0 = env.get_state()["state"]
+        backend = os.environ.get("PLB_DIST_BACKEND", "nccl")     # "gloo" lets two ranks share one GPU (testing only)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
+    red_dev = device if (dist is None or dist.get_backend() == "nccl") else torch.device("cpu")
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    if W > 0:
+    def agree(ok):
+        """True only if every rank succeeded."""
+        if dist is None:
+            return ok
+        t = torch.tensor([1.0 if ok else 0.0], device=red_dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(t.item() > 0.5)
+
+    K, W = args.steps, args.warmup
+    slabs = world > 1 and not args.replicas
+    env, state0 = None, None
+    if slabs:
+        note = ""
+        try:
+            env, parallelism = build_env(args, device, rank, world, slabs=True)
+            ok = True
+        except Exception as e:                                    # noqa: BLE001
+            ok, note = False, f"{type(e).__name__}: {e}"
+        if agree(ok):
+            try:                                                  # the warm-up doubles as the feasibility check
+                state0 = env.get_state()["state"]
+                env.set_state(state0, 666.0, False)
+                rollout(env, seeded_actions(max(W, K), env.primitives.action_dim))
+                ok = True
+            except Exception as e:                                # noqa: BLE001
+                ok, note = False, f"{type(e).__name__}: {e}"
+            ok = agree(ok)
+        else:
+            ok = False
+        if not ok:
+            if rank == 0:
+                print(f"[bench] slab path unavailable ({note or 'another rank failed'}); falling back to replicas", file=sys.stderr)
+            env, slabs, state0 = None, False, None
+            if 'torch' in sys.modules:
+                torch.cuda.empty_cache()
+    if env is None:
+        env, parallelism = build_env(args, device, rank, world, slabs=False)
+        state0 = env.get_state()["state"]
+    sim = env.simulator
+    sub = sim.substeps
+    A = env.primitives.action_dim
+
+    if W > 0 and not slabs:
         env.set_state(state0, 666.0, False)
         rollout(env, seeded_actions(W, A))
     env.set_state(state0, 666.0, False)          # inputs resident in HBM before the timed region
@@ -179,23 +233,24 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    total_substeps = K * sub * world
+    total_substeps = K * sub * (1 if slabs else world)         # slabs: one shared workload; replicas: one each
     value = total_substeps / elapsed
 
     out = {
         "metric": "MPM substeps/sec (fwd+bwd)", "value": value, "unit": "substeps/s", "n_gpus": world,
-        "steps": K, "warmup": W, "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True, "scaling": "weak",
+        "steps": K, "warmup": W, "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True, "scaling": "strong" if slabs else "weak",
         "vs_baseline": None, "dtype": "f32" if args.dtype == "float32" else "f64", "data": "synthetic",
-        "config": {"workload": "config3_cube128", "n_grid": sim.n_grid, "n_particles": sim.n_particles,
+        "config": {"workload": "config3_cube128", "n_grid": sim.n_grid,
+                   "n_particles": args.particles if slabs else sim.n_particles,
                    "substeps_per_step": sub, "primitives": 2, "positions": "f64", "loss": "sdf+density+hard contact",
-                   "parallelism": "single GPU" if world == 1 else f"{world} independent replicas (no collective)"},
+                   "parallelism": parallelism},
         "final_loss": float(loss),
     }
 
-    if rank == 0 and not args.no_roofline:
+    if rank == 0 and not args.no_roofline and world == 1:
         # per-kernel durations, measured live with HIP events on the launch stream over the same K-step rollout
         env.set_state(state0, 666.0, False)
         nodes, blocks = sim.engine.grid_stats(0)
@@ -222,7 +277,7 @@ def main():
                            "substep_kernel_sum_us": sum_us,
                            "substep_frac": (alg_substep / (sum_us * 1e-6)) / (HBM_PEAK_GBS * 1e9),
                            "kernels": kernels}
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(args, env)
     if rank == 0:
         print(json.dumps(out))

@@ -1,2 +1,2 @@
 cd $GRAFT_REPO_ROOT
-timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -6
+timeout 1200 python -m pytest tests/test_gpu_distributed.py -m gpu -x -q 2>&1 | tail -3

@@ -95,24 +95,29 @@ class HaloComm:
     def __init__(self, layout: SlabLayout, rank: int, group=None):
         self.layout, self.rank, self.group = layout, rank, group
         self.stage_host = dist.get_backend(group) == "gloo"      # gloo P2P wants host tensors
+        # small host records (loss sums) are reduced on the device when the backend is RCCL
+        self.scalar_device = torch.device("cpu") if self.stage_host else torch.device("cuda", torch.cuda.current_device())
 
     def _wire(self, t: torch.Tensor) -> torch.Tensor:
         return t.cpu() if (self.stage_host and t.is_cuda) else t
 
-    def exchange(self, pack: Callable[[int, int], torch.Tensor], unpack_add: Callable[[int, int, torch.Tensor], None]):
+    def exchange(self, *fields):
+        """fields: (pack, unpack_add) pairs, ``pack(za, zb) -> tensor`` and ``unpack_add(za, zb, tensor)``.
+        All fields of all faces travel in ONE batch of point-to-point ops (one latency per substep phase)."""
         faces = self.layout.faces(self.rank)
         if not faces:
             return
-        sends, recvs, ops = [], [], []
+        work, ops = [], []
         for nbr, za, zb in faces:
-            s = self._wire(pack(za, zb)).contiguous()
-            r = torch.empty_like(s)
-            sends.append(s); recvs.append(r)
-            ops.append(dist.P2POp(dist.isend, s, nbr, self.group))
-            ops.append(dist.P2POp(dist.irecv, r, nbr, self.group))
+            for pack, unpack_add in fields:
+                s = self._wire(pack(za, zb)).contiguous()
+                r = torch.empty_like(s)
+                work.append((za, zb, r, s, unpack_add))
+                ops.append(dist.P2POp(dist.isend, s, nbr, self.group))
+                ops.append(dist.P2POp(dist.irecv, r, nbr, self.group))
         for req in dist.batch_isend_irecv(ops):
             req.wait()
-        for (nbr, za, zb), r, s in zip(faces, recvs, sends):
+        for za, zb, r, _s, unpack_add in work:
             unpack_add(za, zb, r)
 
     def all_reduce_(self, t: torch.Tensor, op=dist.ReduceOp.SUM):
@@ -130,7 +135,7 @@ class HaloComm:
         """Combine the 32-double partial record of ``plmpm_loss_partials`` across ranks."""
         if self.layout.world == 1:
             return rec
-        t = torch.as_tensor(rec, dtype=torch.float64).clone()
+        t = torch.as_tensor(rec, dtype=torch.float64).clone().to(self.scalar_device)
         out = t.clone()
         s = t.clone(); dist.all_reduce(s, op=dist.ReduceOp.SUM, group=self.group)
         if phase == 0:
@@ -146,7 +151,7 @@ class HaloComm:
                 out[8:16] = mn[8:16]                  # hard contact: min over all particles
         else:
             out[8:16] = s[8:16]                       # soft contact: weighted sum (local sums used the global norm)
-        return out.numpy()
+        return out.cpu().numpy()
 
 
 class SlabEngine:
@@ -164,8 +169,8 @@ class SlabEngine:
     # ---- halos
     def _halo(self, field, f, flags=False):
         e = self._e
-        self.comm.exchange(lambda za, zb: e.halo_pack(field, f, za, zb),
-                           lambda za, zb, buf: e.halo_unpack_add(field, f, za, zb, buf.to(e.device)))
+        fields = [(lambda za, zb: e.halo_pack(field, f, za, zb),
+                   lambda za, zb, buf: e.halo_unpack_add(field, f, za, zb, buf.to(e.device)))]
         if flags:
             def pack(za, zb):
                 return e.flags_view(f, za // 4, (zb + 3) // 4).clone()
@@ -173,7 +178,8 @@ class SlabEngine:
             def merge(za, zb, buf):
                 v = e.flags_view(f, za // 4, (zb + 3) // 4)
                 v.bitwise_or_(buf.to(v.device))
-            self.comm.exchange(pack, merge)
+            fields.append((pack, merge))
+        self.comm.exchange(*fields)
 
     # ---- hot path
     def step(self, first, n):
