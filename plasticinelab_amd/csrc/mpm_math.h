@@ -49,6 +49,49 @@ template <> PLB_HD double t_log1p<double>(double x) { return log1p(x); }
 template <class T> PLB_HD T t_expm1(T x);
 template <> PLB_HD float t_expm1<float>(float x) { return expm1f(x); }
 template <> PLB_HD double t_expm1<double>(double x) { return expm1(x); }
+// 1-ulp hardware reciprocal / rsqrt / sqrt on the fp32 device path (v_rcp_f32, v_rsq_f32, v_sqrt_f32) instead
+// of the ~10-instruction IEEE sequences; exact operations for double and on the host.
+template <class T> PLB_HD T t_rcp(T x) { return T(1) / x; }
+template <> PLB_HD float t_rcp<float>(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_rcpf(x);
+#else
+    return 1.0f / x;
+#endif
+}
+template <class T> PLB_HD T t_rsqrt(T x) { return T(1) / t_sqrt(x); }
+template <> PLB_HD float t_rsqrt<float>(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_rsqf(x);
+#else
+    return 1.0f / sqrtf(x);
+#endif
+}
+template <class T> PLB_HD T t_fsqrt(T x) { return t_sqrt(x); }
+template <> PLB_HD float t_fsqrt<float>(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_sqrtf(x);
+#else
+    return sqrtf(x);
+#endif
+}
+// log(1+s) / exp(e)-1 with full relative accuracy at small arguments; short series on the fp32 device path
+template <class T> PLB_HD T t_log1p_fast(T s) { return t_log1p(s); }
+template <class T> PLB_HD T t_expm1_fast(T e) { return t_expm1(e); }
+#if defined(__HIP_DEVICE_COMPILE__)
+template <> PLB_HD float t_log1p_fast<float>(float s) {
+    if (fabsf(s) < 0.25f) {                       // log1p(s) = 2 atanh(s / (2 + s)), |z| < 0.143
+        float z = s * __builtin_amdgcn_rcpf(2.0f + s), z2 = z * z;
+        return 2.0f * z * (1.0f + z2 * (1.0f / 3 + z2 * (1.0f / 5 + z2 * (1.0f / 7 + z2 * (1.0f / 9 + z2 * (1.0f / 11))))));
+    }
+    return __logf(1.0f + s);
+}
+template <> PLB_HD float t_expm1_fast<float>(float e) {
+    if (fabsf(e) < 0.25f)
+        return e * (1.0f + e * (0.5f + e * (1.0f / 6 + e * (1.0f / 24 + e * (1.0f / 120 + e * (1.0f / 720 + e * (1.0f / 5040)))))));
+    return __expf(e) - 1.0f;
+}
+#endif
 template <class T> PLB_HD T t_abs(T x) { return x < T(0) ? -x : x; }
 template <class T> PLB_HD T t_max(T a, T b) { return a > b ? a : b; }
 template <class T> PLB_HD T t_min(T a, T b) { return a < b ? a : b; }
@@ -136,12 +179,12 @@ template <class T> PLB_HD void jacobi_pair(T& app, T& aqq, T& apq, T& arp, T& ar
     const T d = aqq - app;
     T t;
     if (t_abs(apq) < Tol<T>::small_angle() * t_abs(d)) {
-        t = apq / d;                 // tan(theta) ~ apq/(aqq-app): keeps theta = d/(2 apq) from overflowing
+        t = apq * t_rcp(d);          // tan(theta) ~ apq/(aqq-app): keeps theta = d/(2 apq) from overflowing
     } else {
-        T theta = d / (T(2) * apq);
-        t = (theta >= T(0) ? T(1) : T(-1)) / (t_abs(theta) + t_sqrt(theta * theta + T(1)));
+        T theta = d * t_rcp(T(2) * apq);
+        t = (theta >= T(0) ? T(1) : T(-1)) * t_rcp(t_abs(theta) + t_fsqrt(theta * theta + T(1)));
     }
-    T c = T(1) / t_sqrt(t * t + T(1));
+    T c = t_rsqrt(t * t + T(1));
     T s = t * c;
     app -= t * apq;
     aqq += t * apq;
@@ -179,13 +222,13 @@ template <class T> PLB_HD void svd_eform(const T* Et, Svd3<T>& r) {
     }
     r.lam[0] = a00; r.lam[1] = a11; r.lam[2] = a22;
     for (int i = 0; i < 3; ++i) {
-        T sg = t_sqrt(t_max(T(1) + r.lam[i], T(0)));
+        T sg = t_fsqrt(t_max(T(1) + r.lam[i], T(0)));
         r.sig[i] = sg;
-        r.s[i] = r.lam[i] / (T(1) + sg);
+        r.s[i] = r.lam[i] * t_rcp(T(1) + sg);
     }
     // U = F V Sigma^-1, F = I + Et
     for (int i = 0; i < 3; ++i) {
-        T inv = T(1) / t_max(r.sig[i], T(1e-30));
+        T inv = t_rcp(t_max(r.sig[i], T(1e-30)));
         for (int k = 0; k < 3; ++k)
             r.U[3 * k + i] = (V[3 * k + i] + Et[3 * k] * V[i] + Et[3 * k + 1] * V[3 + i] + Et[3 * k + 2] * V[6 + i]) * inv;
     }
@@ -234,21 +277,21 @@ template <class T> PLB_HD void constitutive_fwd(const T* Et, T mu, T lam, T ys, 
     T mean = T(0);
     for (int i = 0; i < 3; ++i) {
         k.unc[i] = T(0.05) < S.sig[i];          // ti.max(sig, 0.05): adjoint to sig iff 0.05 < sig
-        k.eps[i] = k.unc[i] ? t_log1p(S.s[i]) : t_log(T(0.05));
+        k.eps[i] = k.unc[i] ? t_log1p_fast(S.s[i]) : T(-2.995732273553991);     // log(0.05)
         mean += k.eps[i];
     }
     mean *= T(1) / T(3);
     T n2 = T(1e-8);
     for (int i = 0; i < 3; ++i) { k.eh[i] = k.eps[i] - mean; n2 += k.eh[i] * k.eh[i]; }
-    k.nrm = t_sqrt(n2);
-    k.c = ys / (T(2) * mu);
+    k.nrm = t_fsqrt(n2);
+    k.c = ys * t_rcp(T(2) * mu);
     k.yield = (k.nrm - k.c) > T(0);
     T detsign = T(1);
     if (k.yield) {
-        T f = (k.nrm - k.c) / k.nrm;
+        T f = (k.nrm - k.c) * t_rcp(k.nrm);
         for (int i = 0; i < 3; ++i) {
             k.epsn[i] = k.eps[i] - f * k.eh[i];
-            k.gm1[i] = t_expm1(k.epsn[i]);
+            k.gm1[i] = t_expm1_fast(k.epsn[i]);
             k.g[i] = T(1) + k.gm1[i];
         }
         T US[9];
@@ -284,12 +327,13 @@ template <class T> PLB_HD void constitutive_fwd(const T* Et, T mu, T lam, T ys, 
 template <class T> PLB_HD T dd_exp(T a, T b) {       // (e^a - e^b)/(a - b)
     T d = a - b;
     if (t_abs(d) < Tol<T>::dd()) return t_exp(b) * (T(1) + d * (T(0.5) + d * (T(1) / T(6) + d * (T(1) / T(24)))));
-    return (t_exp(a) - t_exp(b)) / d;
+    return (t_exp(a) - t_exp(b)) * t_rcp(d);
 }
 template <class T> PLB_HD T dd_log(T a, T b) {       // (log a - log b)/(a - b), a,b > 0
-    T t = (a - b) / b;
-    if (t_abs(t) < Tol<T>::dd()) return (T(1) - t * (T(0.5) - t * (T(1) / T(3) - t * T(0.25)))) / b;
-    return t_log1p(t) / (t * b);
+    T ib = t_rcp(b);
+    T t = (a - b) * ib;
+    if (t_abs(t) < Tol<T>::dd()) return (T(1) - t * (T(0.5) - t * (T(1) / T(3) - t * T(0.25)))) * ib;
+    return t_log1p_fast(t) * t_rcp(t * b);
 }
 
 // VJP of (new_F, stress) w.r.t. F_tmp: returns Ft_adj = d<GF,new_F>/dFt + d<GS,stress>/dFt.
@@ -304,13 +348,13 @@ template <class T> PLB_HD void constitutive_vjp(const Consti<T>& k, T mu, T lam,
     for (int i = 0; i < 3; ++i)
         for (int j = 0; j < 3; ++j) {
             T dl = t_abs(S.lam[j] - S.lam[i]);
-            att[i][j] = (svd_clamp > T(0) && dl < svd_clamp) ? dl / svd_clamp : T(1);
+            att[i][j] = (svd_clamp > T(0) && dl < svd_clamp) ? dl * t_rcp(svd_clamp) : T(1);
         }
     T J = k.J;
     if (!k.yield) {
         T dvol = lam * (T(2) * J - T(1));
         for (int q = 0; q < 3; ++q) {
-            T Jq = J / sig[q];      // dJ/dsig_q
+            T Jq = J * t_rcp(sig[q]);      // dJ/dsig_q
             if (sig[q] < T(1e-20)) Jq = T(0);
             M[4 * q] = T(2) * mu * (T(2) * sig[q] - T(1)) * Gs[4 * q] + dvol * Jq * (Gs[0] + Gs[4] + Gs[8]);
         }
@@ -318,7 +362,7 @@ template <class T> PLB_HD void constitutive_vjp(const Consti<T>& k, T mu, T lam,
             for (int j = 0; j < 3; ++j) {
                 if (i == j) continue;
                 T ssum = sig[i] + sig[j];
-                T inv = ssum > T(1e-20) ? T(1) / ssum : T(0);
+                T inv = ssum > T(1e-20) ? t_rcp(ssum) : T(0);
                 T kij = T(2) * mu * (ssum - T(1)) * inv;
                 M[3 * i + j] = kij * sig[j] * (Gs[3 * i + j] + Gs[3 * j + i])
                     + (T(1) - att[i][j]) * T(2) * mu * (Gs[3 * i + j] * sig[j] - Gs[3 * j + i] * sig[i]) * inv;
@@ -331,14 +375,15 @@ template <class T> PLB_HD void constitutive_vjp(const Consti<T>& k, T mu, T lam,
     mat_mul_tn(S.U, GF, tmp); mat_mul(tmp, S.V, Gf);            // U^T GF V
     // d g_i / d sig_q
     T dg[3][3], dJ[3];
-    T cn = k.c / k.nrm, cn3 = k.c / (k.nrm * k.nrm * k.nrm);
+    T inrm = t_rcp(k.nrm);
+    T cn = k.c * inrm, cn3 = k.c * inrm * inrm * inrm;
     for (int q = 0; q < 3; ++q) {
-        T dsc = k.unc[q] ? T(1) / sig[q] : T(0);                // d eps_q / d sig_q
+        T dsc = k.unc[q] ? t_rcp(sig[q]) : T(0);                // d eps_q / d sig_q
         dJ[q] = T(0);
         for (int i = 0; i < 3; ++i) {
             T de = T(1) / T(3) + cn * ((i == q ? T(1) : T(0)) - T(1) / T(3)) - cn3 * k.eh[i] * k.eh[q];
             dg[i][q] = k.g[i] * de * dsc;
-            dJ[q] += (J / k.g[i]) * dg[i][q];
+            dJ[q] += (J * t_rcp(k.g[i])) * dg[i][q];
         }
     }
     T dvol = lam * (T(2) * J - T(1));
@@ -358,10 +403,10 @@ template <class T> PLB_HD void constitutive_vjp(const Consti<T>& k, T mu, T lam,
                 ddg = dd_exp(k.epsn[i], k.epsn[j]) * cn * dd_log(sig[i], sig[j]);
             } else {
                 T ds = sig[i] - sig[j];
-                ddg = ds != T(0) ? (k.g[i] - k.g[j]) / ds : T(0);
+                ddg = ds != T(0) ? (k.g[i] - k.g[j]) * t_rcp(ds) : T(0);
             }
             T ssum = sig[i] + sig[j];
-            T inv = ssum > T(1e-20) ? T(1) / ssum : T(0);
+            T inv = ssum > T(1e-20) ? t_rcp(ssum) : T(0);
             T sumr = (k.g[i] + k.g[j]) * inv;
             T a = T(0.5) * (ddg + sumr), b = T(0.5) * (ddg - sumr);
             T kk = T(2) * mu * (k.g[i] + k.g[j] - T(1)) * ddg * inv;
@@ -553,7 +598,7 @@ PLB_HD void p2g_particle_grad(const SimP<T>& P, const X* x, const T* v, const T*
         T acc = s1[d];
         for (int a = 0; a < 3; ++a) {
             for (int b = 0; b < 3; ++b) acc += A[3 * a + b] * M[9 * a + 3 * b + d];
-            acc -= P.dx * A[3 * a + d] * va[a] / P.p_mass;       // d/d dp: sum_o w_o A^T gva_o, dp = (k - fx) dx
+            acc -= P.dx * A[3 * a + d] * va[a] * t_rcp(P.p_mass);       // d/d dp: sum_o w_o A^T gva_o, dp = (k - fx) dx
         }
         fxa[d] = acc;
     }

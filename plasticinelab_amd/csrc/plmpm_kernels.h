@@ -19,6 +19,13 @@
 namespace plb {
 
 constexpr int kBlock = 256;          // threads per workgroup in particle kernels
+// minimum waves per SIMD the register allocator must leave room for (second __launch_bounds__ argument)
+#ifndef PLB_P2G_WAVES
+#define PLB_P2G_WAVES 4
+#endif
+#ifndef PLB_P2G_GRAD_WAVES
+#define PLB_P2G_GRAD_WAVES 1
+#endif
 constexpr int kMaxPrim = 8;
 // LDS tile capacity (nodes) of the scatter/gather kernels: 16 KiB per tile for either scalar type
 template <class T> struct TileCap;
@@ -183,7 +190,7 @@ __device__ __forceinline__ Tile block_tile(const int* base, bool valid, int* sre
 // p2g: compute_F_tmp + svd + von Mises + stress + APIC scatter      (mpm_simulator.py:82-90,157-184)
 // WRITE_F: store F[f+1] (forward) or not (recompute in substep_grad).
 template <class T, bool WRITE_F>
-__global__ __launch_bounds__(kBlock) void k_p2g(Dev<T> D, int f) {
+__global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_p2g(Dev<T> D, int f) {
     __shared__ int sred[32];
     // accumulate in double: on gfx950 ds_add_f64 is ~5x cheaper per instruction than ds_add_f32
     // (profiles/microbench/lds_atomics.hip), and the node sums lose no precision
@@ -465,7 +472,7 @@ __global__ __launch_bounds__(kBlock) void k_grid_op_grad(Dev<T> D, int f) {
 // ------------------------------------------------------------------------------------------------
 // p2g.grad + svd_grad + compute_F_tmp.grad: gather grid_in_adj, finish adjoint frame `dst`
 template <class T>
-__global__ __launch_bounds__(kBlock) void k_p2g_grad(Dev<T> D, int f, int src, int dst) {
+__global__ __launch_bounds__(kBlock, PLB_P2G_GRAD_WAVES) void k_p2g_grad(Dev<T> D, int f, int src, int dst) {
     __shared__ int sred[32];
     __shared__ Vec4<T> tile[TileCap<T>::nodes];
     const int p = blockIdx.x * kBlock + threadIdx.x;
