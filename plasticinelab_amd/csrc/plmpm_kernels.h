@@ -20,6 +20,9 @@ namespace plb {
 
 constexpr int kBlock = 256;          // threads per workgroup in particle kernels
 // minimum waves per SIMD the register allocator must leave room for (second __launch_bounds__ argument)
+#ifndef PLB_ABLATE
+#define PLB_ABLATE 0          // profiling only: 1 no LDS atomics, 2 no tile flush, 4 no scatter at all
+#endif
 #ifndef PLB_P2G_WAVES
 #define PLB_P2G_WAVES 4
 #endif
@@ -160,6 +163,33 @@ template <class T> __device__ __forceinline__ T seg_sum(T v, const Seg<T>& s) {
     v += row_shl<8>(v) * s.m8;
     return v;
 }
+// Several values at once.  For float the four steps are single fused v_fmac_f32_dpp instructions (hipcc does
+// not fold v_mov_b32_dpp into the multiply-add by itself); interleaving the values keeps >= 2 instructions
+// between a write and the DPP read of the same register, the leading s_nop covers the producer before the block.
+template <class T> __device__ __forceinline__ void seg_sum4(T& a, T& b, T& c, T& d, const Seg<T>& s) {
+    a = seg_sum(a, s); b = seg_sum(b, s); c = seg_sum(c, s); d = seg_sum(d, s);
+}
+template <class T> __device__ __forceinline__ void seg_sum3(T& a, T& b, T& c, const Seg<T>& s) {
+    a = seg_sum(a, s); b = seg_sum(b, s); c = seg_sum(c, s);
+}
+#define PLB_DPP_STEP(x, m, n) "v_fmac_f32_dpp " x ", " x ", " m " row_shl:" n " row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+template <> __device__ __forceinline__ void seg_sum4<float>(float& a, float& b, float& c, float& d, const Seg<float>& s) {
+    asm("s_nop 1\n"
+        PLB_DPP_STEP("%0", "%4", "1") PLB_DPP_STEP("%1", "%4", "1") PLB_DPP_STEP("%2", "%4", "1") PLB_DPP_STEP("%3", "%4", "1")
+        PLB_DPP_STEP("%0", "%5", "2") PLB_DPP_STEP("%1", "%5", "2") PLB_DPP_STEP("%2", "%5", "2") PLB_DPP_STEP("%3", "%5", "2")
+        PLB_DPP_STEP("%0", "%6", "4") PLB_DPP_STEP("%1", "%6", "4") PLB_DPP_STEP("%2", "%6", "4") PLB_DPP_STEP("%3", "%6", "4")
+        PLB_DPP_STEP("%0", "%7", "8") PLB_DPP_STEP("%1", "%7", "8") PLB_DPP_STEP("%2", "%7", "8") PLB_DPP_STEP("%3", "%7", "8")
+        : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(s.m1), "v"(s.m2), "v"(s.m4), "v"(s.m8));
+}
+template <> __device__ __forceinline__ void seg_sum3<float>(float& a, float& b, float& c, const Seg<float>& s) {
+    asm("s_nop 1\n"
+        PLB_DPP_STEP("%0", "%3", "1") PLB_DPP_STEP("%1", "%3", "1") PLB_DPP_STEP("%2", "%3", "1") "s_nop 0\n"
+        PLB_DPP_STEP("%0", "%4", "2") PLB_DPP_STEP("%1", "%4", "2") PLB_DPP_STEP("%2", "%4", "2") "s_nop 0\n"
+        PLB_DPP_STEP("%0", "%5", "4") PLB_DPP_STEP("%1", "%5", "4") PLB_DPP_STEP("%2", "%5", "4") "s_nop 0\n"
+        PLB_DPP_STEP("%0", "%6", "8") PLB_DPP_STEP("%1", "%6", "8") PLB_DPP_STEP("%2", "%6", "8")
+        : "+v"(a), "+v"(b), "+v"(c) : "v"(s.m1), "v"(s.m2), "v"(s.m4), "v"(s.m8));
+}
+#undef PLB_DPP_STEP
 
 // all threads call; valid == false for padding lanes.  sred: LDS int[6*4+8]
 __device__ __forceinline__ Tile block_tile(const int* base, bool valid, int* sred, int cap) {
@@ -228,7 +258,10 @@ __global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_p2g(Dev<T> D, int f) 
             const int ox = base[0] - tl.o[0], oy = base[1] - tl.o[1], oz = base[2] - tl.o[2];
             const int ex = tl.e[0], exy = tl.e[0] * tl.e[1];
             p2g_particle<T, double>(D.P, x, v, C, E, mu, lam, ys, En, b2, [&](int i, int j, int l, T mass, const T* mom) {
-                T a0 = seg_sum(mass, sg), a1 = seg_sum(mom[0], sg), a2 = seg_sum(mom[1], sg), a3 = seg_sum(mom[2], sg);
+                T a0 = mass, a1 = mom[0], a2 = mom[1], a3 = mom[2];
+                if (PLB_ABLATE & 4) { if (a0 + a1 + a2 + a3 == T(-1e30)) tile[0].x = 1.0; return; }
+                seg_sum4(a0, a1, a2, a3, sg);
+                if (PLB_ABLATE & 1) { if (a0 + a1 + a2 + a3 == T(-1e30)) tile[0].x = 1.0; return; }
                 if (emitter) {
                     double* q = reinterpret_cast<double*>(&tile[(oz + l) * exy + (oy + j) * ex + (ox + i)]);
                     atomicAdd(q, (double)a0); atomicAdd(q + 1, (double)a1); atomicAdd(q + 2, (double)a2); atomicAdd(q + 3, (double)a3);
@@ -236,7 +269,8 @@ __global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_p2g(Dev<T> D, int f) 
             });
         } else {
             p2g_particle<T, double>(D.P, x, v, C, E, mu, lam, ys, En, b2, [&](int i, int j, int l, T mass, const T* mom) {
-                T a0 = seg_sum(mass, sg), a1 = seg_sum(mom[0], sg), a2 = seg_sum(mom[1], sg), a3 = seg_sum(mom[2], sg);
+                T a0 = mass, a1 = mom[0], a2 = mom[1], a3 = mom[2];
+                seg_sum4(a0, a1, a2, a3, sg);
                 if (emitter) {
                     int idx = node_index(D.nb, base[0] + i, base[1] + j, base[2] + l);
                     atomicAdd(&D.gin[0][idx], a0); atomicAdd(&D.gin[1][idx], a1);
@@ -250,7 +284,7 @@ __global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_p2g(Dev<T> D, int f) 
             for (int d = 0; d < 9; ++d) R1[(12 + d) * Np + p] = En[d];
         }
     }
-    if (tl.ok) {
+    if (tl.ok && !(PLB_ABLATE & 2)) {
         __syncthreads();
         const int ex = tl.e[0], exy = tl.e[0] * tl.e[1];
         for (int i = threadIdx.x; i < tn; i += kBlock) {
@@ -380,7 +414,8 @@ __global__ __launch_bounds__(kBlock) void k_g2p_grad(Dev<T> D, int f, int src, i
                     gv[0] = a.x; gv[1] = a.y; gv[2] = a.z;
                 },
                 [&](int i, int j, int l, const T* ga) {
-                    T a0 = seg_sum(ga[0], sg), a1 = seg_sum(ga[1], sg), a2 = seg_sum(ga[2], sg);
+                    T a0 = ga[0], a1 = ga[1], a2 = ga[2];
+                    seg_sum3(a0, a1, a2, sg);
                     if (emitter) {
                         double* q = reinterpret_cast<double*>(&tile_a[(oz + l) * exy + (oy + j) * ex + (ox + i)]);
                         atomicAdd(q, (double)a0); atomicAdd(q + 1, (double)a1); atomicAdd(q + 2, (double)a2);
@@ -396,7 +431,8 @@ __global__ __launch_bounds__(kBlock) void k_g2p_grad(Dev<T> D, int f, int src, i
                     }
                 },
                 [&](int i, int j, int l, const T* ga) {
-                    T a0 = seg_sum(ga[0], sg), a1 = seg_sum(ga[1], sg), a2 = seg_sum(ga[2], sg);
+                    T a0 = ga[0], a1 = ga[1], a2 = ga[2];
+                    seg_sum3(a0, a1, a2, sg);
                     if (emitter) {
                         int idx = node_index(D.nb, base[0] + i, base[1] + j, base[2] + l);
                         atomicAdd(&D.goa[0][idx], a0); atomicAdd(&D.goa[1][idx], a1); atomicAdd(&D.goa[2][idx], a2);
