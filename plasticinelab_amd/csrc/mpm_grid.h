@@ -25,6 +25,7 @@ template <class T> struct PrimT {
     int movable;             // action_dim > 0: pose adjoints are wanted
     double par[3];           // Sphere: radius | Capsule: h, r | Cylinder: h(=radius), r(=half height) | Torus: tx, ty | Box: size
     T friction;
+    float rb;                // radius of a sphere around pos that contains the shape (cheap fp32 cull)
     double pos[3], rot[4];   // pose at frame f
     double pos1[3], rot1[4]; // pose at frame f+1
 };
@@ -186,8 +187,27 @@ template <class T> struct CollideTmp {
     double dist, rel[3], iq[4];
 };
 
+// radius of a sphere centred on the primitive position that contains the whole shape
+PLB_HD float prim_bounding_radius(int shape, const double* par) {
+    switch (shape) {
+    case SHAPE_SPHERE: return (float)par[0];
+    case SHAPE_CAPSULE: return (float)(par[0] * 0.5 + par[1]);
+    case SHAPE_CYLINDER: return (float)sqrt(par[0] * par[0] + par[1] * par[1]);
+    case SHAPE_TORUS: return (float)(par[0] + par[1]);
+    default: return (float)sqrt(par[0] * par[0] + par[1] * par[1] + par[2] * par[2]);
+    }
+}
+
 template <class T> PLB_HD bool collide_eval(const PrimT<T>& pr, T softness, T dt, const double* gp, const T* v,
                                             CollideTmp<T>& c, T* vnew) {
+    {   // conservative fp32 cull: sdf(p) >= |p - pos| - rb, and contact needs sdf <= max(0, ln(10)/softness).
+        // Nodes that fail this test take exactly the branch the full evaluation would take (no contact);
+        // the 1e-3 margin dwarfs fp32 rounding, so results are unchanged.  Skips the double-precision geometry
+        // for the ~98 % of active nodes that are nowhere near a manipulator.
+        float dx = (float)(gp[0] - pr.pos[0]), dy = (float)(gp[1] - pr.pos[1]), dz = (float)(gp[2] - pr.pos[2]);
+        float reach = pr.rb + (softness > T(0) ? 2.302585093f / (float)softness : 0.0f) + 1e-3f;
+        if (dx * dx + dy * dy + dz * dz > reach * reach) return false;
+    }
     c.dist = prim_sdf(pr, gp);
     T ex = t_exp((T)(-c.dist * (double)softness));
     c.infl = ex < T(1) ? ex : T(1);
@@ -351,49 +371,59 @@ PLB_HD bool grid_node_fwd(const SimP<T>& P, const int* I, T m, const T* mv, int 
     return true;
 }
 
-// grid_op adjoint for one node.  vout_a: adjoint of grid_v_out.  Outputs m_a, mv_a; pose adjoints
-// are handed to sink(p, PoseAdj) for every primitive this node touches.
+// grid_op adjoint for one node.  vout_a: adjoint of grid_v_out.  Outputs m_a, mv_a.  sink(p, PoseAdj, hit) is
+// called for EVERY primitive by EVERY caller (hit = false, zero adjoint when the node does not touch it), so a
+// GPU sink may use wave-wide collectives.
 template <class T, class Sink>
 PLB_HD void grid_node_bwd(const SimP<T>& P, const int* I, T m, const T* mv, int nprim, const PrimT<T>* prims,
                           const T* vout_a, T* m_a, T* mv_a, Sink&& sink) {
     *m_a = T(0); mv_a[0] = mv_a[1] = mv_a[2] = T(0);
-    if (!(m > T(1e-12))) return;
-    T inv = T(1) / m;
+    // Control flow is kept convergent around sink(): every caller walks the same primitive loop and calls it
+    // once per primitive, the node-specific work sits in `if (live)` blocks in between.
+    const bool live = m > T(1e-12);
+    const T inv = live ? T(1) / m : T(0);
     T v0[3] = {inv * mv[0] + P.grav[0], inv * mv[1] + P.grav[1], inv * mv[2] + P.grav[2]};
     double gp[3] = {I[0] / (double)P.n, I[1] / (double)P.n, I[2] / (double)P.n};
-    // forward to the state after all collides
-    T vc[3] = {v0[0], v0[1], v0[2]};
-    for (int p = 0; p < nprim; ++p) {
-        CollideTmp<T> c;
-        T vn[3];
-        if (collide_eval(prims[p], P.softness, P.dt, gp, vc, c, vn)) { vc[0] = vn[0]; vc[1] = vn[1]; vc[2] = vn[2]; }
-    }
-    // boundary stages
-    T vb0[3] = {vc[0], vc[1], vc[2]}, vb1[3], vb2[3];
-    T t[3] = {vc[0], vc[1], vc[2]};
-    boundary_axis(P, I, 0, t); vb1[0] = t[0]; vb1[1] = t[1]; vb1[2] = t[2];
-    boundary_axis(P, I, 1, t); vb2[0] = t[0]; vb2[1] = t[1]; vb2[2] = t[2];
-    T a[3] = {vout_a[0], vout_a[1], vout_a[2]};
-    boundary_axis_grad(P, I, 2, vb2, a);
-    boundary_axis_grad(P, I, 1, vb1, a);
-    boundary_axis_grad(P, I, 0, vb0, a);
-    // collides in reverse; the velocity entering collide p is recomputed from v0
-    for (int p = nprim - 1; p >= 0; --p) {
-        T vin[3] = {v0[0], v0[1], v0[2]};
-        for (int q = 0; q < p; ++q) {
+    T a[3] = {T(0), T(0), T(0)};
+    if (live) {
+        // forward to the state after all collides
+        T vc[3] = {v0[0], v0[1], v0[2]};
+        for (int p = 0; p < nprim; ++p) {
             CollideTmp<T> c;
             T vn[3];
-            if (collide_eval(prims[q], P.softness, P.dt, gp, vin, c, vn)) { vin[0] = vn[0]; vin[1] = vn[1]; vin[2] = vn[2]; }
+            if (collide_eval(prims[p], P.softness, P.dt, gp, vc, c, vn)) { vc[0] = vn[0]; vc[1] = vn[1]; vc[2] = vn[2]; }
         }
+        // boundary stages
+        T vb0[3] = {vc[0], vc[1], vc[2]}, vb1[3], vb2[3];
+        T t[3] = {vc[0], vc[1], vc[2]};
+        boundary_axis(P, I, 0, t); vb1[0] = t[0]; vb1[1] = t[1]; vb1[2] = t[2];
+        boundary_axis(P, I, 1, t); vb2[0] = t[0]; vb2[1] = t[1]; vb2[2] = t[2];
+        a[0] = vout_a[0]; a[1] = vout_a[1]; a[2] = vout_a[2];
+        boundary_axis_grad(P, I, 2, vb2, a);
+        boundary_axis_grad(P, I, 1, vb1, a);
+        boundary_axis_grad(P, I, 0, vb0, a);
+    }
+    // collides in reverse; the velocity entering collide p is recomputed from v0
+    for (int p = nprim - 1; p >= 0; --p) {
         PoseAdj<T> pa;
         pa.zero();
-        T va[3];
-        bool hit = collide_grad(prims[p], P.softness, P.dt, gp, vin, a, va, &pa);
-        a[0] = va[0]; a[1] = va[1]; a[2] = va[2];
-        if (hit && prims[p].movable) sink(p, pa);
+        bool hit = false;
+        if (live) {
+            T vin[3] = {v0[0], v0[1], v0[2]};
+            for (int q = 0; q < p; ++q) {
+                CollideTmp<T> c;
+                T vn[3];
+                if (collide_eval(prims[q], P.softness, P.dt, gp, vin, c, vn)) { vin[0] = vn[0]; vin[1] = vn[1]; vin[2] = vn[2]; }
+            }
+            T va[3];
+            hit = collide_grad(prims[p], P.softness, P.dt, gp, vin, a, va, &pa);
+            a[0] = va[0]; a[1] = va[1]; a[2] = va[2];
+        }
+        sink(p, pa, hit && prims[p].movable);
     }
     // v0 = mv / m + g
-    for (int i = 0; i < 3; ++i) { mv_a[i] = a[i] * inv; *m_a -= a[i] * mv[i] * inv * inv; }
+    if (live)
+        for (int i = 0; i < 3; ++i) { mv_a[i] = a[i] * inv; *m_a -= a[i] * mv[i] * inv * inv; }
 }
 
 // ------------------------------------------------------------------ primitive kinematics (always double)

@@ -317,6 +317,7 @@ template <class T> __device__ __forceinline__ PrimT<T> prim_at(const Dev<T>& D, 
     PrimT<T> p;
     p.shape = D.prim[q].shape; p.movable = D.prim[q].movable; p.friction = (T)D.prim[q].friction;
     for (int i = 0; i < 3; ++i) { p.par[i] = D.prim[q].par[i]; p.pos[i] = p.pos1[i] = D.ppos[((size_t)f * D.nprim + q) * 3 + i]; }
+    p.rb = prim_bounding_radius(p.shape, p.par);
     for (int i = 0; i < 4; ++i) p.rot[i] = p.rot1[i] = D.prot[((size_t)f * D.nprim + q) * 4 + i];
     return p;
 }

@@ -88,6 +88,7 @@ template <class T> __device__ __forceinline__ void load_prims(const Dev<T>& D, i
         PrimT<T> p;
         p.shape = D.prim[t].shape; p.movable = D.prim[t].movable; p.friction = (T)D.prim[t].friction;
         for (int i = 0; i < 3; ++i) p.par[i] = D.prim[t].par[i];
+        p.rb = prim_bounding_radius(p.shape, p.par);
         const double* a = D.ppos + ((size_t)f * D.nprim + t) * 3;
         const double* b = D.ppos + ((size_t)(f + 1) * D.nprim + t) * 3;
         const double* c = D.prot + ((size_t)f * D.nprim + t) * 4;
@@ -481,12 +482,25 @@ __global__ __launch_bounds__(kBlock) void k_grid_op_grad(Dev<T> D, int f) {
         T mv[3] = {D.gin[1][idx], D.gin[2][idx], D.gin[3][idx]};
         T va[3] = {D.goa[0][idx], D.goa[1][idx], D.goa[2][idx]}, ma, mva[3];
         const bool owned = I[2] >= D.z0 && I[2] < D.z1;     // halo nodes are computed on two ranks: count once
-        grid_node_bwd<T>(D.P, I, gm, mv, D.nprim, sp, va, &ma, mva, [&](int q, const PoseAdj<T>& pa) {
-            if (!owned) return;
-            double* o = &sacc[q * 14];
-            for (int d = 0; d < 3; ++d) { atomicAdd(&o[d], pa.pos[d]); atomicAdd(&o[7 + d], pa.pos1[d]); }
-            for (int d = 0; d < 4; ++d) { atomicAdd(&o[3 + d], pa.rot[d]); atomicAdd(&o[10 + d], pa.rot1[d]); }
-            shit = 1;
+        grid_node_bwd<T>(D.P, I, gm, mv, D.nprim, sp, va, &ma, mva, [&](int q, const PoseAdj<T>& pa, bool hit) {
+            // every lane of the wave gets here for every primitive: sum the 14 pose-adjoint components across the
+            // wave with shuffles and let one lane touch LDS (64 lanes hitting the same 14 addresses with
+            // ds_add_f64 serialise badly)
+            const bool h = hit && owned;
+            if (!__any(h)) return;
+            double vals[14];
+            for (int d = 0; d < 3; ++d) { vals[d] = h ? pa.pos[d] : 0.0; vals[7 + d] = h ? pa.pos1[d] : 0.0; }
+            for (int d = 0; d < 4; ++d) { vals[3 + d] = h ? pa.rot[d] : 0.0; vals[10 + d] = h ? pa.rot1[d] : 0.0; }
+            for (int c = 0; c < 14; ++c) {
+                double v = vals[c];
+                for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+                vals[c] = v;
+            }
+            if ((threadIdx.x & 63) == 0) {
+                double* o = &sacc[q * 14];
+                for (int c = 0; c < 14; ++c) atomicAdd(&o[c], vals[c]);
+                shit = 1;
+            }
         });
         D.grid_in_adj[idx] = Vec4<T>{ma, mva[0], mva[1], mva[2]};
         D.goa[0][idx] = T(0); D.goa[1][idx] = T(0); D.goa[2][idx] = T(0);

@@ -36,6 +36,7 @@ template <class T> static std::vector<PrimT<T>> make_prims(const emul_cfg& c, co
     std::vector<PrimT<T>> out(c.n_prim);
     for (int i = 0; i < c.n_prim; ++i) {
         out[i].shape = p[i].shape; out[i].movable = p[i].movable; out[i].friction = (T)p[i].friction;
+        out[i].rb = prim_bounding_radius(p[i].shape, p[i].par);
         for (int k = 0; k < 3; ++k) { out[i].par[k] = p[i].par[k]; out[i].pos[k] = p[i].pos[k]; out[i].pos1[k] = p[i].pos1[k]; }
         for (int k = 0; k < 4; ++k) { out[i].rot[k] = p[i].rot[k]; out[i].rot1[k] = p[i].rot1[k]; }
     }
@@ -141,7 +142,8 @@ template <class T> static int substep_grad_t(const emul_cfg& c, const emul_prim*
         int Iv[3] = {i, j, k};
         T ma, mva[3];
         grid_node_bwd<T>(P, Iv, g.m[I], &g.mv[3 * I], (int)prims.size(), prims.data(), &vout_a[3 * I], &ma, mva,
-            [&](int p, const PoseAdj<T>& pa) {
+            [&](int p, const PoseAdj<T>& pa, bool hit) {
+                if (!hit) return;
                 double* o = &padj[(size_t)p * 14];
                 for (int d = 0; d < 3; ++d) { o[d] += pa.pos[d]; o[7 + d] += pa.pos1[d]; }
                 for (int d = 0; d < 4; ++d) { o[3 + d] += pa.rot[d]; o[10 + d] += pa.rot1[d]; }
