@@ -160,6 +160,57 @@ template <class T> PLB_HD void shape_normal_local(int shape, const T* par, const
     }
 }
 
+// Reverse mode of (shape_sdf_local, shape_normal_local) w.r.t. the local point p: given the adjoints
+// da of the distance and na[3] of the normal, accumulate pa[3] += d<da*sdf + na.n>/dp.  Hand-derived for the
+// shapes the reference's tasks actually move (Capsule: writer.yml, Torus: torus.yml); min/max follow Taichi's
+// adjoint routing.  Returns false for shapes without a derived adjoint.
+template <class T> PLB_HD bool shape_local_adj(int shape, const T* par, const T* p, T da, const T* na, T* pa) {
+    switch (shape) {
+    case SHAPE_CAPSULE: {
+        T t = p[1] + par[0] / T(2);
+        T mx = t_max(t, T(0));                          // max(t, 0): adjoint to t iff 0 < t
+        T cl = t_min(mx, par[0]);                       // min(mx, h): adjoint to mx iff mx < h
+        T dcl = (T(0) < t && mx < par[0]) ? T(1) : T(0);
+        T y = t - cl, dy = T(1) - dcl;                  // y' and dy'/dy
+        T L = len14(p[0], y, p[2]);
+        T n[3] = {p[0] / L, y / L, p[2] / L};
+        T nd = n[0] * na[0] + n[1] * na[1] + n[2] * na[2];
+        T g[3];                                         // adjoint of p2 = (x, y', z)
+        for (int i = 0; i < 3; ++i) g[i] = da * n[i] + (na[i] - n[i] * nd) / L;
+        pa[0] += g[0]; pa[1] += g[1] * dy; pa[2] += g[2];
+        return true;
+    }
+    case SHAPE_TORUS: {
+        T l = len14(p[0], p[2]);
+        T q0 = l - par[0], q1 = p[1];
+        T Lq = len14(q0, q1);
+        T n20 = q0 / Lq, n21 = q1 / Lq;
+        T x20 = p[0] / l, x21 = p[2] / l;
+        T n3[3] = {x20 * n20, n21, x21 * n20};
+        T L3 = len14(n3[0], n3[1], n3[2]);
+        T n[3] = {n3[0] / L3, n3[1] / L3, n3[2] / L3};
+        T nd = n[0] * na[0] + n[1] * na[1] + n[2] * na[2];
+        T n3a[3];
+        for (int i = 0; i < 3; ++i) n3a[i] = (na[i] - n[i] * nd) / L3;
+        T x20a = n3a[0] * n20, x21a = n3a[2] * n20;
+        T n20a = n3a[0] * x20 + n3a[2] * x21, n21a = n3a[1];
+        // n2 = q / Lq (normal) and sdf = Lq - ty
+        T n2d = n20 * n20a + n21 * n21a;
+        T q0a = (n20a - n20 * n2d) / Lq + da * n20;
+        T q1a = (n21a - n21 * n2d) / Lq + da * n21;
+        T la = q0a;
+        // x2 = (x, z) / l
+        T xa = x20a / l, za = x21a / l;
+        la -= (x20a * p[0] + x21a * p[2]) / (l * l);
+        // l = len14(x, z)
+        xa += la * p[0] / l; za += la * p[2] / l;
+        pa[0] += xa; pa[1] += q1a; pa[2] += za;
+        return true;
+    }
+    default: return false;
+    }
+}
+
 // world-frame signed distance / normal (Primitive.sdf / normal; Sphere overrides ignore rotation)
 template <class T> PLB_HD double prim_sdf(const PrimT<T>& pr, const double* gp) {
     if (pr.shape == SHAPE_SPHERE)
@@ -304,6 +355,16 @@ template <class T> PLB_HD bool collide_grad(const PrimT<T>& pr, T softness, T dt
             double da = dista * d[i] / L + (Dad[i] - Dd[i] * dD) / L;   // adjoint of d = gp - c
             pa->pos[i] -= da;
         }
+    } else {
+        // dist = sdf_local(loc), D = qrot(rot, n_local(loc)), loc = inv_trans(gp, pos, rot)
+        double Dad[3] = {(double)Da[0], (double)Da[1], (double)Da[2]};
+        double nl[3], cr[4], nla[3], loca[3] = {0.0, 0.0, 0.0};
+        shape_normal_local(pr.shape, pr.par, c.rel, nl);
+        qrot_adj_q(pr.rot, nl, Dad, pa->rot);            // d D / d rot (direct)
+        qconj(pr.rot, cr);
+        qrot(cr, Dad, nla);                              // adjoint of n_local (qrot is linear in its vector argument)
+        shape_local_adj(pr.shape, pr.par, c.rel, dista, nla, loca);
+        inv_trans_adj(gp, pr.pos, pr.rot, c.iq, loca, pa->pos, pa->rot);
     }
     return true;
 }

@@ -351,8 +351,8 @@ template <class T> __global__ void k_contact(Dev<T> D, int f, int mode, double* 
 template <class T>
 __global__ void k_loss_grad(Dev<T> D, int f, int which, const T* gm, const T* td, const T* ts, const double* ls,
                             double w_sdf, double w_density, double w_contact, int soft) {
-    __shared__ double sacc[kMaxPrim * 3];
-    if (threadIdx.x < kMaxPrim * 3) sacc[threadIdx.x] = 0.0;
+    __shared__ double sacc[kMaxPrim * 7];
+    if (threadIdx.x < kMaxPrim * 7) sacc[threadIdx.x] = 0.0;
     __syncthreads();
     int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p < D.N) {
@@ -388,22 +388,32 @@ __global__ void k_loss_grad(Dev<T> D, int f, int which, const T* gm, const T* td
                 double sw = 1.0 / den, dsw = -20000.0 * sd / (den * den);
                 coef = w_contact * 2.0 * md * (sw + sd * dsw - md * dsw) / dn;
             }
-            // Sphere: d sdf/dx = (x - c)/len ; d sdf/dc = -that
-            double dvec[3] = {x[0] - pr.pos[0], x[1] - pr.pos[1], x[2] - pr.pos[2]};
-            double L = len14(dvec[0], dvec[1], dvec[2]);
-            for (int d = 0; d < 3; ++d) {
-                double g = coef * dvec[d] / L;
-                xa[d] += g;
-                atomicAdd(&sacc[q * 3 + d], -g);
+            double pa[3] = {0, 0, 0}, ra[4] = {0, 0, 0, 0};
+            if (pr.shape == SHAPE_SPHERE) {                 // d sdf/dx = (x - c)/len ; d sdf/dc = -that
+                double dvec[3] = {x[0] - pr.pos[0], x[1] - pr.pos[1], x[2] - pr.pos[2]};
+                double L = len14(dvec[0], dvec[1], dvec[2]);
+                for (int d = 0; d < 3; ++d) { double g = coef * dvec[d] / L; xa[d] += g; pa[d] = -g; }
+            } else {                                        // sdf = sdf_local(inv_trans(x, pos, rot))
+                double loc[3], iq[4], na0[3] = {0, 0, 0}, loca[3] = {0, 0, 0};
+                inv_trans(x, pr.pos, pr.rot, loc, iq);
+                shape_local_adj(pr.shape, pr.par, loc, coef, na0, loca);
+                inv_trans_adj(x, pr.pos, pr.rot, iq, loca, pa, ra);
+                for (int d = 0; d < 3; ++d) xa[d] -= pa[d];  // d/dx = -d/dpos
             }
+            for (int d = 0; d < 3; ++d) if (pa[d] != 0.0) atomicAdd(&sacc[q * 7 + d], pa[d]);
+            for (int d = 0; d < 4; ++d) if (ra[d] != 0.0) atomicAdd(&sacc[q * 7 + 3 + d], ra[d]);
         }
         T* A = D.adj[which];
         for (int d = 0; d < 3; ++d) A[d * D.Npad + p] += (T)xa[d];
     }
     __syncthreads();
-    if (threadIdx.x < D.nprim * 3) {
+    if (threadIdx.x < D.nprim * 7) {
         double v = sacc[threadIdx.x];
-        if (v != 0.0) atomicAdd(&D.ppos_a[((size_t)f * D.nprim + threadIdx.x / 3) * 3 + threadIdx.x % 3], v);
+        int q = threadIdx.x / 7, c = threadIdx.x % 7;
+        if (v != 0.0) {
+            if (c < 3) atomicAdd(&D.ppos_a[((size_t)f * D.nprim + q) * 3 + c], v);
+            else atomicAdd(&D.prot_a[((size_t)f * D.nprim + q) * 4 + (c - 3)], v);
+        }
     }
 }
 // target SDF sweep (loss.py:81-101), double, linear [i][j][k] layout
@@ -633,9 +643,10 @@ int plmpm_create(const plmpm_config* cfg, const plmpm_primitive* prims, plmpm_ha
     for (int p = 0; p < s->P; ++p) {
         s->prims[p] = prims[p];
         if (prims[p].action_dim < 0 || prims[p].action_dim > PLMPM_MAX_ACTION_DIM) { delete s; return fail("bad action_dim"); }
-        if (prims[p].action_dim > 0 && prims[p].shape != PLMPM_SPHERE) {
+        if (prims[p].action_dim > 0 && prims[p].shape != PLMPM_SPHERE && prims[p].shape != PLMPM_CAPSULE &&
+            prims[p].shape != PLMPM_TORUS) {
             delete s;
-            return fail("movable primitive %d: only Sphere has pose adjoints so far (shape %d)", p, prims[p].shape);
+            return fail("movable primitive %d: pose adjoints exist for Sphere, Capsule and Torus only (shape %d)", p, prims[p].shape);
         }
         s->act_ofs[p + 1] = s->act_ofs[p] + prims[p].action_dim;
     }
