@@ -51,8 +51,8 @@ typedef struct plmpm_config {
     double svd_grad_clamp;    /* :143-151 clamp of backward_svd; 1e-6 = reference, 0 = exact derivative */
     /* z-slab owned by this rank for multi-GPU runs: nodes z in [slab_z0, slab_z1); 0,n_grid = whole grid */
     int32_t slab_z0, slab_z1;
-    /* 1: keep grid_m / grid_v_in of every frame resident (max_frames x 16 n^3 bytes at fp32) so that
-     * substep_grad skips the p2g recompute of mpm_simulator.py:265-267 (same results, less work);
+    /* 1: keep grid_m / grid_v_in and grid_v_out of every frame resident (max_frames x 32 n^3 bytes at fp32) so
+     * that substep_grad skips the forward recompute of mpm_simulator.py:262-268 (same results, less work);
      * 0: recompute like the reference (use this for very large grids / copy-mode-only use). */
     int32_t store_grid;
     /* node layers beyond [slab_z0, slab_z1) that this rank's particles may still reach (fixed ownership, no

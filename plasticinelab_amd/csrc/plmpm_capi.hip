@@ -71,7 +71,8 @@ struct plmpm_sim {
     int adj_frame[2] = {-1, -1};
     // per-frame grid_m / grid_v_in store (cfg.store_grid)
     bool store = false;
-    char* gstore = nullptr;
+    char* gstore = nullptr;      // grid_m / grid_v_in per frame (SoA, 4 comps)
+    char* vstore = nullptr;      // grid_v_out per frame (AoS T4)
     int* fstore = nullptr;
     size_t gstride = 0;
     std::vector<char> dirty;          // frame f holds a scattered grid that has not been consumed/cleared
@@ -135,7 +136,8 @@ template <class T> static Dev<T> make_dev(const plmpm_sim* s, int frame = -1) {
     char* gin_base = framed ? s->gstore + (size_t)frame * s->gstride : s->grid_in;
     for (int c = 0; c < 4; ++c) D.gin[c] = (T*)gin_base + (size_t)c * s->G;
     for (int c = 0; c < 3; ++c) D.goa[c] = (T*)s->grid_out_adj + (size_t)c * s->G;
-    D.grid_out = (Vec4<T>*)s->grid_out; D.grid_in_adj = (Vec4<T>*)s->grid_in_adj;
+    D.grid_out = (Vec4<T>*)(framed ? s->vstore + (size_t)frame * s->gstride : s->grid_out);
+    D.grid_in_adj = (Vec4<T>*)s->grid_in_adj;
     D.flags = framed ? s->fstore + (size_t)frame * s->nblk : s->flags;
     D.ppos = s->ppos; D.prot = s->prot;
     D.ppos_a = s->dist ? s->ppos_l : s->ppos_a;
@@ -495,14 +497,14 @@ template <class T> static int substep_fwd(plmpm_sim* s, int f) {
 template <class T> static int substep_bwd(plmpm_sim* s, int f) {
     Dev<T> D = make_dev<T>(s, f);
     const int src = (f + 1) & 1, dst = f & 1;
-    if (!(s->store && s->dirty[f]))          // grid_m / grid_v_in of this frame are not resident: recompute (mpm_simulator.py:265-267)
+    if (!(s->store && s->dirty[f])) {        // this frame's grid is not resident: recompute it (mpm_simulator.py:265-268)
         LAUNCH(s, K_P2G_RE, (k_p2g<T, false>), dim3(nblocks_particles(s)), D, f);
-    LAUNCH(s, K_GRID_OP_RE, (k_grid_op<T, false>), dim3(nblocks_grid(s)), D, f);
+        LAUNCH(s, K_GRID_OP_RE, (k_grid_op<T, false>), dim3(nblocks_grid(s)), D, f);
+    }
     LAUNCH(s, K_G2P_GRAD, (k_g2p_grad<T>), dim3(nblocks_particles(s)), D, f, src, dst);
     LAUNCH(s, K_GRID_OP_GRAD, (k_grid_op_grad<T>), dim3(nblocks_grid(s)), D, f);
     LAUNCH(s, K_P2G_GRAD, (k_p2g_grad<T>), dim3(nblocks_particles(s)), D, f, src, dst);
-    LAUNCH(s, K_CLEAR, (k_clear_active<T>), dim3(nblocks_grid(s)), D);
-    if (s->store) s->dirty[f] = 0;
+    if (s->store) s->dirty[f] = 0;           // k_grid_op_grad left grid_in / flags of this frame clean
     s->adj_frame[dst] = f;
     return 0;
 }
@@ -523,7 +525,6 @@ template <class T> static int phase_grid_g2p(plmpm_sim* s, int f) {
 }
 template <class T> static int phase_grad_scatter(plmpm_sim* s, int f) {
     Dev<T> D = make_dev<T>(s, f);
-    LAUNCH(s, K_GRID_OP_RE, (k_grid_op<T, false>), dim3(nblocks_grid(s)), D, f);
     LAUNCH(s, K_G2P_GRAD, (k_g2p_grad<T>), dim3(nblocks_particles(s)), D, f, (f + 1) & 1, f & 1);
     return 0;
 }
@@ -531,7 +532,6 @@ template <class T> static int phase_grad_gather(plmpm_sim* s, int f) {
     Dev<T> D = make_dev<T>(s, f);
     LAUNCH(s, K_GRID_OP_GRAD, (k_grid_op_grad<T>), dim3(nblocks_grid(s)), D, f);
     LAUNCH(s, K_P2G_GRAD, (k_p2g_grad<T>), dim3(nblocks_particles(s)), D, f, (f + 1) & 1, f & 1);
-    LAUNCH(s, K_CLEAR, (k_clear_active<T>), dim3(nblocks_grid(s)), D);
     s->dirty[f] = 0;
     s->adj_frame[f & 1] = f;
     return 0;
@@ -665,7 +665,7 @@ int plmpm_create(const plmpm_config* cfg, const plmpm_primitive* prims, plmpm_ha
     if (s->dist) s->ws.misc_bytes += 2 * align_up((size_t)(s->F + 1) * P1 * 4 * 8, 256);
     s->store = cfg->store_grid != 0;
     s->gstride = align_up(s->G * 4 * s->tsz, 256);
-    if (s->store) s->ws.grid_bytes += (size_t)s->F * s->gstride + align_up((size_t)s->F * s->nblk * 4, 256);
+    if (s->store) s->ws.grid_bytes += 2 * (size_t)s->F * s->gstride + align_up((size_t)s->F * s->nblk * 4, 256);
     s->dirty.assign(s->F + 1, 0);
     s->ws.misc_bytes = 2 * align_up((size_t)(s->F + 1) * P1 * 7 * 8, 256) + 2 * align_up((size_t)(s->F + 1) * P1 * 8 * 8, 256)  // poses(+adj), padded
                        + 4 * align_up((size_t)(s->F + 1) * P1 * 3 * 8, 256)                       // v,w (+adj)
@@ -707,6 +707,7 @@ int plmpm_bind_workspace(plmpm_handle s, void* state, void* adjoint, void* grid,
     s->loss_gm = take(s->G * s->tsz); s->loss_td = take(s->G * s->tsz); s->loss_ts = take(s->G * s->tsz);
     if (s->store) {
         s->gstore = take((size_t)s->F * s->gstride);
+        s->vstore = take((size_t)s->F * s->gstride);
         s->fstore = (int*)take((size_t)s->F * s->nblk * 4);
     }
     REQUIRE((size_t)(p - s->gridw) <= s->ws.grid_bytes, "internal: grid workspace overflow");

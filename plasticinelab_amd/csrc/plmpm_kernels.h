@@ -504,6 +504,10 @@ __global__ __launch_bounds__(kBlock) void k_grid_op_grad(Dev<T> D, int f) {
         });
         D.grid_in_adj[idx] = Vec4<T>{ma, mva[0], mva[1], mva[2]};
         D.goa[0][idx] = T(0); D.goa[1][idx] = T(0); D.goa[2][idx] = T(0);
+        // this frame's grid is consumed: leave grid_in / flags clean for the next scatter into them.  grid_in_adj
+        // is never cleared -- p2g.grad only reads nodes of active blocks, which are all rewritten every substep.
+        D.gin[0][idx] = T(0); D.gin[1][idx] = T(0); D.gin[2][idx] = T(0); D.gin[3][idx] = T(0);
+        if (lane == 0) D.flags[blk] = 0;
     }
     __syncthreads();
     if (shit && threadIdx.x < D.nprim * 14) {
@@ -637,7 +641,8 @@ __global__ void k_halo_unpack_add(T* dst, size_t G, int ncomp, int n, int nb, in
     if (v != T(0)) dst[(size_t)c * G + node_index(nb, x, y, z)] += v;
 }
 
-// after substep_grad: zero grid_in / grid_in_adj / flags of the active blocks
+// zero grid_in / flags of the active blocks (a stored frame that is scattered into again without a backward
+// pass in between, and plmpm_grid_stats; the reverse pass clears inside k_grid_op_grad)
 template <class T>
 __global__ __launch_bounds__(kBlock) void k_clear_active(Dev<T> D) {
     const int blk = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
@@ -646,7 +651,6 @@ __global__ __launch_bounds__(kBlock) void k_clear_active(Dev<T> D) {
     const int lane = threadIdx.x & 63;
     const int idx = (blk << 6) | lane;
     D.gin[0][idx] = T(0); D.gin[1][idx] = T(0); D.gin[2][idx] = T(0); D.gin[3][idx] = T(0);
-    D.grid_in_adj[idx] = Vec4<T>{T(0), T(0), T(0), T(0)};
     if (lane == 0) D.flags[blk] = 0;
 }
 

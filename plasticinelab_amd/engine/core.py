@@ -46,7 +46,8 @@ class Engine:
         cfg.ground_friction, cfg.svd_grad_clamp = float(ground_friction), float(svd_grad_clamp)
         cfg.slab_z0, cfg.slab_z1 = (0, n_grid) if slab is None else (int(slab[0]), int(slab[1]))
         if store_grid == "auto":       # per-frame grid_m/grid_v_in: worth it while it stays a modest slice of 288 GB
-            store_grid = max_frames * 4 * (8 if cfg.dtype == L.F64 else 4) * n_grid ** 3 <= 48 * 2 ** 30
+            # grid_m/grid_v_in + grid_v_out of every frame: 8 scalars per node
+            store_grid = max_frames * 8 * (8 if cfg.dtype == L.F64 else 4) * n_grid ** 3 <= 64 * 2 ** 30
         cfg.store_grid = int(bool(store_grid))
         cfg.slab_halo = int(slab_halo)
         self.store_grid = bool(store_grid)
