@@ -40,6 +40,7 @@ ALG = {
     "p2g": (36, 4), "grid_op": (0, 11), "g2p": (15, 3),
     "p2g_recompute": (27, 8), "grid_op_recompute": (0, 7), "g2p_grad": (18, 9),
     "grid_op_grad": (0, 11), "p2g_grad": (54, 4), "clear_active": (0, 0),
+    "g2p_p2g": (51, 7),        # g2p(f-1) + p2g(f) fused
 }
 HBM_PEAK_GBS = 8000.0          # MI355X spec (MI355X_MICROARCH.md); measured copy peak there: 6290 GB/s
 
@@ -269,7 +270,7 @@ def main():
                              "GBps": 4e-9 * (cN * N + cA * nodes) / (1e-3 * avg) if avg > 0 else 0.0}
         dom = max(kernels, key=lambda k: kernels[k]["avg_us"] * kernels[k]["launches"])
         alg_substep = 4.0 * (150 * N + 57 * nodes)
-        sum_us = sum(v["avg_us"] for v in kernels.values())
+        sum_us = sum(v["avg_us"] * v["launches"] for v in kernels.values()) / (K * sub)     # per fwd+bwd substep
         out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": kernels[dom]["GBps"], "peak": HBM_PEAK_GBS,
                            "unit": "GB/s", "frac": kernels[dom]["GBps"] / HBM_PEAK_GBS, "traffic": None,
                            "active_nodes": nodes, "active_blocks": blocks,

@@ -83,9 +83,9 @@ struct plmpm_sim {
     size_t ev_next = 0;
 };
 
-enum KernelId { K_P2G = 0, K_GRID_OP, K_G2P, K_P2G_RE, K_GRID_OP_RE, K_G2P_GRAD, K_GRID_OP_GRAD, K_P2G_GRAD, K_CLEAR, K_COUNT };
+enum KernelId { K_P2G = 0, K_GRID_OP, K_G2P, K_P2G_RE, K_GRID_OP_RE, K_G2P_GRAD, K_GRID_OP_GRAD, K_P2G_GRAD, K_CLEAR, K_G2P_P2G, K_COUNT };
 static const char* kKernelNames[K_COUNT] = {"p2g", "grid_op", "g2p", "p2g_recompute", "grid_op_recompute",
-                                            "g2p_grad", "grid_op_grad", "p2g_grad", "clear_active"};
+                                            "g2p_grad", "grid_op_grad", "p2g_grad", "clear_active", "g2p_p2g"};
 
 static void prof_begin(plmpm_sim* s, int id) {
     if (!s->prof) return;
@@ -102,6 +102,7 @@ static void prof_end(plmpm_sim* s) {
     if (!s->prof) return;
     (void)hipEventRecord(s->ev_pool[s->ev_used.back().second + 1], s->stream);
 }
+#define LAUNCHG_CLEAR(s, D) LAUNCH(s, K_CLEAR, (k_clear_active<T>), dim3(nblocks_grid(s)), D)
 #define LAUNCH(s, id, kern, grid, ...)                                                     \
     do {                                                                                   \
         prof_begin(s, id);                                                                 \
@@ -506,6 +507,25 @@ template <class T> static int substep_bwd(plmpm_sim* s, int f) {
     LAUNCH(s, K_P2G_GRAD, (k_p2g_grad<T>), dim3(nblocks_particles(s)), D, f, src, dst);
     if (s->store) s->dirty[f] = 0;           // k_grid_op_grad left grid_in / flags of this frame clean
     s->adj_frame[dst] = f;
+    return 0;
+}
+
+// Whole env step forward in store mode: p2g(f0) | grid_op(f0) | [g2p(f-1)+p2g(f) fused | grid_op(f)] ... | g2p(last)
+template <class T> static int step_fwd_fused(plmpm_sim* s, int first, int n) {
+    for (int f = first; f < first + n; ++f) {
+        Dev<T> D = make_dev<T>(s, f);
+        if (s->dirty[f]) LAUNCHG_CLEAR(s, D);
+        if (f == first) {
+            LAUNCH(s, K_P2G, (k_p2g<T, true>), dim3(nblocks_particles(s)), D, f);
+        } else {
+            const Vec4<T>* vprev = (const Vec4<T>*)(s->vstore + (size_t)(f - 1) * s->gstride);
+            LAUNCH(s, K_G2P_P2G, (k_g2p_p2g<T>), dim3(nblocks_particles(s)), D, f, vprev);
+        }
+        LAUNCH(s, K_GRID_OP, (k_grid_op<T, false>), dim3(nblocks_grid(s)), D, f);
+        s->dirty[f] = 1;
+    }
+    Dev<T> D = make_dev<T>(s, first + n - 1);
+    LAUNCH(s, K_G2P, (k_g2p<T>), dim3(nblocks_particles(s)), D, first + n - 1);
     return 0;
 }
 
@@ -916,7 +936,8 @@ int plmpm_step(plmpm_handle s, int first_frame, int n_substeps) {
     REQUIRE(first_frame >= 0 && n_substeps > 0 && first_frame + n_substeps <= s->F, "step: frames [%d,%d] exceed max_frames %d",
             first_frame, first_frame + n_substeps, s->F);
     launch_fk(s, first_frame, n_substeps);
-    for (int f = first_frame; f < first_frame + n_substeps; ++f) DISPATCH(s, substep_fwd, s, f);
+    if (s->store && n_substeps > 1) DISPATCH(s, step_fwd_fused, s, first_frame, n_substeps);
+    else for (int f = first_frame; f < first_frame + n_substeps; ++f) DISPATCH(s, substep_fwd, s, f);
     HIPCHK(hipGetLastError());
     return 0;
 }

@@ -372,6 +372,128 @@ __global__ __launch_bounds__(kBlock) void k_g2p(Dev<T> D, int f) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Fused forward kernel: g2p of substep f-1 followed by p2g of substep f for the same particle.  x,v,C of frame f
+// are written once and go straight on (in registers) into the scatter; the LDS region first holds the
+// grid_v_out(f-1) tile, then -- after the gather -- is reused for the f64 accumulation tile of grid_in(f).
+// D is built for frame f (grid_in / flags of f); vout_prev is grid_v_out of substep f-1.
+template <class T>
+__global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_g2p_p2g(Dev<T> D, int f, const Vec4<T>* vout_prev) {
+    __shared__ int sred[32];
+    __shared__ Vec4<double> tile[TileCap<T>::nodes];
+    Vec4<T>* tile_v = reinterpret_cast<Vec4<T>*>(tile);          // first use of the same LDS
+    const int p = blockIdx.x * kBlock + threadIdx.x;
+    const bool valid = p < D.N;
+    const int Np = D.Npad;
+    // ---------------- g2p(f-1): gather
+    const double* X0 = frame_x(D, f - 1);
+    double x0[3] = {0.5, 0.5, 0.5};
+    if (valid) { x0[0] = X0[p]; x0[1] = X0[Np + p]; x0[2] = X0[2 * Np + p]; }
+    // state that does not depend on the gather: issue these loads now so they fly during the tile phase
+    T E[9];
+    for (int d = 0; d < 9; ++d) E[d] = T(0);
+    T mu = T(1), lam = T(1), ys = T(1);
+    if (valid) {
+        const T* R = frame_r(D, f);
+        for (int d = 0; d < 9; ++d) E[d] = R[(12 + d) * Np + p];
+        mu = D.mu[p]; lam = D.lam[p]; ys = D.ys[p];
+    }
+    int base0[3];
+    for (int d = 0; d < 3; ++d) base0[d] = (int)(x0[d] * (double)D.P.inv_dx - 0.5);
+    // capacity of the same LDS bytes in Vec4<T> nodes
+    Tile ta = block_tile(base0, valid, sred, (int)(TileCap<T>::nodes * sizeof(Vec4<double>) / sizeof(Vec4<T>)));
+    {
+        const int ex = ta.e[0], exy = ta.e[0] * ta.e[1], tn = exy * ta.e[2];
+        if (ta.ok) {
+            for (int i = threadIdx.x; i < tn; i += kBlock) {
+                int lz = i / exy, r = i - lz * exy, ly = r / ex, lx = r - ly * ex;
+                tile_v[i] = vout_prev[node_index(D.nb, ta.o[0] + lx, ta.o[1] + ly, ta.o[2] + lz)];
+            }
+            __syncthreads();
+        }
+    }
+    double x[3] = {0.5, 0.5, 0.5};
+    T v[3] = {T(0), T(0), T(0)}, C[9];
+    for (int d = 0; d < 9; ++d) C[d] = T(0);
+    if (valid) {
+        if (ta.ok) {
+            const int ex = ta.e[0], exy = ta.e[0] * ta.e[1];
+            const int ox = base0[0] - ta.o[0], oy = base0[1] - ta.o[1], oz = base0[2] - ta.o[2];
+            g2p_particle<T, double>(D.P, x0, x, v, C, [&](int i, int j, int l, T* gv) {
+                Vec4<T> a = tile_v[(oz + l) * exy + (oy + j) * ex + (ox + i)];
+                gv[0] = a.x; gv[1] = a.y; gv[2] = a.z;
+            });
+        } else {
+            g2p_particle<T, double>(D.P, x0, x, v, C, [&](int i, int j, int l, T* gv) {
+                Vec4<T> a = vout_prev[node_index(D.nb, base0[0] + i, base0[1] + j, base0[2] + l)];
+                gv[0] = a.x; gv[1] = a.y; gv[2] = a.z;
+            });
+        }
+        double* X1 = frame_x_w(D, f);
+        T* R1 = frame_r(D, f);
+        for (int d = 0; d < 3; ++d) { X1[d * Np + p] = x[d]; R1[d * Np + p] = v[d]; }
+        for (int d = 0; d < 9; ++d) R1[(3 + d) * Np + p] = C[d];
+    }
+    // ---------------- p2g(f): scatter
+    int base[3];
+    for (int d = 0; d < 3; ++d) base[d] = (int)(x[d] * (double)D.P.inv_dx - 0.5);
+    if (valid && (base[2] < D.zlo || base[2] + 2 >= D.zhi)) atomicOr(D.err, 1);
+    __syncthreads();                                                     // everyone is done reading tile_v
+    Tile tl = block_tile(base, valid, sred, TileCap<T>::nodes);
+    const int tn = tl.e[0] * tl.e[1] * tl.e[2];
+    if (tl.ok) {
+        for (int i = threadIdx.x; i < tn; i += kBlock) tile[i] = Vec4<double>{0.0, 0.0, 0.0, 0.0};
+        __syncthreads();
+    }
+    {
+        T En[9];
+        const Seg<T> sg = wave_segments<T>(valid ? (base[2] * D.P.n + base[1]) * D.P.n + base[0] : -1);
+        const bool emitter = sg.head && valid;
+        int b2[3];
+        if (tl.ok) {
+            const int ox = base[0] - tl.o[0], oy = base[1] - tl.o[1], oz = base[2] - tl.o[2];
+            const int ex = tl.e[0], exy = tl.e[0] * tl.e[1];
+            p2g_particle<T, double>(D.P, x, v, C, E, mu, lam, ys, En, b2, [&](int i, int j, int l, T mass, const T* mom) {
+                T a0 = mass, a1 = mom[0], a2 = mom[1], a3 = mom[2];
+                seg_sum4(a0, a1, a2, a3, sg);
+                if (emitter) {
+                    double* q = reinterpret_cast<double*>(&tile[(oz + l) * exy + (oy + j) * ex + (ox + i)]);
+                    atomicAdd(q, (double)a0); atomicAdd(q + 1, (double)a1); atomicAdd(q + 2, (double)a2); atomicAdd(q + 3, (double)a3);
+                }
+            });
+        } else {
+            p2g_particle<T, double>(D.P, x, v, C, E, mu, lam, ys, En, b2, [&](int i, int j, int l, T mass, const T* mom) {
+                T a0 = mass, a1 = mom[0], a2 = mom[1], a3 = mom[2];
+                seg_sum4(a0, a1, a2, a3, sg);
+                if (emitter) {
+                    int idx = node_index(D.nb, base[0] + i, base[1] + j, base[2] + l);
+                    atomicAdd(&D.gin[0][idx], a0); atomicAdd(&D.gin[1][idx], a1);
+                    atomicAdd(&D.gin[2][idx], a2); atomicAdd(&D.gin[3][idx], a3);
+                    D.flags[idx >> 6] = 1;
+                }
+            });
+        }
+        if (valid) {
+            T* R2 = frame_r(D, f + 1);
+            for (int d = 0; d < 9; ++d) R2[(12 + d) * Np + p] = En[d];
+        }
+    }
+    if (tl.ok) {
+        __syncthreads();
+        const int ex = tl.e[0], exy = tl.e[0] * tl.e[1];
+        for (int i = threadIdx.x; i < tn; i += kBlock) {
+            Vec4<double> a = tile[i];
+            if (a.x != 0.0 || a.y != 0.0 || a.z != 0.0 || a.w != 0.0) {
+                int lz = i / exy, r = i - lz * exy, ly = r / ex, lx = r - ly * ex;
+                int idx = node_index(D.nb, tl.o[0] + lx, tl.o[1] + ly, tl.o[2] + lz);
+                atomicAdd(&D.gin[0][idx], (T)a.x); atomicAdd(&D.gin[1][idx], (T)a.y);
+                atomicAdd(&D.gin[2][idx], (T)a.z); atomicAdd(&D.gin[3][idx], (T)a.w);
+                D.flags[idx >> 6] = 1;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // g2p.grad: scatter grid_v_out.grad, x[f].grad partial -> adjoint frame `dst`
 template <class T>
 __global__ __launch_bounds__(kBlock) void k_g2p_grad(Dev<T> D, int f, int src, int dst) {
