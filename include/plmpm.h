@@ -191,6 +191,9 @@ int plmpm_loss_set_globals(plmpm_handle h, const double* in32);
 int plmpm_loss_finish(plmpm_handle h, const double* global32, double* out6);   /* host arithmetic of loss.py:137-162,252-254 */
 int plmpm_loss_backward_local(plmpm_handle h, int frame);
 int plmpm_check_error(plmpm_handle h, int* flags);
+/* tuning aid: {error word, workgroups of the fused forward kernel that fell back to global atomics, workgroups on
+ * the LDS-tile path, sum of their tile sizes in nodes} since the last call */
+int plmpm_debug_counters(plmpm_handle h, int* out4);
 
 /* ---- introspection ------------------------------------------------------------------------- */
 /* number of grid nodes with mass > 0 and number of active 4^3 blocks after the last forward substep */

@@ -91,6 +91,7 @@ SYMBOLS = {
     "plmpm_loss_finish": (_I, [_P, _P, _P]),
     "plmpm_loss_backward_local": (_I, [_P, _I]),
     "plmpm_check_error": (_I, [_P, C.POINTER(_I)]),
+    "plmpm_debug_counters": (_I, [_P, _P]),
     "plmpm_profile_enable": (_I, [_P, _I]),
     "plmpm_profile_kernel_count": (_I, []),
     "plmpm_profile_kernel_name": (C.c_char_p, [_I]),

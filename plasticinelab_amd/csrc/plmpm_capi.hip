@@ -1299,6 +1299,13 @@ int plmpm_action_grad_region(plmpm_handle s, void** dev_ptr, size_t* count) {
     *dev_ptr = s->act_a; *count = (size_t)(s->F + 1) * std::max(s->P, 1) * PLMPM_MAX_ACTION_DIM;
     return 0;
 }
+int plmpm_debug_counters(plmpm_handle s, int* out4) {
+    NEED_BOUND(s);
+    HIPCHK(hipMemcpyAsync(out4, s->err_d, 16, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    HIPCHK(hipMemsetAsync(s->err_d + 1, 0, 12, s->stream));
+    return 0;
+}
 int plmpm_check_error(plmpm_handle s, int* flags) {
     NEED_BOUND(s);
     REQUIRE(flags, "null argument");

@@ -124,6 +124,29 @@ __device__ __forceinline__ int wave_max(int v) {
     return v;
 }
 
+// Wave-local reassignment of particles to lanes so that particles sharing a stencil base sit in adjacent lanes
+// (bitonic sort of (cell key, lane) over the 64 lanes).  The storage order is only sorted at episode reset; as
+// particles drift, same-cell lanes stop being neighbours and the run-based pre-reduction below would leave
+// same-address LDS atomics behind (measured: scatter kernels 2x slower after 8 env steps).  Returns the lane whose
+// particle this lane should process.
+__device__ __forceinline__ int wave_sort_lanes(long long key) {
+    const int lane = threadIdx.x & 63;
+    unsigned long long v = ((unsigned long long)key << 6) | (unsigned)lane;
+#pragma unroll
+    for (int k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            unsigned lo = __shfl_xor((unsigned)(v & 0xffffffffu), j), hi = __shfl_xor((unsigned)(v >> 32), j);
+            unsigned long long o = ((unsigned long long)hi << 32) | lo;
+            const bool up = (lane & k) == 0;              // ascending block
+            const bool lower = (lane & j) == 0;           // this lane keeps the smaller element
+            const bool take = (lower == up) ? (o < v) : (o > v);
+            v = take ? o : v;
+        }
+    }
+    return (int)(v & 63);
+}
+
 // Wave-level segmented reduction.  Particles are stored cell-sorted, so lanes that share a stencil base
 // form runs; the 27 x 4 per-particle contributions of a run are summed with shuffles and only the run's
 // head lane touches LDS / HBM atomics (same-address atomics serialise, shuffles do not).
@@ -217,6 +240,27 @@ __device__ __forceinline__ Tile block_tile(const int* base, bool valid, int* sre
     return t;
 }
 
+// Load this lane's particle after the wave-local sort by stencil base: p = particle index, x = position,
+// base = stencil base.  Padding lanes (beyond N) sort to the end and return false.
+template <class T>
+__device__ __forceinline__ bool load_sorted_particle(const Dev<T>& D, const double* X, int& p, double* x, int* base) {
+    const int Np = D.Npad;
+    const int p0 = blockIdx.x * kBlock + threadIdx.x;
+    long long key = (1LL << 40);                                    // padding lanes last
+    if (p0 < D.N) {
+        int b[3];
+        for (int d = 0; d < 3; ++d) b[d] = (int)(X[d * Np + p0] * (double)D.P.inv_dx - 0.5);
+        key = ((long long)b[2] * D.P.n + b[1]) * D.P.n + b[0];
+    }
+    const int src = wave_sort_lanes(key);
+    p = (p0 & ~63) + src;
+    const bool valid = p < D.N;
+    x[0] = x[1] = x[2] = 0.5;
+    if (valid) { x[0] = X[p]; x[1] = X[Np + p]; x[2] = X[2 * Np + p]; }
+    for (int d = 0; d < 3; ++d) base[d] = (int)(x[d] * (double)D.P.inv_dx - 0.5);
+    return valid;
+}
+
 // ------------------------------------------------------------------------------------------------
 // p2g: compute_F_tmp + svd + von Mises + stress + APIC scatter      (mpm_simulator.py:82-90,157-184)
 // WRITE_F: store F[f+1] (forward) or not (recompute in substep_grad).
@@ -226,15 +270,12 @@ __global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_p2g(Dev<T> D, int f) 
     // accumulate in double: on gfx950 ds_add_f64 is ~5x cheaper per instruction than ds_add_f32
     // (profiles/microbench/lds_atomics.hip), and the node sums lose no precision
     __shared__ Vec4<double> tile[TileCap<T>::nodes];
-    const int p = blockIdx.x * kBlock + threadIdx.x;
-    const bool valid = p < D.N;
     const double* X = frame_x(D, f);
     const T* R = frame_r(D, f);
     const int Np = D.Npad;
-    double x[3] = {0.5, 0.5, 0.5};
-    if (valid) { x[0] = X[p]; x[1] = X[Np + p]; x[2] = X[2 * Np + p]; }
-    int base[3];
-    for (int d = 0; d < 3; ++d) base[d] = (int)(x[d] * (double)D.P.inv_dx - 0.5);
+    int p, base[3];
+    double x[3];
+    const bool valid = load_sorted_particle(D, X, p, x, base);
     if (WRITE_F && valid && (base[2] < D.zlo || base[2] + 2 >= D.zhi)) atomicOr(D.err, 1);
     Tile tl = block_tile(base, valid, sred, TileCap<T>::nodes);
     const int tn = tl.e[0] * tl.e[1] * tl.e[2];
@@ -381,13 +422,14 @@ __global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_g2p_p2g(Dev<T> D, int
     __shared__ int sred[32];
     __shared__ Vec4<double> tile[TileCap<T>::nodes];
     Vec4<T>* tile_v = reinterpret_cast<Vec4<T>*>(tile);          // first use of the same LDS
-    const int p = blockIdx.x * kBlock + threadIdx.x;
-    const bool valid = p < D.N;
     const int Np = D.Npad;
     // ---------------- g2p(f-1): gather
+    // lanes are sorted by the stencil base of frame f-1; particles move less than a cell per substep, so the
+    // runs are (almost) the same for the scatter of frame f
     const double* X0 = frame_x(D, f - 1);
-    double x0[3] = {0.5, 0.5, 0.5};
-    if (valid) { x0[0] = X0[p]; x0[1] = X0[Np + p]; x0[2] = X0[2 * Np + p]; }
+    int p, base0[3];
+    double x0[3];
+    const bool valid = load_sorted_particle(D, X0, p, x0, base0);
     // state that does not depend on the gather: issue these loads now so they fly during the tile phase
     T E[9];
     for (int d = 0; d < 9; ++d) E[d] = T(0);
@@ -397,8 +439,6 @@ __global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_g2p_p2g(Dev<T> D, int
         for (int d = 0; d < 9; ++d) E[d] = R[(12 + d) * Np + p];
         mu = D.mu[p]; lam = D.lam[p]; ys = D.ys[p];
     }
-    int base0[3];
-    for (int d = 0; d < 3; ++d) base0[d] = (int)(x0[d] * (double)D.P.inv_dx - 0.5);
     // capacity of the same LDS bytes in Vec4<T> nodes
     Tile ta = block_tile(base0, valid, sred, (int)(TileCap<T>::nodes * sizeof(Vec4<double>) / sizeof(Vec4<T>)));
     {
@@ -440,6 +480,7 @@ __global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_g2p_p2g(Dev<T> D, int
     __syncthreads();                                                     // everyone is done reading tile_v
     Tile tl = block_tile(base, valid, sred, TileCap<T>::nodes);
     const int tn = tl.e[0] * tl.e[1] * tl.e[2];
+    if (threadIdx.x == 0) { atomicAdd(D.err + (tl.ok ? 2 : 1), 1); if (tl.ok) atomicAdd(D.err + 3, tn); }
     if (tl.ok) {
         for (int i = threadIdx.x; i < tn; i += kBlock) tile[i] = Vec4<double>{0.0, 0.0, 0.0, 0.0};
         __syncthreads();
@@ -500,14 +541,11 @@ __global__ __launch_bounds__(kBlock) void k_g2p_grad(Dev<T> D, int f, int src, i
     __shared__ int sred[32];
     __shared__ Vec4<T> tile[TileCap<T>::nodes];      // v_out values
     __shared__ Vec4<double> tile_a[TileCap<T>::nodes];    // v_out adjoint accumulation (f64, see k_p2g)
-    const int p = blockIdx.x * kBlock + threadIdx.x;
-    const bool valid = p < D.N;
     const double* X = frame_x(D, f);
     const int Np = D.Npad;
-    double x[3] = {0.5, 0.5, 0.5};
-    if (valid) { x[0] = X[p]; x[1] = X[Np + p]; x[2] = X[2 * Np + p]; }
-    int base[3];
-    for (int d = 0; d < 3; ++d) base[d] = (int)(x[d] * (double)D.P.inv_dx - 0.5);
+    int p, base[3];
+    double x[3];
+    const bool valid = load_sorted_particle(D, X, p, x, base);
     Tile tl = block_tile(base, valid, sred, TileCap<T>::nodes);
     const int ex = tl.e[0], exy = tl.e[0] * tl.e[1], tn = exy * tl.e[2];
     if (tl.ok) {
@@ -700,13 +738,10 @@ template <class T>
 __global__ __launch_bounds__(kBlock) void k_grid_mass(Dev<T> D, int f, T* gm) {
     __shared__ int sred[32];
     __shared__ double tile[TileCap<T>::nodes * 4];
-    const int p = blockIdx.x * kBlock + threadIdx.x;
-    const bool valid = p < D.N;
     const double* X = frame_x(D, f);
-    const int Np = D.Npad;
-    double x[3] = {0.5, 0.5, 0.5};
-    if (valid) { x[0] = X[p]; x[1] = X[Np + p]; x[2] = X[2 * Np + p]; }
-    int base[3];
+    int p, base[3];
+    double x[3];
+    const bool valid = load_sorted_particle(D, X, p, x, base);
     T fx[3], w[3][3];
     stencil<T, double>(x, D.P.inv_dx, base, fx, w, nullptr);
     Tile tl = block_tile(base, valid, sred, TileCap<T>::nodes * 4);
