@@ -35,6 +35,10 @@ enum plmpm_shape {
     PLMPM_SPHERE = 0, PLMPM_CAPSULE = 1, PLMPM_CYLINDER = 2, PLMPM_TORUS = 3, PLMPM_BOX = 4
 };
 
+/* forward_kinematics flavour: base class (primive_base.py:117-121, world-frame rotation) or
+ * RollingPin (primitives.py:66-80: roll about own axis, turn about world y, move in y; shape = Capsule) */
+enum plmpm_kinematics { PLMPM_KIN_DEFAULT = 0, PLMPM_KIN_ROLLINGPIN = 1 };
+
 /* Simulator constants; mirrors MPMSimulator.__init__ (mpm_simulator.py:6-51). */
 typedef struct plmpm_config {
     int32_t dtype;            /* plmpm_dtype: arithmetic type of the hot path            */
@@ -70,6 +74,8 @@ typedef struct plmpm_primitive {
     double friction;                      /* primive_base.py:162                                      */
     double action_scale[PLMPM_MAX_ACTION_DIM];
     double lower_bound[3], upper_bound[3];/* xyz_limit, primive_base.py:160                           */
+    int32_t kinematics;                   /* plmpm_kinematics: which forward_kinematics the primitive uses */
+    int32_t reserved;
 } plmpm_primitive;
 
 /* Sizes (bytes) of the four device workspaces of one simulator. */

@@ -207,7 +207,7 @@ def inv_trans(pos, position, rotation):   # utils.py:43-47
 def _shape_sdf(p: PrimCfg, gp):
     """local-frame _sdf; primitives.py:42-47 (Capsule), :163-167 (Cylinder),
     :199-202 (Torus), :232-238 (Box)."""
-    if p.shape in ("Capsule", "RollingPin"):
+    if p.shape in ("Capsule", "RollingPin"):     # RollingPin(Capsule), primitives.py:64
         y = gp[:, 1] + p.h / 2
         y = y - ti_min(ti_max(y, 0.0), p.h)
         p2 = torch.stack([gp[:, 0], y, gp[:, 2]], -1)
@@ -312,12 +312,21 @@ def collide(p: PrimCfg, softness: float, pos_f, rot_f, pos_f1, rot_f1, gp, v_out
 
 
 def forward_kinematics(p: PrimCfg, pos, rot, v, w):
-    """primive_base.py:117-121 (world-frame rotation update).  RollingPin and
-    Chopsticks override this (primitives.py:66-80, :94-98) -- not restated yet."""
-    if p.shape in ("RollingPin", "Chopsticks"):
+    """primive_base.py:117-121 (world-frame rotation update); RollingPin override primitives.py:66-80.
+    Chopsticks (primitives.py:94-98, gap degree of freedom) is not restated yet."""
+    if p.shape == "Chopsticks":
         raise NotImplementedError(p.shape)
     lo = torch.tensor(p.lower_bound, dtype=DT)
     hi = torch.tensor(p.upper_bound, dtype=DT)
+    if p.shape == "RollingPin":                      # primitives.py:66-80
+        dw, dth, dy = v[0], v[1], v[2]               # roll about own y, turn about world y, move down
+        y_dir = qrot(rot, torch.tensor([0.0, -1.0, 0.0], dtype=DT))
+        x_dir = torch.linalg.cross(torch.tensor([0.0, 1.0, 0.0], dtype=DT), y_dir) * dw * 0.03
+        x_dir = torch.stack([x_dir[0], dy, x_dir[2]])
+        zero = torch.zeros((), dtype=DT)
+        new_rot = qmul(w2quat(torch.stack([zero, -dth, zero])), qmul(rot, w2quat(torch.stack([zero, dw, zero]))))
+        new_pos = ti_max(ti_min(pos + x_dir, hi), lo)
+        return new_pos, new_rot
     new_pos = ti_max(ti_min(pos + v, hi), lo)
     new_rot = qmul(w2quat(w), rot)
     return new_pos, new_rot

@@ -15,7 +15,8 @@ LIB_PATH = os.path.join(_HERE, "libplmpm.so")
 MAX_PRIMITIVES = 8
 MAX_ACTION_DIM = 7
 F32, F64 = 0, 1
-SHAPES = {"Sphere": 0, "Capsule": 1, "Cylinder": 2, "Torus": 3, "Box": 4}
+SHAPES = {"Sphere": 0, "Capsule": 1, "Cylinder": 2, "Torus": 3, "Box": 4, "RollingPin": 1}   # RollingPin is a Capsule
+KINEMATICS = {"RollingPin": 1}
 
 
 class Config(C.Structure):
@@ -30,7 +31,8 @@ class Config(C.Structure):
 class Primitive(C.Structure):
     _fields_ = [("shape", C.c_int32), ("action_dim", C.c_int32), ("params", C.c_double * 3),
                 ("friction", C.c_double), ("action_scale", C.c_double * MAX_ACTION_DIM),
-                ("lower_bound", C.c_double * 3), ("upper_bound", C.c_double * 3)]
+                ("lower_bound", C.c_double * 3), ("upper_bound", C.c_double * 3),
+                ("kinematics", C.c_int32), ("reserved", C.c_int32)]
 
 
 class Workspace(C.Structure):

@@ -516,6 +516,41 @@ PLB_HD void fk_fwd_d(const double* pos, const double* rot, const double* v, cons
     double inv = 1.0 / sqrt(o[0] * o[0] + o[1] * o[1] + o[2] * o[2] + o[3] * o[3]);
     for (int i = 0; i < 4; ++i) rot1[i] = o[i] * inv;
 }
+// o = normalize(q (x) r):  given o_a, accumulate q_a, r_a
+PLB_HD void qmul_adj_d(const double* q, const double* r, const double* o_a, double* q_a, double* r_a) {
+    double o[4];
+    qmul_raw_d(q, r, o);
+    double nrm = sqrt(o[0] * o[0] + o[1] * o[1] + o[2] * o[2] + o[3] * o[3]);
+    double on[4], dotv = 0;
+    for (int i = 0; i < 4; ++i) { on[i] = o[i] / nrm; dotv += on[i] * o_a[i]; }
+    double oa[4];
+    for (int i = 0; i < 4; ++i) oa[i] = (o_a[i] - on[i] * dotv) / nrm;
+    r_a[0] += oa[0] * q[0] + oa[1] * q[1] + oa[2] * q[2] + oa[3] * q[3];
+    r_a[1] += -oa[0] * q[1] + oa[1] * q[0] + oa[2] * q[3] - oa[3] * q[2];
+    r_a[2] += -oa[0] * q[2] - oa[1] * q[3] + oa[2] * q[0] + oa[3] * q[1];
+    r_a[3] += -oa[0] * q[3] + oa[1] * q[2] - oa[2] * q[1] + oa[3] * q[0];
+    q_a[0] += oa[0] * r[0] + oa[1] * r[1] + oa[2] * r[2] + oa[3] * r[3];
+    q_a[1] += -oa[0] * r[1] + oa[1] * r[0] - oa[2] * r[3] + oa[3] * r[2];
+    q_a[2] += -oa[0] * r[2] + oa[1] * r[3] + oa[2] * r[0] - oa[3] * r[1];
+    q_a[3] += -oa[0] * r[3] - oa[1] * r[2] + oa[2] * r[1] + oa[3] * r[0];
+}
+PLB_HD void qmul_d(const double* q, const double* r, double* o) {
+    qmul_raw_d(q, r, o);
+    double inv = 1.0 / sqrt(o[0] * o[0] + o[1] * o[1] + o[2] * o[2] + o[3] * o[3]);
+    for (int i = 0; i < 4; ++i) o[i] *= inv;
+}
+// q = w2quat(a): given q_a, accumulate a_a
+PLB_HD void w2quat_adj_d(const double* a, const double* qa, double* a_a) {
+    double th = sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]);
+    if (th > 1e-9) {
+        double n[3] = {a[0] / th, a[1] / th, a[2] / th};
+        double sh = sin(th / 2), ch = cos(th / 2);
+        double nq = n[0] * qa[1] + n[1] * qa[2] + n[2] * qa[3];
+        for (int i = 0; i < 3; ++i)
+            a_a[i] += -0.5 * sh * n[i] * qa[0] + (sh / th) * (qa[1 + i] - n[i] * nq) + 0.5 * ch * n[i] * nq;
+    }
+}
+
 // adjoint: pos1_a, rot1_a in; accumulates pos_a, rot_a (pose at f); writes v_a, w_a (overwrite)
 PLB_HD void fk_bwd_d(const double* pos, const double* rot, const double* v, const double* w,
                      const double* lo, const double* hi, const double* pos1_a, const double* rot1_a,
@@ -528,34 +563,64 @@ PLB_HD void fk_bwd_d(const double* pos, const double* rot, const double* v, cons
         pos_a[i] += gate * pos1_a[i];
         v_a[i] = gate * pos1_a[i];
     }
-    double q[4], o[4];
+    double q[4], qa[4] = {0, 0, 0, 0};
     w2quat_d(w, q);
-    qmul_raw_d(q, rot, o);
-    double nrm = sqrt(o[0] * o[0] + o[1] * o[1] + o[2] * o[2] + o[3] * o[3]);
-    double on[4], dotv = 0;
-    for (int i = 0; i < 4; ++i) { on[i] = o[i] / nrm; dotv += on[i] * rot1_a[i]; }
-    double oa[4];
-    for (int i = 0; i < 4; ++i) oa[i] = (rot1_a[i] - on[i] * dotv) / nrm;
-    const double* r = rot;
-    // o = q (x) r, bilinear
-    rot_a[0] += oa[0] * q[0] + oa[1] * q[1] + oa[2] * q[2] + oa[3] * q[3];
-    rot_a[1] += -oa[0] * q[1] + oa[1] * q[0] + oa[2] * q[3] - oa[3] * q[2];
-    rot_a[2] += -oa[0] * q[2] - oa[1] * q[3] + oa[2] * q[0] + oa[3] * q[1];
-    rot_a[3] += -oa[0] * q[3] + oa[1] * q[2] - oa[2] * q[1] + oa[3] * q[0];
-    double qa[4];
-    qa[0] = oa[0] * r[0] + oa[1] * r[1] + oa[2] * r[2] + oa[3] * r[3];
-    qa[1] = -oa[0] * r[1] + oa[1] * r[0] - oa[2] * r[3] + oa[3] * r[2];
-    qa[2] = -oa[0] * r[2] + oa[1] * r[3] + oa[2] * r[0] - oa[3] * r[1];
-    qa[3] = -oa[0] * r[3] - oa[1] * r[2] + oa[2] * r[1] + oa[3] * r[0];
-    double th = sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+    qmul_adj_d(q, rot, rot1_a, qa, rot_a);
     w_a[0] = w_a[1] = w_a[2] = 0.0;
-    if (th > 1e-9) {
-        double n[3] = {w[0] / th, w[1] / th, w[2] / th};
-        double sh = sin(th / 2), ch = cos(th / 2);
-        double nq = n[0] * qa[1] + n[1] * qa[2] + n[2] * qa[3];
-        for (int i = 0; i < 3; ++i)
-            w_a[i] = -0.5 * sh * n[i] * qa[0] + (sh / th) * (qa[1 + i] - n[i] * nq) + 0.5 * ch * n[i] * nq;
+    w2quat_adj_d(w, qa, w_a);
+}
+
+// RollingPin.forward_kinematics (primitives.py:66-80): v = (roll about own axis, turn about world y, move in y)
+PLB_HD void fk_rollingpin_fwd_d(const double* pos, const double* rot, const double* v, const double* lo,
+                                const double* hi, double* pos1, double* rot1) {
+    const double dw = v[0], dth = v[1], dy = v[2];
+    const double e[3] = {0.0, -1.0, 0.0};
+    double yd[3];
+    qrot(rot, e, yd);
+    const double xd[3] = {0.03 * dw * yd[2], dy, -0.03 * dw * yd[0]};     // ((0,1,0) x y_dir) * dw * 0.03, y := dy
+    for (int i = 0; i < 3; ++i) {
+        double y = pos[i] + xd[i];
+        double mn = y < hi[i] ? y : hi[i];
+        pos1[i] = lo[i] < mn ? mn : lo[i];
     }
+    const double a1[3] = {0.0, dw, 0.0}, a2[3] = {0.0, -dth, 0.0};
+    double q1[4], q2[4], inner[4];
+    w2quat_d(a1, q1); w2quat_d(a2, q2);
+    qmul_d(rot, q1, inner);
+    qmul_d(q2, inner, rot1);
+}
+PLB_HD void fk_rollingpin_bwd_d(const double* pos, const double* rot, const double* v, const double* lo,
+                                const double* hi, const double* pos1_a, const double* rot1_a,
+                                double* pos_a, double* rot_a, double* v_a) {
+    const double dw = v[0], dth = v[1], dy = v[2];
+    const double e[3] = {0.0, -1.0, 0.0};
+    double yd[3];
+    qrot(rot, e, yd);
+    const double xd[3] = {0.03 * dw * yd[2], dy, -0.03 * dw * yd[0]};
+    double xda[3];
+    for (int i = 0; i < 3; ++i) {
+        double y = pos[i] + xd[i];
+        double mn = y < hi[i] ? y : hi[i];
+        double gate = (y < hi[i] && lo[i] < mn) ? 1.0 : 0.0;
+        pos_a[i] += gate * pos1_a[i];
+        xda[i] = gate * pos1_a[i];
+    }
+    double dwa = 0.03 * (yd[2] * xda[0] - yd[0] * xda[2]);
+    const double dya = xda[1];
+    const double yda[3] = {-0.03 * dw * xda[2], 0.0, 0.03 * dw * xda[0]};
+    qrot_adj_q(rot, e, yda, rot_a);
+    const double a1[3] = {0.0, dw, 0.0}, a2[3] = {0.0, -dth, 0.0};
+    double q1[4], q2[4], inner[4];
+    w2quat_d(a1, q1); w2quat_d(a2, q2);
+    qmul_d(rot, q1, inner);
+    double q2a[4] = {0, 0, 0, 0}, inner_a[4] = {0, 0, 0, 0}, q1a[4] = {0, 0, 0, 0};
+    qmul_adj_d(q2, inner, rot1_a, q2a, inner_a);
+    qmul_adj_d(rot, q1, inner_a, rot_a, q1a);
+    double a1a[3] = {0, 0, 0}, a2a[3] = {0, 0, 0};
+    w2quat_adj_d(a1, q1a, a1a);
+    w2quat_adj_d(a2, q2a, a2a);
+    dwa += a1a[1];
+    v_a[0] = dwa; v_a[1] = -a2a[1]; v_a[2] = dya;
 }
 
 }  // namespace plb

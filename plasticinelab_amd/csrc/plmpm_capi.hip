@@ -231,6 +231,7 @@ __global__ void k_merge_pose_adj(double* g, double* l, size_t n) {
 struct PrimChainArgs {
     int P;
     int action_dim[kMaxPrim];
+    int kin[kMaxPrim];
     double scale[kMaxPrim][PLMPM_MAX_ACTION_DIM];
     double lo[kMaxPrim][3], hi[kMaxPrim][3];
 };
@@ -256,7 +257,10 @@ __global__ void k_fk_chain(PrimChainArgs A, int first, int n, double* ppos, doub
     if (p >= A.P) return;
     for (int s = first; s < first + n; ++s) {
         size_t a = (size_t)s * A.P + p, b = (size_t)(s + 1) * A.P + p;
-        fk_fwd_d(ppos + a * 3, prot + a * 4, pv + a * 3, pw + a * 3, A.lo[p], A.hi[p], ppos + b * 3, prot + b * 4);
+        if (A.kin[p] == PLMPM_KIN_ROLLINGPIN)
+            fk_rollingpin_fwd_d(ppos + a * 3, prot + a * 4, pv + a * 3, A.lo[p], A.hi[p], ppos + b * 3, prot + b * 4);
+        else
+            fk_fwd_d(ppos + a * 3, prot + a * 4, pv + a * 3, pw + a * 3, A.lo[p], A.hi[p], ppos + b * 3, prot + b * 4);
     }
 }
 // forward_kinematics.grad for frames first+n-1..first, then set_velocity.grad for env step `step`
@@ -268,9 +272,13 @@ __global__ void k_fk_chain_grad(PrimChainArgs A, int first, int n, int step, con
     double va_sum[3] = {0, 0, 0}, wa_sum[3] = {0, 0, 0};
     for (int s = first + n - 1; s >= first; --s) {
         size_t a = (size_t)s * A.P + p, b = (size_t)(s + 1) * A.P + p;
-        double va[3], wa[3];
-        fk_bwd_d(ppos + a * 3, prot + a * 4, pv + a * 3, pw + a * 3, A.lo[p], A.hi[p], ppos_a + b * 3, prot_a + b * 4,
-                 ppos_a + a * 3, prot_a + a * 4, va, wa);
+        double va[3], wa[3] = {0.0, 0.0, 0.0};
+        if (A.kin[p] == PLMPM_KIN_ROLLINGPIN)
+            fk_rollingpin_bwd_d(ppos + a * 3, prot + a * 4, pv + a * 3, A.lo[p], A.hi[p], ppos_a + b * 3, prot_a + b * 4,
+                                ppos_a + a * 3, prot_a + a * 4, va);
+        else
+            fk_bwd_d(ppos + a * 3, prot + a * 4, pv + a * 3, pw + a * 3, A.lo[p], A.hi[p], ppos_a + b * 3, prot_a + b * 4,
+                     ppos_a + a * 3, prot_a + a * 4, va, wa);
         for (int k = 0; k < 3; ++k) { pv_a[a * 3 + k] = va[k]; pw_a[a * 3 + k] = wa[k]; va_sum[k] += va[k]; wa_sum[k] += wa[k]; }
     }
     double* aa = act_a + ((size_t)step * A.P + p) * PLMPM_MAX_ACTION_DIM;
@@ -473,6 +481,7 @@ static PrimChainArgs chain_args(const plmpm_sim* s) {
     A.P = s->P;
     for (int p = 0; p < s->P; ++p) {
         A.action_dim[p] = s->prims[p].action_dim;
+        A.kin[p] = s->prims[p].kinematics;
         for (int k = 0; k < PLMPM_MAX_ACTION_DIM; ++k) A.scale[p][k] = s->prims[p].action_scale[k];
         for (int k = 0; k < 3; ++k) { A.lo[p][k] = s->prims[p].lower_bound[k]; A.hi[p][k] = s->prims[p].upper_bound[k]; }
     }
@@ -663,6 +672,7 @@ int plmpm_create(const plmpm_config* cfg, const plmpm_primitive* prims, plmpm_ha
     for (int p = 0; p < s->P; ++p) {
         s->prims[p] = prims[p];
         if (prims[p].action_dim < 0 || prims[p].action_dim > PLMPM_MAX_ACTION_DIM) { delete s; return fail("bad action_dim"); }
+        if (prims[p].kinematics != PLMPM_KIN_DEFAULT && prims[p].kinematics != PLMPM_KIN_ROLLINGPIN) { delete s; return fail("unknown kinematics %d", prims[p].kinematics); }
         if (prims[p].action_dim > 0 && prims[p].shape != PLMPM_SPHERE && prims[p].shape != PLMPM_CAPSULE &&
             prims[p].shape != PLMPM_TORUS) {
             delete s;

@@ -32,7 +32,10 @@ constexpr int kBlock = 256;          // threads per workgroup in particle kernel
 constexpr int kMaxPrim = 8;
 // LDS tile capacity (nodes) of the scatter/gather kernels: 16 KiB per tile for either scalar type
 template <class T> struct TileCap;
-template <> struct TileCap<float> { static constexpr int nodes = 1024; };
+#ifndef PLB_TILECAP
+#define PLB_TILECAP 1024
+#endif
+template <> struct TileCap<float> { static constexpr int nodes = PLB_TILECAP; };
 template <> struct TileCap<double> { static constexpr int nodes = 512; };
 
 template <class T> struct Vec4 { T x, y, z, w; };

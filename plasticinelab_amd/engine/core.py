@@ -55,6 +55,7 @@ class Engine:
         self.action_dims = []
         for i, p in enumerate(primitives):
             parr[i].shape = L.SHAPES[p["shape"]]
+            parr[i].kinematics = L.KINEMATICS.get(p["shape"], 0)
             parr[i].action_dim = int(p.get("action_dim", 0))
             pr = list(p.get("params", ())) + [0.0, 0.0, 0.0]
             parr[i].params = (C.c_double * 3)(*pr[:3])

@@ -18,12 +18,12 @@ from ..config import CfgNode, as_value
 _SHAPE_PARAMS = {
     "Sphere": (("radius",), (1.0,)),
     "Capsule": (("h", "r"), (0.06, 0.03)),
+    "RollingPin": (("h", "r"), (0.06, 0.03)),        # a Capsule with its own forward_kinematics (primitives.py:64-80)
     "Cylinder": (("h", "r"), (0.2, 0.1)),
     "Torus": (("tx", "ty"), (0.2, 0.1)),
     "Box": (("size",), ((0.1, 0.1, 0.1),)),
 }
 _UNSUPPORTED = {
-    "RollingPin": "custom forward_kinematics (primitives.py:64-80)",
     "Chopsticks": "gap degree of freedom (primitives.py:83-154)",
 }
 

@@ -1,4 +1,4 @@
-"""Built-in scene registry for the tasks BASELINE.json names.
+"""Built-in scene registry: nine of the reference's ten task families (Chopsticks needs its gap DOF, not built).
 
 The reference keeps one YAML per task under plb/envs/*.yml with five VARIANTS
 each (move.yml:1-80, triplemove.yml:1-89, rope.yml:1-73).  The same parameter
@@ -90,7 +90,73 @@ def _rope(version):
     }
 
 
-_BUILDERS = {"Move": _move, "TripleMove": _triplemove, "Rope": _rope}
+def _manip(shape, pos, scale, friction=0.9, **kw):
+    d = {"shape": shape, "init_pos": pos, "color": (0.8, 0.8, 0.8), "friction": friction,
+         "action": {"dim": 3, "scale": scale}}
+    d.update(kw)
+    return d
+
+
+def _box(width, pos, **kw):
+    d = {"shape": "box", "width": width, "init_pos": pos}
+    d.update(kw)
+    return d
+
+
+def _writer(version):        # writer.yml:1-30
+    return {"SIMULATOR": {"E": 5000.0, "n_particles": 10000, "yield_stress": 50.0, "ground_friction": 100.0},
+            "SHAPES": [_box((0.3, 0.1, 0.3), (0.5, 0.05, 0.5), color=(((200 << 8) + 200) << 8) + 0)],
+            "PRIMITIVES": [_manip("Capsule", (0.5, 0.13, 0.5), (0.01, 0.01, 0.01), friction=0.0, h=0.06, r=0.03,
+                                  init_rot=(0.0, 0.0, 0.0, 1.0), lower_bound=(0.0, 0.05, 0.0))],
+            "ENV": {"loss": {"target_path": f"envs/assets/Writer3D-v{version}.npy"}}}
+
+
+def _torus(version):         # torus.yml:1-30
+    return {"SIMULATOR": {"yield_stress": 50.0, "ground_friction": 100.0},
+            "SHAPES": [_box((0.3, 0.1, 0.3), (0.5, 0.05, 0.5), color=((200 << 8) + 200) << 8)],
+            "PRIMITIVES": [_manip("Torus", (0.5, 0.2, 0.5), (0.004, 0.004, 0.004), tx=0.05, ty=0.03,
+                                  init_rot=(0.0, 0.0, 0.0, 1.0), lower_bound=(0.0, 0.05, 0.0))],
+            "ENV": {"loss": {"target_path": f"envs/assets/Torus3D-v{version}.npy"}}}
+
+
+def _rollingpin(version):    # rollingpin.yml:1-30
+    return {"SIMULATOR": {"E": 5000.0, "n_particles": 10000, "yield_stress": 50.0, "ground_friction": 1.5},
+            "SHAPES": [_box((0.3, 0.1, 0.3), (0.5, 0.05, 0.5), color=100)],
+            "PRIMITIVES": [_manip("RollingPin", (0.5, 0.123, 0.5), (0.6666666666666667, 0.06666666666666668, 0.001),
+                                  h=0.3, r=0.03, init_rot=(0.707, 0.707, 0.0, 0.0))],
+            "ENV": {"loss": {"target_path": f"envs/assets/Rollingpin3D-v{version}.npy"}}}
+
+
+def _pinch(version):         # pinch.yml
+    return {"SIMULATOR": {"yield_stress": 50.0, "ground_friction": 100.0},
+            "SHAPES": [_box((0.2, 0.2, 0.2), (0.5, 0.1, 0.5), n_particles=6000, color=(150 << 8) + (150 << 16))],
+            "PRIMITIVES": [_manip("Sphere", (0.5, 0.35, 0.5), (0.02, 0.02, 0.02), radius=0.04,
+                                  lower_bound=(0.1, 0.1, 0.1), upper_bound=(0.9, 0.9, 0.9))],
+            "ENV": {"loss": {"target_path": f"envs/assets/Pinch3D-v{version}.npy"}}}
+
+
+def _table(version):         # table.yml
+    legs = [_box((0.04, 0.1, 0.04), (0.5 + sx * 0.075, 0.1, 0.5 + sz * 0.075), n_particles=2000)
+            for sx, sz in ((-1, -1), (-1, 1), (1, -1), (1, 1))]
+    top = _box((0.2, 0.05, 0.2), (0.5, 0.18, 0.5), color=((200 << 8) + 200) << 8, n_particles=2000)
+    return {"SIMULATOR": {"yield_stress": 50.0, "nu": 0.05, "ground_friction": 0.3},
+            "SHAPES": legs + [top],
+            "PRIMITIVES": [_manip("Sphere", (0.5, 0.06, 0.5), (0.03, 0.0, 0.03), radius=0.04)],
+            "ENV": {"loss": {"target_path": f"envs/assets/Table3D-v{version}.npy"}}}
+
+
+def _assembly(version):      # assembly.yml
+    return {"SIMULATOR": {"yield_stress": 100.0, "ground_friction": 100.0},
+            "SHAPES": [_box((0.16, 0.16, 0.16), (0.6, 0.08, 0.5), n_particles=6000, color=(150 << 8) + (150 << 16)),
+                       {"shape": "sphere", "radius": 0.06, "init_pos": (0.3, 0.06, 0.5), "n_particles": 4000,
+                        "color": (0 << 8) + (150 << 16) + 150}],
+            "PRIMITIVES": [_manip("Sphere", (0.38, 0.06, 0.5), (0.009, 0.009, 0.009), radius=0.04),
+                           _manip("Sphere", (0.22, 0.06, 0.5), (0.009, 0.009, 0.009), radius=0.04)],
+            "ENV": {"loss": {"target_path": f"envs/assets/Assembly3D-v{version}.npy"}}}
+
+
+_BUILDERS = {"Move": _move, "TripleMove": _triplemove, "Rope": _rope, "Writer": _writer, "Torus": _torus,
+             "Rollingpin": _rollingpin, "Pinch": _pinch, "Table": _table, "Assembly": _assembly}
 ENV_NAMES = tuple(_BUILDERS)
 
 

@@ -8,7 +8,7 @@ import subprocess
 import numpy as np
 
 HERE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "host_emul")
-SHAPE_ID = {"Sphere": 0, "Capsule": 1, "Cylinder": 2, "Torus": 3, "Box": 4}
+SHAPE_ID = {"Sphere": 0, "Capsule": 1, "Cylinder": 2, "Torus": 3, "Box": 4, "RollingPin": 1}
 
 
 class EmulCfg(C.Structure):
@@ -45,7 +45,7 @@ def _p(a):
 def prim_par(p):
     if p.shape == "Sphere":
         return (p.radius, 0.0, 0.0)
-    if p.shape in ("Capsule", "Cylinder"):
+    if p.shape in ("Capsule", "Cylinder", "RollingPin"):
         return (p.h, p.r, 0.0)
     if p.shape == "Torus":
         return (p.tx, p.ty, 0.0)
@@ -111,3 +111,17 @@ def fk_bwd(pos, rot, v, w, lo, hi, pos1_a, rot1_a):
     pos_a, rot_a, v_a, w_a = np.zeros(3), np.zeros(4), np.zeros(3), np.zeros(3)
     lib().emul_fk_bwd(*[_p(t) for t in a], _p(pos_a), _p(rot_a), _p(v_a), _p(w_a))
     return pos_a, rot_a, v_a, w_a
+
+
+def fk_rollingpin_fwd(pos, rot, v, lo, hi):
+    a = [np.ascontiguousarray(t, np.float64) for t in (pos, rot, v, lo, hi)]
+    pos1, rot1 = np.empty(3), np.empty(4)
+    lib().emul_fk_rollingpin_fwd(*[_p(t) for t in a], _p(pos1), _p(rot1))
+    return pos1, rot1
+
+
+def fk_rollingpin_bwd(pos, rot, v, lo, hi, pos1_a, rot1_a):
+    a = [np.ascontiguousarray(t, np.float64) for t in (pos, rot, v, lo, hi, pos1_a, rot1_a)]
+    pos_a, rot_a, v_a = np.zeros(3), np.zeros(4), np.zeros(3)
+    lib().emul_fk_rollingpin_bwd(*[_p(t) for t in a], _p(pos_a), _p(rot_a), _p(v_a))
+    return pos_a, rot_a, v_a

@@ -187,6 +187,12 @@ int emul_substep_grad(const emul_cfg* c, const emul_prim* pr, int N, const doubl
 }
 void emul_fk_fwd(const double* pos, const double* rot, const double* v, const double* w, const double* lo,
                  const double* hi, double* pos1, double* rot1) { fk_fwd_d(pos, rot, v, w, lo, hi, pos1, rot1); }
+void emul_fk_rollingpin_fwd(const double* pos, const double* rot, const double* v, const double* lo, const double* hi,
+                            double* pos1, double* rot1) { fk_rollingpin_fwd_d(pos, rot, v, lo, hi, pos1, rot1); }
+void emul_fk_rollingpin_bwd(const double* pos, const double* rot, const double* v, const double* lo, const double* hi,
+                            const double* pos1_a, const double* rot1_a, double* pos_a, double* rot_a, double* v_a) {
+    fk_rollingpin_bwd_d(pos, rot, v, lo, hi, pos1_a, rot1_a, pos_a, rot_a, v_a);
+}
 void emul_fk_bwd(const double* pos, const double* rot, const double* v, const double* w, const double* lo,
                  const double* hi, const double* pos1_a, const double* rot1_a, double* pos_a, double* rot_a,
                  double* v_a, double* w_a) { fk_bwd_d(pos, rot, v, w, lo, hi, pos1_a, rot1_a, pos_a, rot_a, v_a, w_a); }

@@ -130,3 +130,22 @@ def test_capsule_torus_pose_adjoints(shape, kw):
     for k in range(P):
         ref = np.concatenate([gs[4 + 2 * k].numpy(), gs[5 + 2 * k].numpy(), gs[4 + 2 * P + 2 * k].numpy(), gs[5 + 2 * P + 2 * k].numpy()])
         assert np.abs(ref[3:7]).max() > 0 and relerr(pose[k], ref) < 1e-10
+
+
+def test_rollingpin_kinematics_and_adjoint():
+    """RollingPin.forward_kinematics (primitives.py:66-80) and its hand-derived adjoint vs oracle autograd."""
+    torch.manual_seed(5)
+    p = O.PrimCfg(shape="RollingPin", h=0.3, r=0.03, lower_bound=(0.0, 0.0, 0.0), upper_bound=(1.0, 1.0, 1.0), action_dim=3,
+                  action_scale=(0.6666666666666667, 0.06666666666666668, 0.001))
+    pos = torch.tensor([0.5, 0.123, 0.5], dtype=O.DT, requires_grad=True)
+    rot = torch.tensor([0.707, 0.707, 0.1, -0.05], dtype=O.DT); rot = (rot / rot.norm()).requires_grad_(True)
+    v = torch.tensor([0.035, -0.0035, -5e-5], dtype=O.DT, requires_grad=True)
+    pos1, rot1 = O.forward_kinematics(p, pos, rot, v, torch.zeros(3, dtype=O.DT))
+    e_pos1, e_rot1 = emul.fk_rollingpin_fwd(pos.detach().numpy(), rot.detach().numpy(), v.detach().numpy(), p.lower_bound, p.upper_bound)
+    assert np.allclose(e_pos1, pos1.detach().numpy(), atol=1e-15) and np.allclose(e_rot1, rot1.detach().numpy(), atol=1e-15)
+    cp, cr = torch.randn(3, dtype=O.DT), torch.randn(4, dtype=O.DT)
+    gs = torch.autograd.grad((pos1 * cp).sum() + (rot1 * cr).sum(), [pos, rot, v])
+    got = emul.fk_rollingpin_bwd(pos.detach().numpy(), rot.detach().numpy(), v.detach().numpy(), p.lower_bound, p.upper_bound,
+                                 cp.numpy(), cr.numpy())
+    for a, b in zip(got, gs):
+        assert np.allclose(a, b.numpy(), rtol=1e-12, atol=1e-13)

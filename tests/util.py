@@ -30,7 +30,7 @@ def oracle_prims(cfg):
                   upper_bound=tuple(as_value(p.get("upper_bound", (1.0, 1.0, 1.0)))),
                   friction=float(p.get("friction", 0.9)),
                   action_dim=int(act.get("dim", 0)), action_scale=tuple(as_value(act.get("scale", ()))))
-        if p["shape"] == "Cylinder":
+        if p["shape"] in ("Cylinder",):
             kw.update(h=float(p.get("h", 0.2)), r=float(p.get("r", 0.1)))
         else:
             for k in ("radius", "h", "r", "tx", "ty"):
