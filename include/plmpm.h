@@ -138,6 +138,10 @@ int plmpm_substep_grad(plmpm_handle h, int frame);
 /* reverse of plmpm_step: substep_grad for frames first+n-1 .. first, then forward_kinematics.grad and
  * set_velocity.grad for env step `step` (primive_base.py:117-121,184-192) */
 int plmpm_step_grad(plmpm_handle h, int first_frame, int n_substeps, int step);
+/* segment-checkpointed backward (plb/optimizer/long_term_gradient.ipynb, copy_and_clear): after the forward of the
+ * earlier segment has been re-run, hand the adjoint of `from_frame` (first frame of the later segment) over to
+ * `to_frame` (last frame of the earlier one); pose adjoints move along, all other primitive / action adjoints clear */
+int plmpm_segment_carry(plmpm_handle h, int from_frame, int to_frame);
 /* add a host-provided cotangent to the current adjoint of `frame` (x,v:(N,3) F,C:(N,3,3), any may be NULL);
  * used by tests and by callers that differentiate their own loss */
 int plmpm_add_frame_grad(plmpm_handle h, int frame, const double* xa, const double* va, const double* Fa,

@@ -64,6 +64,7 @@ SYMBOLS = {
     "plmpm_grad_begin": (_I, [_P, _I]),
     "plmpm_substep_grad": (_I, [_P, _I]),
     "plmpm_step_grad": (_I, [_P, _I, _I, _I]),
+    "plmpm_segment_carry": (_I, [_P, _I, _I]),
     "plmpm_add_frame_grad": (_I, [_P, _I, _P, _P, _P, _P]),
     "plmpm_get_frame_grad": (_I, [_P, _I, _P, _P, _P, _P]),
     "plmpm_get_primitive_grad": (_I, [_P, _I, _I, _P]),

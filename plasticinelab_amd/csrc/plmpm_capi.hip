@@ -971,6 +971,40 @@ int plmpm_grad_begin(plmpm_handle s, int last_frame) {
     return 0;
 }
 
+// Segment-checkpointed backward (plb/optimizer/long_term_gradient.ipynb cell 2, copy_and_clear): the adjoint held
+// for frame `from_frame` (start of the later segment) becomes the adjoint of `to_frame` (end of the earlier
+// segment, whose forward was just re-run); primitive pose adjoints move with it, every other pose / velocity /
+// action adjoint is cleared.
+__global__ void k_move_double(double* dst, const double* src, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[i];
+}
+int plmpm_segment_carry(plmpm_handle s, int from_frame, int to_frame) {
+    NEED_BOUND(s);
+    NEED_FRAME(s, from_frame);
+    NEED_FRAME(s, to_frame);
+    REQUIRE(s->adj_frame[from_frame & 1] == from_frame, "segment_carry: adjoint of frame %d is not resident", from_frame);
+    if ((from_frame & 1) != (to_frame & 1))
+        HIPCHK(hipMemcpyAsync(s->adj[to_frame & 1], s->adj[from_frame & 1], (size_t)24 * s->Npad * s->tsz, hipMemcpyDeviceToDevice, s->stream));
+    s->adj_frame[to_frame & 1] = to_frame;
+    s->adj_frame[(to_frame + 1) & 1] = -1;
+    size_t P1 = std::max(s->P, 1), F1 = s->F + 1;
+    if (s->P > 0) {
+        double* tmp = s->staging;                       // 7 * P doubles of scratch
+        hipLaunchKernelGGL(k_move_double, dim3(1), dim3(64), 0, s->stream, tmp, s->ppos_a + (size_t)from_frame * s->P * 3, s->P * 3);
+        hipLaunchKernelGGL(k_move_double, dim3(1), dim3(64), 0, s->stream, tmp + 32, s->prot_a + (size_t)from_frame * s->P * 4, s->P * 4);
+        HIPCHK(hipMemsetAsync(s->ppos_a, 0, F1 * P1 * 3 * 8, s->stream));
+        HIPCHK(hipMemsetAsync(s->prot_a, 0, F1 * P1 * 4 * 8, s->stream));
+        hipLaunchKernelGGL(k_move_double, dim3(1), dim3(64), 0, s->stream, s->ppos_a + (size_t)to_frame * s->P * 3, tmp, s->P * 3);
+        hipLaunchKernelGGL(k_move_double, dim3(1), dim3(64), 0, s->stream, s->prot_a + (size_t)to_frame * s->P * 4, tmp + 32, s->P * 4);
+    }
+    HIPCHK(hipMemsetAsync(s->pv_a, 0, F1 * P1 * 3 * 8, s->stream));
+    HIPCHK(hipMemsetAsync(s->pw_a, 0, F1 * P1 * 3 * 8, s->stream));
+    HIPCHK(hipMemsetAsync(s->act_a, 0, F1 * P1 * PLMPM_MAX_ACTION_DIM * 8, s->stream));
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 int plmpm_substep_grad(plmpm_handle s, int frame) {
     NEED_BOUND(s);
     REQUIRE(frame >= 0 && frame < s->F, "substep_grad: frame %d out of range", frame);

@@ -163,6 +163,9 @@ class Engine:
     def step_grad(self, first, n, step):
         L.check(self.lib.plmpm_step_grad(self.h, first, n, step))
 
+    def segment_carry(self, from_frame, to_frame):
+        L.check(self.lib.plmpm_segment_carry(self.h, from_frame, to_frame))
+
     def add_frame_grad(self, f, xa=None, va=None, Fa=None, Ca=None):
         N = self.n_particles
         xa, va, Fa, Ca = _f64(xa, (N, 3)), _f64(va, (N, 3)), _f64(Fa, (N, 3, 3)), _f64(Ca, (N, 3, 3))

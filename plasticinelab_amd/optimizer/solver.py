@@ -31,12 +31,17 @@ class Solver:
     def default_config(cls):                             # solver.py:74-83
         return CfgNode({"optim": {"lr": 0.1, "bounds": (-1.0, 1.0), "type": "Adam"},
                         "n_iters": 100, "softness": 666.0, "horizon": 50, "init_range": 0.0,
-                        "init_sampler": "uniform"})
+                        "init_sampler": "uniform",
+                        "checkpoint_segment": 0})      # > 0: segment-checkpointed backward (optimizer/checkpoint.py)
 
     def forward(self, sim_state, action):                # solver.py:31-44
         env = self.env
         if self.logger is not None:
             self.logger.reset()
+        if self.cfg.checkpoint_segment and self.cfg.checkpoint_segment < len(action):
+            from .checkpoint import forward_checkpointed
+            self.total_steps += len(action)
+            return forward_checkpointed(env, sim_state, action, self.cfg.checkpoint_segment, self.cfg.softness)
         env.set_state(sim_state, self.cfg.softness, False)
         with Tape(env):
             for i in range(len(action)):

@@ -112,3 +112,20 @@ def test_autograd_function_matches_tape():
     (2.0 * loss).backward()
     assert abs(float(loss) - float(g["loss"])) / abs(float(g["loss"])) < 1e-10
     assert relerr(a.grad.numpy() / 2.0, g["grad"]) < 1e-7
+
+
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_checkpointed_gradient_equals_tape_gradient(dtype):
+    """The reference's only gradient check (long_term_gradient.ipynb cell 4): segment-checkpointed gradient vs the
+    stored-trajectory gradient, |diff| < 1e-4 there (observed 1.5e-5); here both run through the HIP engine."""
+    from plasticinelab_amd.optimizer.checkpoint import forward_checkpointed
+    g = np.load(os.path.join(GOLDEN, "rollout_small.npz"))
+    env = make_env_sub("Move", int(g["n_particles"]), dtype)
+    state0 = env.get_state()["state"]
+    loss, grad = run_forward(env, g["actions"], state0)
+    for seg in (1, 2):
+        loss2, grad2 = forward_checkpointed(env, state0, g["actions"], seg)
+        tol = 1e-11 if dtype == "float64" else 2e-5
+        assert abs(loss2 - loss) / abs(loss) < tol
+        assert relerr(grad2, grad) < (1e-9 if dtype == "float64" else 1e-3)
+        assert relerr(grad2, g["grad"]) < (1e-7 if dtype == "float64" else 1e-3)
