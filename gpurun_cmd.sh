@@ -1,2 +1,2 @@
-cd $GRAFT_REPO_ROOT
-timeout 1500 python -m pytest tests/test_gpu_rollout.py -m gpu -x -q -k checkpointed 2>&1 | tail -8
+cd /root/repo
+python -m pytest tests/test_gpu_shapes.py -m gpu -x -q 2>&1 | tail -15

@@ -32,12 +32,15 @@ extern "C" {
 
 enum plmpm_dtype { PLMPM_F32 = 0, PLMPM_F64 = 1 };
 enum plmpm_shape {
-    PLMPM_SPHERE = 0, PLMPM_CAPSULE = 1, PLMPM_CYLINDER = 2, PLMPM_TORUS = 3, PLMPM_BOX = 4
+    PLMPM_SPHERE = 0, PLMPM_CAPSULE = 1, PLMPM_CYLINDER = 2, PLMPM_TORUS = 3, PLMPM_BOX = 4,
+    PLMPM_CHOPSTICKS = 5      /* primitives.py:83-154: two Capsules `gap` apart hanging below the pose */
 };
 
-/* forward_kinematics flavour: base class (primive_base.py:117-121, world-frame rotation) or
- * RollingPin (primitives.py:66-80: roll about own axis, turn about world y, move in y; shape = Capsule) */
-enum plmpm_kinematics { PLMPM_KIN_DEFAULT = 0, PLMPM_KIN_ROLLINGPIN = 1 };
+/* forward_kinematics flavour: base class (primive_base.py:117-121, world-frame rotation),
+ * RollingPin (primitives.py:66-80: roll about own axis, turn about world y, move in y; shape = Capsule) or
+ * Chopsticks (primitives.py:94-98: body-frame rotation + gap[f+1] = max(gap[f] - gap_vel[f], minimal_gap);
+ * 7-dim action, shape = PLMPM_CHOPSTICKS) */
+enum plmpm_kinematics { PLMPM_KIN_DEFAULT = 0, PLMPM_KIN_ROLLINGPIN = 1, PLMPM_KIN_CHOPSTICKS = 2 };
 
 /* Simulator constants; mirrors MPMSimulator.__init__ (mpm_simulator.py:6-51). */
 typedef struct plmpm_config {
@@ -70,7 +73,8 @@ typedef struct plmpm_config {
 typedef struct plmpm_primitive {
     int32_t shape;                        /* plmpm_shape                                              */
     int32_t action_dim;                   /* cfg.action.dim (0 = static)                              */
-    double params[3];                     /* Sphere: radius | Capsule: h,r | Cylinder: h,r | Torus: tx,ty | Box: size */
+    double params[3];                     /* Sphere: radius | Capsule: h,r | Cylinder: h,r | Torus: tx,ty | Box: size
+                                           * | Chopsticks: h, r, minimal_gap                          */
     double friction;                      /* primive_base.py:162                                      */
     double action_scale[PLMPM_MAX_ACTION_DIM];
     double lower_bound[3], upper_bound[3];/* xyz_limit, primive_base.py:160                           */
@@ -110,9 +114,10 @@ int plmpm_set_frame(plmpm_handle h, int frame, const double* x, const double* v,
 int plmpm_get_frame(plmpm_handle h, int frame, double* x, double* v, double* F, double* C);
 /* copyframe (mpm_simulator.py:302-312) incl. primitive poses */
 int plmpm_copy_frame(plmpm_handle h, int source, int target);
-/* Primitive.set_state / get_state (primive_base.py:129-151): 7 doubles = position(3) + rotation(4) */
-int plmpm_set_primitive_state(plmpm_handle h, int prim, int frame, const double* state7);
-int plmpm_get_primitive_state(plmpm_handle h, int prim, int frame, double* state7);
+/* Primitive.set_state / get_state (primive_base.py:129-151; Chopsticks primitives.py:135-146):
+ * 8 doubles = position(3) + rotation(4) + gap(1); the gap slot is carried but unused by the other shapes */
+int plmpm_set_primitive_state(plmpm_handle h, int prim, int frame, const double* state8);
+int plmpm_get_primitive_state(plmpm_handle h, int prim, int frame, double* state8);
 /* Primitives.set_softness (primitives.py:303-305) */
 int plmpm_set_softness(plmpm_handle h, double softness);
 
@@ -148,8 +153,8 @@ int plmpm_add_frame_grad(plmpm_handle h, int frame, const double* xa, const doub
                          const double* Ca);
 /* read back the adjoint currently held for `frame` (x.grad[f] etc. in the reference) */
 int plmpm_get_frame_grad(plmpm_handle h, int frame, double* xa, double* va, double* Fa, double* Ca);
-/* primitive pose adjoints position.grad[f], rotation.grad[f] (7 doubles) */
-int plmpm_get_primitive_grad(plmpm_handle h, int prim, int frame, double* grad7);
+/* primitive pose adjoints position.grad[f], rotation.grad[f], gap.grad[f] (8 doubles) */
+int plmpm_get_primitive_grad(plmpm_handle h, int prim, int frame, double* grad8);
 
 /* ---- loss (Loss, loss.py) ------------------------------------------------------------------ */
 /* Loss.load_target_density + update_target (loss.py:46-57,81-106): density is (n,n,n) float64, [i][j][k] */
@@ -189,7 +194,7 @@ int plmpm_halo_unpack_add(plmpm_handle h, int field, int frame, int za, int zb, 
  * with a neighbour's, and the primitive pose adjoints (double) for the cross-rank sum */
 int plmpm_flags_region(plmpm_handle h, int frame, int bz_a, int bz_b, void** dev_ptr, size_t* count);
 int plmpm_pose_grad_region(plmpm_handle h, int first_frame, int n_frames, void** pos_adj, size_t* pos_count,
-                           void** rot_adj, size_t* rot_count);
+                           void** rot_adj, size_t* rot_count, void** gap_adj, size_t* gap_count);
 int plmpm_action_grad_region(plmpm_handle h, void** dev_ptr, size_t* count);
 /* loss in phases: scatter (then exchange PLMPM_HALO_LOSS_MASS), local partial sums over owned nodes /
  * particles, set globally reduced contact scalars, local adjoint.

@@ -92,6 +92,8 @@ class PrimCfg:
     tx: float = 0.2              # Torus
     ty: float = 0.1
     size: Tuple[float, float, float] = (0.1, 0.1, 0.1)   # Box
+    minimal_gap: float = 0.06    # Chopsticks (primitives.py:150-151)
+    init_gap: float = 0.06
 
 
 # --------------------------------------------------------------------------- #
@@ -204,9 +206,18 @@ def inv_trans(pos, position, rotation):   # utils.py:43-47
 # --------------------------------------------------------------------------- #
 # primitive shapes (primitives.py)
 # --------------------------------------------------------------------------- #
-def _shape_sdf(p: PrimCfg, gp):
+def _capsule_of(p: PrimCfg):
+    return PrimCfg(shape="Capsule", h=p.h, r=p.r)
+
+
+def _shape_sdf(p: PrimCfg, gp, gap=None):
     """local-frame _sdf; primitives.py:42-47 (Capsule), :163-167 (Cylinder),
     :199-202 (Torus), :232-238 (Box)."""
+    if p.shape == "Chopsticks":                  # primitives.py:111-117: two capsules gap apart, hanging below the pose
+        cap = _capsule_of(p)
+        delta = torch.stack([gap / 2, torch.zeros((), dtype=DT), torch.zeros((), dtype=DT)])
+        q = gp - torch.tensor([0.0, -p.h / 2, 0.0], dtype=DT)
+        return ti_min(_shape_sdf(cap, q - delta), _shape_sdf(cap, q + delta))
     if p.shape in ("Capsule", "RollingPin"):     # RollingPin(Capsule), primitives.py:64
         y = gp[:, 1] + p.h / 2
         y = y - ti_min(ti_max(y, 0.0), p.h)
@@ -226,8 +237,15 @@ def _shape_sdf(p: PrimCfg, gp):
     raise NotImplementedError(p.shape)
 
 
-def _shape_normal(p: PrimCfg, gp):
-    """local-frame _normal; primitives.py:49-54, :169-183, :204-213, :240-251."""
+def _shape_normal(p: PrimCfg, gp, gap=None):
+    """local-frame _normal; primitives.py:49-54, :169-183, :204-213, :240-251; Chopsticks :119-129."""
+    if p.shape == "Chopsticks":
+        cap = _capsule_of(p)
+        delta = torch.stack([gap / 2, torch.zeros((), dtype=DT), torch.zeros((), dtype=DT)])
+        q = gp - torch.tensor([0.0, -p.h / 2, 0.0], dtype=DT)
+        a, b = _shape_sdf(cap, q - delta), _shape_sdf(cap, q + delta)
+        m = (a <= b).to(DT)[:, None].detach()          # ti.cast of a comparison: no gradient
+        return m * _shape_normal(cap, q - delta) + (1 - m) * _shape_normal(cap, q + delta)
     if p.shape in ("Capsule", "RollingPin"):
         y = gp[:, 1] + p.h / 2
         y = y - ti_min(ti_max(y, 0.0), p.h)
@@ -265,19 +283,19 @@ def _shape_normal(p: PrimCfg, gp):
     raise NotImplementedError(p.shape)
 
 
-def prim_sdf(p: PrimCfg, pos_f, rot_f, gp):
+def prim_sdf(p: PrimCfg, pos_f, rot_f, gp, gap_f=None):
     """Primitive.sdf (primive_base.py:57-60); Sphere override primitives.py:22-24."""
     if p.shape == "Sphere":
         return length14(gp - pos_f) - p.radius
-    return _shape_sdf(p, inv_trans(gp, pos_f, rot_f))
+    return _shape_sdf(p, inv_trans(gp, pos_f, rot_f), gap_f)
 
 
-def prim_normal(p: PrimCfg, pos_f, rot_f, gp):
+def prim_normal(p: PrimCfg, pos_f, rot_f, gp, gap_f=None):
     """Primitive.normal (primive_base.py:75-80); Sphere override primitives.py:26-28."""
     if p.shape == "Sphere":
         d = gp - pos_f
         return d / length14(d)[:, None]
-    return qrot(rot_f, _shape_normal(p, inv_trans(gp, pos_f, rot_f)))
+    return qrot(rot_f, _shape_normal(p, inv_trans(gp, pos_f, rot_f), gap_f))
 
 
 def collider_v(pos_f, rot_f, pos_f1, rot_f1, gp, dt):
@@ -287,9 +305,9 @@ def collider_v(pos_f, rot_f, pos_f1, rot_f1, gp, dt):
     return (new_pos - gp) / dt
 
 
-def collide(p: PrimCfg, softness: float, pos_f, rot_f, pos_f1, rot_f1, gp, v_out, dt):
-    """Primitive.collide, primive_base.py:91-115.  gp, v_out: (A,3)."""
-    dist = prim_sdf(p, pos_f, rot_f, gp)
+def collide(p: PrimCfg, softness: float, pos_f, rot_f, pos_f1, rot_f1, gp, v_out, dt, gap_f=None):
+    """Primitive.collide, primive_base.py:91-115.  gp, v_out: (A,3).  ``gap_f``: Chopsticks gap[f]."""
+    dist = prim_sdf(p, pos_f, rot_f, gp, gap_f)
     influence = ti_min(torch.exp(-dist * softness), 1.0)
     mask = (dist <= 0)
     if softness > 0:
@@ -298,7 +316,7 @@ def collide(p: PrimCfg, softness: float, pos_f, rot_f, pos_f1, rot_f1, gp, v_out
     if idx.numel() == 0:
         return v_out
     g, v, infl = gp[idx], v_out[idx], influence[idx]
-    D = prim_normal(p, pos_f, rot_f, g)
+    D = prim_normal(p, pos_f, rot_f, g, gap_f)
     cv = collider_v(pos_f, rot_f, pos_f1, rot_f1, g, dt)
     input_v = v - cv
     nc = (input_v * D).sum(-1)
@@ -311,13 +329,15 @@ def collide(p: PrimCfg, softness: float, pos_f, rot_f, pos_f1, rot_f1, gp, v_out
     return v_out.index_put((idx,), v_new)
 
 
-def forward_kinematics(p: PrimCfg, pos, rot, v, w):
-    """primive_base.py:117-121 (world-frame rotation update); RollingPin override primitives.py:66-80.
-    Chopsticks (primitives.py:94-98, gap degree of freedom) is not restated yet."""
-    if p.shape == "Chopsticks":
-        raise NotImplementedError(p.shape)
+def forward_kinematics(p: PrimCfg, pos, rot, v, w, gap=None, gap_vel=None):
+    """primive_base.py:117-121 (world-frame rotation update); RollingPin override primitives.py:66-80;
+    Chopsticks override primitives.py:94-98 (body-frame rotation update + gap) returns (pos, rot, gap)."""
     lo = torch.tensor(p.lower_bound, dtype=DT)
     hi = torch.tensor(p.upper_bound, dtype=DT)
+    if p.shape == "Chopsticks":
+        new_gap = ti_max(gap - gap_vel, p.minimal_gap)
+        new_pos = ti_max(ti_min(pos + v, hi), lo)
+        return new_pos, qmul(rot, w2quat(w)), new_gap
     if p.shape == "RollingPin":                      # primitives.py:66-80
         dw, dth, dy = v[0], v[1], v[2]               # roll about own y, turn about world y, move down
         y_dir = qrot(rot, torch.tensor([0.0, -1.0, 0.0], dtype=DT))
@@ -333,13 +353,16 @@ def forward_kinematics(p: PrimCfg, pos, rot, v, w):
 
 
 def set_velocity(p: PrimCfg, action, n_substeps):
-    """primive_base.py:184-192: per-substep (v, w) from one env-step action."""
+    """primive_base.py:184-192: per-substep (v, w) from one env-step action; Chopsticks (primitives.py:101-109)
+    adds the gap velocity as a third entry."""
     scale = torch.tensor(p.action_scale, dtype=DT)
     v = action[:3] * scale[:3] / n_substeps
     if p.action_dim > 3:
         w = action[3:6] * scale[3:6] / n_substeps
     else:
         w = torch.zeros(3, dtype=DT)
+    if p.shape == "Chopsticks":
+        return v, w, action[6] * scale[6] / n_substeps
     return v, w
 
 
@@ -413,8 +436,8 @@ def grid_op(cfg: SimCfg, prims: Sequence[PrimCfg], softness, poses_f, poses_f1, 
     v_out = (1 / gm[act])[:, None] * gv_in[act]
     v_out = v_out + cfg.dt * torch.tensor(cfg.gravity, dtype=DT) * 30
     gp = I.to(DT) * cfg.dx
-    for p, (pf, rf), (pf1, rf1) in zip(prims, poses_f, poses_f1):
-        v_out = collide(p, softness, pf, rf, pf1, rf1, gp, v_out, cfg.dt)
+    for p, pf, pf1 in zip(prims, poses_f, poses_f1):      # a pose is (pos, rot) or, for Chopsticks, (pos, rot, gap)
+        v_out = collide(p, softness, pf[0], pf[1], pf1[0], pf1[1], gp, v_out, cfg.dt, *pf[2:])
     bound = 3
     If = I.to(DT)
     for d in range(3):
@@ -556,8 +579,8 @@ def compute_loss(cfg: SimCfg, lcfg: LossCfg, prims, x, poses_f, target_density, 
     sdf_loss = (target_sdf * gm).sum()                           # :150-153
     contact_loss = torch.zeros((), dtype=DT)
     movable = [(p, pose) for p, pose in zip(prims, poses_f) if p.action_dim > 0]   # :20-24
-    for p, (pf, rf) in movable:
-        d = ti_max(prim_sdf(p, pf, rf, x), 0.0)
+    for p, pose in movable:
+        d = ti_max(prim_sdf(p, pose[0], pose[1], x, *pose[2:]), 0.0)
         if lcfg.soft_contact:                                    # :116-121, :130-135
             sw = soft_weight(d)
             dist_norm = sw.sum()
@@ -594,7 +617,8 @@ def env_step(cfg, prims, softness, state, mats, poses, action):
                    else (torch.zeros(3, dtype=DT), torch.zeros(3, dtype=DT)))
         ofs += p.action_dim
     for _ in range(cfg.substeps):
-        nxt = [forward_kinematics(p, pos, rot, v, w) for p, (pos, rot), (v, w) in zip(prims, poses, vel)]
+        nxt = [forward_kinematics(p, pose[0], pose[1], vw[0], vw[1], *pose[2:], *vw[2:])
+               for p, pose, vw in zip(prims, poses, vel)]
         state = substep(cfg, prims, softness, state, mats, poses, nxt)
         poses = nxt
     return state, poses
@@ -607,7 +631,7 @@ def rollout_loss_and_grad(cfg, lcfg, prims, softness, state0, mats, poses0, acti
     a time from saved step-boundary states (same result as one tape, less
     memory)."""
     H = actions.shape[0]
-    states, poses_l = [tuple(t.detach() for t in state0)], [[(p.detach(), r.detach()) for p, r in poses0]]
+    states, poses_l = [tuple(t.detach() for t in state0)], [[tuple(t.detach() for t in po) for po in poses0]]
     total = 0.0
     info = []
     with torch.no_grad():
@@ -617,28 +641,32 @@ def rollout_loss_and_grad(cfg, lcfg, prims, softness, state0, mats, poses0, acti
             total += float(l)
             info.append({k: float(v) for k, v in parts.items() if k != "grid_m"})
             states.append(tuple(t.detach() for t in s))
-            poses_l.append([(p.detach(), r.detach()) for p, r in po])
+            poses_l.append([tuple(t.detach() for t in q) for q in po])
     if not want_grad:
         return total, None, states, poses_l, info
     grad = torch.zeros_like(actions)
     adj_state = [torch.zeros_like(t) for t in states[-1]]
-    adj_pose = [(torch.zeros(3, dtype=DT), torch.zeros(4, dtype=DT)) for _ in prims]
+    adj_pose = [tuple(torch.zeros_like(t) for t in po) for po in poses_l[-1]]
     for i in reversed(range(H)):
         s_in = tuple(t.clone().requires_grad_(True) for t in states[i])
-        p_in = [(p.clone().requires_grad_(True), r.clone().requires_grad_(True)) for p, r in poses_l[i]]
+        p_in = [tuple(t.clone().requires_grad_(True) for t in po) for po in poses_l[i]]
         a_in = actions[i].clone().requires_grad_(True)
         s_out, p_out = env_step(cfg, prims, softness, s_in, mats, p_in, a_in)
         l, _ = compute_loss(cfg, lcfg, prims, s_out[0], p_out, target_density, target_sdf)
         obj = l
         for t, a in zip(s_out, adj_state):
             obj = obj + (t * a).sum()
-        for (p, r), (ap, ar) in zip(p_out, adj_pose):
-            obj = obj + (p * ap).sum() + (r * ar).sum()
+        for po, ap in zip(p_out, adj_pose):
+            for t, a in zip(po, ap):
+                obj = obj + (t * a).sum()
         inputs = list(s_in) + [t for pr in p_in for t in pr] + [a_in]
         gs = torch.autograd.grad(obj, inputs, allow_unused=True)
         gs = [torch.zeros_like(t) if g is None else g for g, t in zip(gs, inputs)]
         adj_state = gs[:4]
-        adj_pose = [(gs[4 + 2 * k], gs[5 + 2 * k]) for k in range(len(prims))]
+        adj_pose, o = [], 4
+        for po in p_in:
+            adj_pose.append(tuple(gs[o:o + len(po)]))
+            o += len(po)
         grad[i] = gs[-1]
     return total, grad, states, poses_l, info
 
@@ -652,7 +680,9 @@ def init_state(x0: np.ndarray):
 
 
 def init_poses(prims):
-    return [(torch.tensor(p.init_pos, dtype=DT), torch.tensor(p.init_rot, dtype=DT)) for p in prims]
+    """(pos, rot) per primitive; Chopsticks carry their gap as a third entry (primitives.py:131-133)."""
+    return [(torch.tensor(p.init_pos, dtype=DT), torch.tensor(p.init_rot, dtype=DT))
+            + ((torch.tensor(p.init_gap, dtype=DT),) if p.shape == "Chopsticks" else ()) for p in prims]
 
 
 def materials(cfg: SimCfg, ys=None):

@@ -15,8 +15,9 @@ LIB_PATH = os.path.join(_HERE, "libplmpm.so")
 MAX_PRIMITIVES = 8
 MAX_ACTION_DIM = 7
 F32, F64 = 0, 1
-SHAPES = {"Sphere": 0, "Capsule": 1, "Cylinder": 2, "Torus": 3, "Box": 4, "RollingPin": 1}   # RollingPin is a Capsule
-KINEMATICS = {"RollingPin": 1}
+SHAPES = {"Sphere": 0, "Capsule": 1, "Cylinder": 2, "Torus": 3, "Box": 4, "RollingPin": 1,   # RollingPin is a Capsule
+          "Chopsticks": 5}
+KINEMATICS = {"RollingPin": 1, "Chopsticks": 2}
 
 
 class Config(C.Structure):
@@ -86,7 +87,8 @@ SYMBOLS = {
     "plmpm_halo_pack": (_I, [_P, _I, _I, _I, _I, _P]),
     "plmpm_halo_unpack_add": (_I, [_P, _I, _I, _I, _I, _P]),
     "plmpm_flags_region": (_I, [_P, _I, _I, _I, C.POINTER(_P), C.POINTER(C.c_size_t)]),
-    "plmpm_pose_grad_region": (_I, [_P, _I, _I, C.POINTER(_P), C.POINTER(C.c_size_t), C.POINTER(_P), C.POINTER(C.c_size_t)]),
+    "plmpm_pose_grad_region": (_I, [_P, _I, _I, C.POINTER(_P), C.POINTER(C.c_size_t), C.POINTER(_P), C.POINTER(C.c_size_t),
+                                    C.POINTER(_P), C.POINTER(C.c_size_t)]),
     "plmpm_action_grad_region": (_I, [_P, C.POINTER(_P), C.POINTER(C.c_size_t)]),
     "plmpm_loss_scatter": (_I, [_P, _I]),
     "plmpm_loss_partials": (_I, [_P, _I, _I, _P]),

@@ -5,7 +5,7 @@
 // Follows /root/reference/plb/engine/mpm_simulator.py:189-221 (grid_op),
 // plb/engine/primitive/primive_base.py:57-121,184-192 (sdf/normal/collider_v/
 // collide/forward_kinematics/set_velocity), primitives.py:17-34 (Sphere),
-// :36-61 (Capsule), :157-183 (Cylinder), :193-213 (Torus), :223-251 (Box) and
+// :36-61 (Capsule), :83-154 (Chopsticks), :157-183 (Cylinder), :193-213 (Torus), :223-251 (Box) and
 // primitive/utils.py:3-48 (quaternions).  Shared by the HIP kernels and by
 // tests/host_emul (see mpm_math.h).
 #pragma once
@@ -13,7 +13,7 @@
 
 namespace plb {
 
-enum ShapeKind { SHAPE_SPHERE = 0, SHAPE_CAPSULE = 1, SHAPE_CYLINDER = 2, SHAPE_TORUS = 3, SHAPE_BOX = 4 };
+enum ShapeKind { SHAPE_SPHERE = 0, SHAPE_CAPSULE = 1, SHAPE_CYLINDER = 2, SHAPE_TORUS = 3, SHAPE_BOX = 4, SHAPE_CHOPSTICKS = 5 };
 
 // One primitive as a grid node sees it during substep f: static description + pose at f and f+1.
 // Rigid-body geometry (signed distance, normal, collider velocity and the pose adjoints) is always
@@ -24,6 +24,7 @@ template <class T> struct PrimT {
     int shape;
     int movable;             // action_dim > 0: pose adjoints are wanted
     double par[3];           // Sphere: radius | Capsule: h, r | Cylinder: h(=radius), r(=half height) | Torus: tx, ty | Box: size
+                             // | Chopsticks: h, r, gap[f] (the kernels fill par[2] from the gap trajectory)
     T friction;
     float rb;                // radius of a sphere around pos that contains the shape (cheap fp32 cull)
     double pos[3], rot[4];   // pose at frame f
@@ -32,9 +33,11 @@ template <class T> struct PrimT {
 
 template <class T> struct PoseAdj {
     double pos[3], rot[4], pos1[3], rot1[4];
+    double gap;              // Chopsticks: adjoint of gap[f]
     PLB_HD void zero() {
         for (int i = 0; i < 3; ++i) pos[i] = pos1[i] = 0.0;
         for (int i = 0; i < 4; ++i) rot[i] = rot1[i] = 0.0;
+        gap = 0.0;
     }
 };
 
@@ -87,12 +90,40 @@ template <class T> PLB_HD void inv_trans_adj(const T* p, const T* pos, const T* 
 template <class T> PLB_HD T len14(T a, T b) { return t_sqrt(a * a + b * b + T(1e-14)); }
 template <class T> PLB_HD T len14(T a, T b, T c) { return t_sqrt(a * a + b * b + c * c + T(1e-14)); }
 
+template <class T> PLB_HD T capsule_sdf(const T* par, const T* p) {          // primitives.py:42-47
+    T y = p[1] + par[0] / T(2);
+    y -= t_min(t_max(y, T(0)), par[0]);
+    return len14(p[0], y, p[2]) - par[1];
+}
+template <class T> PLB_HD void capsule_normal(const T* par, const T* p, T* n) {   // primitives.py:49-54
+    T y = p[1] + par[0] / T(2);
+    y -= t_min(t_max(y, T(0)), par[0]);
+    T inv = T(1) / len14(p[0], y, p[2]);
+    n[0] = p[0] * inv; n[1] = y * inv; n[2] = p[2] * inv;
+}
+// reverse mode of (capsule_sdf, capsule_normal) w.r.t. p; min/max follow Taichi's adjoint routing
+template <class T> PLB_HD void capsule_adj(const T* par, const T* p, T da, const T* na, T* pa) {
+    T t = p[1] + par[0] / T(2);
+    T mx = t_max(t, T(0));                          // max(t, 0): adjoint to t iff 0 < t
+    T dcl = (T(0) < t && mx < par[0]) ? T(1) : T(0);   // min(mx, h): adjoint to mx iff mx < h
+    T cl = t_min(mx, par[0]);
+    T y = t - cl, dy = T(1) - dcl;                  // y' and dy'/dy
+    T L = len14(p[0], y, p[2]);
+    T n[3] = {p[0] / L, y / L, p[2] / L};
+    T nd = n[0] * na[0] + n[1] * na[1] + n[2] * na[2];
+    T g[3];                                         // adjoint of p2 = (x, y', z)
+    for (int i = 0; i < 3; ++i) g[i] = da * n[i] + (na[i] - n[i] * nd) / L;
+    pa[0] += g[0]; pa[1] += g[1] * dy; pa[2] += g[2];
+}
+
 template <class T> PLB_HD T shape_sdf_local(int shape, const T* par, const T* p) {
     switch (shape) {
-    case SHAPE_CAPSULE: {                                 // primitives.py:42-47
-        T y = p[1] + par[0] / T(2);
-        y -= t_min(t_max(y, T(0)), par[0]);
-        return len14(p[0], y, p[2]) - par[1];
+    case SHAPE_CAPSULE: return capsule_sdf(par, p);
+    case SHAPE_CHOPSTICKS: {                              // primitives.py:111-117: min over two capsules, gap = par[2]
+        T qa[3] = {p[0] - par[2] / T(2), p[1] + par[0] / T(2), p[2]};
+        T qb[3] = {p[0] + par[2] / T(2), qa[1], p[2]};
+        T a = capsule_sdf(par, qa), b = capsule_sdf(par, qb);
+        return a < b ? a : b;
     }
     case SHAPE_CYLINDER: {                                // primitives.py:163-167 (h = radius, r = half height)
         T d0 = t_abs(len14(p[0], p[2])) - par[0], d1 = t_abs(p[1]) - par[1];
@@ -113,13 +144,14 @@ template <class T> PLB_HD T shape_sdf_local(int shape, const T* par, const T* p)
 
 template <class T> PLB_HD void shape_normal_local(int shape, const T* par, const T* p, T* n) {
     switch (shape) {
-    case SHAPE_CAPSULE: {                                 // primitives.py:49-54
-        T y = p[1] + par[0] / T(2);
-        y -= t_min(t_max(y, T(0)), par[0]);
-        T inv = T(1) / len14(p[0], y, p[2]);
-        n[0] = p[0] * inv; n[1] = y * inv; n[2] = p[2] * inv;
+    case SHAPE_CHOPSTICKS: {                              // primitives.py:119-129: the normal of the nearer capsule
+        T qa[3] = {p[0] - par[2] / T(2), p[1] + par[0] / T(2), p[2]};
+        T qb[3] = {p[0] + par[2] / T(2), qa[1], p[2]};
+        T a = capsule_sdf(par, qa), b = capsule_sdf(par, qb);
+        capsule_normal(par, a <= b ? qa : qb, n);
         return;
     }
+    case SHAPE_CAPSULE: capsule_normal(par, p, n); return;
     case SHAPE_CYLINDER: {                                // primitives.py:169-183
         T l = len14(p[0], p[2]);
         T d0 = l - par[0], d1 = t_abs(p[1]) - par[1];
@@ -163,23 +195,27 @@ template <class T> PLB_HD void shape_normal_local(int shape, const T* par, const
 // Reverse mode of (shape_sdf_local, shape_normal_local) w.r.t. the local point p: given the adjoints
 // da of the distance and na[3] of the normal, accumulate pa[3] += d<da*sdf + na.n>/dp.  Hand-derived for the
 // shapes the reference's tasks actually move (Capsule: writer.yml, Torus: torus.yml); min/max follow Taichi's
-// adjoint routing.  Returns false for shapes without a derived adjoint.
-template <class T> PLB_HD bool shape_local_adj(int shape, const T* par, const T* p, T da, const T* na, T* pa) {
+// adjoint routing.  Returns false for shapes without a derived adjoint.  `ga` (Chopsticks only)
+// accumulates the adjoint of the gap par[2].
+template <class T> PLB_HD bool shape_local_adj(int shape, const T* par, const T* p, T da, const T* na, T* pa,
+                                               double* ga = nullptr) {
     switch (shape) {
-    case SHAPE_CAPSULE: {
-        T t = p[1] + par[0] / T(2);
-        T mx = t_max(t, T(0));                          // max(t, 0): adjoint to t iff 0 < t
-        T cl = t_min(mx, par[0]);                       // min(mx, h): adjoint to mx iff mx < h
-        T dcl = (T(0) < t && mx < par[0]) ? T(1) : T(0);
-        T y = t - cl, dy = T(1) - dcl;                  // y' and dy'/dy
-        T L = len14(p[0], y, p[2]);
-        T n[3] = {p[0] / L, y / L, p[2] / L};
-        T nd = n[0] * na[0] + n[1] * na[1] + n[2] * na[2];
-        T g[3];                                         // adjoint of p2 = (x, y', z)
-        for (int i = 0; i < 3; ++i) g[i] = da * n[i] + (na[i] - n[i] * nd) / L;
-        pa[0] += g[0]; pa[1] += g[1] * dy; pa[2] += g[2];
+    case SHAPE_CHOPSTICKS: {
+        // sdf = ti.min(a, b): adjoint to a iff a < b, else to b.  normal: m = (a <= b) carries no gradient and
+        // selects a's normal on ties.  Each branch is a Capsule evaluated at q = p + (0, h/2, 0) -/+ (gap/2, 0, 0).
+        T qa[3] = {p[0] - par[2] / T(2), p[1] + par[0] / T(2), p[2]};
+        T qb[3] = {p[0] + par[2] / T(2), qa[1], p[2]};
+        T a = capsule_sdf(par, qa), b = capsule_sdf(par, qb);
+        const T zero3[3] = {T(0), T(0), T(0)};
+        const bool sdf_a = a < b, nrm_a = a <= b;
+        T ga_[3] = {T(0), T(0), T(0)}, gb_[3] = {T(0), T(0), T(0)};
+        capsule_adj(par, qa, sdf_a ? da : T(0), nrm_a ? na : zero3, ga_);
+        capsule_adj(par, qb, sdf_a ? T(0) : da, nrm_a ? zero3 : na, gb_);
+        for (int i = 0; i < 3; ++i) pa[i] += ga_[i] + gb_[i];
+        if (ga) *ga += (double)((gb_[0] - ga_[0]) / T(2));
         return true;
     }
+    case SHAPE_CAPSULE: capsule_adj(par, p, da, na, pa); return true;
     case SHAPE_TORUS: {
         T l = len14(p[0], p[2]);
         T q0 = l - par[0], q1 = p[1];
@@ -243,6 +279,7 @@ PLB_HD float prim_bounding_radius(int shape, const double* par) {
     switch (shape) {
     case SHAPE_SPHERE: return (float)par[0];
     case SHAPE_CAPSULE: return (float)(par[0] * 0.5 + par[1]);
+    case SHAPE_CHOPSTICKS: return (float)(sqrt(par[0] * par[0] + 0.25 * par[2] * par[2]) + par[1]);
     case SHAPE_CYLINDER: return (float)sqrt(par[0] * par[0] + par[1] * par[1]);
     case SHAPE_TORUS: return (float)(par[0] + par[1]);
     default: return (float)sqrt(par[0] * par[0] + par[1] * par[1] + par[2] * par[2]);
@@ -363,7 +400,7 @@ template <class T> PLB_HD bool collide_grad(const PrimT<T>& pr, T softness, T dt
         qrot_adj_q(pr.rot, nl, Dad, pa->rot);            // d D / d rot (direct)
         qconj(pr.rot, cr);
         qrot(cr, Dad, nla);                              // adjoint of n_local (qrot is linear in its vector argument)
-        shape_local_adj(pr.shape, pr.par, c.rel, dista, nla, loca);
+        shape_local_adj(pr.shape, pr.par, c.rel, dista, nla, loca, &pa->gap);
         inv_trans_adj(gp, pr.pos, pr.rot, c.iq, loca, pa->pos, pa->rot);
     }
     return true;
@@ -566,6 +603,43 @@ PLB_HD void fk_bwd_d(const double* pos, const double* rot, const double* v, cons
     double q[4], qa[4] = {0, 0, 0, 0};
     w2quat_d(w, q);
     qmul_adj_d(q, rot, rot1_a, qa, rot_a);
+    w_a[0] = w_a[1] = w_a[2] = 0.0;
+    w2quat_adj_d(w, qa, w_a);
+}
+
+// Chopsticks.forward_kinematics (primitives.py:94-98): gap closes by gap_vel down to minimal_gap, position as the
+// base class, rotation updated in the BODY frame: rot[f+1] = qmul(rot[f], w2quat(w)).
+PLB_HD void fk_chopsticks_fwd_d(const double* pos, const double* rot, const double* v, const double* w, double gap,
+                                double gap_vel, double min_gap, const double* lo, const double* hi, double* pos1,
+                                double* rot1, double* gap1) {
+    for (int i = 0; i < 3; ++i) {
+        double y = pos[i] + v[i];
+        double mn = y < hi[i] ? y : hi[i];
+        pos1[i] = lo[i] < mn ? mn : lo[i];
+    }
+    double g = gap - gap_vel;
+    *gap1 = min_gap < g ? g : min_gap;
+    double q[4];
+    w2quat_d(w, q);
+    qmul_d(rot, q, rot1);
+}
+PLB_HD void fk_chopsticks_bwd_d(const double* pos, const double* rot, const double* v, const double* w, double gap,
+                                double gap_vel, double min_gap, const double* lo, const double* hi,
+                                const double* pos1_a, const double* rot1_a, double gap1_a, double* pos_a,
+                                double* rot_a, double* gap_a, double* v_a, double* w_a, double* gap_vel_a) {
+    for (int i = 0; i < 3; ++i) {
+        double y = pos[i] + v[i];
+        double mn = y < hi[i] ? y : hi[i];
+        double gate = (y < hi[i] && lo[i] < mn) ? 1.0 : 0.0;
+        pos_a[i] += gate * pos1_a[i];
+        v_a[i] = gate * pos1_a[i];
+    }
+    double ggate = (min_gap < gap - gap_vel) ? 1.0 : 0.0;      // max(lhs, rhs): adjoint to lhs iff rhs < lhs
+    *gap_a += ggate * gap1_a;
+    *gap_vel_a = -ggate * gap1_a;
+    double q[4], qa[4] = {0, 0, 0, 0};
+    w2quat_d(w, q);
+    qmul_adj_d(rot, q, rot1_a, rot_a, qa);
     w_a[0] = w_a[1] = w_a[2] = 0.0;
     w2quat_adj_d(w, qa, w_a);
 }

@@ -56,11 +56,12 @@ struct plmpm_sim {
     int* flags;
     char *loss_gm, *loss_td, *loss_ts;
     double *ppos, *prot, *ppos_a, *prot_a, *pv, *pw, *pv_a, *pw_a, *act, *act_a, *lscal, *staging;
+    double *pgap, *pgap_a, *pgv, *pgv_a;           // Chopsticks gap trajectory, gap velocity and adjoints: [(F+1)][P]
     int* err_d = nullptr;
     // multi-GPU: pose adjoints produced by this rank's nodes/particles accumulate in *_l, get summed over
     // ranks by the host and are then merged into the global ppos_a/prot_a the kinematics chain reads
     bool dist = false;
-    double *ppos_l = nullptr, *prot_l = nullptr;
+    double *ppos_l = nullptr, *prot_l = nullptr, *pgap_l = nullptr;
     // host state
     std::vector<int32_t> perm;
     double softness = 0.0;
@@ -140,9 +141,10 @@ template <class T> static Dev<T> make_dev(const plmpm_sim* s, int frame = -1) {
     D.grid_out = (Vec4<T>*)(framed ? s->vstore + (size_t)frame * s->gstride : s->grid_out);
     D.grid_in_adj = (Vec4<T>*)s->grid_in_adj;
     D.flags = framed ? s->fstore + (size_t)frame * s->nblk : s->flags;
-    D.ppos = s->ppos; D.prot = s->prot;
+    D.ppos = s->ppos; D.prot = s->prot; D.pgap = s->pgap;
     D.ppos_a = s->dist ? s->ppos_l : s->ppos_a;
     D.prot_a = s->dist ? s->prot_l : s->prot_a;
+    D.pgap_a = s->dist ? s->pgap_l : s->pgap_a;
     for (int i = 0; i < s->P; ++i) {
         D.prim[i].shape = s->prims[i].shape;
         D.prim[i].movable = s->prims[i].action_dim > 0;
@@ -234,11 +236,17 @@ struct PrimChainArgs {
     int kin[kMaxPrim];
     double scale[kMaxPrim][PLMPM_MAX_ACTION_DIM];
     double lo[kMaxPrim][3], hi[kMaxPrim][3];
+    double min_gap[kMaxPrim];
+};
+// primitive trajectories the serial kinematics kernels walk (all double, [(F+1)][P][.])
+struct ChainBufs {
+    double *ppos, *prot, *pgap, *pv, *pw, *pgv;
+    double *ppos_a, *prot_a, *pgap_a, *pv_a, *pw_a, *pgv_a, *act_a;
 };
 struct ActionArg { double a[kMaxPrim * PLMPM_MAX_ACTION_DIM]; };
 
 // set_action: action_buffer[step] = clipped action; v,w for the step's frames (primive_base.py:166-198)
-__global__ void k_set_action(PrimChainArgs A, ActionArg act, int step, int nsub, double* actbuf, double* pv, double* pw) {
+__global__ void k_set_action(PrimChainArgs A, ActionArg act, int step, int nsub, double* actbuf, double* pv, double* pw, double* pgv) {
     int p = threadIdx.x;
     if (p >= A.P) return;
     double* ab = actbuf + ((size_t)step * A.P + p) * PLMPM_MAX_ACTION_DIM;
@@ -249,31 +257,44 @@ __global__ void k_set_action(PrimChainArgs A, ActionArg act, int step, int nsub,
         double* w = pw + ((size_t)j * A.P + p) * 3;
         for (int k = 0; k < 3; ++k) v[k] = ab[k] * A.scale[p][k] / nsub;
         if (A.action_dim[p] > 3) for (int k = 0; k < 3; ++k) w[k] = ab[k + 3] * A.scale[p][k + 3] / nsub;
+        if (A.kin[p] == PLMPM_KIN_CHOPSTICKS) pgv[(size_t)j * A.P + p] = ab[6] * A.scale[p][6] / nsub;   // primitives.py:109
     }
 }
 // forward_kinematics over frames [first, first+n) (primive_base.py:117-121)
-__global__ void k_fk_chain(PrimChainArgs A, int first, int n, double* ppos, double* prot, const double* pv, const double* pw) {
+__global__ void k_fk_chain(PrimChainArgs A, int first, int n, ChainBufs B) {
     int p = threadIdx.x;
     if (p >= A.P) return;
+    double *ppos = B.ppos, *prot = B.prot;
+    const double *pv = B.pv, *pw = B.pw;
     for (int s = first; s < first + n; ++s) {
         size_t a = (size_t)s * A.P + p, b = (size_t)(s + 1) * A.P + p;
-        if (A.kin[p] == PLMPM_KIN_ROLLINGPIN)
+        if (A.kin[p] == PLMPM_KIN_CHOPSTICKS)
+            fk_chopsticks_fwd_d(ppos + a * 3, prot + a * 4, pv + a * 3, pw + a * 3, B.pgap[a], B.pgv[a], A.min_gap[p], A.lo[p],
+                                A.hi[p], ppos + b * 3, prot + b * 4, B.pgap + b);
+        else if (A.kin[p] == PLMPM_KIN_ROLLINGPIN)
             fk_rollingpin_fwd_d(ppos + a * 3, prot + a * 4, pv + a * 3, A.lo[p], A.hi[p], ppos + b * 3, prot + b * 4);
         else
             fk_fwd_d(ppos + a * 3, prot + a * 4, pv + a * 3, pw + a * 3, A.lo[p], A.hi[p], ppos + b * 3, prot + b * 4);
     }
 }
 // forward_kinematics.grad for frames first+n-1..first, then set_velocity.grad for env step `step`
-__global__ void k_fk_chain_grad(PrimChainArgs A, int first, int n, int step, const double* ppos, const double* prot,
-                                const double* pv, const double* pw, double* ppos_a, double* prot_a, double* pv_a,
-                                double* pw_a, double* act_a) {
+__global__ void k_fk_chain_grad(PrimChainArgs A, int first, int n, int step, ChainBufs B) {
     int p = threadIdx.x;
     if (p >= A.P || A.action_dim[p] <= 0) return;
-    double va_sum[3] = {0, 0, 0}, wa_sum[3] = {0, 0, 0};
+    const double *ppos = B.ppos, *prot = B.prot, *pv = B.pv, *pw = B.pw;
+    double *ppos_a = B.ppos_a, *prot_a = B.prot_a, *pv_a = B.pv_a, *pw_a = B.pw_a, *act_a = B.act_a;
+    double va_sum[3] = {0, 0, 0}, wa_sum[3] = {0, 0, 0}, ga_sum = 0.0;
     for (int s = first + n - 1; s >= first; --s) {
         size_t a = (size_t)s * A.P + p, b = (size_t)(s + 1) * A.P + p;
         double va[3], wa[3] = {0.0, 0.0, 0.0};
-        if (A.kin[p] == PLMPM_KIN_ROLLINGPIN)
+        if (A.kin[p] == PLMPM_KIN_CHOPSTICKS) {
+            double gva = 0.0;
+            fk_chopsticks_bwd_d(ppos + a * 3, prot + a * 4, pv + a * 3, pw + a * 3, B.pgap[a], B.pgv[a], A.min_gap[p], A.lo[p],
+                                A.hi[p], ppos_a + b * 3, prot_a + b * 4, B.pgap_a[b], ppos_a + a * 3, prot_a + a * 4,
+                                B.pgap_a + a, va, wa, &gva);
+            B.pgv_a[a] = gva;
+            ga_sum += gva;
+        } else if (A.kin[p] == PLMPM_KIN_ROLLINGPIN)
             fk_rollingpin_bwd_d(ppos + a * 3, prot + a * 4, pv + a * 3, A.lo[p], A.hi[p], ppos_a + b * 3, prot_a + b * 4,
                                 ppos_a + a * 3, prot_a + a * 4, va);
         else
@@ -284,6 +305,7 @@ __global__ void k_fk_chain_grad(PrimChainArgs A, int first, int n, int step, con
     double* aa = act_a + ((size_t)step * A.P + p) * PLMPM_MAX_ACTION_DIM;
     for (int k = 0; k < 3; ++k) aa[k] += va_sum[k] * A.scale[p][k] / n;
     if (A.action_dim[p] > 3) for (int k = 0; k < 3; ++k) aa[k + 3] += wa_sum[k] * A.scale[p][k + 3] / n;
+    if (A.kin[p] == PLMPM_KIN_CHOPSTICKS) aa[6] += ga_sum * A.scale[p][6] / n;
 }
 
 // ---- loss -----------------------------------------------------------------------------------
@@ -328,6 +350,7 @@ template <class T> __device__ __forceinline__ PrimT<T> prim_at(const Dev<T>& D, 
     PrimT<T> p;
     p.shape = D.prim[q].shape; p.movable = D.prim[q].movable; p.friction = (T)D.prim[q].friction;
     for (int i = 0; i < 3; ++i) { p.par[i] = D.prim[q].par[i]; p.pos[i] = p.pos1[i] = D.ppos[((size_t)f * D.nprim + q) * 3 + i]; }
+    if (p.shape == SHAPE_CHOPSTICKS) p.par[2] = D.pgap[(size_t)f * D.nprim + q];
     p.rb = prim_bounding_radius(p.shape, p.par);
     for (int i = 0; i < 4; ++i) p.rot[i] = p.rot1[i] = D.prot[((size_t)f * D.nprim + q) * 4 + i];
     return p;
@@ -362,8 +385,8 @@ template <class T> __global__ void k_contact(Dev<T> D, int f, int mode, double* 
 template <class T>
 __global__ void k_loss_grad(Dev<T> D, int f, int which, const T* gm, const T* td, const T* ts, const double* ls,
                             double w_sdf, double w_density, double w_contact, int soft) {
-    __shared__ double sacc[kMaxPrim * 7];
-    if (threadIdx.x < kMaxPrim * 7) sacc[threadIdx.x] = 0.0;
+    __shared__ double sacc[kMaxPrim * 8];
+    if (threadIdx.x < kMaxPrim * 8) sacc[threadIdx.x] = 0.0;
     __syncthreads();
     int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p < D.N) {
@@ -399,7 +422,7 @@ __global__ void k_loss_grad(Dev<T> D, int f, int which, const T* gm, const T* td
                 double sw = 1.0 / den, dsw = -20000.0 * sd / (den * den);
                 coef = w_contact * 2.0 * md * (sw + sd * dsw - md * dsw) / dn;
             }
-            double pa[3] = {0, 0, 0}, ra[4] = {0, 0, 0, 0};
+            double pa[3] = {0, 0, 0}, ra[4] = {0, 0, 0, 0}, ga = 0.0;
             if (pr.shape == SHAPE_SPHERE) {                 // d sdf/dx = (x - c)/len ; d sdf/dc = -that
                 double dvec[3] = {x[0] - pr.pos[0], x[1] - pr.pos[1], x[2] - pr.pos[2]};
                 double L = len14(dvec[0], dvec[1], dvec[2]);
@@ -407,23 +430,25 @@ __global__ void k_loss_grad(Dev<T> D, int f, int which, const T* gm, const T* td
             } else {                                        // sdf = sdf_local(inv_trans(x, pos, rot))
                 double loc[3], iq[4], na0[3] = {0, 0, 0}, loca[3] = {0, 0, 0};
                 inv_trans(x, pr.pos, pr.rot, loc, iq);
-                shape_local_adj(pr.shape, pr.par, loc, coef, na0, loca);
+                shape_local_adj(pr.shape, pr.par, loc, coef, na0, loca, &ga);
                 inv_trans_adj(x, pr.pos, pr.rot, iq, loca, pa, ra);
                 for (int d = 0; d < 3; ++d) xa[d] -= pa[d];  // d/dx = -d/dpos
             }
-            for (int d = 0; d < 3; ++d) if (pa[d] != 0.0) atomicAdd(&sacc[q * 7 + d], pa[d]);
-            for (int d = 0; d < 4; ++d) if (ra[d] != 0.0) atomicAdd(&sacc[q * 7 + 3 + d], ra[d]);
+            for (int d = 0; d < 3; ++d) if (pa[d] != 0.0) atomicAdd(&sacc[q * 8 + d], pa[d]);
+            for (int d = 0; d < 4; ++d) if (ra[d] != 0.0) atomicAdd(&sacc[q * 8 + 3 + d], ra[d]);
+            if (ga != 0.0) atomicAdd(&sacc[q * 8 + 7], ga);
         }
         T* A = D.adj[which];
         for (int d = 0; d < 3; ++d) A[d * D.Npad + p] += (T)xa[d];
     }
     __syncthreads();
-    if (threadIdx.x < D.nprim * 7) {
+    if (threadIdx.x < D.nprim * 8) {
         double v = sacc[threadIdx.x];
-        int q = threadIdx.x / 7, c = threadIdx.x % 7;
+        int q = threadIdx.x / 8, c = threadIdx.x % 8;
         if (v != 0.0) {
             if (c < 3) atomicAdd(&D.ppos_a[((size_t)f * D.nprim + q) * 3 + c], v);
-            else atomicAdd(&D.prot_a[((size_t)f * D.nprim + q) * 4 + (c - 3)], v);
+            else if (c < 7) atomicAdd(&D.prot_a[((size_t)f * D.nprim + q) * 4 + (c - 3)], v);
+            else atomicAdd(&D.pgap_a[(size_t)f * D.nprim + q], v);
         }
     }
 }
@@ -484,8 +509,16 @@ static PrimChainArgs chain_args(const plmpm_sim* s) {
         A.kin[p] = s->prims[p].kinematics;
         for (int k = 0; k < PLMPM_MAX_ACTION_DIM; ++k) A.scale[p][k] = s->prims[p].action_scale[k];
         for (int k = 0; k < 3; ++k) { A.lo[p][k] = s->prims[p].lower_bound[k]; A.hi[p][k] = s->prims[p].upper_bound[k]; }
+        A.min_gap[p] = s->prims[p].params[2];           // Chopsticks: params = h, r, minimal_gap
     }
     return A;
+}
+static ChainBufs chain_bufs(const plmpm_sim* s) {
+    ChainBufs B;
+    B.ppos = s->ppos; B.prot = s->prot; B.pgap = s->pgap; B.pv = s->pv; B.pw = s->pw; B.pgv = s->pgv;
+    B.ppos_a = s->ppos_a; B.prot_a = s->prot_a; B.pgap_a = s->pgap_a; B.pv_a = s->pv_a; B.pw_a = s->pw_a;
+    B.pgv_a = s->pgv_a; B.act_a = s->act_a;
+    return B;
 }
 static inline int nblocks_particles(const plmpm_sim* s) { return s->Npad / kBlock; }
 static inline int nblocks_grid(const plmpm_sim* s) { return (s->nblk + (kBlock / 64) - 1) / (kBlock / 64); }
@@ -672,11 +705,19 @@ int plmpm_create(const plmpm_config* cfg, const plmpm_primitive* prims, plmpm_ha
     for (int p = 0; p < s->P; ++p) {
         s->prims[p] = prims[p];
         if (prims[p].action_dim < 0 || prims[p].action_dim > PLMPM_MAX_ACTION_DIM) { delete s; return fail("bad action_dim"); }
-        if (prims[p].kinematics != PLMPM_KIN_DEFAULT && prims[p].kinematics != PLMPM_KIN_ROLLINGPIN) { delete s; return fail("unknown kinematics %d", prims[p].kinematics); }
-        if (prims[p].action_dim > 0 && prims[p].shape != PLMPM_SPHERE && prims[p].shape != PLMPM_CAPSULE &&
-            prims[p].shape != PLMPM_TORUS) {
+        if (prims[p].kinematics < PLMPM_KIN_DEFAULT || prims[p].kinematics > PLMPM_KIN_CHOPSTICKS) { delete s; return fail("unknown kinematics %d", prims[p].kinematics); }
+        if ((prims[p].shape == PLMPM_CHOPSTICKS) != (prims[p].kinematics == PLMPM_KIN_CHOPSTICKS)) {
             delete s;
-            return fail("movable primitive %d: pose adjoints exist for Sphere, Capsule and Torus only (shape %d)", p, prims[p].shape);
+            return fail("primitive %d: the Chopsticks shape and PLMPM_KIN_CHOPSTICKS go together", p);
+        }
+        if (prims[p].shape == PLMPM_CHOPSTICKS && prims[p].action_dim != 7) {
+            delete s;
+            return fail("primitive %d: Chopsticks take a 7-dim action (3 linear, 3 angular, 1 grasp; primitives.py:92)", p);
+        }
+        if (prims[p].action_dim > 0 && prims[p].shape != PLMPM_SPHERE && prims[p].shape != PLMPM_CAPSULE &&
+            prims[p].shape != PLMPM_TORUS && prims[p].shape != PLMPM_CHOPSTICKS) {
+            delete s;
+            return fail("movable primitive %d: pose adjoints exist for Sphere, Capsule, Torus and Chopsticks only (shape %d)", p, prims[p].shape);
         }
         s->act_ofs[p + 1] = s->act_ofs[p] + prims[p].action_dim;
     }
@@ -692,13 +733,14 @@ int plmpm_create(const plmpm_config* cfg, const plmpm_primitive* prims, plmpm_ha
     s->ws.adjoint_bytes = align_up(2 * 24 * s->Npad * s->tsz, 256) + 3 * align_up(s->Npad * s->tsz, 256) + align_up((size_t)s->Npad * 4, 256);
     s->ws.grid_bytes = 4 * align_up(s->G * 4 * s->tsz, 256) + align_up((size_t)s->nblk * 4, 256) + 3 * align_up(s->G * s->tsz, 256);
     s->dist = s->cfg.slab_z0 > 0 || s->cfg.slab_z1 < cfg->n_grid || cfg->slab_halo > 0;
-    if (s->dist) s->ws.misc_bytes += 2 * align_up((size_t)(s->F + 1) * P1 * 4 * 8, 256);
+    if (s->dist) s->ws.misc_bytes += 3 * align_up((size_t)(s->F + 1) * P1 * 4 * 8, 256);
     s->store = cfg->store_grid != 0;
     s->gstride = align_up(s->G * 4 * s->tsz, 256);
     if (s->store) s->ws.grid_bytes += 2 * (size_t)s->F * s->gstride + align_up((size_t)s->F * s->nblk * 4, 256);
     s->dirty.assign(s->F + 1, 0);
     s->ws.misc_bytes = 2 * align_up((size_t)(s->F + 1) * P1 * 7 * 8, 256) + 2 * align_up((size_t)(s->F + 1) * P1 * 8 * 8, 256)  // poses(+adj), padded
                        + 4 * align_up((size_t)(s->F + 1) * P1 * 3 * 8, 256)                       // v,w (+adj)
+                       + 4 * align_up((size_t)(s->F + 1) * P1 * 8, 256)                           // gap, gap_vel (+adj)
                        + 2 * align_up((size_t)(s->F + 1) * P1 * PLMPM_MAX_ACTION_DIM * 8, 256)    // action buffers (+adj)
                        + align_up(LS_COUNT * 8, 256) + align_up((size_t)s->N * 24 * 8, 256) + 256;
     s->perm.resize(s->N);
@@ -747,11 +789,13 @@ int plmpm_bind_workspace(plmpm_handle s, void* state, void* adjoint, void* grid,
     s->ppos_a = (double*)take(F1 * P1 * 3 * 8); s->prot_a = (double*)take(F1 * P1 * 4 * 8);
     s->pv = (double*)take(F1 * P1 * 3 * 8); s->pw = (double*)take(F1 * P1 * 3 * 8);
     s->pv_a = (double*)take(F1 * P1 * 3 * 8); s->pw_a = (double*)take(F1 * P1 * 3 * 8);
+    s->pgap = (double*)take(F1 * P1 * 8); s->pgap_a = (double*)take(F1 * P1 * 8);
+    s->pgv = (double*)take(F1 * P1 * 8); s->pgv_a = (double*)take(F1 * P1 * 8);
     s->act = (double*)take(F1 * P1 * PLMPM_MAX_ACTION_DIM * 8); s->act_a = (double*)take(F1 * P1 * PLMPM_MAX_ACTION_DIM * 8);
     s->lscal = (double*)take(LS_COUNT * 8);
     s->staging = (double*)take((size_t)s->N * 24 * 8);
     s->err_d = (int*)take(256);
-    if (s->dist) { s->ppos_l = (double*)take(F1 * P1 * 3 * 8); s->prot_l = (double*)take(F1 * P1 * 4 * 8); }
+    if (s->dist) { s->ppos_l = (double*)take(F1 * P1 * 3 * 8); s->prot_l = (double*)take(F1 * P1 * 4 * 8); s->pgap_l = (double*)take(F1 * P1 * 8); }
     REQUIRE((size_t)(p - s->miscw) <= s->ws.misc_bytes, "internal: misc workspace overflow");
     // initial contents: zero grids / adjoints / primitive buffers, identity order
     HIPCHK(hipMemsetAsync(s->adjw, 0, s->ws.adjoint_bytes, s->stream));
@@ -858,6 +902,7 @@ int plmpm_copy_frame(plmpm_handle s, int source, int target) {
     if (s->P > 0) {
         HIPCHK(hipMemcpyAsync(s->ppos + (size_t)target * s->P * 3, s->ppos + (size_t)source * s->P * 3, (size_t)s->P * 3 * 8, hipMemcpyDeviceToDevice, s->stream));
         HIPCHK(hipMemcpyAsync(s->prot + (size_t)target * s->P * 4, s->prot + (size_t)source * s->P * 4, (size_t)s->P * 4 * 8, hipMemcpyDeviceToDevice, s->stream));
+        HIPCHK(hipMemcpyAsync(s->pgap + (size_t)target * s->P, s->pgap + (size_t)source * s->P, (size_t)s->P * 8, hipMemcpyDeviceToDevice, s->stream));
     }
     return 0;
 }
@@ -868,6 +913,7 @@ int plmpm_set_primitive_state(plmpm_handle s, int prim, int frame, const double*
     REQUIRE(prim >= 0 && prim < s->P && st, "bad primitive index");
     HIPCHK(hipMemcpyAsync(s->ppos + ((size_t)frame * s->P + prim) * 3, st, 3 * 8, hipMemcpyHostToDevice, s->stream));
     HIPCHK(hipMemcpyAsync(s->prot + ((size_t)frame * s->P + prim) * 4, st + 3, 4 * 8, hipMemcpyHostToDevice, s->stream));
+    HIPCHK(hipMemcpyAsync(s->pgap + (size_t)frame * s->P + prim, st + 7, 8, hipMemcpyHostToDevice, s->stream));
     HIPCHK(hipStreamSynchronize(s->stream));
     return 0;
 }
@@ -877,6 +923,7 @@ int plmpm_get_primitive_state(plmpm_handle s, int prim, int frame, double* st) {
     REQUIRE(prim >= 0 && prim < s->P && st, "bad primitive index");
     HIPCHK(hipMemcpyAsync(st, s->ppos + ((size_t)frame * s->P + prim) * 3, 3 * 8, hipMemcpyDeviceToHost, s->stream));
     HIPCHK(hipMemcpyAsync(st + 3, s->prot + ((size_t)frame * s->P + prim) * 4, 4 * 8, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipMemcpyAsync(st + 7, s->pgap + (size_t)frame * s->P + prim, 8, hipMemcpyDeviceToHost, s->stream));
     HIPCHK(hipStreamSynchronize(s->stream));
     return 0;
 }
@@ -886,6 +933,7 @@ int plmpm_get_primitive_grad(plmpm_handle s, int prim, int frame, double* g) {
     REQUIRE(prim >= 0 && prim < s->P && g, "bad primitive index");
     HIPCHK(hipMemcpyAsync(g, s->ppos_a + ((size_t)frame * s->P + prim) * 3, 3 * 8, hipMemcpyDeviceToHost, s->stream));
     HIPCHK(hipMemcpyAsync(g + 3, s->prot_a + ((size_t)frame * s->P + prim) * 4, 4 * 8, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipMemcpyAsync(g + 7, s->pgap_a + (size_t)frame * s->P + prim, 8, hipMemcpyDeviceToHost, s->stream));
     HIPCHK(hipStreamSynchronize(s->stream));
     return 0;
 }
@@ -908,7 +956,7 @@ int plmpm_set_action(plmpm_handle s, int step, int n_substeps, const double* act
             double v = action[s->act_ofs[p] + k];
             a.a[p * PLMPM_MAX_ACTION_DIM + k] = std::min(1.0, std::max(-1.0, v));      // primitives.py:290
         }
-    hipLaunchKernelGGL(k_set_action, dim3(1), dim3(kMaxPrim), 0, s->stream, chain_args(s), a, step, n_substeps, s->act, s->pv, s->pw);
+    hipLaunchKernelGGL(k_set_action, dim3(1), dim3(kMaxPrim), 0, s->stream, chain_args(s), a, step, n_substeps, s->act, s->pv, s->pw, s->pgv);
     return 0;
 }
 
@@ -928,7 +976,7 @@ int plmpm_get_action_grad(plmpm_handle s, int n_steps, double* out) {
 
 static int launch_fk(plmpm_sim* s, int first, int n) {
     if (s->P > 0)
-        hipLaunchKernelGGL(k_fk_chain, dim3(1), dim3(kMaxPrim), 0, s->stream, chain_args(s), first, n, s->ppos, s->prot, s->pv, s->pw);
+        hipLaunchKernelGGL(k_fk_chain, dim3(1), dim3(kMaxPrim), 0, s->stream, chain_args(s), first, n, chain_bufs(s));
     return 0;
 }
 
@@ -961,10 +1009,13 @@ int plmpm_grad_begin(plmpm_handle s, int last_frame) {
     HIPCHK(hipMemsetAsync(s->prot_a, 0, F1 * P1 * 4 * 8, s->stream));
     HIPCHK(hipMemsetAsync(s->pv_a, 0, F1 * P1 * 3 * 8, s->stream));
     HIPCHK(hipMemsetAsync(s->pw_a, 0, F1 * P1 * 3 * 8, s->stream));
+    HIPCHK(hipMemsetAsync(s->pgap_a, 0, F1 * P1 * 8, s->stream));
+    HIPCHK(hipMemsetAsync(s->pgv_a, 0, F1 * P1 * 8, s->stream));
     HIPCHK(hipMemsetAsync(s->act_a, 0, F1 * P1 * PLMPM_MAX_ACTION_DIM * 8, s->stream));
     if (s->dist) {
         HIPCHK(hipMemsetAsync(s->ppos_l, 0, F1 * P1 * 3 * 8, s->stream));
         HIPCHK(hipMemsetAsync(s->prot_l, 0, F1 * P1 * 4 * 8, s->stream));
+        HIPCHK(hipMemsetAsync(s->pgap_l, 0, F1 * P1 * 8, s->stream));
     }
     s->adj_frame[last_frame & 1] = last_frame;
     s->adj_frame[(last_frame + 1) & 1] = -1;
@@ -990,16 +1041,20 @@ int plmpm_segment_carry(plmpm_handle s, int from_frame, int to_frame) {
     s->adj_frame[(to_frame + 1) & 1] = -1;
     size_t P1 = std::max(s->P, 1), F1 = s->F + 1;
     if (s->P > 0) {
-        double* tmp = s->staging;                       // 7 * P doubles of scratch
+        double* tmp = s->staging;                       // 8 * P doubles of scratch (staging holds >= 24 * N)
         hipLaunchKernelGGL(k_move_double, dim3(1), dim3(64), 0, s->stream, tmp, s->ppos_a + (size_t)from_frame * s->P * 3, s->P * 3);
         hipLaunchKernelGGL(k_move_double, dim3(1), dim3(64), 0, s->stream, tmp + 32, s->prot_a + (size_t)from_frame * s->P * 4, s->P * 4);
+        hipLaunchKernelGGL(k_move_double, dim3(1), dim3(64), 0, s->stream, tmp + 64, s->pgap_a + (size_t)from_frame * s->P, s->P);
         HIPCHK(hipMemsetAsync(s->ppos_a, 0, F1 * P1 * 3 * 8, s->stream));
         HIPCHK(hipMemsetAsync(s->prot_a, 0, F1 * P1 * 4 * 8, s->stream));
+        HIPCHK(hipMemsetAsync(s->pgap_a, 0, F1 * P1 * 8, s->stream));
         hipLaunchKernelGGL(k_move_double, dim3(1), dim3(64), 0, s->stream, s->ppos_a + (size_t)to_frame * s->P * 3, tmp, s->P * 3);
         hipLaunchKernelGGL(k_move_double, dim3(1), dim3(64), 0, s->stream, s->prot_a + (size_t)to_frame * s->P * 4, tmp + 32, s->P * 4);
+        hipLaunchKernelGGL(k_move_double, dim3(1), dim3(64), 0, s->stream, s->pgap_a + (size_t)to_frame * s->P, tmp + 64, s->P);
     }
     HIPCHK(hipMemsetAsync(s->pv_a, 0, F1 * P1 * 3 * 8, s->stream));
     HIPCHK(hipMemsetAsync(s->pw_a, 0, F1 * P1 * 3 * 8, s->stream));
+    HIPCHK(hipMemsetAsync(s->pgv_a, 0, F1 * P1 * 8, s->stream));
     HIPCHK(hipMemsetAsync(s->act_a, 0, F1 * P1 * PLMPM_MAX_ACTION_DIM * 8, s->stream));
     HIPCHK(hipGetLastError());
     return 0;
@@ -1023,7 +1078,7 @@ int plmpm_step_grad(plmpm_handle s, int first_frame, int n_substeps, int step) {
     }
     if (s->P > 0)
         hipLaunchKernelGGL(k_fk_chain_grad, dim3(1), dim3(kMaxPrim), 0, s->stream, chain_args(s), first_frame, n_substeps, step,
-                           s->ppos, s->prot, s->pv, s->pw, s->ppos_a, s->prot_a, s->pv_a, s->pw_a, s->act_a);
+                           chain_bufs(s));
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -1272,10 +1327,13 @@ int plmpm_chain_grad(plmpm_handle s, int first_frame, int n_substeps, int step) 
                            s->ppos_a + (size_t)first_frame * s->P * 3, s->ppos_l + (size_t)first_frame * s->P * 3, np);
         hipLaunchKernelGGL(k_merge_pose_adj, dim3((unsigned)((nr + 255) / 256)), dim3(256), 0, s->stream,
                            s->prot_a + (size_t)first_frame * s->P * 4, s->prot_l + (size_t)first_frame * s->P * 4, nr);
+        size_t ng = (size_t)(n_substeps + 1) * s->P;
+        hipLaunchKernelGGL(k_merge_pose_adj, dim3((unsigned)((ng + 255) / 256)), dim3(256), 0, s->stream,
+                           s->pgap_a + (size_t)first_frame * s->P, s->pgap_l + (size_t)first_frame * s->P, ng);
     }
     if (s->P > 0)
         hipLaunchKernelGGL(k_fk_chain_grad, dim3(1), dim3(kMaxPrim), 0, s->stream, chain_args(s), first_frame, n_substeps, step,
-                           s->ppos, s->prot, s->pv, s->pw, s->ppos_a, s->prot_a, s->pv_a, s->pw_a, s->act_a);
+                           chain_bufs(s));
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -1329,13 +1387,17 @@ int plmpm_flags_region(plmpm_handle s, int frame, int bz_a, int bz_b, void** dev
     *count = (size_t)(bz_b - bz_a) * s->nb * s->nb;
     return 0;
 }
-int plmpm_pose_grad_region(plmpm_handle s, int first_frame, int n_frames, void** pos_adj, size_t* pos_count, void** rot_adj, size_t* rot_count) {
+int plmpm_pose_grad_region(plmpm_handle s, int first_frame, int n_frames, void** pos_adj, size_t* pos_count, void** rot_adj,
+                           size_t* rot_count, void** gap_adj, size_t* gap_count) {
     NEED_BOUND(s);
     REQUIRE(first_frame >= 0 && n_frames > 0 && first_frame + n_frames <= s->F + 1, "pose_grad_region: bad frame range");
     double* pa = s->dist ? s->ppos_l : s->ppos_a;
     double* ra = s->dist ? s->prot_l : s->prot_a;
     *pos_adj = pa + (size_t)first_frame * s->P * 3; *pos_count = (size_t)n_frames * s->P * 3;
     *rot_adj = ra + (size_t)first_frame * s->P * 4; *rot_count = (size_t)n_frames * s->P * 4;
+    if (gap_adj && gap_count) {
+        *gap_adj = (s->dist ? s->pgap_l : s->pgap_a) + (size_t)first_frame * s->P; *gap_count = (size_t)n_frames * s->P;
+    }
     return 0;
 }
 int plmpm_action_grad_region(plmpm_handle s, void** dev_ptr, size_t* count) {

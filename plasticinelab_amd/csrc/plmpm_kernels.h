@@ -64,9 +64,9 @@ template <class T> struct Dev {
     T* goa[3];                       // grid_v_out.grad x/y/z (SoA, accumulated)
     Vec4<T>*grid_out, *grid_in_adj;  // AoS
     int* flags;
-    // primitives (double): pos[(F+1)][P][3], rot[(F+1)][P][4] and adjoints
-    const double *ppos, *prot;
-    double *ppos_a, *prot_a;
+    // primitives (double): pos[(F+1)][P][3], rot[(F+1)][P][4], gap[(F+1)][P] (Chopsticks) and adjoints
+    const double *ppos, *prot, *pgap;
+    double *ppos_a, *prot_a, *pgap_a;
     PrimStatic prim[kMaxPrim];
 };
 
@@ -91,6 +91,7 @@ template <class T> __device__ __forceinline__ void load_prims(const Dev<T>& D, i
         PrimT<T> p;
         p.shape = D.prim[t].shape; p.movable = D.prim[t].movable; p.friction = (T)D.prim[t].friction;
         for (int i = 0; i < 3; ++i) p.par[i] = D.prim[t].par[i];
+        if (p.shape == SHAPE_CHOPSTICKS) p.par[2] = D.pgap[(size_t)f * D.nprim + t];
         p.rb = prim_bounding_radius(p.shape, p.par);
         const double* a = D.ppos + ((size_t)f * D.nprim + t) * 3;
         const double* b = D.ppos + ((size_t)(f + 1) * D.nprim + t) * 3;
@@ -626,11 +627,11 @@ __global__ __launch_bounds__(kBlock) void k_g2p_grad(Dev<T> D, int f, int src, i
 template <class T>
 __global__ __launch_bounds__(kBlock) void k_grid_op_grad(Dev<T> D, int f) {
     __shared__ PrimT<T> sp[kMaxPrim];
-    __shared__ double sacc[kMaxPrim * 14];
+    __shared__ double sacc[kMaxPrim * 15];
     __shared__ int shit;
     if (!any_block_active(D)) return;
     load_prims(D, f, sp);
-    if (threadIdx.x < kMaxPrim * 14) sacc[threadIdx.x] = 0.0;
+    if (threadIdx.x < kMaxPrim * 15) sacc[threadIdx.x] = 0.0;
     if (threadIdx.x == 0) shit = 0;
     __syncthreads();
     const int blk = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
@@ -646,22 +647,24 @@ __global__ __launch_bounds__(kBlock) void k_grid_op_grad(Dev<T> D, int f) {
         T va[3] = {D.goa[0][idx], D.goa[1][idx], D.goa[2][idx]}, ma, mva[3];
         const bool owned = I[2] >= D.z0 && I[2] < D.z1;     // halo nodes are computed on two ranks: count once
         grid_node_bwd<T>(D.P, I, gm, mv, D.nprim, sp, va, &ma, mva, [&](int q, const PoseAdj<T>& pa, bool hit) {
-            // every lane of the wave gets here for every primitive: sum the 14 pose-adjoint components across the
+            // every lane of the wave gets here for every primitive: sum the 15 pose-adjoint components across the
             // wave with shuffles and let one lane touch LDS (64 lanes hitting the same 14 addresses with
             // ds_add_f64 serialise badly)
             const bool h = hit && owned;
             if (!__any(h)) return;
-            double vals[14];
+            double vals[15];
             for (int d = 0; d < 3; ++d) { vals[d] = h ? pa.pos[d] : 0.0; vals[7 + d] = h ? pa.pos1[d] : 0.0; }
             for (int d = 0; d < 4; ++d) { vals[3 + d] = h ? pa.rot[d] : 0.0; vals[10 + d] = h ? pa.rot1[d] : 0.0; }
-            for (int c = 0; c < 14; ++c) {
+            vals[14] = h ? pa.gap : 0.0;
+            const int nc = sp[q].shape == SHAPE_CHOPSTICKS ? 15 : 14;
+            for (int c = 0; c < nc; ++c) {
                 double v = vals[c];
                 for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
                 vals[c] = v;
             }
             if ((threadIdx.x & 63) == 0) {
-                double* o = &sacc[q * 14];
-                for (int c = 0; c < 14; ++c) atomicAdd(&o[c], vals[c]);
+                double* o = &sacc[q * 15];
+                for (int c = 0; c < nc; ++c) atomicAdd(&o[c], vals[c]);
                 shit = 1;
             }
         });
@@ -673,15 +676,16 @@ __global__ __launch_bounds__(kBlock) void k_grid_op_grad(Dev<T> D, int f) {
         if (lane == 0) D.flags[blk] = 0;
     }
     __syncthreads();
-    if (shit && threadIdx.x < D.nprim * 14) {
-        int q = threadIdx.x / 14, c = threadIdx.x % 14;
+    if (shit && threadIdx.x < D.nprim * 15) {
+        int q = threadIdx.x / 15, c = threadIdx.x % 15;
         double v = sacc[threadIdx.x];
         if (v != 0.0) {
-            // c: 0-2 pos[f], 3-6 rot[f], 7-9 pos[f+1], 10-13 rot[f+1]
+            // c: 0-2 pos[f], 3-6 rot[f], 7-9 pos[f+1], 10-13 rot[f+1], 14 gap[f]
             if (c < 3) atomicAdd(&D.ppos_a[((size_t)f * D.nprim + q) * 3 + c], v);
             else if (c < 7) atomicAdd(&D.prot_a[((size_t)f * D.nprim + q) * 4 + (c - 3)], v);
             else if (c < 10) atomicAdd(&D.ppos_a[((size_t)(f + 1) * D.nprim + q) * 3 + (c - 7)], v);
-            else atomicAdd(&D.prot_a[((size_t)(f + 1) * D.nprim + q) * 4 + (c - 10)], v);
+            else if (c < 14) atomicAdd(&D.prot_a[((size_t)(f + 1) * D.nprim + q) * 4 + (c - 10)], v);
+            else atomicAdd(&D.pgap_a[(size_t)f * D.nprim + q], v);
         }
     }
 }

@@ -199,9 +199,8 @@ class SlabEngine:
             e.grad_scatter(f)
             self._halo(e.HALO_GRID_OUT_ADJ, f)
             e.grad_gather(f)
-        pa, ra = e.pose_grad_views(first, n + 1)
-        self.comm.all_reduce_(pa)
-        self.comm.all_reduce_(ra)
+        for view in e.pose_grad_views(first, n + 1):      # position, rotation, (Chopsticks) gap adjoints
+            self.comm.all_reduce_(view)
         e.chain_grad(first, n, step)
 
     def substep_grad(self, f):

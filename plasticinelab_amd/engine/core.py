@@ -118,17 +118,20 @@ class Engine:
     def copy_frame(self, src, dst):
         L.check(self.lib.plmpm_copy_frame(self.h, src, dst))
 
-    def set_primitive_state(self, prim, f, state7):
-        s = _f64(state7, (7,))
+    def set_primitive_state(self, prim, f, state8):
+        """position(3) + rotation(4) + gap(1, Chopsticks; ignored by the other shapes)."""
+        st = np.asarray(state8, np.float64).reshape(-1)
+        s = np.zeros(8)
+        s[:len(st)] = st                            # 7-long states (no gap) are accepted
         L.check(self.lib.plmpm_set_primitive_state(self.h, prim, f, _ptr(s)))
 
     def get_primitive_state(self, prim, f):
-        s = np.empty(7)
+        s = np.empty(8)
         L.check(self.lib.plmpm_get_primitive_state(self.h, prim, f, _ptr(s)))
         return s
 
     def get_primitive_grad(self, prim, f):
-        s = np.empty(7)
+        s = np.empty(8)
         L.check(self.lib.plmpm_get_primitive_grad(self.h, prim, f, _ptr(s)))
         return s
 
@@ -269,9 +272,11 @@ class Engine:
         return self._view(p.value, cnt.value, torch.int32)
 
     def pose_grad_views(self, first, n_frames):
-        pa, pc, ra, rc = C.c_void_p(), C.c_size_t(), C.c_void_p(), C.c_size_t()
-        L.check(self.lib.plmpm_pose_grad_region(self.h, first, n_frames, C.byref(pa), C.byref(pc), C.byref(ra), C.byref(rc)))
-        return self._view(pa.value, pc.value, torch.float64), self._view(ra.value, rc.value, torch.float64)
+        pa, pc, ra, rc, ga, gc = C.c_void_p(), C.c_size_t(), C.c_void_p(), C.c_size_t(), C.c_void_p(), C.c_size_t()
+        L.check(self.lib.plmpm_pose_grad_region(self.h, first, n_frames, C.byref(pa), C.byref(pc), C.byref(ra), C.byref(rc),
+                                                C.byref(ga), C.byref(gc)))
+        return (self._view(pa.value, pc.value, torch.float64), self._view(ra.value, rc.value, torch.float64),
+                self._view(ga.value, gc.value, torch.float64))
 
     def loss_scatter(self, f):
         L.check(self.lib.plmpm_loss_scatter(self.h, f))

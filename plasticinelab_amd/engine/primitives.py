@@ -22,10 +22,10 @@ _SHAPE_PARAMS = {
     "Cylinder": (("h", "r"), (0.2, 0.1)),
     "Torus": (("tx", "ty"), (0.2, 0.1)),
     "Box": (("size",), ((0.1, 0.1, 0.1),)),
+    # two Capsules `gap` apart with a 7-dim action (primitives.py:83-154); the gap itself is part of the state
+    "Chopsticks": (("h", "r", "minimal_gap"), (0.06, 0.03, 0.06)),
 }
-_UNSUPPORTED = {
-    "Chopsticks": "gap degree of freedom (primitives.py:83-154)",
-}
+_UNSUPPORTED = {}
 
 
 def _default_cfg(shape: str) -> CfgNode:
@@ -38,6 +38,8 @@ def _default_cfg(shape: str) -> CfgNode:
     names, defaults = _SHAPE_PARAMS[shape]
     for n, d in zip(names, defaults):
         cfg[n] = d
+    if shape == "Chopsticks":
+        cfg["init_gap"] = 0.06                      # primitives.py:152
     return cfg
 
 
@@ -62,6 +64,9 @@ class Primitive:
         self.dim = 3
         self.max_timesteps = max_timesteps
         self.action_dim = int(self.cfg.action.dim)
+        if shape == "Chopsticks":                   # primitives.py:84,92
+            self.state_dim = 8
+            assert self.action_dim == 7, "Chopsticks: 3 linear, 3 angle, 1 for grasp"
         self._softness = 0.0
         self._engine = None
 
@@ -90,18 +95,23 @@ class Primitive:
 
     # ---- reference API
     @property
-    def init_state(self):                       # primive_base.py:153-155
-        return tuple(self.cfg.init_pos) + tuple(self.cfg.init_rot)
+    def init_state(self):                       # primive_base.py:153-155; Chopsticks primitives.py:131-133
+        st = tuple(self.cfg.init_pos) + tuple(self.cfg.init_rot)
+        if self.shape == "Chopsticks":
+            st = st + (float(self.cfg.init_gap),)
+        return st
 
     def initialize(self):                       # primive_base.py:157-164
         self.set_state(0, self.init_state)
 
-    def get_state(self, f):                     # primive_base.py:143-146
-        return self._eng().get_primitive_state(self.index, f)
+    def get_state(self, f):                     # primive_base.py:143-146; Chopsticks appends the gap (:135-136)
+        return self._eng().get_primitive_state(self.index, f)[:self.state_dim]
 
-    def set_state(self, f, state):              # primive_base.py:148-151
-        ss = self.get_state(f)
+    def set_state(self, f, state):              # primive_base.py:148-151; Chopsticks :143-146
         state = np.asarray(state, np.float64).reshape(-1)
+        if self.shape == "Chopsticks":
+            assert len(state) == 8
+        ss = self._eng().get_primitive_state(self.index, f)
         ss[:len(state)] = state
         self._eng().set_primitive_state(self.index, f, ss)
 

@@ -127,6 +127,17 @@ def _rollingpin(version):    # rollingpin.yml:1-30
             "ENV": {"loss": {"target_path": f"envs/assets/Rollingpin3D-v{version}.npy"}}}
 
 
+def _chopsticks(version):    # chopsticks.yml:1-27
+    prim = _manip("Chopsticks", (0.5, 0.15, 0.5), (0.02, 0.02, 0.02, 0.04, 0.04, 0.04, 0.02), friction=10.0, h=0.2, r=0.02,
+                  init_rot=(1.0, 0.0, 0.0, 0.0), init_gap=0.06)
+    prim["action"]["dim"] = 7
+    return {"SIMULATOR": {"n_particles": 10000, "yield_stress": 200.0, "ground_friction": 0.0, "gravity": (0, -5, 0)},
+            "SHAPES": [_box((0.04, 0.04, 0.6), (0.5, 0.02, 0.5), color=100)],
+            "PRIMITIVES": [prim],
+            "RENDERER": {"use_directional_light": True},
+            "ENV": {"loss": {"target_path": f"envs/assets/Chopsticks3D-v{version}.npy"}}}
+
+
 def _pinch(version):         # pinch.yml
     return {"SIMULATOR": {"yield_stress": 50.0, "ground_friction": 100.0},
             "SHAPES": [_box((0.2, 0.2, 0.2), (0.5, 0.1, 0.5), n_particles=6000, color=(150 << 8) + (150 << 16))],
@@ -156,7 +167,7 @@ def _assembly(version):      # assembly.yml
 
 
 _BUILDERS = {"Move": _move, "TripleMove": _triplemove, "Rope": _rope, "Writer": _writer, "Torus": _torus,
-             "Rollingpin": _rollingpin, "Pinch": _pinch, "Table": _table, "Assembly": _assembly}
+             "Rollingpin": _rollingpin, "Chopsticks": _chopsticks, "Pinch": _pinch, "Table": _table, "Assembly": _assembly}
 ENV_NAMES = tuple(_BUILDERS)
 
 

@@ -8,7 +8,7 @@ import subprocess
 import numpy as np
 
 HERE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "host_emul")
-SHAPE_ID = {"Sphere": 0, "Capsule": 1, "Cylinder": 2, "Torus": 3, "Box": 4, "RollingPin": 1}
+SHAPE_ID = {"Sphere": 0, "Capsule": 1, "Cylinder": 2, "Torus": 3, "Box": 4, "RollingPin": 1, "Chopsticks": 5}
 
 
 class EmulCfg(C.Structure):
@@ -51,6 +51,8 @@ def prim_par(p):
         return (p.tx, p.ty, 0.0)
     if p.shape == "Box":
         return tuple(p.size)
+    if p.shape == "Chopsticks":
+        return (p.h, p.r, p.init_gap)          # par[2] = gap[f]; make_prims overwrites it with the pose's gap
     raise NotImplementedError(p.shape)
 
 
@@ -65,9 +67,13 @@ def make_cfg(sim, n_prim, softness, use_float=False, svd_clamp=1e-6):
 
 def make_prims(prims, poses_f, poses_f1):
     arr = (EmulPrim * max(len(prims), 1))()
-    for i, (p, (pf, rf), (pf1, rf1)) in enumerate(zip(prims, poses_f, poses_f1)):
+    for i, (p, pose, pose1) in enumerate(zip(prims, poses_f, poses_f1)):
+        (pf, rf), (pf1, rf1) = pose[:2], pose1[:2]
         arr[i].shape, arr[i].movable = SHAPE_ID[p.shape], int(p.action_dim > 0)
-        arr[i].par = (C.c_double * 3)(*prim_par(p))
+        par = list(prim_par(p))
+        if len(pose) > 2:
+            par[2] = float(pose[2])
+        arr[i].par = (C.c_double * 3)(*par)
         arr[i].friction = p.friction
         arr[i].pos = (C.c_double * 3)(*np.asarray(pf, float))
         arr[i].rot = (C.c_double * 4)(*np.asarray(rf, float))
@@ -93,7 +99,7 @@ def substep_grad(cfg, parr, state, mats, v1, out_adj):
     v1 = np.ascontiguousarray(v1, np.float64)
     N = x.shape[0]
     xa, va, Ca, Fa = np.empty_like(x), np.empty_like(v), np.empty_like(Cm), np.empty_like(F)
-    pose = np.zeros((cfg.n_prim, 14))
+    pose = np.zeros((cfg.n_prim, 15))      # pos[f] rot[f] pos[f+1] rot[f+1] gap[f]
     lib().emul_substep_grad(C.byref(cfg), parr, N, _p(x), _p(v), _p(Cm), _p(F), _p(mu), _p(lam), _p(ys), _p(v1),
                             _p(x1a), _p(v1a), _p(C1a), _p(F1a), _p(xa), _p(va), _p(Ca), _p(Fa), _p(pose))
     return (xa, va, Ca, Fa), pose
@@ -125,3 +131,23 @@ def fk_rollingpin_bwd(pos, rot, v, lo, hi, pos1_a, rot1_a):
     pos_a, rot_a, v_a = np.zeros(3), np.zeros(4), np.zeros(3)
     lib().emul_fk_rollingpin_bwd(*[_p(t) for t in a], _p(pos_a), _p(rot_a), _p(v_a))
     return pos_a, rot_a, v_a
+
+
+def fk_chopsticks_fwd(pos, rot, v, w, gap, gap_vel, min_gap, lo, hi):
+    a = [np.ascontiguousarray(t, np.float64) for t in (pos, rot, v, w)]
+    b = [np.ascontiguousarray(t, np.float64) for t in (lo, hi)]
+    pos1, rot1, gap1 = np.empty(3), np.empty(4), C.c_double()
+    lib().emul_fk_chopsticks_fwd(*[_p(t) for t in a], C.c_double(gap), C.c_double(gap_vel), C.c_double(min_gap),
+                                 *[_p(t) for t in b], _p(pos1), _p(rot1), C.byref(gap1))
+    return pos1, rot1, gap1.value
+
+
+def fk_chopsticks_bwd(pos, rot, v, w, gap, gap_vel, min_gap, lo, hi, pos1_a, rot1_a, gap1_a):
+    a = [np.ascontiguousarray(t, np.float64) for t in (pos, rot, v, w)]
+    b = [np.ascontiguousarray(t, np.float64) for t in (lo, hi, pos1_a, rot1_a)]
+    pos_a, rot_a, v_a, w_a = np.zeros(3), np.zeros(4), np.zeros(3), np.zeros(3)
+    gap_a, gv_a = C.c_double(0.0), C.c_double(0.0)
+    lib().emul_fk_chopsticks_bwd(*[_p(t) for t in a], C.c_double(gap), C.c_double(gap_vel), C.c_double(min_gap),
+                                 *[_p(t) for t in b], C.c_double(gap1_a), _p(pos_a), _p(rot_a), C.byref(gap_a),
+                                 _p(v_a), _p(w_a), C.byref(gv_a))
+    return pos_a, rot_a, gap_a.value, v_a, w_a, gv_a.value

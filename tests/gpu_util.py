@@ -30,8 +30,8 @@ def load_state(eng, frame, state, mats, poses, resort=True):
     x, v, C, F = [t.detach().numpy() for t in state]
     eng.set_frame(frame, x=x, v=v, F=F, C_=C, resort=resort)
     eng.set_materials(*[m.numpy() for m in mats])
-    for k, (p, r) in enumerate(poses):
-        eng.set_primitive_state(k, frame, np.concatenate([p.detach().numpy(), r.detach().numpy()]))
+    for k, pose in enumerate(poses):                # (pos, rot) or (pos, rot, gap)
+        eng.set_primitive_state(k, frame, np.concatenate([t.detach().numpy().reshape(-1) for t in pose]))
 
 
 def relerr(a, b):

@@ -136,7 +136,7 @@ template <class T> static int substep_grad_t(const emul_cfg& c, const emul_prim*
         for (int d = 0; d < 3; ++d) xa_t[3 * p + d] = xat[d];
     }
     // grid_op.grad
-    std::vector<double> padj((size_t)c.n_prim * 14, 0.0);
+    std::vector<double> padj((size_t)c.n_prim * 15, 0.0);
     for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) for (int k = 0; k < n; ++k) {
         size_t I = g.idx(i, j, k);
         int Iv[3] = {i, j, k};
@@ -144,9 +144,10 @@ template <class T> static int substep_grad_t(const emul_cfg& c, const emul_prim*
         grid_node_bwd<T>(P, Iv, g.m[I], &g.mv[3 * I], (int)prims.size(), prims.data(), &vout_a[3 * I], &ma, mva,
             [&](int p, const PoseAdj<T>& pa, bool hit) {
                 if (!hit) return;
-                double* o = &padj[(size_t)p * 14];
+                double* o = &padj[(size_t)p * 15];
                 for (int d = 0; d < 3; ++d) { o[d] += pa.pos[d]; o[7 + d] += pa.pos1[d]; }
                 for (int d = 0; d < 4; ++d) { o[3 + d] += pa.rot[d]; o[10 + d] += pa.rot1[d]; }
+                o[14] += pa.gap;
             });
         in_a[4 * I] = ma; in_a[4 * I + 1] = mva[0]; in_a[4 * I + 2] = mva[1]; in_a[4 * I + 3] = mva[2];
     }
@@ -192,6 +193,18 @@ void emul_fk_rollingpin_fwd(const double* pos, const double* rot, const double* 
 void emul_fk_rollingpin_bwd(const double* pos, const double* rot, const double* v, const double* lo, const double* hi,
                             const double* pos1_a, const double* rot1_a, double* pos_a, double* rot_a, double* v_a) {
     fk_rollingpin_bwd_d(pos, rot, v, lo, hi, pos1_a, rot1_a, pos_a, rot_a, v_a);
+}
+void emul_fk_chopsticks_fwd(const double* pos, const double* rot, const double* v, const double* w, double gap,
+                            double gap_vel, double min_gap, const double* lo, const double* hi, double* pos1,
+                            double* rot1, double* gap1) {
+    fk_chopsticks_fwd_d(pos, rot, v, w, gap, gap_vel, min_gap, lo, hi, pos1, rot1, gap1);
+}
+void emul_fk_chopsticks_bwd(const double* pos, const double* rot, const double* v, const double* w, double gap,
+                            double gap_vel, double min_gap, const double* lo, const double* hi, const double* pos1_a,
+                            const double* rot1_a, double gap1_a, double* pos_a, double* rot_a, double* gap_a,
+                            double* v_a, double* w_a, double* gap_vel_a) {
+    fk_chopsticks_bwd_d(pos, rot, v, w, gap, gap_vel, min_gap, lo, hi, pos1_a, rot1_a, gap1_a, pos_a, rot_a, gap_a,
+                        v_a, w_a, gap_vel_a);
 }
 void emul_fk_bwd(const double* pos, const double* rot, const double* v, const double* w, const double* lo,
                  const double* hi, const double* pos1_a, const double* rot1_a, double* pos_a, double* rot_a,

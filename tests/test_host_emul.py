@@ -54,7 +54,7 @@ def test_substep_math_matches_oracle(case, use_float, tol):
     for k in range(P):
         ref = np.concatenate([gs[4 + 2 * k].numpy(), gs[5 + 2 * k].numpy(),
                               gs[4 + 2 * P + 2 * k].numpy(), gs[5 + 2 * P + 2 * k].numpy()])
-        assert np.abs(ref).max() > 0 and relerr(pose[k], ref) < 3 * tol
+        assert np.abs(ref).max() > 0 and relerr(pose[k][:14], ref) < 3 * tol
 
 
 def test_kinematics_chain_and_adjoint():
@@ -129,7 +129,7 @@ def test_capsule_torus_pose_adjoints(shape, kw):
     P = len(prims)
     for k in range(P):
         ref = np.concatenate([gs[4 + 2 * k].numpy(), gs[5 + 2 * k].numpy(), gs[4 + 2 * P + 2 * k].numpy(), gs[5 + 2 * P + 2 * k].numpy()])
-        assert np.abs(ref[3:7]).max() > 0 and relerr(pose[k], ref) < 1e-10
+        assert np.abs(ref[3:7]).max() > 0 and relerr(pose[k][:14], ref) < 1e-10
 
 
 def test_rollingpin_kinematics_and_adjoint():
@@ -149,3 +149,71 @@ def test_rollingpin_kinematics_and_adjoint():
                                  cp.numpy(), cr.numpy())
     for a, b in zip(got, gs):
         assert np.allclose(a, b.numpy(), rtol=1e-12, atol=1e-13)
+
+
+def _np_pose(pose):
+    return tuple(t.detach().numpy() for t in pose)
+
+
+def test_chopsticks_contact_and_gap_adjoints():
+    """Chopsticks (primitives.py:83-154): double-capsule sdf/normal, body-frame rotation, gap degree of freedom.
+    One substep after a short closing rollout; pose adjoints at f and f+1 AND the gap adjoint vs oracle autograd."""
+    torch.manual_seed(0)
+    cfg, sim, _, x0 = oracle_scene("Move", 1, n_particles=1500)
+    rot = np.array([0.95, 0.1, -0.2, 0.15]); rot /= np.linalg.norm(rot)
+    prims = [O.PrimCfg(shape="Chopsticks", h=0.2, r=0.02, init_pos=(0.67, 0.74, 0.75), init_rot=tuple(rot), friction=10.0,
+                       action_dim=7, action_scale=(0.02, 0.02, 0.02, 0.04, 0.04, 0.04, 0.02), init_gap=0.12,
+                       minimal_gap=0.06)]
+    state, mats, poses = O.init_state(x0), O.materials(sim), O.init_poses(prims)
+    act = torch.tensor([0.2, -0.9, 0.1, 0.3, -0.2, 0.4, 0.5], dtype=O.DT)
+    with torch.no_grad():
+        for _ in range(2):
+            state, poses = O.env_step(sim, prims, 666.0, state, mats, poses, act)
+    vel = [O.set_velocity(prims[0], act, sim.substeps)]
+    nxt = [O.forward_kinematics(p, po[0], po[1], vw[0], vw[1], po[2], vw[2]) for p, po, vw in zip(prims, poses, vel)]
+    assert 0.06 < float(nxt[0][2]) < 0.12
+    sin = tuple(t.clone().requires_grad_(True) for t in state)
+    pin = [tuple(t.clone().requires_grad_(True) for t in po) for po in poses]
+    nin = [tuple(t.clone().requires_grad_(True) for t in po) for po in nxt]
+    out = O.substep(sim, prims, 666.0, sin, mats, pin, nin)
+    cot = [torch.randn_like(t) for t in out]
+    inputs = list(sin) + list(pin[0]) + list(nin[0])
+    gs = torch.autograd.grad(sum((o * c).sum() for o, c in zip(out, cot)), inputs, allow_unused=True)
+    gs = [torch.zeros_like(t) if g is None else g for g, t in zip(gs, inputs)]
+    ec = emul.make_cfg(sim, 1, 666.0)
+    pa = emul.make_prims(prims, [_np_pose(p) for p in poses], [_np_pose(p) for p in nxt])
+    st, mt = [t.numpy() for t in state], [t.numpy() for t in mats]
+    e = emul.substep(ec, pa, st, mt)
+    for a, b in zip(e, out):
+        assert relerr(a, b.detach().numpy()) < 1e-11
+    (xa, va, Ca, Fa), pose = emul.substep_grad(ec, pa, st, mt, out[1].detach().numpy(), [c.numpy() for c in cot])
+    for a, b in zip((xa, va, Ca, Fa), gs[:4]):
+        assert relerr(a, b.numpy()) < 1e-10
+    ref = np.concatenate([gs[4].numpy(), gs[5].numpy(), gs[7].numpy(), gs[8].numpy(), gs[6].numpy().reshape(1)])
+    assert abs(ref[14]) > 0 and np.abs(ref[3:7]).max() > 0
+    assert relerr(pose[0], ref) < 1e-10
+
+
+def test_chopsticks_kinematics_and_adjoint():
+    """Chopsticks.forward_kinematics (primitives.py:94-98) and its adjoint, on both sides of the minimal-gap clamp."""
+    torch.manual_seed(7)
+    p = O.PrimCfg(shape="Chopsticks", h=0.2, r=0.02, action_dim=7, action_scale=(0.02,) * 7, minimal_gap=0.06,
+                  lower_bound=(0.0, 0.0, 0.0), upper_bound=(1.0, 1.0, 1.0))
+    for gap0, gv0 in ((0.1, 0.01), (0.065, 0.01), (0.06, 0.0)):
+        pos = torch.tensor([0.5, 0.15, 0.5], dtype=O.DT, requires_grad=True)
+        rot = torch.tensor([0.8, 0.3, 0.1, -0.4], dtype=O.DT); rot = (rot / rot.norm()).requires_grad_(True)
+        v = torch.tensor([0.001, -0.002, 0.0005], dtype=O.DT, requires_grad=True)
+        w = torch.tensor([0.002, -0.001, 0.003], dtype=O.DT, requires_grad=True)
+        gap = torch.tensor(gap0, dtype=O.DT, requires_grad=True)
+        gv = torch.tensor(gv0, dtype=O.DT, requires_grad=True)
+        pos1, rot1, gap1 = O.forward_kinematics(p, pos, rot, v, w, gap, gv)
+        args = [t.detach().numpy() for t in (pos, rot, v, w)] + [gap0, gv0, p.minimal_gap, p.lower_bound, p.upper_bound]
+        e = emul.fk_chopsticks_fwd(*args)
+        assert np.allclose(e[0], pos1.detach().numpy(), atol=1e-15) and np.allclose(e[1], rot1.detach().numpy(), atol=1e-15)
+        assert e[2] == float(gap1)
+        cp, cr, cg = torch.randn(3, dtype=O.DT), torch.randn(4, dtype=O.DT), torch.randn((), dtype=O.DT)
+        gs = torch.autograd.grad((pos1 * cp).sum() + (rot1 * cr).sum() + gap1 * cg, [pos, rot, gap, v, w, gv], allow_unused=True)
+        got = emul.fk_chopsticks_bwd(*args, cp.numpy(), cr.numpy(), float(cg))
+        for a, b in zip(got, gs):
+            b = 0.0 if b is None else b.numpy()
+            assert np.allclose(a, b, rtol=1e-12, atol=1e-13)

@@ -40,7 +40,12 @@ def test_primitives_container_mirrors_reference():
     with pytest.raises(RuntimeError):
         prims[0].get_state(0)                       # not attached to a simulator yet
     with pytest.raises(NotImplementedError):
+        Primitive({"shape": "Spatula"}, 0)
+    with pytest.raises(AssertionError):             # primitives.py:92: Chopsticks need the 7-dim action
         Primitive({"shape": "Chopsticks"}, 0)
+    c = Primitive({"shape": "Chopsticks", "h": 0.2, "r": 0.02, "init_gap": 0.08, "action": {"dim": 7, "scale": (0.02,) * 7}}, 0)
+    assert c.state_dim == 8 and len(c.init_state) == 8 and c.init_state[7] == 0.08
+    assert c.describe()["params"] == (0.2, 0.02, 0.06)
     with pytest.raises(KeyError):
         Primitive({"shape": "Sphere", "radiuss": 1.0}, 0)      # unknown keys are rejected like yacs does
 

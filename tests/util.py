@@ -33,7 +33,7 @@ def oracle_prims(cfg):
         if p["shape"] in ("Cylinder",):
             kw.update(h=float(p.get("h", 0.2)), r=float(p.get("r", 0.1)))
         else:
-            for k in ("radius", "h", "r", "tx", "ty"):
+            for k in ("radius", "h", "r", "tx", "ty", "minimal_gap", "init_gap"):
                 if k in p:
                     kw[k] = float(as_value(p[k]))
             if "size" in p:
