@@ -1,7 +1,7 @@
 """Regenerates the fixtures under tests/golden/.  Run in the BUILD container only
 (it reads /root/reference, which does not exist on the GPU box):
 
-    python tests/golden/make_golden.py shapes targets rollout_small rollout_move
+    python tests/golden/make_golden.py shapes targets rollout_small rollout_move rollout_shapes
 
 What each fixture pins
   shapes.npz           the reference's own particle sampler (plb/engine/shapes/shape_maker.py, the one
@@ -114,6 +114,42 @@ def make_rollout_small():
 def make_rollout_move():
     from tests.util import seeded_actions
     _rollout("move_v1", "Move", None, 50, lambda H, A: seeded_actions(H, A, seed=0, scale=0.01))
+
+
+def make_rollout_shapes():
+    """Oracle loss / action gradient / final manipulator state for tests/shape_cases.py."""
+    import ctypes
+    import torch
+    from tests.util import O, oracle_prims, sparse_target
+    from tests.shape_cases import CASES, TARGET, case_cfg, subsample
+    from plasticinelab_amd.engine.shapes import Shapes
+    tgt = sparse_target(TARGET)
+    lib = ctypes.CDLL(os.path.join(ROOT, "oracle", "libplb_oracle_c.so"))
+    n = tgt.shape[0]
+    sdf = np.empty((n, n, n)); npn = np.empty((n, n, n, 3))
+    lib.plb_oracle_target_sdf.restype = ctypes.c_int
+    lib.plb_oracle_target_sdf(np.ascontiguousarray(tgt).ctypes.data_as(ctypes.c_void_p), ctypes.c_int(n),
+                              ctypes.c_double(1.0 / n), ctypes.c_double(1000.0), ctypes.c_int(2 * n),
+                              sdf.ctypes.data_as(ctypes.c_void_p), npn.ctypes.data_as(ctypes.c_void_p))
+    out = {}
+    for name in CASES:
+        cfg, soft, acts = case_cfg(name)
+        x0 = subsample(Shapes(cfg.SHAPES).get()[0])
+        prims = oracle_prims(cfg)
+        s = cfg.SIMULATOR
+        sim = O.SimCfg(n_particles=len(x0), yield_stress=s.yield_stress, E=s.E, nu=s.nu, ground_friction=s.ground_friction,
+                       gravity=tuple(s.gravity))
+        t = time.time()
+        L, g, states, poses, _ = O.rollout_loss_and_grad(
+            sim, O.LossCfg(soft_contact=soft), prims, 666.0, O.init_state(x0), O.materials(sim), O.init_poses(prims),
+            torch.as_tensor(acts, dtype=O.DT), torch.as_tensor(tgt.reshape(-1)), torch.as_tensor(sdf.reshape(-1)))
+        print(name, "loss", L, "time", time.time() - t)
+        out[f"{name}_actions"] = acts
+        out[f"{name}_loss"] = np.array(L)
+        out[f"{name}_grad"] = g.numpy()
+        out[f"{name}_x_final"] = states[-1][0].numpy()
+        out[f"{name}_prim_final"] = np.array([np.concatenate([t.numpy().reshape(-1) for t in po]) for po in poses[-1]])
+    np.savez_compressed(os.path.join(HERE, "rollout_shapes.npz"), **out)
 
 
 if __name__ == "__main__":
