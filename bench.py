@@ -41,6 +41,7 @@ ALG = {
     "p2g_recompute": (27, 8), "grid_op_recompute": (0, 7), "g2p_grad": (18, 9),
     "grid_op_grad": (0, 11), "p2g_grad": (54, 4), "clear_active": (0, 0),
     "g2p_p2g": (51, 7),        # g2p(f-1) + p2g(f) fused
+    "compact_blocks": (0, 0),  # block flags -> active-block list (reads 4 B per 4^3 block of the whole grid)
 }
 HBM_PEAK_GBS = 8000.0          # MI355X spec (MI355X_MICROARCH.md); measured copy peak there: 6290 GB/s
 
@@ -264,7 +265,7 @@ def main():
         for name, (ms, cnt) in prof.items():
             if cnt == 0:
                 continue
-            cN, cA = ALG[name]
+            cN, cA = ALG.get(name, (0, 0))
             avg = ms / cnt
             kernels[name] = {"avg_us": 1e3 * avg, "launches": cnt, "alg_MB": 4e-6 * (cN * N + cA * nodes),
                              "GBps": 4e-9 * (cN * N + cA * nodes) / (1e-3 * avg) if avg > 0 else 0.0}

@@ -175,24 +175,23 @@ template <class T> struct Svd3 {
 };
 
 template <class T> PLB_HD void jacobi_pair(T& app, T& aqq, T& apq, T& arp, T& arq, T* V, int p, int q) {
-    if (apq == T(0)) return;
+    // tan of the rotation angle that zeroes apq, smaller root: t = 2 apq / (d + sign(d) sqrt(d^2 + 4 apq^2)).
+    // Branch-free on purpose (divergent branches here cost the GPU more than the arithmetic they skip); the
+    // form has no theta = d / (2 apq) intermediate, so a vanishing apq cannot overflow it, and apq == 0 gives
+    // t = 0, c = 1, s = 0: an exact no-op.
     const T d = aqq - app;
-    T t;
-    if (t_abs(apq) < Tol<T>::small_angle() * t_abs(d)) {
-        t = apq * t_rcp(d);          // tan(theta) ~ apq/(aqq-app): keeps theta = d/(2 apq) from overflowing
-    } else {
-        T theta = d * t_rcp(T(2) * apq);
-        t = (theta >= T(0) ? T(1) : T(-1)) * t_rcp(t_abs(theta) + t_fsqrt(theta * theta + T(1)));
-    }
-    T c = t_rsqrt(t * t + T(1));
-    T s = t * c;
+    const T h = t_fsqrt(d * d + T(4) * apq * apq);
+    const T den = d + (d >= T(0) ? h : -h);
+    const T t = h > T(0) ? T(2) * apq * t_rcp(den) : T(0);
+    const T c = t_rsqrt(t * t + T(1));
+    const T s = t * c;
     app -= t * apq;
     aqq += t * apq;
     apq = T(0);
-    T rp = c * arp - s * arq, rq = s * arp + c * arq;
+    const T rp = c * arp - s * arq, rq = s * arp + c * arq;
     arp = rp; arq = rq;
     for (int k = 0; k < 3; ++k) {
-        T vp = V[3 * k + p], vq = V[3 * k + q];
+        const T vp = V[3 * k + p], vq = V[3 * k + q];
         V[3 * k + p] = c * vp - s * vq;
         V[3 * k + q] = s * vp + c * vq;
     }
@@ -212,7 +211,7 @@ template <class T> PLB_HD void svd_eform(const T* Et, Svd3<T>& r) {
     T* V = r.V;
     V[0] = V[4] = V[8] = T(1);
     V[1] = V[2] = V[3] = V[5] = V[6] = V[7] = T(0);
-#if defined(__HIPCC__)
+#if defined(__HIPCC__) && !defined(PLB_SVD_UNROLL)
 #pragma unroll 1
 #endif
     for (int sw = 0; sw < Tol<T>::sweeps; ++sw) {
@@ -510,38 +509,43 @@ PLB_HD void g2p_particle_grad(const SimP<T>& P, const X* x, const T* vn, const T
         xa[d] = gate * xn_a[d];
         nva[d] = vn_a[d] + P.dt * gate * xn_a[d];
     }
-    T c4 = T(4) * P.inv_dx;
-    T fxa[3] = {T(0), T(0), T(0)};
+    // new_v.grad + C.grad reach node o through t_a(o) = nva[a] + c4 (Cn_a[a] . dp_o), dp_o = o - fx: affine in the
+    // node offset, so it is stepped along the loops instead of re-evaluated (3 adds per node).
+    // Its dp-derivative, -c4 sum_o w_o gv_o[a] Cn_a[a][b], needs sum_o w_o gv_o = new_v: the stored v[f+1] (vn).
+    const T c4 = T(4) * P.inv_dx;
+    T tc[9], t0[3], fxa[3] = {T(0), T(0), T(0)};
+    for (int a = 0; a < 3; ++a) {
+        for (int b = 0; b < 3; ++b) tc[3 * a + b] = c4 * Cn_a[3 * a + b];
+        t0[a] = nva[a] - (tc[3 * a] * fx[0] + tc[3 * a + 1] * fx[1] + tc[3 * a + 2] * fx[2]);
+        for (int b = 0; b < 3; ++b) fxa[b] -= vn[a] * tc[3 * a + b];
+    }
+    T ti[3] = {t0[0], t0[1], t0[2]};
     PLB_ROLL
     for (int i = 0; i < 3; ++i) {
         const T wi = sel3(i, w[0][0], w[1][0], w[2][0]);
         const T dwi = sel3(i, dw[0][0], dw[1][0], dw[2][0]);
+        T tj[3] = {ti[0], ti[1], ti[2]};
         PLB_ROLL
         for (int j = 0; j < 3; ++j) {
             const T wj = sel3(j, w[0][1], w[1][1], w[2][1]);
             const T dwj = sel3(j, dw[0][1], dw[1][1], dw[2][1]);
+            const T wij = wi * wj, gx = dwi * wj, gy = wi * dwj;
+            T t[3] = {tj[0], tj[1], tj[2]};
             for (int l = 0; l < 3; ++l) {
                 T gv[3];
                 fetch(i, j, l, gv);
-                T wt = wi * wj * w[l][2];
-                T dp[3] = {T(i) - fx[0], T(j) - fx[1], T(l) - fx[2]};
-                T ga[3], wa = T(0);
-                for (int a = 0; a < 3; ++a) {
-                    T cd = Cn_a[3 * a] * dp[0] + Cn_a[3 * a + 1] * dp[1] + Cn_a[3 * a + 2] * dp[2];
-                    T t = nva[a] + c4 * cd;
-                    ga[a] = wt * t;
-                    wa += gv[a] * t;
-                    // d/d dp_b : c4 * wt * gv_a * Cn_a[a][b]; dp = k - fx
-                    fxa[0] -= c4 * wt * gv[a] * Cn_a[3 * a];
-                    fxa[1] -= c4 * wt * gv[a] * Cn_a[3 * a + 1];
-                    fxa[2] -= c4 * wt * gv[a] * Cn_a[3 * a + 2];
-                }
+                const T wt = wij * w[l][2];
+                const T ga[3] = {wt * t[0], wt * t[1], wt * t[2]};
+                const T wa = gv[0] * t[0] + gv[1] * t[1] + gv[2] * t[2];
                 emit(i, j, l, ga);
-                fxa[0] += wa * dwi * wj * w[l][2];
-                fxa[1] += wa * wi * dwj * w[l][2];
-                fxa[2] += wa * wi * wj * dw[l][2];
+                fxa[0] += wa * (gx * w[l][2]);
+                fxa[1] += wa * (gy * w[l][2]);
+                fxa[2] += wa * (wij * dw[l][2]);
+                for (int a = 0; a < 3; ++a) t[a] += tc[3 * a + 2];
             }
+            for (int a = 0; a < 3; ++a) tj[a] += tc[3 * a + 1];
         }
+        for (int a = 0; a < 3; ++a) ti[a] += tc[3 * a];
     }
     for (int d = 0; d < 3; ++d) xa[d] += P.inv_dx * fxa[d];
 }
@@ -560,41 +564,72 @@ PLB_HD void p2g_particle_grad(const SimP<T>& P, const X* x, const T* v, const T*
     //   va   = m sum_o w_o gva_o                 Aa[a][b] = sum_o w_o gva_o[a] dp_o[b]
     //   s1[d] = sum_o (m gm_o + gva_o . m v) dw_o/dfx_d
     //   M[a][b][d] = sum_o gva_o[a] dp_o[b] dw_o/dfx_d        (so that sum_o (gva_o^T A dp_o) dw_o = A : M)
+    // (w_o = w_i w_j w_l, dw_o/dfx_d = the same product with dw on axis d, dp_o = (o - fx) dx.)
     // The SVD / return mapping then runs after the loop and its ~60 registers are not live across it.
-    T mv[3] = {P.p_mass * v[0], P.p_mass * v[1], P.p_mass * v[2]};
-    T Aa[9], s1[3] = {T(0), T(0), T(0)}, M[27];
-    for (int i = 0; i < 9; ++i) Aa[i] = T(0);
-    for (int i = 0; i < 27; ++i) M[i] = T(0);
-    va[0] = va[1] = va[2] = T(0);
-    PLB_ROLL
-    for (int i = 0; i < 3; ++i) {
-        const T wi = sel3(i, w[0][0], w[1][0], w[2][0]);
-        const T dwi = sel3(i, dw[0][0], dw[1][0], dw[2][0]);
+    // Every accumulator is a sum over the 27 nodes of (one fetched field) x (a product of one 1-D factor per axis),
+    // the factor being W = w, D = dw/dfx, ZW = (k - fx) w or ZD = (k - fx) dw.  The sums are therefore contracted
+    // one axis at a time (z inside, then y, then x): ~800 multiply-adds per particle instead of ~1700.
+    //   fields: g[0] = grid_m.grad (types W, D only), g[1..3] = grid_v_in.grad
+    T Aa[9], s1[3], M[27];
+    {
+        enum { W = 0, Dd = 1, ZW = 2, ZD = 3 };
+        // (type on y, type on z) pairs needed after the z- and y-contractions, and the (type on x, pair) combos
+        // that make the final accumulators.  Everything below indexes these tables with compile-time constants.
+        constexpr int kPairY[9] = {W, Dd, W, ZW, ZD, ZW, W, Dd, W};
+        constexpr int kPairZ[9] = {W, W, Dd, W, W, Dd, ZW, ZW, ZD};
+        //            va  Aa0 Aa1 Aa2 M00 M01 M02 M10 M11 M12 M20 M21 M22 s0  s1  s2
+        constexpr int kCombX[16] = {W, ZW, W, W, ZD, ZW, ZW, Dd, W, W, Dd, W, W, Dd, W, W};
+        constexpr int kCombP[16] = {0, 0, 3, 6, 0, 1, 2, 3, 4, 5, 6, 7, 8, 0, 1, 2};
+        T cz[4][3];                                    // factors along z, all three stencil offsets
+        for (int n = 0; n < 3; ++n) {
+            const T z = T(n) - fx[2];
+            cz[W][n] = w[n][2]; cz[Dd][n] = dw[n][2]; cz[ZW][n] = z * w[n][2]; cz[ZD][n] = z * dw[n][2];
+        }
+        T Fv[16][3], Fm[3];                            // final sums: vector field, mass field
+        for (int c = 0; c < 16; ++c) Fv[c][0] = Fv[c][1] = Fv[c][2] = T(0);
+        Fm[0] = Fm[1] = Fm[2] = T(0);
         PLB_ROLL
-        for (int j = 0; j < 3; ++j) {
-            const T wj = sel3(j, w[0][1], w[1][1], w[2][1]);
-            const T dwj = sel3(j, dw[0][1], dw[1][1], dw[2][1]);
-            for (int l = 0; l < 3; ++l) {
-                T g[4];
-                fetch(i, j, l, g);
-                const T* gva = g + 1;
-                T wt = wi * wj * w[l][2];
-                T dp[3] = {(T(i) - fx[0]) * P.dx, (T(j) - fx[1]) * P.dx, (T(l) - fx[2]) * P.dx};
-                T gw[3] = {dwi * wj * w[l][2], wi * dwj * w[l][2], wi * wj * dw[l][2]};
-                T sc = P.p_mass * g[0] + gva[0] * mv[0] + gva[1] * mv[1] + gva[2] * mv[2];
-                for (int d = 0; d < 3; ++d) s1[d] += sc * gw[d];
-                for (int a = 0; a < 3; ++a) {
-                    va[a] += P.p_mass * wt * gva[a];
-                    for (int b = 0; b < 3; ++b) {
-                        T gd = gva[a] * dp[b];
-                        Aa[3 * a + b] += wt * gd;
-                        M[9 * a + 3 * b] += gd * gw[0];
-                        M[9 * a + 3 * b + 1] += gd * gw[1];
-                        M[9 * a + 3 * b + 2] += gd * gw[2];
-                    }
+        for (int i = 0; i < 3; ++i) {
+            T Sv[9][3], Sm[3];                         // sums over (j, l) for this i
+            for (int q = 0; q < 9; ++q) Sv[q][0] = Sv[q][1] = Sv[q][2] = T(0);
+            Sm[0] = Sm[1] = Sm[2] = T(0);
+            PLB_ROLL
+            for (int j = 0; j < 3; ++j) {
+                T Rv[4][3], Rm[2];                     // sums over l for this (i, j)
+                for (int t = 0; t < 4; ++t) Rv[t][0] = Rv[t][1] = Rv[t][2] = T(0);
+                Rm[0] = Rm[1] = T(0);
+                for (int l = 0; l < 3; ++l) {
+                    T g[4];
+                    fetch(i, j, l, g);
+                    Rm[W] += cz[W][l] * g[0];
+                    Rm[Dd] += cz[Dd][l] * g[0];
+                    for (int t = 0; t < 4; ++t)
+                        for (int a = 0; a < 3; ++a) Rv[t][a] += cz[t][l] * g[1 + a];
                 }
+                const T yw = sel3(j, w[0][1], w[1][1], w[2][1]), yd = sel3(j, dw[0][1], dw[1][1], dw[2][1]);
+                const T zy = T(j) - fx[1];
+                const T cy[4] = {yw, yd, zy * yw, zy * yd};
+                for (int q = 0; q < 9; ++q)
+                    for (int a = 0; a < 3; ++a) Sv[q][a] += cy[kPairY[q]] * Rv[kPairZ[q]][a];
+                Sm[0] += cy[W] * Rm[W]; Sm[1] += cy[Dd] * Rm[W]; Sm[2] += cy[W] * Rm[Dd];
+            }
+            const T xw = sel3(i, w[0][0], w[1][0], w[2][0]), xd = sel3(i, dw[0][0], dw[1][0], dw[2][0]);
+            const T zx = T(i) - fx[0];
+            const T cx[4] = {xw, xd, zx * xw, zx * xd};
+            for (int c = 0; c < 16; ++c)
+                for (int a = 0; a < 3; ++a) Fv[c][a] += cx[kCombX[c]] * Sv[kCombP[c]][a];
+            Fm[0] += cx[Dd] * Sm[0]; Fm[1] += cx[W] * Sm[1]; Fm[2] += cx[W] * Sm[2];
+        }
+        // dp = (k - fx) dx carries the dx
+        for (int a = 0; a < 3; ++a) {
+            va[a] = P.p_mass * Fv[0][a];
+            for (int b = 0; b < 3; ++b) {
+                Aa[3 * a + b] = P.dx * Fv[1 + b][a];
+                for (int d = 0; d < 3; ++d) M[9 * a + 3 * b + d] = P.dx * Fv[4 + 3 * b + d][a];
             }
         }
+        for (int d = 0; d < 3; ++d)                    // sc_o = m gm_o + gva_o . (m v)
+            s1[d] = P.p_mass * (Fm[d] + Fv[13 + d][0] * v[0] + Fv[13 + d][1] * v[1] + Fv[13 + d][2] * v[2]);
     }
     T Et[9], En[9], stress[9], A[9];
     f_tmp_eform(C, E, P.dt, Et);

@@ -30,6 +30,8 @@ constexpr int kBlock = 256;          // threads per workgroup in particle kernel
 #define PLB_P2G_GRAD_WAVES 1
 #endif
 constexpr int kMaxPrim = 8;
+constexpr int kListOfs = 64;         // ints between the active-block count and the list (own 256-byte line)
+constexpr int kGridWG = 512;         // workgroups of the persistent grid kernels (4 waves each, one wave per block)
 // LDS tile capacity (nodes) of the scatter/gather kernels: 16 KiB per tile for either scalar type
 template <class T> struct TileCap;
 #ifndef PLB_TILECAP
@@ -64,6 +66,7 @@ template <class T> struct Dev {
     T* goa[3];                       // grid_v_out.grad x/y/z (SoA, accumulated)
     Vec4<T>*grid_out, *grid_in_adj;  // AoS
     int* flags;
+    int* blist;                      // [0] = number of active blocks, [kListOfs + e] = their block indices
     // primitives (double): pos[(F+1)][P][3], rot[(F+1)][P][4], gap[(F+1)][P] (Chopsticks) and adjoints
     const double *ppos, *prot, *pgap;
     double *ppos_a, *prot_a, *pgap_a;
@@ -103,12 +106,21 @@ template <class T> __device__ __forceinline__ void load_prims(const Dev<T>& D, i
     }
 }
 
-// true when at least one of the 4^3 blocks this workgroup covers was touched (workgroup-uniform)
-template <class T> __device__ __forceinline__ bool any_block_active(const Dev<T>& D) {
-    const int b0 = blockIdx.x * (kBlock / 64), nblk = D.nb * D.nb * D.nb;
-    int any = 0;
-    for (int i = 0; i < kBlock / 64; ++i) any |= (b0 + i < nblk) ? D.flags[b0 + i] : 0;
-    return any != 0;
+// Active-block list: k_compact_blocks turns the per-block flags the scatter kernels set into a dense list, and the
+// grid kernels run a fixed number of waves that stride over that list.  (Launching one wave per block of the
+// whole grid and returning early on the ~95 % empty ones costs more than the work on the active blocks: every
+// early-exit workgroup still waits for its flag load, ~16 occupancy rounds of that per launch at 128^3.)
+// The count is zeroed by the scatter kernel that precedes the compaction in the stream.
+__global__ __launch_bounds__(256) void k_compact_blocks(const int* flags, int nblk, int* blist) {
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    const bool on = b < nblk && flags[b] != 0;
+    const unsigned long long m = __ballot(on);
+    if (m == 0) return;
+    const int lane = threadIdx.x & 63;
+    int base = 0;
+    if (lane == 0) base = atomicAdd(&blist[0], __popcll(m));
+    base = __shfl(base, 0);
+    if (on) blist[kListOfs + base + __popcll(m & ((1ULL << lane) - 1))] = b;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -280,6 +292,7 @@ __global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_p2g(Dev<T> D, int f) 
     int p, base[3];
     double x[3];
     const bool valid = load_sorted_particle(D, X, p, x, base);
+    if (blockIdx.x == 0 && threadIdx.x == 0) D.blist[0] = 0;            // the compaction that follows counts from 0
     if (WRITE_F && valid && (base[2] < D.zlo || base[2] + 2 >= D.zhi)) atomicOr(D.err, 1);
     Tile tl = block_tile(base, valid, sred, TileCap<T>::nodes);
     const int tn = tl.e[0] * tl.e[1] * tl.e[2];
@@ -352,23 +365,24 @@ __global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_p2g(Dev<T> D, int f) 
 template <class T, bool CLEAR>
 __global__ __launch_bounds__(kBlock) void k_grid_op(Dev<T> D, int f) {
     __shared__ PrimT<T> sp[kMaxPrim];
-    if (!any_block_active(D)) return;
+    const int count = D.blist[0];
+    if (blockIdx.x * (kBlock / 64) >= count) return;
     load_prims(D, f, sp);
     __syncthreads();
-    const int blk = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
-    const int nblk = D.nb * D.nb * D.nb;
-    if (blk >= nblk || D.flags[blk] == 0) return;
     const int lane = threadIdx.x & 63;
-    const int idx = (blk << 6) | lane;
-    const int bx = blk % D.nb, by = (blk / D.nb) % D.nb, bz = blk / (D.nb * D.nb);
-    int I[3] = {(bx << 2) | (lane & 3), (by << 2) | ((lane >> 2) & 3), (bz << 2) | (lane >> 4)};
-    T m = D.gin[0][idx];
-    T mv[3] = {D.gin[1][idx], D.gin[2][idx], D.gin[3][idx]}, vo[3];
-    grid_node_fwd<T>(D.P, I, m, mv, D.nprim, sp, vo);
-    D.grid_out[idx] = Vec4<T>{vo[0], vo[1], vo[2], T(0)};
-    if (CLEAR) {
-        D.gin[0][idx] = T(0); D.gin[1][idx] = T(0); D.gin[2][idx] = T(0); D.gin[3][idx] = T(0);
-        if (lane == 0) D.flags[blk] = 0;
+    for (int e = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6); e < count; e += gridDim.x * (kBlock / 64)) {
+        const int blk = D.blist[kListOfs + e];
+        const int idx = (blk << 6) | lane;
+        const int bx = blk % D.nb, by = (blk / D.nb) % D.nb, bz = blk / (D.nb * D.nb);
+        int I[3] = {(bx << 2) | (lane & 3), (by << 2) | ((lane >> 2) & 3), (bz << 2) | (lane >> 4)};
+        T m = D.gin[0][idx];
+        T mv[3] = {D.gin[1][idx], D.gin[2][idx], D.gin[3][idx]}, vo[3];
+        grid_node_fwd<T>(D.P, I, m, mv, D.nprim, sp, vo);
+        D.grid_out[idx] = Vec4<T>{vo[0], vo[1], vo[2], T(0)};
+        if (CLEAR) {
+            D.gin[0][idx] = T(0); D.gin[1][idx] = T(0); D.gin[2][idx] = T(0); D.gin[3][idx] = T(0);
+            if (lane == 0) D.flags[blk] = 0;
+        }
     }
 }
 
@@ -434,6 +448,7 @@ __global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_g2p_p2g(Dev<T> D, int
     int p, base0[3];
     double x0[3];
     const bool valid = load_sorted_particle(D, X0, p, x0, base0);
+    if (blockIdx.x == 0 && threadIdx.x == 0) D.blist[0] = 0;            // the compaction that follows counts from 0
     // state that does not depend on the gather: issue these loads now so they fly during the tile phase
     T E[9];
     for (int d = 0; d < 9; ++d) E[d] = T(0);
@@ -484,7 +499,9 @@ __global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_g2p_p2g(Dev<T> D, int
     __syncthreads();                                                     // everyone is done reading tile_v
     Tile tl = block_tile(base, valid, sred, TileCap<T>::nodes);
     const int tn = tl.e[0] * tl.e[1] * tl.e[2];
+#ifdef PLB_DEBUG_COUNTERS      // tile statistics for plmpm_debug_counters (same-address atomics: keep out of production builds)
     if (threadIdx.x == 0) { atomicAdd(D.err + (tl.ok ? 2 : 1), 1); if (tl.ok) atomicAdd(D.err + 3, tn); }
+#endif
     if (tl.ok) {
         for (int i = threadIdx.x; i < tn; i += kBlock) tile[i] = Vec4<double>{0.0, 0.0, 0.0, 0.0};
         __syncthreads();
@@ -499,7 +516,9 @@ __global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_g2p_p2g(Dev<T> D, int
             const int ex = tl.e[0], exy = tl.e[0] * tl.e[1];
             p2g_particle<T, double>(D.P, x, v, C, E, mu, lam, ys, En, b2, [&](int i, int j, int l, T mass, const T* mom) {
                 T a0 = mass, a1 = mom[0], a2 = mom[1], a3 = mom[2];
+                if (PLB_ABLATE & 4) { if (a0 + a1 + a2 + a3 == T(-1e30)) tile[0].x = 1.0; return; }
                 seg_sum4(a0, a1, a2, a3, sg);
+                if (PLB_ABLATE & 1) { if (a0 + a1 + a2 + a3 == T(-1e30)) tile[0].x = 1.0; return; }
                 if (emitter) {
                     double* q = reinterpret_cast<double*>(&tile[(oz + l) * exy + (oy + j) * ex + (ox + i)]);
                     atomicAdd(q, (double)a0); atomicAdd(q + 1, (double)a1); atomicAdd(q + 2, (double)a2); atomicAdd(q + 3, (double)a3);
@@ -522,7 +541,7 @@ __global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_g2p_p2g(Dev<T> D, int
             for (int d = 0; d < 9; ++d) R2[(12 + d) * Np + p] = En[d];
         }
     }
-    if (tl.ok) {
+    if (tl.ok && !(PLB_ABLATE & 2)) {
         __syncthreads();
         const int ex = tl.e[0], exy = tl.e[0] * tl.e[1];
         for (int i = threadIdx.x; i < tn; i += kBlock) {
@@ -580,7 +599,9 @@ __global__ __launch_bounds__(kBlock) void k_g2p_grad(Dev<T> D, int f, int src, i
                 },
                 [&](int i, int j, int l, const T* ga) {
                     T a0 = ga[0], a1 = ga[1], a2 = ga[2];
+                    if (PLB_ABLATE & 4) { if (a0 + a1 + a2 == T(-1e30)) tile_a[0].x = 1.0; return; }
                     seg_sum3(a0, a1, a2, sg);
+                    if (PLB_ABLATE & 1) { if (a0 + a1 + a2 == T(-1e30)) tile_a[0].x = 1.0; return; }
                     if (emitter) {
                         double* q = reinterpret_cast<double*>(&tile_a[(oz + l) * exy + (oy + j) * ex + (ox + i)]);
                         atomicAdd(q, (double)a0); atomicAdd(q + 1, (double)a1); atomicAdd(q + 2, (double)a2);
@@ -609,7 +630,7 @@ __global__ __launch_bounds__(kBlock) void k_g2p_grad(Dev<T> D, int f, int src, i
             for (int d = 0; d < 3; ++d) A0[d * Np + p] = xa[d];
         }
     }
-    if (tl.ok) {
+    if (tl.ok && !(PLB_ABLATE & 2)) {
         __syncthreads();
         for (int i = threadIdx.x; i < tn; i += kBlock) {
             Vec4<double> a = tile_a[i];
@@ -629,16 +650,15 @@ __global__ __launch_bounds__(kBlock) void k_grid_op_grad(Dev<T> D, int f) {
     __shared__ PrimT<T> sp[kMaxPrim];
     __shared__ double sacc[kMaxPrim * 15];
     __shared__ int shit;
-    if (!any_block_active(D)) return;
+    const int count = D.blist[0];
+    if (blockIdx.x * (kBlock / 64) >= count) return;
     load_prims(D, f, sp);
     if (threadIdx.x < kMaxPrim * 15) sacc[threadIdx.x] = 0.0;
     if (threadIdx.x == 0) shit = 0;
     __syncthreads();
-    const int blk = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
-    const int nblk = D.nb * D.nb * D.nb;
-    const bool active = blk < nblk && D.flags[blk] != 0;
-    if (active) {
-        const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63;
+    for (int e = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6); e < count; e += gridDim.x * (kBlock / 64)) {
+        const int blk = D.blist[kListOfs + e];
         const int idx = (blk << 6) | lane;
         const int bx = blk % D.nb, by = (blk / D.nb) % D.nb, bz = blk / (D.nb * D.nb);
         int I[3] = {(bx << 2) | (lane & 3), (by << 2) | ((lane >> 2) & 3), (bz << 2) | (lane >> 4)};
@@ -662,7 +682,7 @@ __global__ __launch_bounds__(kBlock) void k_grid_op_grad(Dev<T> D, int f) {
                 for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
                 vals[c] = v;
             }
-            if ((threadIdx.x & 63) == 0) {
+            if (lane == 0) {
                 double* o = &sacc[q * 15];
                 for (int c = 0; c < nc; ++c) atomicAdd(&o[c], vals[c]);
                 shit = 1;

@@ -45,7 +45,7 @@ def test_substep_forward_and_adjoint(rolled, dtype):
     # primitive pose at frame 1
     for k in range(len(prims)):
         st = eng.get_primitive_state(k, 1)
-        assert np.allclose(st[:3], nxt[k][0].numpy(), atol=1e-14) and np.allclose(st[3:], nxt[k][1].numpy(), atol=1e-14)
+        assert np.allclose(st[:3], nxt[k][0].numpy(), atol=1e-14) and np.allclose(st[3:7], nxt[k][1].numpy(), atol=1e-14)
 
     g = torch.Generator().manual_seed(1)
     cot = [torch.randn(t.shape, generator=g, dtype=O.DT) for t in out]
@@ -62,7 +62,7 @@ def test_substep_forward_and_adjoint(rolled, dtype):
         assert relerr(ga[key], ref.numpy()) < 5 * tol, key
     P = len(prims)
     for k in range(P):
-        g0, g1 = eng.get_primitive_grad(k, 0), eng.get_primitive_grad(k, 1)
+        g0, g1 = eng.get_primitive_grad(k, 0)[:7], eng.get_primitive_grad(k, 1)[:7]
         ref0 = np.concatenate([gs[4 + 2 * k].numpy(), gs[5 + 2 * k].numpy()])
         ref1 = np.concatenate([gs[4 + 2 * P + 2 * k].numpy(), gs[5 + 2 * P + 2 * k].numpy()])
         assert relerr(g0, ref0) < 5 * tol and relerr(g1, ref1) < 5 * tol
