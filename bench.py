@@ -41,7 +41,6 @@ ALG = {
     "p2g_recompute": (27, 8), "grid_op_recompute": (0, 7), "g2p_grad": (18, 9),
     "grid_op_grad": (0, 11), "p2g_grad": (54, 4), "clear_active": (0, 0),
     "g2p_p2g": (51, 7),        # g2p(f-1) + p2g(f) fused
-    "compact_blocks": (0, 0),  # block flags -> active-block list (reads 4 B per 4^3 block of the whole grid)
 }
 HBM_PEAK_GBS = 8000.0          # MI355X spec (MI355X_MICROARCH.md); measured copy peak there: 6290 GB/s
 

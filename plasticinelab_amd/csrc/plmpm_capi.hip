@@ -75,8 +75,6 @@ struct plmpm_sim {
     char* gstore = nullptr;      // grid_m / grid_v_in per frame (SoA, 4 comps)
     char* vstore = nullptr;      // grid_v_out per frame (AoS T4)
     int* fstore = nullptr;
-    int* blist = nullptr;        // active-block lists: per frame with the grid store, else one (kListOfs + nblk ints each)
-    size_t lstride = 0;
     size_t gstride = 0;
     std::vector<char> dirty;          // frame f holds a scattered grid that has not been consumed/cleared
     // optional per-kernel timing with HIP events on the launch stream (plmpm_profile_*)
@@ -86,9 +84,9 @@ struct plmpm_sim {
     size_t ev_next = 0;
 };
 
-enum KernelId { K_P2G = 0, K_GRID_OP, K_G2P, K_P2G_RE, K_GRID_OP_RE, K_G2P_GRAD, K_GRID_OP_GRAD, K_P2G_GRAD, K_CLEAR, K_G2P_P2G, K_COMPACT, K_COUNT };
+enum KernelId { K_P2G = 0, K_GRID_OP, K_G2P, K_P2G_RE, K_GRID_OP_RE, K_G2P_GRAD, K_GRID_OP_GRAD, K_P2G_GRAD, K_CLEAR, K_G2P_P2G, K_COUNT };
 static const char* kKernelNames[K_COUNT] = {"p2g", "grid_op", "g2p", "p2g_recompute", "grid_op_recompute",
-                                            "g2p_grad", "grid_op_grad", "p2g_grad", "clear_active", "g2p_p2g", "compact_blocks"};
+                                            "g2p_grad", "grid_op_grad", "p2g_grad", "clear_active", "g2p_p2g"};
 
 static void prof_begin(plmpm_sim* s, int id) {
     if (!s->prof) return;
@@ -143,7 +141,6 @@ template <class T> static Dev<T> make_dev(const plmpm_sim* s, int frame = -1) {
     D.grid_out = (Vec4<T>*)(framed ? s->vstore + (size_t)frame * s->gstride : s->grid_out);
     D.grid_in_adj = (Vec4<T>*)s->grid_in_adj;
     D.flags = framed ? s->fstore + (size_t)frame * s->nblk : s->flags;
-    D.blist = s->blist + (framed ? (size_t)(frame + 1) * s->lstride : 0);
     D.ppos = s->ppos; D.prot = s->prot; D.pgap = s->pgap;
     D.ppos_a = s->dist ? s->ppos_l : s->ppos_a;
     D.prot_a = s->dist ? s->prot_l : s->prot_a;
@@ -525,25 +522,18 @@ static ChainBufs chain_bufs(const plmpm_sim* s) {
 }
 static inline int nblocks_particles(const plmpm_sim* s) { return s->Npad / kBlock; }
 static inline int nblocks_grid(const plmpm_sim* s) { return (s->nblk + (kBlock / 64) - 1) / (kBlock / 64); }
-// persistent grid kernels: a fixed number of workgroups strides over the compacted active-block list
+// persistent grid kernels: a fixed number of workgroups, each striding over its share of the block flags
 static inline int nwg_grid(const plmpm_sim* s) { return std::min(nblocks_grid(s), kGridWG); }
-template <class T> static void launch_compact(plmpm_sim* s, const Dev<T>& D) {
-    prof_begin(s, K_COMPACT);
-    hipLaunchKernelGGL(k_compact_blocks, dim3((s->nblk + 255) / 256), dim3(256), 0, s->stream, D.flags, s->nblk, D.blist);
-    prof_end(s);
-}
 
 template <class T> static int substep_fwd(plmpm_sim* s, int f) {
     Dev<T> D = make_dev<T>(s, f);
     if (s->store) {
         if (s->dirty[f]) LAUNCH(s, K_CLEAR, (k_clear_active<T>), dim3(nblocks_grid(s)), D);   // frame reused without a backward pass
         LAUNCH(s, K_P2G, (k_p2g<T, true>), dim3(nblocks_particles(s)), D, f);
-        launch_compact(s, D);
         LAUNCH(s, K_GRID_OP, (k_grid_op<T, false>), dim3(nwg_grid(s)), D, f);                    // keep grid_in for substep_grad
         s->dirty[f] = 1;
     } else {
         LAUNCH(s, K_P2G, (k_p2g<T, true>), dim3(nblocks_particles(s)), D, f);
-        launch_compact(s, D);
         LAUNCH(s, K_GRID_OP, (k_grid_op<T, true>), dim3(nwg_grid(s)), D, f);
     }
     LAUNCH(s, K_G2P, (k_g2p<T>), dim3(nblocks_particles(s)), D, f);
@@ -554,11 +544,10 @@ template <class T> static int substep_bwd(plmpm_sim* s, int f) {
     const int src = (f + 1) & 1, dst = f & 1;
     if (!(s->store && s->dirty[f])) {        // this frame's grid is not resident: recompute it (mpm_simulator.py:265-268)
         LAUNCH(s, K_P2G_RE, (k_p2g<T, false>), dim3(nblocks_particles(s)), D, f);
-        launch_compact(s, D);
         LAUNCH(s, K_GRID_OP_RE, (k_grid_op<T, false>), dim3(nwg_grid(s)), D, f);
     }
     LAUNCH(s, K_G2P_GRAD, (k_g2p_grad<T>), dim3(nblocks_particles(s)), D, f, src, dst);
-    LAUNCH(s, K_GRID_OP_GRAD, (k_grid_op_grad<T>), dim3(nwg_grid(s)), D, f);      // list: this frame's, from the forward pass
+    LAUNCH(s, K_GRID_OP_GRAD, (k_grid_op_grad<T>), dim3(nwg_grid(s)), D, f);
     LAUNCH(s, K_P2G_GRAD, (k_p2g_grad<T>), dim3(nblocks_particles(s)), D, f, src, dst);
     if (s->store) s->dirty[f] = 0;           // k_grid_op_grad left grid_in / flags of this frame clean
     s->adj_frame[dst] = f;
@@ -576,7 +565,6 @@ template <class T> static int step_fwd_fused(plmpm_sim* s, int first, int n) {
             const Vec4<T>* vprev = (const Vec4<T>*)(s->vstore + (size_t)(f - 1) * s->gstride);
             LAUNCH(s, K_G2P_P2G, (k_g2p_p2g<T>), dim3(nblocks_particles(s)), D, f, vprev);
         }
-        launch_compact(s, D);
         LAUNCH(s, K_GRID_OP, (k_grid_op<T, false>), dim3(nwg_grid(s)), D, f);
         s->dirty[f] = 1;
     }
@@ -595,7 +583,6 @@ template <class T> static int phase_p2g(plmpm_sim* s, int f) {
 }
 template <class T> static int phase_grid_g2p(plmpm_sim* s, int f) {
     Dev<T> D = make_dev<T>(s, f);
-    launch_compact(s, D);                                   // after the neighbours' flags were OR-merged in
     LAUNCH(s, K_GRID_OP, (k_grid_op<T, false>), dim3(nwg_grid(s)), D, f);
     LAUNCH(s, K_G2P, (k_g2p<T>), dim3(nblocks_particles(s)), D, f);
     return 0;
@@ -752,8 +739,6 @@ int plmpm_create(const plmpm_config* cfg, const plmpm_primitive* prims, plmpm_ha
     s->store = cfg->store_grid != 0;
     s->gstride = align_up(s->G * 4 * s->tsz, 256);
     if (s->store) s->ws.grid_bytes += 2 * (size_t)s->F * s->gstride + align_up((size_t)s->F * s->nblk * 4, 256);
-    s->lstride = align_up((size_t)(kListOfs + s->nblk) * 4, 256) / 4;
-    s->ws.grid_bytes += (size_t)(s->store ? s->F + 1 : 1) * s->lstride * 4;
     s->dirty.assign(s->F + 1, 0);
     s->ws.misc_bytes = 2 * align_up((size_t)(s->F + 1) * P1 * 7 * 8, 256) + 2 * align_up((size_t)(s->F + 1) * P1 * 8 * 8, 256)  // poses(+adj), padded
                        + 4 * align_up((size_t)(s->F + 1) * P1 * 3 * 8, 256)                       // v,w (+adj)
@@ -799,7 +784,6 @@ int plmpm_bind_workspace(plmpm_handle s, void* state, void* adjoint, void* grid,
         s->vstore = take((size_t)s->F * s->gstride);
         s->fstore = (int*)take((size_t)s->F * s->nblk * 4);
     }
-    s->blist = (int*)take((size_t)(s->store ? s->F + 1 : 1) * s->lstride * 4);
     REQUIRE((size_t)(p - s->gridw) <= s->ws.grid_bytes, "internal: grid workspace overflow");
     p = s->miscw;
     size_t P1 = std::max(s->P, 1), F1 = s->F + 1;

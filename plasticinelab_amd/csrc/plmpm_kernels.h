@@ -30,7 +30,6 @@ constexpr int kBlock = 256;          // threads per workgroup in particle kernel
 #define PLB_P2G_GRAD_WAVES 1
 #endif
 constexpr int kMaxPrim = 8;
-constexpr int kListOfs = 64;         // ints between the active-block count and the list (own 256-byte line)
 constexpr int kGridWG = 512;         // workgroups of the persistent grid kernels (4 waves each, one wave per block)
 // LDS tile capacity (nodes) of the scatter/gather kernels: 16 KiB per tile for either scalar type
 template <class T> struct TileCap;
@@ -66,7 +65,6 @@ template <class T> struct Dev {
     T* goa[3];                       // grid_v_out.grad x/y/z (SoA, accumulated)
     Vec4<T>*grid_out, *grid_in_adj;  // AoS
     int* flags;
-    int* blist;                      // [0] = number of active blocks, [kListOfs + e] = their block indices
     // primitives (double): pos[(F+1)][P][3], rot[(F+1)][P][4], gap[(F+1)][P] (Chopsticks) and adjoints
     const double *ppos, *prot, *pgap;
     double *ppos_a, *prot_a, *pgap_a;
@@ -106,21 +104,22 @@ template <class T> __device__ __forceinline__ void load_prims(const Dev<T>& D, i
     }
 }
 
-// Active-block list: k_compact_blocks turns the per-block flags the scatter kernels set into a dense list, and the
-// grid kernels run a fixed number of waves that stride over that list.  (Launching one wave per block of the
-// whole grid and returning early on the ~95 % empty ones costs more than the work on the active blocks: every
-// early-exit workgroup still waits for its flag load, ~16 occupancy rounds of that per launch at 128^3.)
-// The count is zeroed by the scatter kernel that precedes the compaction in the stream.
-__global__ __launch_bounds__(256) void k_compact_blocks(const int* flags, int nblk, int* blist) {
-    const int b = blockIdx.x * 256 + threadIdx.x;
-    const bool on = b < nblk && flags[b] != 0;
-    const unsigned long long m = __ballot(on);
-    if (m == 0) return;
-    const int lane = threadIdx.x & 63;
-    int base = 0;
-    if (lane == 0) base = atomicAdd(&blist[0], __popcll(m));
-    base = __shfl(base, 0);
-    if (on) blist[kListOfs + base + __popcll(m & ((1ULL << lane) - 1))] = b;
+// Grid kernels run kGridWG persistent workgroups.  Workgroup g owns blocks g, g + G, g + 2G, ... (G = gridDim.x): the
+// active blocks are spatially clustered, so this interleaving hands every workgroup about the same number of them.
+// A wave reads 64 of its workgroup's flags at a time (one strided load), ballots, and the workgroup's 4 waves
+// take the set bits round-robin.  (One wave per block of the whole grid with an early return for the ~95 % empty
+// ones needs ~16 occupancy rounds of flag loads per launch at 128^3; a separate compaction kernel costs a 5 us
+// dispatch on the critical path.)
+template <class T, class Body> __device__ __forceinline__ void for_each_active_block(const Dev<T>& D, Body&& body) {
+    const int nblk = D.nb * D.nb * D.nb, G = gridDim.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int b0 = blockIdx.x; b0 < nblk; b0 += 64 * G) {
+        const int b = b0 + lane * G;
+        const unsigned long long m = __ballot(b < nblk && D.flags[b] != 0);
+        __syncthreads();             // bodies may clear flags: every wave must have taken the same snapshot first
+        int rank = 0;
+        for (unsigned long long r = m; r; r &= r - 1, ++rank)
+            if ((rank & (kBlock / 64 - 1)) == wave) body(b0 + (__ffsll((long long)r) - 1) * G);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -292,7 +291,6 @@ __global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_p2g(Dev<T> D, int f) 
     int p, base[3];
     double x[3];
     const bool valid = load_sorted_particle(D, X, p, x, base);
-    if (blockIdx.x == 0 && threadIdx.x == 0) D.blist[0] = 0;            // the compaction that follows counts from 0
     if (WRITE_F && valid && (base[2] < D.zlo || base[2] + 2 >= D.zhi)) atomicOr(D.err, 1);
     Tile tl = block_tile(base, valid, sred, TileCap<T>::nodes);
     const int tn = tl.e[0] * tl.e[1] * tl.e[2];
@@ -365,13 +363,10 @@ __global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_p2g(Dev<T> D, int f) 
 template <class T, bool CLEAR>
 __global__ __launch_bounds__(kBlock) void k_grid_op(Dev<T> D, int f) {
     __shared__ PrimT<T> sp[kMaxPrim];
-    const int count = D.blist[0];
-    if (blockIdx.x * (kBlock / 64) >= count) return;
     load_prims(D, f, sp);
     __syncthreads();
     const int lane = threadIdx.x & 63;
-    for (int e = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6); e < count; e += gridDim.x * (kBlock / 64)) {
-        const int blk = D.blist[kListOfs + e];
+    for_each_active_block(D, [&](int blk) {
         const int idx = (blk << 6) | lane;
         const int bx = blk % D.nb, by = (blk / D.nb) % D.nb, bz = blk / (D.nb * D.nb);
         int I[3] = {(bx << 2) | (lane & 3), (by << 2) | ((lane >> 2) & 3), (bz << 2) | (lane >> 4)};
@@ -383,7 +378,7 @@ __global__ __launch_bounds__(kBlock) void k_grid_op(Dev<T> D, int f) {
             D.gin[0][idx] = T(0); D.gin[1][idx] = T(0); D.gin[2][idx] = T(0); D.gin[3][idx] = T(0);
             if (lane == 0) D.flags[blk] = 0;
         }
-    }
+    });
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -448,7 +443,6 @@ __global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_g2p_p2g(Dev<T> D, int
     int p, base0[3];
     double x0[3];
     const bool valid = load_sorted_particle(D, X0, p, x0, base0);
-    if (blockIdx.x == 0 && threadIdx.x == 0) D.blist[0] = 0;            // the compaction that follows counts from 0
     // state that does not depend on the gather: issue these loads now so they fly during the tile phase
     T E[9];
     for (int d = 0; d < 9; ++d) E[d] = T(0);
@@ -650,15 +644,12 @@ __global__ __launch_bounds__(kBlock) void k_grid_op_grad(Dev<T> D, int f) {
     __shared__ PrimT<T> sp[kMaxPrim];
     __shared__ double sacc[kMaxPrim * 15];
     __shared__ int shit;
-    const int count = D.blist[0];
-    if (blockIdx.x * (kBlock / 64) >= count) return;
     load_prims(D, f, sp);
     if (threadIdx.x < kMaxPrim * 15) sacc[threadIdx.x] = 0.0;
     if (threadIdx.x == 0) shit = 0;
     __syncthreads();
     const int lane = threadIdx.x & 63;
-    for (int e = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6); e < count; e += gridDim.x * (kBlock / 64)) {
-        const int blk = D.blist[kListOfs + e];
+    for_each_active_block(D, [&](int blk) {
         const int idx = (blk << 6) | lane;
         const int bx = blk % D.nb, by = (blk / D.nb) % D.nb, bz = blk / (D.nb * D.nb);
         int I[3] = {(bx << 2) | (lane & 3), (by << 2) | ((lane >> 2) & 3), (bz << 2) | (lane >> 4)};
@@ -694,7 +685,7 @@ __global__ __launch_bounds__(kBlock) void k_grid_op_grad(Dev<T> D, int f) {
         // is never cleared -- p2g.grad only reads nodes of active blocks, which are all rewritten every substep.
         D.gin[0][idx] = T(0); D.gin[1][idx] = T(0); D.gin[2][idx] = T(0); D.gin[3][idx] = T(0);
         if (lane == 0) D.flags[blk] = 0;
-    }
+    });
     __syncthreads();
     if (shit && threadIdx.x < D.nprim * 15) {
         int q = threadIdx.x / 15, c = threadIdx.x % 15;
