@@ -75,6 +75,7 @@ struct plmpm_sim {
     char* gstore = nullptr;      // grid_m / grid_v_in per frame (SoA, 4 comps)
     char* vstore = nullptr;      // grid_v_out per frame (AoS T4)
     int* fstore = nullptr;
+    int* tiles = nullptr;        // per-frame stencil boxes of the particle workgroups: [(F+1)][Npad/256][8]
     size_t gstride = 0;
     std::vector<char> dirty;          // frame f holds a scattered grid that has not been consumed/cleared
     // optional per-kernel timing with HIP events on the launch stream (plmpm_profile_*)
@@ -141,6 +142,7 @@ template <class T> static Dev<T> make_dev(const plmpm_sim* s, int frame = -1) {
     D.grid_out = (Vec4<T>*)(framed ? s->vstore + (size_t)frame * s->gstride : s->grid_out);
     D.grid_in_adj = (Vec4<T>*)s->grid_in_adj;
     D.flags = framed ? s->fstore + (size_t)frame * s->nblk : s->flags;
+    D.tiles = s->tiles;
     D.ppos = s->ppos; D.prot = s->prot; D.pgap = s->pgap;
     D.ppos_a = s->dist ? s->ppos_l : s->ppos_a;
     D.prot_a = s->dist ? s->prot_l : s->prot_a;
@@ -739,12 +741,13 @@ int plmpm_create(const plmpm_config* cfg, const plmpm_primitive* prims, plmpm_ha
     s->store = cfg->store_grid != 0;
     s->gstride = align_up(s->G * 4 * s->tsz, 256);
     if (s->store) s->ws.grid_bytes += 2 * (size_t)s->F * s->gstride + align_up((size_t)s->F * s->nblk * 4, 256);
+    s->ws.grid_bytes += align_up((size_t)(s->F + 1) * (s->Npad / kBlock) * 8 * 4, 256);
     s->dirty.assign(s->F + 1, 0);
     s->ws.misc_bytes = 2 * align_up((size_t)(s->F + 1) * P1 * 7 * 8, 256) + 2 * align_up((size_t)(s->F + 1) * P1 * 8 * 8, 256)  // poses(+adj), padded
                        + 4 * align_up((size_t)(s->F + 1) * P1 * 3 * 8, 256)                       // v,w (+adj)
                        + 4 * align_up((size_t)(s->F + 1) * P1 * 8, 256)                           // gap, gap_vel (+adj)
                        + 2 * align_up((size_t)(s->F + 1) * P1 * PLMPM_MAX_ACTION_DIM * 8, 256)    // action buffers (+adj)
-                       + align_up(LS_COUNT * 8, 256) + align_up((size_t)s->N * 24 * 8, 256) + 256;
+                       + align_up(LS_COUNT * 8, 256) + align_up((size_t)s->N * 24 * 8, 256) + 512;
     s->perm.resize(s->N);
     for (int i = 0; i < s->N; ++i) s->perm[i] = i;
     *out = s;
@@ -784,6 +787,7 @@ int plmpm_bind_workspace(plmpm_handle s, void* state, void* adjoint, void* grid,
         s->vstore = take((size_t)s->F * s->gstride);
         s->fstore = (int*)take((size_t)s->F * s->nblk * 4);
     }
+    s->tiles = (int*)take((size_t)(s->F + 1) * (s->Npad / kBlock) * 8 * 4);
     REQUIRE((size_t)(p - s->gridw) <= s->ws.grid_bytes, "internal: grid workspace overflow");
     p = s->miscw;
     size_t P1 = std::max(s->P, 1), F1 = s->F + 1;
@@ -796,7 +800,7 @@ int plmpm_bind_workspace(plmpm_handle s, void* state, void* adjoint, void* grid,
     s->act = (double*)take(F1 * P1 * PLMPM_MAX_ACTION_DIM * 8); s->act_a = (double*)take(F1 * P1 * PLMPM_MAX_ACTION_DIM * 8);
     s->lscal = (double*)take(LS_COUNT * 8);
     s->staging = (double*)take((size_t)s->N * 24 * 8);
-    s->err_d = (int*)take(256);
+    s->err_d = (int*)take(512);
     if (s->dist) { s->ppos_l = (double*)take(F1 * P1 * 3 * 8); s->prot_l = (double*)take(F1 * P1 * 4 * 8); s->pgap_l = (double*)take(F1 * P1 * 8); }
     REQUIRE((size_t)(p - s->miscw) <= s->ws.misc_bytes, "internal: misc workspace overflow");
     // initial contents: zero grids / adjoints / primitive buffers, identity order
@@ -1429,6 +1433,15 @@ int plmpm_debug_counters(plmpm_handle s, int* out4) {
     HIPCHK(hipMemsetAsync(s->err_d + 1, 0, 12, s->stream));
     return 0;
 }
+#ifdef PLB_PHASE_TIMING
+extern "C" int plmpm_debug_phases(plmpm_handle s, unsigned long long* out30) {      // profiling builds only
+    NEED_BOUND(s);
+    HIPCHK(hipMemcpyAsync(out30, s->err_d + 16, 240, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    HIPCHK(hipMemsetAsync(s->err_d + 16, 0, 240, s->stream));
+    return 0;
+}
+#endif
 int plmpm_check_error(plmpm_handle s, int* flags) {
     NEED_BOUND(s);
     REQUIRE(flags, "null argument");

@@ -39,6 +39,19 @@ template <class T> struct TileCap;
 template <> struct TileCap<float> { static constexpr int nodes = PLB_TILECAP; };
 template <> struct TileCap<double> { static constexpr int nodes = 512; };
 
+// profiling builds only (-DPLB_PHASE_TIMING): per-phase wave time of the particle kernels, summed into u64 slots
+// behind the error word (plmpm_debug_phases).  PT_MARK(k) closes phase k; nothing is emitted in normal builds.
+#ifdef PLB_PHASE_TIMING
+#define PT_BEGIN() unsigned long long pt_t = __builtin_readcyclecounter(), pt_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
+#define PT_MARK(k) do { unsigned long long n_ = __builtin_readcyclecounter(); pt_acc[k] += n_ - pt_t; pt_t = n_; } while (0)
+#define PT_END(D, slot0) do { if ((threadIdx.x & 63) == 0) for (int k_ = 0; k_ < 10; ++k_) if (pt_acc[k_]) \
+        atomicAdd(reinterpret_cast<unsigned long long*>(D.err + 16) + (slot0) + k_, pt_acc[k_]); } while (0)
+#else
+#define PT_BEGIN() do {} while (0)
+#define PT_MARK(k) do {} while (0)
+#define PT_END(D, slot0) do {} while (0)
+#endif
+
 template <class T> struct Vec4 { T x, y, z, w; };
 template <> struct __attribute__((aligned(16))) Vec4<float> { float x, y, z, w; };
 template <> struct __attribute__((aligned(32))) Vec4<double> { double x, y, z, w; };
@@ -65,6 +78,7 @@ template <class T> struct Dev {
     T* goa[3];                       // grid_v_out.grad x/y/z (SoA, accumulated)
     Vec4<T>*grid_out, *grid_in_adj;  // AoS
     int* flags;
+    int* tiles;                      // [(F+1)][workgroups][8]: stencil box of each 256-particle workgroup, per frame
     // primitives (double): pos[(F+1)][P][3], rot[(F+1)][P][4], gap[(F+1)][P] (Chopsticks) and adjoints
     const double *ppos, *prot, *pgap;
     double *ppos_a, *prot_a, *pgap_a;
@@ -255,6 +269,51 @@ __device__ __forceinline__ Tile block_tile(const int* base, bool valid, int* sre
     return t;
 }
 
+// The box of frame f is computed once, by the kernel that scatters frame f (it has to reduce over the workgroup
+// anyway), and kept per frame: every later kernel over the same frame -- g2p, g2p.grad, p2g.grad -- reads 6 ints
+// and can start filling its LDS tile at once, in parallel with its particle loads, instead of load -> reduce ->
+// barrier -> fill.
+template <class T> __device__ __forceinline__ void store_tile(const Dev<T>& D, int f, const Tile& t) {
+    if (threadIdx.x < 6) {
+        int* q = D.tiles + ((size_t)f * gridDim.x + blockIdx.x) * 8;
+        q[threadIdx.x] = threadIdx.x < 3 ? t.o[threadIdx.x] : t.e[threadIdx.x - 3];
+    }
+}
+template <class T> __device__ __forceinline__ Tile load_tile(const Dev<T>& D, int f, int cap) {
+    const int* q = D.tiles + ((size_t)f * gridDim.x + blockIdx.x) * 8;
+    Tile t;
+    int nodes = 1;
+    for (int d = 0; d < 3; ++d) { t.o[d] = q[d]; t.e[d] = q[3 + d]; nodes *= t.e[d]; }
+    t.ok = (nodes > 0 && nodes <= cap) ? 1 : 0;
+    return t;
+}
+
+// Sorted particle load in two halves so that independent memory traffic can be issued in between.
+struct SortLoad { double x0[3]; long long key; };
+template <class T> __device__ __forceinline__ SortLoad sorted_begin(const Dev<T>& D, const double* X) {
+    const int Np = D.Npad;
+    const int p0 = blockIdx.x * kBlock + threadIdx.x;
+    SortLoad s;
+    s.x0[0] = s.x0[1] = s.x0[2] = 0.5;
+    if (p0 < D.N) for (int d = 0; d < 3; ++d) s.x0[d] = X[d * Np + p0];
+    return s;
+}
+template <class T>
+__device__ __forceinline__ bool sorted_finish(const Dev<T>& D, SortLoad& s, int& p, double* x, int* base) {
+    const int p0 = blockIdx.x * kBlock + threadIdx.x;
+    s.key = (1LL << 40);                                            // padding lanes last
+    if (p0 < D.N) {
+        int b[3];
+        for (int d = 0; d < 3; ++d) b[d] = (int)(s.x0[d] * (double)D.P.inv_dx - 0.5);
+        s.key = ((long long)b[2] * D.P.n + b[1]) * D.P.n + b[0];
+    }
+    const int src = wave_sort_lanes(s.key);
+    p = (p0 & ~63) + src;
+    for (int d = 0; d < 3; ++d) x[d] = __shfl(s.x0[d], src);       // the position travels with the sort
+    for (int d = 0; d < 3; ++d) base[d] = (int)(x[d] * (double)D.P.inv_dx - 0.5);
+    return p < D.N;
+}
+
 // Load this lane's particle after the wave-local sort by stencil base: p = particle index, x = position,
 // base = stencil base.  Padding lanes (beyond N) sort to the end and return false.
 template <class T>
@@ -262,18 +321,18 @@ __device__ __forceinline__ bool load_sorted_particle(const Dev<T>& D, const doub
     const int Np = D.Npad;
     const int p0 = blockIdx.x * kBlock + threadIdx.x;
     long long key = (1LL << 40);                                    // padding lanes last
+    double x0[3] = {0.5, 0.5, 0.5};
     if (p0 < D.N) {
         int b[3];
-        for (int d = 0; d < 3; ++d) b[d] = (int)(X[d * Np + p0] * (double)D.P.inv_dx - 0.5);
+        for (int d = 0; d < 3; ++d) { x0[d] = X[d * Np + p0]; b[d] = (int)(x0[d] * (double)D.P.inv_dx - 0.5); }
         key = ((long long)b[2] * D.P.n + b[1]) * D.P.n + b[0];
     }
     const int src = wave_sort_lanes(key);
     p = (p0 & ~63) + src;
-    const bool valid = p < D.N;
-    x[0] = x[1] = x[2] = 0.5;
-    if (valid) { x[0] = X[p]; x[1] = X[Np + p]; x[2] = X[2 * Np + p]; }
+    // the position travels with the sort (shuffles) instead of a second, dependent trip to memory
+    for (int d = 0; d < 3; ++d) x[d] = __shfl(x0[d], src);
     for (int d = 0; d < 3; ++d) base[d] = (int)(x[d] * (double)D.P.inv_dx - 0.5);
-    return valid;
+    return p < D.N;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -293,6 +352,7 @@ __global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_p2g(Dev<T> D, int f) 
     const bool valid = load_sorted_particle(D, X, p, x, base);
     if (WRITE_F && valid && (base[2] < D.zlo || base[2] + 2 >= D.zhi)) atomicOr(D.err, 1);
     Tile tl = block_tile(base, valid, sred, TileCap<T>::nodes);
+    store_tile(D, f, tl);
     const int tn = tl.e[0] * tl.e[1] * tl.e[2];
     if (tl.ok) {
         for (int i = threadIdx.x; i < tn; i += kBlock) tile[i] = Vec4<double>{0.0, 0.0, 0.0, 0.0};
@@ -385,17 +445,14 @@ __global__ __launch_bounds__(kBlock) void k_grid_op(Dev<T> D, int f) {
 // g2p (mpm_simulator.py:223-242): gather v_out through an LDS tile, write x,v,C of frame f+1
 template <class T>
 __global__ __launch_bounds__(kBlock) void k_g2p(Dev<T> D, int f) {
-    __shared__ int sred[32];
     __shared__ Vec4<T> tile[TileCap<T>::nodes];
     const int p = blockIdx.x * kBlock + threadIdx.x;
     const bool valid = p < D.N;
     const double* X = frame_x(D, f);
     const int Np = D.Npad;
+    const Tile tl = load_tile(D, f, TileCap<T>::nodes);             // written by the scatter of this frame
     double x[3] = {0.5, 0.5, 0.5};
     if (valid) { x[0] = X[p]; x[1] = X[Np + p]; x[2] = X[2 * Np + p]; }
-    int base[3];
-    for (int d = 0; d < 3; ++d) base[d] = (int)(x[d] * (double)D.P.inv_dx - 0.5);
-    Tile tl = block_tile(base, valid, sred, TileCap<T>::nodes);
     const int ex = tl.e[0], exy = tl.e[0] * tl.e[1], tn = exy * tl.e[2];
     if (tl.ok) {
         for (int i = threadIdx.x; i < tn; i += kBlock) {
@@ -404,6 +461,8 @@ __global__ __launch_bounds__(kBlock) void k_g2p(Dev<T> D, int f) {
         }
         __syncthreads();
     }
+    int base[3];
+    for (int d = 0; d < 3; ++d) base[d] = (int)(x[d] * (double)D.P.inv_dx - 0.5);
     if (!valid) return;
     double xn[3];
     T vn[3], Cn[9];
@@ -442,8 +501,22 @@ __global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_g2p_p2g(Dev<T> D, int
     const double* X0 = frame_x(D, f - 1);
     int p, base0[3];
     double x0[3];
-    const bool valid = load_sorted_particle(D, X0, p, x0, base0);
-    // state that does not depend on the gather: issue these loads now so they fly during the tile phase
+    PT_BEGIN();
+    // box of frame f-1 (stored by the kernel that scattered it; capacity: the same LDS bytes in Vec4<T> nodes):
+    // the tile fill is issued right behind the position loads and overlaps with them and with the sort
+    const Tile ta = load_tile(D, f - 1, (int)(TileCap<T>::nodes * sizeof(Vec4<double>) / sizeof(Vec4<T>)));
+    SortLoad sl = sorted_begin(D, X0);
+    {
+        const int ex = ta.e[0], exy = ta.e[0] * ta.e[1], tn = exy * ta.e[2];
+        if (ta.ok)
+            for (int i = threadIdx.x; i < tn; i += kBlock) {
+                int lz = i / exy, r = i - lz * exy, ly = r / ex, lx = r - ly * ex;
+                tile_v[i] = vout_prev[node_index(D.nb, ta.o[0] + lx, ta.o[1] + ly, ta.o[2] + lz)];
+            }
+    }
+    PT_MARK(0);
+    const bool valid = sorted_finish(D, sl, p, x0, base0);
+    // state that does not depend on the gather: issue these loads now so they fly during the gather
     T E[9];
     for (int d = 0; d < 9; ++d) E[d] = T(0);
     T mu = T(1), lam = T(1), ys = T(1);
@@ -452,18 +525,8 @@ __global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_g2p_p2g(Dev<T> D, int
         for (int d = 0; d < 9; ++d) E[d] = R[(12 + d) * Np + p];
         mu = D.mu[p]; lam = D.lam[p]; ys = D.ys[p];
     }
-    // capacity of the same LDS bytes in Vec4<T> nodes
-    Tile ta = block_tile(base0, valid, sred, (int)(TileCap<T>::nodes * sizeof(Vec4<double>) / sizeof(Vec4<T>)));
-    {
-        const int ex = ta.e[0], exy = ta.e[0] * ta.e[1], tn = exy * ta.e[2];
-        if (ta.ok) {
-            for (int i = threadIdx.x; i < tn; i += kBlock) {
-                int lz = i / exy, r = i - lz * exy, ly = r / ex, lx = r - ly * ex;
-                tile_v[i] = vout_prev[node_index(D.nb, ta.o[0] + lx, ta.o[1] + ly, ta.o[2] + lz)];
-            }
-            __syncthreads();
-        }
-    }
+    __syncthreads();                                                 // tile_v complete
+    PT_MARK(1);
     double x[3] = {0.5, 0.5, 0.5};
     T v[3] = {T(0), T(0), T(0)}, C[9];
     for (int d = 0; d < 9; ++d) C[d] = T(0);
@@ -486,12 +549,14 @@ __global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_g2p_p2g(Dev<T> D, int
         for (int d = 0; d < 3; ++d) { X1[d * Np + p] = x[d]; R1[d * Np + p] = v[d]; }
         for (int d = 0; d < 9; ++d) R1[(3 + d) * Np + p] = C[d];
     }
+    PT_MARK(2);
     // ---------------- p2g(f): scatter
     int base[3];
     for (int d = 0; d < 3; ++d) base[d] = (int)(x[d] * (double)D.P.inv_dx - 0.5);
     if (valid && (base[2] < D.zlo || base[2] + 2 >= D.zhi)) atomicOr(D.err, 1);
     __syncthreads();                                                     // everyone is done reading tile_v
     Tile tl = block_tile(base, valid, sred, TileCap<T>::nodes);
+    store_tile(D, f, tl);
     const int tn = tl.e[0] * tl.e[1] * tl.e[2];
 #ifdef PLB_DEBUG_COUNTERS      // tile statistics for plmpm_debug_counters (same-address atomics: keep out of production builds)
     if (threadIdx.x == 0) { atomicAdd(D.err + (tl.ok ? 2 : 1), 1); if (tl.ok) atomicAdd(D.err + 3, tn); }
@@ -500,6 +565,7 @@ __global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_g2p_p2g(Dev<T> D, int
         for (int i = threadIdx.x; i < tn; i += kBlock) tile[i] = Vec4<double>{0.0, 0.0, 0.0, 0.0};
         __syncthreads();
     }
+    PT_MARK(3);
     {
         T En[9];
         const Seg<T> sg = wave_segments<T>(valid ? (base[2] * D.P.n + base[1]) * D.P.n + base[0] : -1);
@@ -535,6 +601,7 @@ __global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_g2p_p2g(Dev<T> D, int
             for (int d = 0; d < 9; ++d) R2[(12 + d) * Np + p] = En[d];
         }
     }
+    PT_MARK(4);
     if (tl.ok && !(PLB_ABLATE & 2)) {
         __syncthreads();
         const int ex = tl.e[0], exy = tl.e[0] * tl.e[1];
@@ -549,6 +616,8 @@ __global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_g2p_p2g(Dev<T> D, int
             }
         }
     }
+    PT_MARK(5);
+    PT_END(D, 0);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -562,17 +631,19 @@ __global__ __launch_bounds__(kBlock) void k_g2p_grad(Dev<T> D, int f, int src, i
     const int Np = D.Npad;
     int p, base[3];
     double x[3];
-    const bool valid = load_sorted_particle(D, X, p, x, base);
-    Tile tl = block_tile(base, valid, sred, TileCap<T>::nodes);
+    PT_BEGIN();
+    const Tile tl = load_tile(D, f, TileCap<T>::nodes);             // stored by the scatter of this frame
+    SortLoad sl = sorted_begin(D, X);
     const int ex = tl.e[0], exy = tl.e[0] * tl.e[1], tn = exy * tl.e[2];
-    if (tl.ok) {
+    if (tl.ok)
         for (int i = threadIdx.x; i < tn; i += kBlock) {
             int lz = i / exy, r = i - lz * exy, ly = r / ex, lx = r - ly * ex;
             tile[i] = D.grid_out[node_index(D.nb, tl.o[0] + lx, tl.o[1] + ly, tl.o[2] + lz)];
             tile_a[i] = Vec4<double>{0.0, 0.0, 0.0, 0.0};
         }
-        __syncthreads();
-    }
+    PT_MARK(0);
+    const bool valid = sorted_finish(D, sl, p, x, base);
+    PT_MARK(1);
     {
         const T* R1 = frame_r(D, f + 1);
         const T* A1 = D.adj[src];
@@ -582,6 +653,8 @@ __global__ __launch_bounds__(kBlock) void k_g2p_grad(Dev<T> D, int f, int src, i
             for (int d = 0; d < 3; ++d) { vn[d] = R1[d * Np + p]; xna[d] = A1[d * Np + p]; vna[d] = A1[(3 + d) * Np + p]; }
             for (int d = 0; d < 9; ++d) Cna[d] = A1[(6 + d) * Np + p];
         }
+        __syncthreads();                             // tile / tile_a complete (the loads above are in flight)
+        PT_MARK(2);
         const Seg<T> sg = wave_segments<T>(valid ? (base[2] * D.P.n + base[1]) * D.P.n + base[0] : -1);
         const bool emitter = sg.head && valid;
         if (tl.ok) {
@@ -624,6 +697,7 @@ __global__ __launch_bounds__(kBlock) void k_g2p_grad(Dev<T> D, int f, int src, i
             for (int d = 0; d < 3; ++d) A0[d * Np + p] = xa[d];
         }
     }
+    PT_MARK(3);
     if (tl.ok && !(PLB_ABLATE & 2)) {
         __syncthreads();
         for (int i = threadIdx.x; i < tn; i += kBlock) {
@@ -635,6 +709,8 @@ __global__ __launch_bounds__(kBlock) void k_g2p_grad(Dev<T> D, int f, int src, i
             }
         }
     }
+    PT_MARK(4);
+    PT_END(D, 10);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -705,18 +781,29 @@ __global__ __launch_bounds__(kBlock) void k_grid_op_grad(Dev<T> D, int f) {
 // p2g.grad + svd_grad + compute_F_tmp.grad: gather grid_in_adj, finish adjoint frame `dst`
 template <class T>
 __global__ __launch_bounds__(kBlock, PLB_P2G_GRAD_WAVES) void k_p2g_grad(Dev<T> D, int f, int src, int dst) {
-    __shared__ int sred[32];
     __shared__ Vec4<T> tile[TileCap<T>::nodes];
     const int p = blockIdx.x * kBlock + threadIdx.x;
     const bool valid = p < D.N;
     const double* X = frame_x(D, f);
     const T* R = frame_r(D, f);
     const int Np = D.Npad;
+    PT_BEGIN();
+    const Tile tl = load_tile(D, f, TileCap<T>::nodes);             // stored by the scatter of this frame
+    // every load of this kernel is issued before the first wait: particle state, incoming adjoint, tile
     double x[3] = {0.5, 0.5, 0.5};
-    if (valid) { x[0] = X[p]; x[1] = X[Np + p]; x[2] = X[2 * Np + p]; }
-    int base[3];
-    for (int d = 0; d < 3; ++d) base[d] = (int)(x[d] * (double)D.P.inv_dx - 0.5);
-    Tile tl = block_tile(base, valid, sred, TileCap<T>::nodes);
+    T v[3] = {T(0), T(0), T(0)}, C[9], E[9], Ena[9], xa[3] = {T(0), T(0), T(0)}, va[3], Ca[9], Ea[9];
+    T mu = T(1), lam = T(1), ys = T(1);
+    const T* A1 = D.adj[src];
+    T* A0 = D.adj[dst];
+    for (int d = 0; d < 9; ++d) { C[d] = T(0); E[d] = T(0); Ena[d] = T(0); }
+    if (valid) {
+        x[0] = X[p]; x[1] = X[Np + p]; x[2] = X[2 * Np + p];
+        for (int d = 0; d < 3; ++d) v[d] = R[d * Np + p];
+        for (int d = 0; d < 9; ++d) { C[d] = R[(3 + d) * Np + p]; E[d] = R[(12 + d) * Np + p]; }
+        for (int d = 0; d < 9; ++d) Ena[d] = A1[(15 + d) * Np + p];
+        for (int d = 0; d < 3; ++d) xa[d] = A0[d * Np + p];
+        mu = D.mu[p]; lam = D.lam[p]; ys = D.ys[p];
+    }
     const int ex = tl.e[0], exy = tl.e[0] * tl.e[1], tn = exy * tl.e[2];
     if (tl.ok) {
         for (int i = threadIdx.x; i < tn; i += kBlock) {
@@ -725,15 +812,10 @@ __global__ __launch_bounds__(kBlock, PLB_P2G_GRAD_WAVES) void k_p2g_grad(Dev<T> 
         }
         __syncthreads();
     }
+    int base[3];
+    for (int d = 0; d < 3; ++d) base[d] = (int)(x[d] * (double)D.P.inv_dx - 0.5);
+    PT_MARK(1);
     if (!valid) return;
-    T v[3], C[9], E[9], Ena[9], xa[3], va[3], Ca[9], Ea[9];
-    for (int d = 0; d < 3; ++d) v[d] = R[d * Np + p];
-    for (int d = 0; d < 9; ++d) { C[d] = R[(3 + d) * Np + p]; E[d] = R[(12 + d) * Np + p]; }
-    const T* A1 = D.adj[src];
-    T* A0 = D.adj[dst];
-    for (int d = 0; d < 9; ++d) Ena[d] = A1[(15 + d) * Np + p];
-    for (int d = 0; d < 3; ++d) xa[d] = A0[d * Np + p];
-    T mu = D.mu[p], lam = D.lam[p], ys = D.ys[p];
     if (tl.ok) {
         const int ox = base[0] - tl.o[0], oy = base[1] - tl.o[1], oz = base[2] - tl.o[2];
         p2g_particle_grad<T, double>(D.P, x, v, C, E, mu, lam, ys, Ena, xa, va, Ca, Ea, [&](int i, int j, int l, T* g) {
@@ -746,8 +828,11 @@ __global__ __launch_bounds__(kBlock, PLB_P2G_GRAD_WAVES) void k_p2g_grad(Dev<T> 
             g[0] = a.x; g[1] = a.y; g[2] = a.z; g[3] = a.w;
         });
     }
+    PT_MARK(2);
     for (int d = 0; d < 3; ++d) { A0[d * Np + p] = xa[d]; A0[(3 + d) * Np + p] = va[d]; }
     for (int d = 0; d < 9; ++d) { A0[(6 + d) * Np + p] = Ca[d]; A0[(15 + d) * Np + p] = Ea[d]; }
+    PT_MARK(3);
+    PT_END(D, 20);
 }
 
 // compute_grid_m_kernel (mpm_simulator.py:382-392): mass-only scatter for the loss, same LDS-tile +
