@@ -143,6 +143,7 @@ template <class T> static Dev<T> make_dev(const plmpm_sim* s, int frame = -1) {
     D.grid_in_adj = (Vec4<T>*)s->grid_in_adj;
     D.flags = framed ? s->fstore + (size_t)frame * s->nblk : s->flags;
     D.tiles = s->tiles;
+    D.trace = (unsigned long long*)s->staging;      // profiling builds only (needs N * 24 * 8 >= 3 * 16384 * 128 bytes)
     D.ppos = s->ppos; D.prot = s->prot; D.pgap = s->pgap;
     D.ppos_a = s->dist ? s->ppos_l : s->ppos_a;
     D.prot_a = s->dist ? s->prot_l : s->prot_a;
@@ -1434,11 +1435,10 @@ int plmpm_debug_counters(plmpm_handle s, int* out4) {
     return 0;
 }
 #ifdef PLB_PHASE_TIMING
-extern "C" int plmpm_debug_phases(plmpm_handle s, unsigned long long* out30) {      // profiling builds only
+extern "C" int plmpm_debug_trace(plmpm_handle s, unsigned long long* out, size_t n) {       // profiling builds only
     NEED_BOUND(s);
-    HIPCHK(hipMemcpyAsync(out30, s->err_d + 16, 240, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipMemcpyAsync(out, s->staging, n * 8, hipMemcpyDeviceToHost, s->stream));
     HIPCHK(hipStreamSynchronize(s->stream));
-    HIPCHK(hipMemsetAsync(s->err_d + 16, 0, 240, s->stream));
     return 0;
 }
 #endif

@@ -39,13 +39,21 @@ template <class T> struct TileCap;
 template <> struct TileCap<float> { static constexpr int nodes = PLB_TILECAP; };
 template <> struct TileCap<double> { static constexpr int nodes = 512; };
 
-// profiling builds only (-DPLB_PHASE_TIMING): per-phase wave time of the particle kernels, summed into u64 slots
-// behind the error word (plmpm_debug_phases).  PT_MARK(k) closes phase k; nothing is emitted in normal builds.
+// profiling builds only (-DPLB_PHASE_TIMING): PT_MARK(k) stamps s_memtime at the end of phase k; for the launch of
+// frame PLB_TRACE_FRAME every wave stores its stamps and its hardware id (XCC / SE / CU / SIMD) with plain stores to
+// D.trace[(kernel slot) * 16384 * 16 + wave * 16 + ...] (plmpm_debug_trace).  No atomics: same-address atomics from
+// every wave clog the memory pipeline and become the thing being measured.  Nothing is emitted in normal builds.
 #ifdef PLB_PHASE_TIMING
-#define PT_BEGIN() unsigned long long pt_t = __builtin_readcyclecounter(), pt_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
-#define PT_MARK(k) do { unsigned long long n_ = __builtin_readcyclecounter(); pt_acc[k] += n_ - pt_t; pt_t = n_; } while (0)
-#define PT_END(D, slot0) do { if ((threadIdx.x & 63) == 0) for (int k_ = 0; k_ < 10; ++k_) if (pt_acc[k_]) \
-        atomicAdd(reinterpret_cast<unsigned long long*>(D.err + 16) + (slot0) + k_, pt_acc[k_]); } while (0)
+#ifndef PLB_TRACE_FRAME
+#define PLB_TRACE_FRAME 20
+#endif
+#define PT_BEGIN() unsigned long long pt_abs[11] = {__builtin_readcyclecounter(), 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
+#define PT_MARK(k) do { pt_abs[1 + (k)] = __builtin_readcyclecounter(); } while (0)
+#define PT_END(D, slot0) do { if ((threadIdx.x & 63) == 0 && f == PLB_TRACE_FRAME) { \
+            unsigned long long* q_ = D.trace + ((size_t)((slot0) / 10) * 16384 + blockIdx.x * 4 + (threadIdx.x >> 6)) * 16; \
+            for (int k_ = 0; k_ < 11; ++k_) q_[k_] = pt_abs[k_]; \
+            q_[11] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)); \
+            q_[12] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)); } } while (0)
 #else
 #define PT_BEGIN() do {} while (0)
 #define PT_MARK(k) do {} while (0)
@@ -79,6 +87,7 @@ template <class T> struct Dev {
     Vec4<T>*grid_out, *grid_in_adj;  // AoS
     int* flags;
     int* tiles;                      // [(F+1)][workgroups][8]: stencil box of each 256-particle workgroup, per frame
+    unsigned long long* trace;       // profiling builds only
     // primitives (double): pos[(F+1)][P][3], rot[(F+1)][P][4], gap[(F+1)][P] (Chopsticks) and adjoints
     const double *ppos, *prot, *pgap;
     double *ppos_a, *prot_a, *pgap_a;

@@ -1,0 +1,20 @@
+import sys, ctypes as C, numpy as np, torch
+sys.path.insert(0, '/root/repo')
+import bench
+class A: pass
+args = A(); args.particles = 500_000; args.quality = 2; args.steps = 2; args.warmup = 1; args.dtype = 'float32'
+dev = torch.device('cuda:0')
+env, _ = bench.build_env(args, dev)
+sim = env.simulator
+acts = bench.seeded_actions(2, env.primitives.action_dim)
+state0 = env.get_state()["state"]
+env.set_state(state0, 666.0, False)
+bench.rollout(env, acts); torch.cuda.synchronize()
+env.set_state(state0, 666.0, False)
+lib = sim.engine.lib
+bench.rollout(env, acts); torch.cuda.synchronize()
+n = 3 * 16384 * 16
+buf = (C.c_ulonglong * n)()
+lib.plmpm_debug_trace.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+lib.plmpm_debug_trace(sim.engine.h, buf, n)
+np.save('/root/repo/gpurun_out/trace.npy', np.array(buf, dtype=np.uint64).reshape(3, 16384, 16))
