@@ -550,13 +550,21 @@ PLB_HD void g2p_particle_grad(const SimP<T>& P, const X* x, const T* vn, const T
     for (int d = 0; d < 3; ++d) xa[d] += P.inv_dx * fxa[d];
 }
 
-// p2g adjoint + svd_grad + compute_F_tmp.grad for one particle.
+// p2g adjoint + svd_grad + compute_F_tmp.grad for one particle, in two halves.
+//   p2g_gather_grad: everything that needs the grid -- uses only the particle's position, so a kernel can run it
+//                    before the rest of the particle state is loaded (fewer live registers across the 27-node loop);
+//   p2g_finish_grad: the constitutive VJP and the chain through F_tmp.
 // Fetch(k0,k1,k2, g[4]) reads {grid_m.grad, grid_v_in.grad[3]}.  En_a = F[f+1].grad.
 // xa_io already holds the g2p contribution and is accumulated into; va, Ca, Ea are written.
+template <class T> struct P2GGather {
+    T va[3];     // m sum_o w_o gva_o
+    T Aa[9];     // sum_o w_o gva_o[a] dp_o[b]
+    T M[27];     // sum_o gva_o[a] dp_o[b] dw_o/dfx_d
+    T sm[3];     // sum_o gm_o dw_o/dfx_d
+    T sv[9];     // sum_o gva_o[a] dw_o/dfx_d   ([3 d + a])
+};
 template <class T, class X, class Fetch>
-PLB_HD void p2g_particle_grad(const SimP<T>& P, const X* x, const T* v, const T* C, const T* E,
-                              T mu, T lam, T ys, const T* En_a, T* xa_io, T* va, T* Ca, T* Ea,
-                              Fetch&& fetch) {
+PLB_HD void p2g_gather_grad(const SimP<T>& P, const X* x, P2GGather<T>& G, Fetch&& fetch) {
     int base[3];
     T fx[3], w[3][3], dw[3][3];
     stencil<T, X>(x, P.inv_dx, base, fx, w, dw);
@@ -570,7 +578,6 @@ PLB_HD void p2g_particle_grad(const SimP<T>& P, const X* x, const T* v, const T*
     // the factor being W = w, D = dw/dfx, ZW = (k - fx) w or ZD = (k - fx) dw.  The sums are therefore contracted
     // one axis at a time (z inside, then y, then x): ~800 multiply-adds per particle instead of ~1700.
     //   fields: g[0] = grid_m.grad (types W, D only), g[1..3] = grid_v_in.grad
-    T Aa[9], s1[3], M[27];
     {
         enum { W = 0, Dd = 1, ZW = 2, ZD = 3 };
         // (type on y, type on z) pairs needed after the z- and y-contractions, and the (type on x, pair) combos
@@ -622,23 +629,32 @@ PLB_HD void p2g_particle_grad(const SimP<T>& P, const X* x, const T* v, const T*
         }
         // dp = (k - fx) dx carries the dx
         for (int a = 0; a < 3; ++a) {
-            va[a] = P.p_mass * Fv[0][a];
+            G.va[a] = P.p_mass * Fv[0][a];
             for (int b = 0; b < 3; ++b) {
-                Aa[3 * a + b] = P.dx * Fv[1 + b][a];
-                for (int d = 0; d < 3; ++d) M[9 * a + 3 * b + d] = P.dx * Fv[4 + 3 * b + d][a];
+                G.Aa[3 * a + b] = P.dx * Fv[1 + b][a];
+                for (int d = 0; d < 3; ++d) G.M[9 * a + 3 * b + d] = P.dx * Fv[4 + 3 * b + d][a];
             }
+            for (int d = 0; d < 3; ++d) G.sv[3 * d + a] = Fv[13 + d][a];
         }
-        for (int d = 0; d < 3; ++d)                    // sc_o = m gm_o + gva_o . (m v)
-            s1[d] = P.p_mass * (Fm[d] + Fv[13 + d][0] * v[0] + Fv[13 + d][1] * v[1] + Fv[13 + d][2] * v[2]);
+        for (int d = 0; d < 3; ++d) G.sm[d] = Fm[d];
     }
+}
+
+template <class T>
+PLB_HD void p2g_finish_grad(const SimP<T>& P, const P2GGather<T>& G, const T* v, const T* C, const T* E, T mu, T lam, T ys,
+                            const T* En_a, T* xa_io, T* va, T* Ca, T* Ea) {
     T Et[9], En[9], stress[9], A[9];
     f_tmp_eform(C, E, P.dt, Et);
     Consti<T> k;
     constitutive_fwd(Et, mu, lam, ys, k, En, stress);
     for (int i = 0; i < 9; ++i) A[i] = P.kappa * stress[i] + P.p_mass * C[i];
+    const T* M = G.M;
+    const T* Aa = G.Aa;
+    for (int a = 0; a < 3; ++a) va[a] = G.va[a];
     T fxa[3];
     for (int d = 0; d < 3; ++d) {
-        T acc = s1[d];
+        // s1[d] = sum_o (m gm_o + gva_o . m v) dw_o/dfx_d
+        T acc = P.p_mass * (G.sm[d] + G.sv[3 * d] * v[0] + G.sv[3 * d + 1] * v[1] + G.sv[3 * d + 2] * v[2]);
         for (int a = 0; a < 3; ++a) {
             for (int b = 0; b < 3; ++b) acc += A[3 * a + b] * M[9 * a + 3 * b + d];
             acc -= P.dx * A[3 * a + d] * va[a] * t_rcp(P.p_mass);       // d/d dp: sum_o w_o A^T gva_o, dp = (k - fx) dx
@@ -658,6 +674,16 @@ PLB_HD void p2g_particle_grad(const SimP<T>& P, const X* x, const T* v, const T*
     for (int i = 0; i < 9; ++i) Ca[i] += P.dt * t1[i];
     mat_mul_tn(C, Fta, t1);
     for (int i = 0; i < 9; ++i) Ea[i] = Fta[i] + P.dt * t1[i];
+}
+
+
+template <class T, class X, class Fetch>
+PLB_HD void p2g_particle_grad(const SimP<T>& P, const X* x, const T* v, const T* C, const T* E,
+                              T mu, T lam, T ys, const T* En_a, T* xa_io, T* va, T* Ca, T* Ea,
+                              Fetch&& fetch) {
+    P2GGather<T> G;
+    p2g_gather_grad<T, X>(P, x, G, fetch);
+    p2g_finish_grad<T>(P, G, v, C, E, mu, lam, ys, En_a, xa_io, va, Ca, Ea);
 }
 
 // mass-only scatter weights for the loss (mpm_simulator.py:382-392) are stencil() + products.

@@ -798,21 +798,8 @@ __global__ __launch_bounds__(kBlock, PLB_P2G_GRAD_WAVES) void k_p2g_grad(Dev<T> 
     const int Np = D.Npad;
     PT_BEGIN();
     const Tile tl = load_tile(D, f, TileCap<T>::nodes);             // stored by the scatter of this frame
-    // every load of this kernel is issued before the first wait: particle state, incoming adjoint, tile
     double x[3] = {0.5, 0.5, 0.5};
-    T v[3] = {T(0), T(0), T(0)}, C[9], E[9], Ena[9], xa[3] = {T(0), T(0), T(0)}, va[3], Ca[9], Ea[9];
-    T mu = T(1), lam = T(1), ys = T(1);
-    const T* A1 = D.adj[src];
-    T* A0 = D.adj[dst];
-    for (int d = 0; d < 9; ++d) { C[d] = T(0); E[d] = T(0); Ena[d] = T(0); }
-    if (valid) {
-        x[0] = X[p]; x[1] = X[Np + p]; x[2] = X[2 * Np + p];
-        for (int d = 0; d < 3; ++d) v[d] = R[d * Np + p];
-        for (int d = 0; d < 9; ++d) { C[d] = R[(3 + d) * Np + p]; E[d] = R[(12 + d) * Np + p]; }
-        for (int d = 0; d < 9; ++d) Ena[d] = A1[(15 + d) * Np + p];
-        for (int d = 0; d < 3; ++d) xa[d] = A0[d * Np + p];
-        mu = D.mu[p]; lam = D.lam[p]; ys = D.ys[p];
-    }
+    if (valid) { x[0] = X[p]; x[1] = X[Np + p]; x[2] = X[2 * Np + p]; }
     const int ex = tl.e[0], exy = tl.e[0] * tl.e[1], tn = exy * tl.e[2];
     if (tl.ok) {
         for (int i = threadIdx.x; i < tn; i += kBlock) {
@@ -825,18 +812,28 @@ __global__ __launch_bounds__(kBlock, PLB_P2G_GRAD_WAVES) void k_p2g_grad(Dev<T> 
     for (int d = 0; d < 3; ++d) base[d] = (int)(x[d] * (double)D.P.inv_dx - 0.5);
     PT_MARK(1);
     if (!valid) return;
+    // the 27-node gather needs the position only: the other 42 words of particle state are fetched after it, so
+    // that they are not live across the loop (the kernel then fits 3 waves per SIMD instead of 2)
+    P2GGather<T> G;
     if (tl.ok) {
         const int ox = base[0] - tl.o[0], oy = base[1] - tl.o[1], oz = base[2] - tl.o[2];
-        p2g_particle_grad<T, double>(D.P, x, v, C, E, mu, lam, ys, Ena, xa, va, Ca, Ea, [&](int i, int j, int l, T* g) {
+        p2g_gather_grad<T, double>(D.P, x, G, [&](int i, int j, int l, T* g) {
             Vec4<T> a = tile[(oz + l) * exy + (oy + j) * ex + (ox + i)];
             g[0] = a.x; g[1] = a.y; g[2] = a.z; g[3] = a.w;
         });
     } else {
-        p2g_particle_grad<T, double>(D.P, x, v, C, E, mu, lam, ys, Ena, xa, va, Ca, Ea, [&](int i, int j, int l, T* g) {
+        p2g_gather_grad<T, double>(D.P, x, G, [&](int i, int j, int l, T* g) {
             Vec4<T> a = D.grid_in_adj[node_index(D.nb, base[0] + i, base[1] + j, base[2] + l)];
             g[0] = a.x; g[1] = a.y; g[2] = a.z; g[3] = a.w;
         });
     }
+    T v[3], C[9], E[9], Ena[9], xa[3], va[3], Ca[9], Ea[9];
+    const T* A1 = D.adj[src];
+    T* A0 = D.adj[dst];
+    for (int d = 0; d < 3; ++d) { v[d] = R[d * Np + p]; xa[d] = A0[d * Np + p]; }
+    for (int d = 0; d < 9; ++d) { C[d] = R[(3 + d) * Np + p]; E[d] = R[(12 + d) * Np + p]; Ena[d] = A1[(15 + d) * Np + p]; }
+    const T mu = D.mu[p], lam = D.lam[p], ys = D.ys[p];
+    p2g_finish_grad<T>(D.P, G, v, C, E, mu, lam, ys, Ena, xa, va, Ca, Ea);
     PT_MARK(2);
     for (int d = 0; d < 3; ++d) { A0[d * Np + p] = xa[d]; A0[(3 + d) * Np + p] = va[d]; }
     for (int d = 0; d < 9; ++d) { A0[(6 + d) * Np + p] = Ca[d]; A0[(15 + d) * Np + p] = Ea[d]; }
