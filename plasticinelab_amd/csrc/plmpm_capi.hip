@@ -264,48 +264,82 @@ __global__ void k_set_action(PrimChainArgs A, ActionArg act, int step, int nsub,
     }
 }
 // forward_kinematics over frames [first, first+n) (primive_base.py:117-121)
+// The chain is serial in the frame index; the pose (and, in reverse, its adjoint) is carried in registers from one
+// frame to the next -- going through memory instead costs a store -> load round trip per frame (~1.5 us each, 39
+// frames per env step).  The per-frame inputs that do not depend on the chain are loaded one frame ahead.
 __global__ void k_fk_chain(PrimChainArgs A, int first, int n, ChainBufs B) {
     int p = threadIdx.x;
     if (p >= A.P) return;
-    double *ppos = B.ppos, *prot = B.prot;
-    const double *pv = B.pv, *pw = B.pw;
+    const size_t a0 = (size_t)first * A.P + p;
+    double pos[3], rot[4], gap = B.pgap[a0];
+    for (int k = 0; k < 3; ++k) pos[k] = B.ppos[a0 * 3 + k];
+    for (int k = 0; k < 4; ++k) rot[k] = B.prot[a0 * 4 + k];
+    double v[3], w[3], gv;
+    for (int k = 0; k < 3; ++k) { v[k] = B.pv[a0 * 3 + k]; w[k] = B.pw[a0 * 3 + k]; }
+    gv = B.pgv[a0];
     for (int s = first; s < first + n; ++s) {
-        size_t a = (size_t)s * A.P + p, b = (size_t)(s + 1) * A.P + p;
+        const size_t b = (size_t)(s + 1) * A.P + p;
+        double vn[3] = {0, 0, 0}, wn[3] = {0, 0, 0}, gvn = 0.0;        // inputs of the next frame, in flight during this one
+        if (s + 1 < first + n) {
+            for (int k = 0; k < 3; ++k) { vn[k] = B.pv[b * 3 + k]; wn[k] = B.pw[b * 3 + k]; }
+            gvn = B.pgv[b];
+        }
+        double pos1[3], rot1[4], gap1 = gap;
         if (A.kin[p] == PLMPM_KIN_CHOPSTICKS)
-            fk_chopsticks_fwd_d(ppos + a * 3, prot + a * 4, pv + a * 3, pw + a * 3, B.pgap[a], B.pgv[a], A.min_gap[p], A.lo[p],
-                                A.hi[p], ppos + b * 3, prot + b * 4, B.pgap + b);
+            fk_chopsticks_fwd_d(pos, rot, v, w, gap, gv, A.min_gap[p], A.lo[p], A.hi[p], pos1, rot1, &gap1);
         else if (A.kin[p] == PLMPM_KIN_ROLLINGPIN)
-            fk_rollingpin_fwd_d(ppos + a * 3, prot + a * 4, pv + a * 3, A.lo[p], A.hi[p], ppos + b * 3, prot + b * 4);
+            fk_rollingpin_fwd_d(pos, rot, v, A.lo[p], A.hi[p], pos1, rot1);
         else
-            fk_fwd_d(ppos + a * 3, prot + a * 4, pv + a * 3, pw + a * 3, A.lo[p], A.hi[p], ppos + b * 3, prot + b * 4);
+            fk_fwd_d(pos, rot, v, w, A.lo[p], A.hi[p], pos1, rot1);
+        for (int k = 0; k < 3; ++k) { B.ppos[b * 3 + k] = pos1[k]; pos[k] = pos1[k]; v[k] = vn[k]; w[k] = wn[k]; }
+        for (int k = 0; k < 4; ++k) { B.prot[b * 4 + k] = rot1[k]; rot[k] = rot1[k]; }
+        if (A.kin[p] == PLMPM_KIN_CHOPSTICKS) B.pgap[b] = gap1;
+        gap = gap1; gv = gvn;
     }
 }
-// forward_kinematics.grad for frames first+n-1..first, then set_velocity.grad for env step `step`
+// forward_kinematics.grad for frames first+n-1..first, then set_velocity.grad for env step `step`.
+// On entry X_a[frame] holds what the contact / loss kernels accumulated; on exit the complete adjoint.
 __global__ void k_fk_chain_grad(PrimChainArgs A, int first, int n, int step, ChainBufs B) {
     int p = threadIdx.x;
     if (p >= A.P || A.action_dim[p] <= 0) return;
-    const double *ppos = B.ppos, *prot = B.prot, *pv = B.pv, *pw = B.pw;
-    double *ppos_a = B.ppos_a, *prot_a = B.prot_a, *pv_a = B.pv_a, *pw_a = B.pw_a, *act_a = B.act_a;
     double va_sum[3] = {0, 0, 0}, wa_sum[3] = {0, 0, 0}, ga_sum = 0.0;
+    const size_t bl = (size_t)(first + n) * A.P + p;
+    double pos1_a[3], rot1_a[4], gap1_a = B.pgap_a[bl];        // complete adjoint of frame s+1, carried
+    for (int k = 0; k < 3; ++k) pos1_a[k] = B.ppos_a[bl * 3 + k];
+    for (int k = 0; k < 4; ++k) rot1_a[k] = B.prot_a[bl * 4 + k];
+    // frame s: pose, velocities and the kernels' share of its adjoint, loaded one frame ahead
+    double pos[3], rot[4], v[3], w[3], gap, gv, own_p[3], own_r[4], own_g;
+    auto load = [&](size_t a, double* P3, double* R4, double* V3, double* W3, double& G, double& GV, double* OP, double* OR, double& OG) {
+        for (int k = 0; k < 3; ++k) { P3[k] = B.ppos[a * 3 + k]; V3[k] = B.pv[a * 3 + k]; W3[k] = B.pw[a * 3 + k]; OP[k] = B.ppos_a[a * 3 + k]; }
+        for (int k = 0; k < 4; ++k) { R4[k] = B.prot[a * 4 + k]; OR[k] = B.prot_a[a * 4 + k]; }
+        G = B.pgap[a]; GV = B.pgv[a]; OG = B.pgap_a[a];
+    };
+    load((size_t)(first + n - 1) * A.P + p, pos, rot, v, w, gap, gv, own_p, own_r, own_g);
     for (int s = first + n - 1; s >= first; --s) {
-        size_t a = (size_t)s * A.P + p, b = (size_t)(s + 1) * A.P + p;
-        double va[3], wa[3] = {0.0, 0.0, 0.0};
+        const size_t a = (size_t)s * A.P + p;
+        double posn[3] = {0, 0, 0}, rotn[4] = {1, 0, 0, 0}, vn[3] = {0, 0, 0}, wn[3] = {0, 0, 0}, gapn = 0, gvn = 0, opn[3] = {0, 0, 0},
+               orn[4] = {0, 0, 0, 0}, ogn = 0;
+        if (s > first) load((size_t)(s - 1) * A.P + p, posn, rotn, vn, wn, gapn, gvn, opn, orn, ogn);
+        double va[3], wa[3] = {0.0, 0.0, 0.0}, pa[3] = {own_p[0], own_p[1], own_p[2]}, ra[4] = {own_r[0], own_r[1], own_r[2], own_r[3]}, ga = own_g;
         if (A.kin[p] == PLMPM_KIN_CHOPSTICKS) {
             double gva = 0.0;
-            fk_chopsticks_bwd_d(ppos + a * 3, prot + a * 4, pv + a * 3, pw + a * 3, B.pgap[a], B.pgv[a], A.min_gap[p], A.lo[p],
-                                A.hi[p], ppos_a + b * 3, prot_a + b * 4, B.pgap_a[b], ppos_a + a * 3, prot_a + a * 4,
-                                B.pgap_a + a, va, wa, &gva);
+            fk_chopsticks_bwd_d(pos, rot, v, w, gap, gv, A.min_gap[p], A.lo[p], A.hi[p], pos1_a, rot1_a, gap1_a, pa, ra, &ga, va, wa, &gva);
             B.pgv_a[a] = gva;
+            B.pgap_a[a] = ga;
             ga_sum += gva;
         } else if (A.kin[p] == PLMPM_KIN_ROLLINGPIN)
-            fk_rollingpin_bwd_d(ppos + a * 3, prot + a * 4, pv + a * 3, A.lo[p], A.hi[p], ppos_a + b * 3, prot_a + b * 4,
-                                ppos_a + a * 3, prot_a + a * 4, va);
+            fk_rollingpin_bwd_d(pos, rot, v, A.lo[p], A.hi[p], pos1_a, rot1_a, pa, ra, va);
         else
-            fk_bwd_d(ppos + a * 3, prot + a * 4, pv + a * 3, pw + a * 3, A.lo[p], A.hi[p], ppos_a + b * 3, prot_a + b * 4,
-                     ppos_a + a * 3, prot_a + a * 4, va, wa);
-        for (int k = 0; k < 3; ++k) { pv_a[a * 3 + k] = va[k]; pw_a[a * 3 + k] = wa[k]; va_sum[k] += va[k]; wa_sum[k] += wa[k]; }
+            fk_bwd_d(pos, rot, v, w, A.lo[p], A.hi[p], pos1_a, rot1_a, pa, ra, va, wa);
+        for (int k = 0; k < 3; ++k) {
+            B.pv_a[a * 3 + k] = va[k]; B.pw_a[a * 3 + k] = wa[k]; va_sum[k] += va[k]; wa_sum[k] += wa[k];
+            B.ppos_a[a * 3 + k] = pa[k]; pos1_a[k] = pa[k];
+            pos[k] = posn[k]; v[k] = vn[k]; w[k] = wn[k]; own_p[k] = opn[k];
+        }
+        for (int k = 0; k < 4; ++k) { B.prot_a[a * 4 + k] = ra[k]; rot1_a[k] = ra[k]; rot[k] = rotn[k]; own_r[k] = orn[k]; }
+        gap1_a = ga; gap = gapn; gv = gvn; own_g = ogn;
     }
-    double* aa = act_a + ((size_t)step * A.P + p) * PLMPM_MAX_ACTION_DIM;
+    double* aa = B.act_a + ((size_t)step * A.P + p) * PLMPM_MAX_ACTION_DIM;
     for (int k = 0; k < 3; ++k) aa[k] += va_sum[k] * A.scale[p][k] / n;
     if (A.action_dim[p] > 3) for (int k = 0; k < 3; ++k) aa[k + 3] += wa_sum[k] * A.scale[p][k + 3] / n;
     if (A.kin[p] == PLMPM_KIN_CHOPSTICKS) aa[6] += ga_sum * A.scale[p][6] / n;
@@ -358,28 +392,44 @@ template <class T> __device__ __forceinline__ PrimT<T> prim_at(const Dev<T>& D, 
     for (int i = 0; i < 4; ++i) p.rot[i] = p.rot1[i] = D.prot[((size_t)f * D.nprim + q) * 4 + i];
     return p;
 }
-// contact distance passes (loss.py:116-135).  mode 0: hard min, 1: soft normaliser, 2: soft weighted sum
+// contact distance passes (loss.py:116-135).  mode 0: hard min, 1: soft normaliser, 2: soft weighted sum.
+// Grid-stride over the particles with a bounded number of workgroups, one result per workgroup and primitive: the
+// partial results all land on the same word, and same-address atomics cost ~5 ns EACH on this chip (one per wave
+// made this kernel 180 us at 500k particles).
+__device__ __forceinline__ double block_min(double v, double* sh) {
+    for (int off = 32; off > 0; off >>= 1) v = fmin(v, __shfl_xor(v, off));
+    int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) sh[w] = v;
+    __syncthreads();
+    double r = sh[0];
+    for (int i = 1; i < (int)(blockDim.x >> 6); ++i) r = fmin(r, sh[i]);
+    __syncthreads();
+    return r;
+}
 template <class T> __global__ void k_contact(Dev<T> D, int f, int mode, double* ls) {
     __shared__ double sh[8];
-    int p = blockIdx.x * blockDim.x + threadIdx.x;
     const double* X = frame_x(D, f);
-    double x[3] = {0, 0, 0};
-    bool valid = p < D.N;
-    if (valid) { x[0] = X[p]; x[1] = X[D.Npad + p]; x[2] = X[2 * D.Npad + p]; }
     for (int q = 0; q < D.nprim; ++q) {
         if (!D.prim[q].movable) continue;
-        PrimT<T> pr = prim_at(D, q, f);
-        double d = valid ? fmax(prim_sdf(pr, x), 0.0) : 0.0;
+        const PrimT<T> pr = prim_at(D, q, f);
+        const double dn = mode == 2 ? ls[LS_DNORM + q] : 1.0;
+        double acc = mode == 0 ? 1e30 : 0.0;
+        for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < D.N; p += gridDim.x * blockDim.x) {
+            const double x[3] = {X[p], X[D.Npad + p], X[2 * D.Npad + p]};
+            const double d = fmax(prim_sdf(pr, x), 0.0);
+            if (mode == 0) acc = fmin(acc, d);
+            else {
+                const double sw = 1.0 / (1.0 + d * d * 10000.0);
+                acc += mode == 1 ? sw : d * sw / dn;
+            }
+        }
         if (mode == 0) {
-            double m = valid ? d : 1e30;
-            for (int off = 32; off > 0; off >>= 1) m = fmin(m, __shfl_xor(m, off));
-            if ((threadIdx.x & 63) == 0)
+            const double m = block_min(acc, sh);
+            // non-negative doubles order like their bit patterns; skip the atomic when it cannot lower the minimum
+            if (threadIdx.x == 0 && m < ls[LS_MIND + q])
                 atomicMin(reinterpret_cast<unsigned long long*>(&ls[LS_MIND + q]), (unsigned long long)__double_as_longlong(m));
         } else {
-            double sw = 1.0 / (1.0 + d * d * 10000.0);
-            double v = 0.0;
-            if (valid) v = mode == 1 ? sw : d * sw / ls[LS_DNORM + q];
-            v = block_sum(v, sh);
+            const double v = block_sum(acc, sh);
             if (threadIdx.x == 0) atomicAdd(&ls[(mode == 1 ? LS_DNORM : LS_MIND) + q], v);
         }
     }
@@ -653,7 +703,7 @@ template <class T> static int loss_contact_pass_t(plmpm_sim* s, int f, int mode)
     Dev<T> D = make_dev<T>(s);
     bool any = false;
     for (int p = 0; p < s->P; ++p) any |= s->prims[p].action_dim > 0;
-    if (any) hipLaunchKernelGGL((k_contact<T>), dim3(s->Npad / 256), dim3(256), 0, s->stream, D, f, mode, s->lscal);
+    if (any) hipLaunchKernelGGL((k_contact<T>), dim3(std::min(s->Npad / 256, 512)), dim3(256), 0, s->stream, D, f, mode, s->lscal);
     return 0;
 }
 static int loss_reset_scalars(plmpm_sim* s) {
@@ -666,7 +716,7 @@ static int loss_reset_scalars(plmpm_sim* s) {
 }
 
 template <class T> static int loss_reduce_t(plmpm_sim* s) {
-    hipLaunchKernelGGL((k_loss_reduce<T>), dim3(1024), dim3(256), 0, s->stream, s->G, s->nb, s->cfg.slab_z0, s->cfg.slab_z1,
+    hipLaunchKernelGGL((k_loss_reduce<T>), dim3(256), dim3(256), 0, s->stream, s->G, s->nb, s->cfg.slab_z0, s->cfg.slab_z1,
                        (const T*)s->loss_gm, (const T*)s->loss_td, (const T*)s->loss_ts, s->lscal);
     return 0;
 }
