@@ -185,6 +185,46 @@ __device__ __forceinline__ int wave_sort_lanes(long long key) {
     return (int)(v & 63);
 }
 
+// 32-bit flavour of the same sort (cell index << 6 | lane fits 32 bits up to n_grid = 256): the 18 exchange steps
+// with a partner inside the 16-lane row are DPP moves (VALU only), only the three cross-row steps go through the LDS
+// crossbar.  The shuffle version spends ~4k cycles of pure latency per wave (42 dependent ds_bpermute round trips,
+// wave trace in profiles/); this one ~1k.
+template <int CTRL> __device__ __forceinline__ unsigned dpp_u32(unsigned v) {
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, true);
+}
+template <int J> __device__ __forceinline__ unsigned partner_xor(unsigned v, int lane) {
+    if (J == 1) return dpp_u32<0xB1>(v);                       // quad_perm [1,0,3,2]
+    if (J == 2) return dpp_u32<0x4E>(v);                       // quad_perm [2,3,0,1]
+    if (J == 4) { unsigned a = dpp_u32<0x124>(v), b = dpp_u32<0x12C>(v); return (lane & 4) ? a : b; }   // row_ror:4 / :12
+    if (J == 8) return dpp_u32<0x128>(v);                      // row_ror:8 == xor 8 inside a row of 16
+    return (unsigned)__shfl_xor((int)v, J);
+}
+template <int K, int J> __device__ __forceinline__ unsigned bitonic_step(unsigned v, int lane) {
+    const unsigned o = partner_xor<J>(v, lane);
+    const unsigned mn = v < o ? v : o, mx = v < o ? o : v;
+    const bool keep_min = ((lane & J) == 0) == ((lane & K) == 0);
+    return keep_min ? mn : mx;
+}
+template <int K> __device__ __forceinline__ unsigned bitonic_merge(unsigned v, int lane) {
+    if (K >= 64) v = bitonic_step<K, 32>(v, lane);
+    if (K >= 32) v = bitonic_step<K, 16>(v, lane);
+    if (K >= 16) v = bitonic_step<K, 8>(v, lane);
+    if (K >= 8) v = bitonic_step<K, 4>(v, lane);
+    if (K >= 4) v = bitonic_step<K, 2>(v, lane);
+    return bitonic_step<K, 1>(v, lane);
+}
+__device__ __forceinline__ int wave_sort_lanes32(unsigned key) {          // key < 2^26
+    const int lane = threadIdx.x & 63;
+    unsigned v = (key << 6) | (unsigned)lane;
+    v = bitonic_merge<2>(v, lane);
+    v = bitonic_merge<4>(v, lane);
+    v = bitonic_merge<8>(v, lane);
+    v = bitonic_merge<16>(v, lane);
+    v = bitonic_merge<32>(v, lane);
+    v = bitonic_merge<64>(v, lane);
+    return (int)(v & 63u);
+}
+
 // Wave-level segmented reduction.  Particles are stored cell-sorted, so lanes that share a stencil base
 // form runs; the 27 x 4 per-particle contributions of a run are summed with shuffles and only the run's
 // head lane touches LDS / HBM atomics (same-address atomics serialise, shuffles do not).
@@ -316,7 +356,8 @@ __device__ __forceinline__ bool sorted_finish(const Dev<T>& D, SortLoad& s, int&
         for (int d = 0; d < 3; ++d) b[d] = (int)(s.x0[d] * (double)D.P.inv_dx - 0.5);
         s.key = ((long long)b[2] * D.P.n + b[1]) * D.P.n + b[0];
     }
-    const int src = wave_sort_lanes(s.key);
+    // padding lanes carry the largest key either way; the 32-bit network needs (cells << 6) to fit
+    const int src = D.P.n <= 256 ? wave_sort_lanes32(p0 < D.N ? (unsigned)s.key : 0x3ffffffu) : wave_sort_lanes(s.key);
     p = (p0 & ~63) + src;
     for (int d = 0; d < 3; ++d) x[d] = __shfl(s.x0[d], src);       // the position travels with the sort
     for (int d = 0; d < 3; ++d) base[d] = (int)(x[d] * (double)D.P.inv_dx - 0.5);
@@ -336,7 +377,7 @@ __device__ __forceinline__ bool load_sorted_particle(const Dev<T>& D, const doub
         for (int d = 0; d < 3; ++d) { x0[d] = X[d * Np + p0]; b[d] = (int)(x0[d] * (double)D.P.inv_dx - 0.5); }
         key = ((long long)b[2] * D.P.n + b[1]) * D.P.n + b[0];
     }
-    const int src = wave_sort_lanes(key);
+    const int src = D.P.n <= 256 ? wave_sort_lanes32(p0 < D.N ? (unsigned)key : 0x3ffffffu) : wave_sort_lanes(key);
     p = (p0 & ~63) + src;
     // the position travels with the sort (shuffles) instead of a second, dependent trip to memory
     for (int d = 0; d < 3; ++d) x[d] = __shfl(x0[d], src);
