@@ -153,14 +153,19 @@ struct Tile {
     int ok;        // fits in the LDS tile
 };
 
-__device__ __forceinline__ int wave_min(int v) {
-    for (int off = 32; off > 0; off >>= 1) v = min(v, __shfl_xor(v, off));
-    return v;
+// wave-wide min / max of an int: DPP scan inside the rows, row_bcast to chain the rows, result read from lane 63
+// (six VALU steps instead of six dependent trips through the LDS crossbar)
+template <bool MAX> __device__ __forceinline__ int wave_minmax(int v) {
+#define PLB_MM(ctrl, rowmask)                                                                      \
+    { int o = __builtin_amdgcn_update_dpp(v, v, ctrl, rowmask, 0xf, false); v = MAX ? max(v, o) : min(v, o); }
+    PLB_MM(0x111, 0xf) PLB_MM(0x112, 0xf) PLB_MM(0x114, 0xf) PLB_MM(0x118, 0xf)      // row_shr 1, 2, 4, 8: lane 15 of each row is complete
+    PLB_MM(0x142, 0xa)                                                                   // row_bcast:15 -> rows 1, 3
+    PLB_MM(0x143, 0xc)                                                                   // row_bcast:31 -> rows 2, 3
+#undef PLB_MM
+    return __builtin_amdgcn_readlane(v, 63);
 }
-__device__ __forceinline__ int wave_max(int v) {
-    for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off));
-    return v;
-}
+__device__ __forceinline__ int wave_min(int v) { return wave_minmax<false>(v); }
+__device__ __forceinline__ int wave_max(int v) { return wave_minmax<true>(v); }
 
 // Wave-local reassignment of particles to lanes so that particles sharing a stencil base sit in adjacent lanes
 // (bitonic sort of (cell key, lane) over the 64 lanes).  The storage order is only sorted at episode reset; as
