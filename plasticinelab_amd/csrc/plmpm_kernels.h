@@ -164,6 +164,22 @@ template <bool MAX> __device__ __forceinline__ int wave_minmax(int v) {
 #undef PLB_MM
     return __builtin_amdgcn_readlane(v, 63);
 }
+// wave-wide sum of a double, complete in lane 63: same six DPP steps (each half of the double moved separately)
+template <int CTRL, int ROWMASK> __device__ __forceinline__ double dpp_move_f64(double v) {
+    long long b = __builtin_bit_cast(long long, v);
+    int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffLL), CTRL, ROWMASK, 0xf, true);
+    int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, ROWMASK, 0xf, true);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ double wave_sum_to_lane63(double v) {
+    v += dpp_move_f64<0x111, 0xf>(v);
+    v += dpp_move_f64<0x112, 0xf>(v);
+    v += dpp_move_f64<0x114, 0xf>(v);
+    v += dpp_move_f64<0x118, 0xf>(v);
+    v += dpp_move_f64<0x142, 0xa>(v);
+    v += dpp_move_f64<0x143, 0xc>(v);
+    return v;
+}
 __device__ __forceinline__ int wave_min(int v) { return wave_minmax<false>(v); }
 __device__ __forceinline__ int wave_max(int v) { return wave_minmax<true>(v); }
 
@@ -790,7 +806,7 @@ __global__ __launch_bounds__(kBlock) void k_grid_op_grad(Dev<T> D, int f) {
         const bool owned = I[2] >= D.z0 && I[2] < D.z1;     // halo nodes are computed on two ranks: count once
         grid_node_bwd<T>(D.P, I, gm, mv, D.nprim, sp, va, &ma, mva, [&](int q, const PoseAdj<T>& pa, bool hit) {
             // every lane of the wave gets here for every primitive: sum the 15 pose-adjoint components across the
-            // wave with shuffles and let one lane touch LDS (64 lanes hitting the same 14 addresses with
+            // wave (DPP scans) and let one lane touch LDS (64 lanes hitting the same 14 addresses with
             // ds_add_f64 serialise badly)
             const bool h = hit && owned;
             if (!__any(h)) return;
