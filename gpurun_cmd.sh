@@ -1,4 +1,2 @@
 cd /root/repo
-bash exp_libs/run.sh dppmm gogdpp
-cp exp_libs/gogdpp.so plasticinelab_amd/libplmpm.so
-python -m pytest tests -m gpu -x -q 2>&1 | tail -3
+python -m pytest tests/test_gpu_policy.py -m gpu -x -q 2>&1 | tail -15

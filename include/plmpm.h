@@ -155,6 +155,9 @@ int plmpm_add_frame_grad(plmpm_handle h, int frame, const double* xa, const doub
 int plmpm_get_frame_grad(plmpm_handle h, int frame, double* xa, double* va, double* Fa, double* Ca);
 /* primitive pose adjoints position.grad[f], rotation.grad[f], gap.grad[f] (8 doubles) */
 int plmpm_get_primitive_grad(plmpm_handle h, int prim, int frame, double* grad8);
+/* position.grad[f] / rotation.grad[f] / gap.grad[f] += grad8: lets an outer program differentiate through an
+ * observation of the manipulator poses (the Taichi MLP's input_primitives kernel, plb/engine/nn/mlp.py:75-84) */
+int plmpm_add_primitive_grad(plmpm_handle h, int prim, int frame, const double* grad8);
 
 /* ---- loss (Loss, loss.py) ------------------------------------------------------------------ */
 /* Loss.load_target_density + update_target (loss.py:46-57,81-106): density is (n,n,n) float64, [i][j][k] */

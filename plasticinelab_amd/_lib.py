@@ -69,6 +69,7 @@ SYMBOLS = {
     "plmpm_add_frame_grad": (_I, [_P, _I, _P, _P, _P, _P]),
     "plmpm_get_frame_grad": (_I, [_P, _I, _P, _P, _P, _P]),
     "plmpm_get_primitive_grad": (_I, [_P, _I, _I, _P]),
+    "plmpm_add_primitive_grad": (_I, [_P, _I, _I, _P]),
     "plmpm_loss_set_target": (_I, [_P, _P]),
     "plmpm_loss_set_weights": (_I, [_P, _D, _D, _D, _I]),
     "plmpm_loss_forward": (_I, [_P, _I, _P]),

@@ -1009,6 +1009,21 @@ int plmpm_get_primitive_grad(plmpm_handle s, int prim, int frame, double* g) {
     HIPCHK(hipStreamSynchronize(s->stream));
     return 0;
 }
+__global__ void k_add_doubles(double* dst, double a0, double a1, double a2, double a3, int n) {
+    const double a[4] = {a0, a1, a2, a3};
+    if ((int)threadIdx.x < n) dst[threadIdx.x] += a[threadIdx.x];
+}
+int plmpm_add_primitive_grad(plmpm_handle s, int prim, int frame, const double* g) {
+    NEED_BOUND(s);
+    NEED_FRAME(s, frame);
+    REQUIRE(prim >= 0 && prim < s->P && g, "bad primitive index");
+    const size_t a = (size_t)frame * s->P + prim;
+    hipLaunchKernelGGL(k_add_doubles, dim3(1), dim3(4), 0, s->stream, s->ppos_a + a * 3, g[0], g[1], g[2], 0.0, 3);
+    hipLaunchKernelGGL(k_add_doubles, dim3(1), dim3(4), 0, s->stream, s->prot_a + a * 4, g[3], g[4], g[5], g[6], 4);
+    hipLaunchKernelGGL(k_add_doubles, dim3(1), dim3(4), 0, s->stream, s->pgap_a + a, g[7], 0.0, 0.0, 0.0, 1);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
 int plmpm_set_softness(plmpm_handle s, double softness) {
     REQUIRE(s, "null handle");
     s->softness = softness;

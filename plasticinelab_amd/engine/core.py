@@ -135,6 +135,12 @@ class Engine:
         L.check(self.lib.plmpm_get_primitive_grad(self.h, prim, f, _ptr(s)))
         return s
 
+    def add_primitive_grad(self, prim, f, grad8):
+        g = np.zeros(8)
+        a = np.asarray(grad8, np.float64).reshape(-1)
+        g[:len(a)] = a
+        L.check(self.lib.plmpm_add_primitive_grad(self.h, prim, f, _ptr(g)))
+
     def set_softness(self, softness):
         L.check(self.lib.plmpm_set_softness(self.h, float(softness)))
 

@@ -88,9 +88,14 @@ class Tape:
     replays their adjoints in reverse -- compute_loss_kernel_grad, the substep_grad's of the
     step, forward_kinematics.grad, set_velocity.grad -- with d(loss) = 1."""
 
-    def __init__(self, env: TaichiEnv):
+    def __init__(self, env: TaichiEnv, after_step_grad=None):
         self.env = env
         self.events = []
+        # optional hook ``after_step_grad(step, first_frame)``, called in the reverse sweep right after the adjoint
+        # of an env step: the adjoint of that step's first frame is resident and d loss / d action[step] is final,
+        # so a policy that produced action[step] from an observation of that frame can push its gradient back in
+        # (Engine.add_frame_grad / add_primitive_grad) -- see optimizer/solver_nn.py
+        self.after_step_grad = after_step_grad
 
     def __enter__(self):
         assert not self.env._is_copy, "gradients need tape mode: set_state(..., is_copy=False)"
@@ -116,4 +121,6 @@ class Tape:
                 self.env.loss.compute_loss_kernel_grad(ev[1])
             else:
                 sim.step_grad(ev[1], ev[2])
+                if self.after_step_grad is not None:
+                    self.after_step_grad(ev[2], ev[1])
         return False
