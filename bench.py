@@ -43,6 +43,10 @@ ALG = {
     "g2p_p2g": (51, 7),        # g2p(f-1) + p2g(f) fused
 }
 HBM_PEAK_GBS = 8000.0          # MI355X spec (MI355X_MICROARCH.md); measured copy peak there: 6290 GB/s
+# HBM bytes per launch of the dominant kernel (k_g2p_p2g) on the DEFAULT workload, from the rocprofv3 PMC passes of this
+# very command committed as profiles/r01_pmc.txt: 2 x FETCH_SIZE (gfx950 correction of MI355X_MICROARCH.md, HBM
+# section) + WRITE_SIZE = 2 x 24 315.7 KB + 85 742.2 KB.  Reported as roofline.traffic only for that workload.
+PMC_TRAFFIC_BYTES = {"g2p_p2g": 2 * 24315.7e3 + 85742.2e3}
 
 
 def workload_cfg(n_particles=500_000, quality=2, max_steps=1024):
@@ -272,7 +276,9 @@ def main():
         alg_substep = 4.0 * (150 * N + 57 * nodes)
         sum_us = sum(v["avg_us"] * v["launches"] for v in kernels.values()) / (K * sub)     # per fwd+bwd substep
         out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": kernels[dom]["GBps"], "peak": HBM_PEAK_GBS,
-                           "unit": "GB/s", "frac": kernels[dom]["GBps"] / HBM_PEAK_GBS, "traffic": None,
+                           "unit": "GB/s", "frac": kernels[dom]["GBps"] / HBM_PEAK_GBS,
+                           "traffic": (PMC_TRAFFIC_BYTES.get(dom) if (args.particles, args.quality, args.dtype) == (500_000, 2, "float32") else None),
+                           "traffic_unit": "bytes per launch (profiles/r01_pmc.txt)", "algorithmic_bytes": kernels[dom]["alg_MB"] * 1e6,
                            "active_nodes": nodes, "active_blocks": blocks,
                            "substep_alg_MB": alg_substep * 1e-6,
                            "substep_kernel_sum_us": sum_us,
