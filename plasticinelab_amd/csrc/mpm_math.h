@@ -24,10 +24,34 @@
 #if defined(__HIPCC__)
 #define PLB_HD __host__ __device__ __forceinline__
 #define PLB_ROLL _Pragma("unroll 1")
+#ifndef PLB_ROLL_G2PG_I
+#define PLB_ROLL_G2PG_I PLB_ROLL
+#endif
+#ifndef PLB_ROLL_G2PG_J
+#define PLB_ROLL_G2PG_J                 // measured: unrolling j (9 nodes per iteration) helps the reverse loops a little,
+#endif                                  // unrolling i as well costs registers and is slower
+#ifndef PLB_ROLL_P2G_I
+#define PLB_ROLL_P2G_I PLB_ROLL
+#endif
+#ifndef PLB_ROLL_G2P_I
+#define PLB_ROLL_G2P_I PLB_ROLL
+#endif
+#ifndef PLB_ROLL_GATH_I
+#define PLB_ROLL_GATH_I PLB_ROLL
+#endif
+#ifndef PLB_ROLL_GATH_J
+#define PLB_ROLL_GATH_J
+#endif
 #define PLB_UNROLL _Pragma("unroll")
 #else
 #define PLB_HD inline
 #define PLB_ROLL
+#define PLB_ROLL_G2PG_I
+#define PLB_ROLL_G2PG_J
+#define PLB_ROLL_GATH_I
+#define PLB_ROLL_GATH_J
+#define PLB_ROLL_P2G_I
+#define PLB_ROLL_G2P_I
 #define PLB_UNROLL
 #endif
 
@@ -442,7 +466,7 @@ PLB_HD void p2g_particle(const SimP<T>& P, const X* x, const T* v, const T* C, c
         ax[a] = A[3 * a] * P.dx; ay[a] = A[3 * a + 1] * P.dx; az[a] = A[3 * a + 2] * P.dx;
         q0[a] = P.p_mass * v[a] - (ax[a] * fx[0] + ay[a] * fx[1] + az[a] * fx[2]);
     }
-    PLB_ROLL
+    PLB_ROLL_P2G_I
     for (int i = 0; i < 3; ++i) {
         const T wi = sel3(i, w[0][0], w[1][0], w[2][0]);
         const T fi = T(i);
@@ -467,7 +491,7 @@ PLB_HD void g2p_particle(const SimP<T>& P, const X* x, X* xn, T* vn, T* Cn, Fetc
     stencil<T, X>(x, P.inv_dx, base, fx, w, nullptr);
     for (int a = 0; a < 3; ++a) vn[a] = T(0);
     for (int a = 0; a < 9; ++a) Cn[a] = T(0);
-    PLB_ROLL
+    PLB_ROLL_G2P_I
     for (int i = 0; i < 3; ++i) {
         const T wi = sel3(i, w[0][0], w[1][0], w[2][0]);
         for (int j = 0; j < 3; ++j)
@@ -520,12 +544,12 @@ PLB_HD void g2p_particle_grad(const SimP<T>& P, const X* x, const T* vn, const T
         for (int b = 0; b < 3; ++b) fxa[b] -= vn[a] * tc[3 * a + b];
     }
     T ti[3] = {t0[0], t0[1], t0[2]};
-    PLB_ROLL
+    PLB_ROLL_G2PG_I
     for (int i = 0; i < 3; ++i) {
         const T wi = sel3(i, w[0][0], w[1][0], w[2][0]);
         const T dwi = sel3(i, dw[0][0], dw[1][0], dw[2][0]);
         T tj[3] = {ti[0], ti[1], ti[2]};
-        PLB_ROLL
+        PLB_ROLL_G2PG_J
         for (int j = 0; j < 3; ++j) {
             const T wj = sel3(j, w[0][1], w[1][1], w[2][1]);
             const T dwj = sel3(j, dw[0][1], dw[1][1], dw[2][1]);
@@ -595,12 +619,12 @@ PLB_HD void p2g_gather_grad(const SimP<T>& P, const X* x, P2GGather<T>& G, Fetch
         T Fv[16][3], Fm[3];                            // final sums: vector field, mass field
         for (int c = 0; c < 16; ++c) Fv[c][0] = Fv[c][1] = Fv[c][2] = T(0);
         Fm[0] = Fm[1] = Fm[2] = T(0);
-        PLB_ROLL
+        PLB_ROLL_GATH_I
         for (int i = 0; i < 3; ++i) {
             T Sv[9][3], Sm[3];                         // sums over (j, l) for this i
             for (int q = 0; q < 9; ++q) Sv[q][0] = Sv[q][1] = Sv[q][2] = T(0);
             Sm[0] = Sm[1] = Sm[2] = T(0);
-            PLB_ROLL
+            PLB_ROLL_GATH_J
             for (int j = 0; j < 3; ++j) {
                 T Rv[4][3], Rm[2];                     // sums over l for this (i, j)
                 for (int t = 0; t < 4; ++t) Rv[t][0] = Rv[t][1] = Rv[t][2] = T(0);
