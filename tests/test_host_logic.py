@@ -98,3 +98,96 @@ def test_tape_replays_in_reverse():
     assert calls == [("grad_begin", 57), ("loss_backward", 57), ("step_grad", 38, 2), ("loss_backward", 38),
                      ("step_grad", 19, 1), ("loss_backward", 19), ("step_grad", 0, 0)]
     assert env.loss.loss == 3.0
+
+
+def test_solver_nn_observation_layout_and_hook_order():
+    """SolverNN host logic on a stub engine: observation layout of plb/engine/nn/mlp.py:63-84 (every obs_step-th
+    particle: x then velocity_weight * v; then 7 pose numbers per manipulator), the clamp of mlp.py:98, and the order
+    in which the reverse sweep pushes the observation adjoint back (right after the adjoint of each env step)."""
+    import torch
+    from plasticinelab_amd.engine.taichi_env import TaichiEnv
+    from plasticinelab_amd.engine.losses import Loss
+    from plasticinelab_amd.optimizer.solver_nn import SolverNN
+    N, A = 40, 6
+    log = []
+
+    class Eng:
+        action_dims = [3, 3]
+
+        def get_frame(self, f, want=("x", "v")):
+            x = np.arange(N * 3, dtype=float).reshape(N, 3) + 1000 * f
+            return {"x": x, "v": -x}
+
+        def get_action_grad(self, n):
+            return np.arange(n * A, dtype=float).reshape(n, A) + 1.0
+
+        def add_frame_grad(self, f, xa=None, va=None, Fa=None, Ca=None):
+            log.append(("frame_grad", f, np.flatnonzero(np.abs(xa).sum(1) + np.abs(va).sum(1)).tolist()))
+
+        def add_primitive_grad(self, i, f, g):
+            log.append(("prim_grad", i, f, len(g)))
+
+        def loss_forward(self, f):
+            return dict(loss=1.0, sdf_loss=0.1, density_loss=0.2, contact_loss=0.3, iou=0.5)
+
+        def __getattr__(self, name):
+            return lambda *a, **k: log.append((name,) + a)
+
+    class Prim:
+        action_dim = 3
+
+        def get_state(self, f):
+            return np.full(7, 0.5)
+
+    class Prims(list):
+        action_dim = A
+
+        def get_softness(self):
+            return 666.0
+
+        def set_softness(self, s):
+            pass
+
+    class Sim:
+        substeps, cur, res, n_grid, dx, dim, n_particles = 19, 0, (64,) * 3, 64, 1 / 64, 3, N
+
+        def __init__(self):
+            self.engine = Eng()
+            self.primitives = Prims([Prim(), Prim()])
+
+        def set_state(self, f, state):
+            self.cur = 0
+
+        def step(self, is_copy, action=None):
+            log.append(("step", self.cur, np.round(np.asarray(action), 6).tolist()))
+            self.cur += self.substeps
+
+        def grad_begin(self, f):
+            log.append(("grad_begin", f))
+
+        def step_grad(self, first, step):
+            log.append(("step_grad", first, step))
+
+    env = TaichiEnv.__new__(TaichiEnv)
+    env.simulator = Sim()
+    env.primitives = env.simulator.primitives
+    env.loss = Loss(type("C", (), {})(), env.simulator)
+    env._is_copy, env._tape = False, None
+    policy = torch.nn.Linear(10 * 6 + 14, A)
+    with torch.no_grad():
+        policy.weight.zero_()
+        policy.bias.copy_(torch.tensor([2.0, -3.0, 0.25, 0.0, 0.5, -0.5]))
+    solver = SolverNN(env, policy, horizon=2, n_observed_particles=10, velocity_weight=0.5)
+    assert solver.obs.obs_step == 4 and solver.obs.dim == 74
+    o = solver.obs.read(19)
+    assert o[:6].tolist() == [19000.0, 19001.0, 19002.0, -9500.0, -9500.5, -9501.0]          # particle 0: x, 0.5 v
+    assert o[6:9].tolist() == [19012.0, 19013.0, 19014.0] and o[60:].tolist() == [0.5] * 14     # particle 4; two poses
+    loss, grad = solver.forward(None)
+    assert loss == 2.0 and grad.shape == (74 * A + A,)
+    steps = [e for e in log if e[0] == "step"]
+    assert steps[0][2] == [1.0, -1.0, 0.25, 0.0, 0.5, -0.5]                                     # clamped to [-1, 1]
+    order = [e[:3] for e in log if e[0] in ("step_grad", "frame_grad", "prim_grad")]
+    assert order == [("step_grad", 19, 1), ("frame_grad", 19, []), ("prim_grad", 0, 19), ("prim_grad", 1, 19),
+                     ("step_grad", 0, 0), ("frame_grad", 0, []), ("prim_grad", 0, 0), ("prim_grad", 1, 0)]
+    # bias gradient = sum over steps of d loss / d action, gated by the clamp (components 0 and 1 are saturated)
+    assert np.allclose(grad[-A:], [0.0, 0.0, 3 + 9, 4 + 10, 5 + 11, 6 + 12])
