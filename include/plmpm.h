@@ -66,6 +66,12 @@ typedef struct plmpm_config {
      * migration yet): a particle whose stencil leaves [slab_z0 - slab_halo, slab_z1 + slab_halo) raises
      * PLMPM_ERR_HALO in plmpm_check_error.  0 on a single GPU. */
     int32_t slab_halo;
+    /* R > 0: every R-th env step, plmpm_step first re-sorts the particles of the step's first frame along the Hilbert
+     * curve of their cells (device radix sort + one gather pass, ~0.2 ms) -- the north star's "particles sorted by
+     * cell", kept true as the material flows; the storage order then changes every R env steps, state / gradient
+     * I/O stays in caller order and the reverse sweep converts the adjoint frame at those boundaries.  Single-GPU
+     * engines only (ignored for slabs).  0: the order chosen at reset is kept for the whole episode. */
+    int32_t resort_steps;
 } plmpm_config;
 
 /* One rigid manipulator; mirrors Primitive.default_config + per-shape params
@@ -118,6 +124,8 @@ int plmpm_copy_frame(plmpm_handle h, int source, int target);
  * 8 doubles = position(3) + rotation(4) + gap(1); the gap slot is carried but unused by the other shapes */
 int plmpm_set_primitive_state(plmpm_handle h, int prim, int frame, const double* state8);
 int plmpm_get_primitive_state(plmpm_handle h, int prim, int frame, double* state8);
+/* switch the per-env-step re-sort of cfg.resort_steps off / on at run time (segment-checkpointed runs keep one order) */
+int plmpm_set_resort(plmpm_handle h, int on);
 /* Primitives.set_softness (primitives.py:303-305) */
 int plmpm_set_softness(plmpm_handle h, double softness);
 

@@ -26,7 +26,7 @@ class Config(C.Structure):
                 ("dt", C.c_double), ("p_vol", C.c_double), ("p_mass", C.c_double),
                 ("gravity", C.c_double * 3), ("ground_friction", C.c_double),
                 ("svd_grad_clamp", C.c_double), ("slab_z0", C.c_int32), ("slab_z1", C.c_int32),
-                ("store_grid", C.c_int32), ("slab_halo", C.c_int32)]
+                ("store_grid", C.c_int32), ("slab_halo", C.c_int32), ("resort_steps", C.c_int32)]
 
 
 class Primitive(C.Structure):
@@ -68,6 +68,7 @@ SYMBOLS = {
     "plmpm_segment_carry": (_I, [_P, _I, _I]),
     "plmpm_add_frame_grad": (_I, [_P, _I, _P, _P, _P, _P]),
     "plmpm_get_frame_grad": (_I, [_P, _I, _P, _P, _P, _P]),
+    "plmpm_set_resort": (_I, [_P, _I]),
     "plmpm_get_primitive_grad": (_I, [_P, _I, _I, _P]),
     "plmpm_add_primitive_grad": (_I, [_P, _I, _I, _P]),
     "plmpm_loss_set_target": (_I, [_P, _P]),

@@ -14,6 +14,11 @@
 #include "../../include/plmpm.h"
 #include "plmpm_kernels.h"
 
+// plmpm_sort.hip
+extern "C" size_t plmpm_sort_temp_bytes(int n);
+extern "C" int plmpm_sort_pairs(void* tmp, size_t bytes, const unsigned* kin, unsigned* kout, const int* vin, int* vout, int n, int key_bits,
+                                void* stream);
+
 using namespace plb;
 
 static thread_local std::string g_err;
@@ -76,6 +81,25 @@ struct plmpm_sim {
     char* vstore = nullptr;      // grid_v_out per frame (AoS T4)
     int* fstore = nullptr;
     int* tiles = nullptr;        // per-frame stencil boxes of the particle workgroups: [(F+1)][Npad/256][8]
+    // Per-env-step storage order ("epochs").  Epoch 0 is the order chosen at reset (perm_d).  With cfg.resort_steps,
+    // plmpm_step re-sorts the step's first frame along the Hilbert curve before it starts (epoch = step index); the
+    // frames a step writes are in its epoch.  The reverse sweep converts the adjoint frame between epochs at the
+    // step boundaries and reads v of the (re-sorted) boundary frame from the copy kept in the old order.
+    bool resort = false;
+    bool prof_no_resort = false;          // plmpm_set_resort(0): keep the current order (segment-checkpointed runs)
+    int n_epochs = 1;
+    int* perm_store = nullptr;            // [n_epochs - 1][Npad]: storage slot -> caller index, epochs 1..
+    char* vend = nullptr;                 // [n_epochs][3 Npad] T: v of the frame that epoch e re-sorted, in the OLD order
+    double* mats_master = nullptr;        // mu, lam, ys in caller order
+    bool have_mats = false;
+    unsigned *skey[2] = {nullptr, nullptr};
+    int* sidx[2] = {nullptr, nullptr};
+    void* sort_tmp = nullptr;
+    size_t sort_tmp_bytes = 0;
+    char* frame_tmp = nullptr;
+    std::vector<int> frame_epoch;
+    int mats_epoch = 0;
+    int adj_epoch[2] = {0, 0};
     size_t gstride = 0;
     std::vector<char> dirty;          // frame f holds a scattered grid that has not been consumed/cleared
     // optional per-kernel timing with HIP events on the launch stream (plmpm_profile_*)
@@ -595,11 +619,13 @@ template <class T> static int substep_fwd(plmpm_sim* s, int f) {
 template <class T> static int substep_bwd(plmpm_sim* s, int f) {
     Dev<T> D = make_dev<T>(s, f);
     const int src = (f + 1) & 1, dst = f & 1;
+    // frame f+1 re-sorted by the env step that starts there: its v in THIS frame's order was kept aside
+    const T* vnext = s->frame_epoch[f + 1] != s->frame_epoch[f] ? (const T*)(s->vend + (size_t)s->frame_epoch[f + 1] * 3 * s->Npad * s->tsz) : nullptr;
     if (!(s->store && s->dirty[f])) {        // this frame's grid is not resident: recompute it (mpm_simulator.py:265-268)
         LAUNCH(s, K_P2G_RE, (k_p2g<T, false>), dim3(nblocks_particles(s)), D, f);
         LAUNCH(s, K_GRID_OP_RE, (k_grid_op<T, false>), dim3(nwg_grid(s)), D, f);
     }
-    LAUNCH(s, K_G2P_GRAD, (k_g2p_grad<T>), dim3(nblocks_particles(s)), D, f, src, dst);
+    LAUNCH(s, K_G2P_GRAD, (k_g2p_grad<T>), dim3(nblocks_particles(s)), D, f, src, dst, vnext);
     LAUNCH(s, K_GRID_OP_GRAD, (k_grid_op_grad<T>), dim3(nwg_grid(s)), D, f);
     LAUNCH(s, K_P2G_GRAD, (k_p2g_grad<T>), dim3(nblocks_particles(s)), D, f, src, dst);
     if (s->store) s->dirty[f] = 0;           // k_grid_op_grad left grid_in / flags of this frame clean
@@ -642,7 +668,7 @@ template <class T> static int phase_grid_g2p(plmpm_sim* s, int f) {
 }
 template <class T> static int phase_grad_scatter(plmpm_sim* s, int f) {
     Dev<T> D = make_dev<T>(s, f);
-    LAUNCH(s, K_G2P_GRAD, (k_g2p_grad<T>), dim3(nblocks_particles(s)), D, f, (f + 1) & 1, f & 1);
+    LAUNCH(s, K_G2P_GRAD, (k_g2p_grad<T>), dim3(nblocks_particles(s)), D, f, (f + 1) & 1, f & 1, (const T*)nullptr);
     return 0;
 }
 template <class T> static int phase_grad_gather(plmpm_sim* s, int f) {
@@ -657,27 +683,104 @@ template <class T> static int phase_grad_gather(plmpm_sim* s, int f) {
 #define DISPATCH(s, fn, ...) ((s)->cfg.dtype == PLMPM_F64 ? fn<double>(__VA_ARGS__) : fn<float>(__VA_ARGS__))
 
 // ---------------------------------------------------------------------------------------------
-template <class T> static int set_materials_t(plmpm_sim* s) {
+static int* perm_of(const plmpm_sim* s, int epoch) { return epoch <= 0 ? s->perm_d : s->perm_store + (size_t)(epoch - 1) * s->Npad; }
+// material arrays in the storage order of `epoch`, from the caller-order master copy
+template <class T> static int set_materials_t(plmpm_sim* s, int epoch) {
     Dev<T> D = make_dev<T>(s);
-    hipLaunchKernelGGL((k_set_mats<T>), dim3(s->Npad / 256), dim3(256), 0, s->stream, D, s->staging, s->perm_d);
+    hipLaunchKernelGGL((k_set_mats<T>), dim3(s->Npad / 256), dim3(256), 0, s->stream, D, s->mats_master, perm_of(s, epoch));
+    s->mats_epoch = epoch;
     return 0;
 }
 
 template <class T> static int unpack_t(plmpm_sim* s, int f, int hx, int hv, int hF, int hC) {
     Dev<T> D = make_dev<T>(s);
-    hipLaunchKernelGGL((k_unpack_frame<T>), dim3(s->Npad / 256), dim3(256), 0, s->stream, D, f, s->staging, s->perm_d, hx, hv, hF, hC);
+    hipLaunchKernelGGL((k_unpack_frame<T>), dim3(s->Npad / 256), dim3(256), 0, s->stream, D, f, s->staging, perm_of(s, s->frame_epoch[f]), hx, hv, hF, hC);
     return 0;
 }
 
 template <class T> static int pack_t(plmpm_sim* s, int f) {
     Dev<T> D = make_dev<T>(s);
-    hipLaunchKernelGGL((k_pack_frame<T>), dim3(s->Npad / 256), dim3(256), 0, s->stream, D, f, s->staging, s->perm_d);
+    hipLaunchKernelGGL((k_pack_frame<T>), dim3(s->Npad / 256), dim3(256), 0, s->stream, D, f, s->staging, perm_of(s, s->frame_epoch[f]));
     return 0;
 }
 
-template <class T> static int adj_io_t(plmpm_sim* s, int which, int add, int hx, int hv, int hF, int hC) {
+template <class T> static int adj_io_t(plmpm_sim* s, int which, int add, int hx, int hv, int hF, int hC, int epoch = -1) {
     Dev<T> D = make_dev<T>(s);
-    hipLaunchKernelGGL((k_adj_io<T>), dim3(s->Npad / 256), dim3(256), 0, s->stream, D, which, s->staging, s->perm_d, add, hx, hv, hF, hC);
+    if (epoch < 0) epoch = s->adj_epoch[which];
+    hipLaunchKernelGGL((k_adj_io<T>), dim3(s->Npad / 256), dim3(256), 0, s->stream, D, which, s->staging, perm_of(s, epoch), add, hx, hv, hF, hC);
+    return 0;
+}
+
+// ---- per-env-step re-sort ------------------------------------------------------------------------------------------
+// Hilbert key of every storage slot of frame f (padding slots sort last and, the sort being stable, stay in place)
+__device__ __forceinline__ unsigned hilbert_key_dev(unsigned x0, unsigned x1, unsigned x2, int bits) {
+    unsigned X[3] = {x0, x1, x2};
+    const unsigned M = 1u << (bits - 1);
+    for (unsigned Q = M; Q > 1; Q >>= 1) {
+        const unsigned P = Q - 1;
+        for (int i = 0; i < 3; ++i) {
+            if (X[i] & Q) X[0] ^= P;
+            else { unsigned t = (X[0] ^ X[i]) & P; X[0] ^= t; X[i] ^= t; }
+        }
+    }
+    for (int i = 1; i < 3; ++i) X[i] ^= X[i - 1];
+    unsigned t = 0;
+    for (unsigned Q = M; Q > 1; Q >>= 1) if (X[2] & Q) t ^= Q - 1;
+    for (int i = 0; i < 3; ++i) X[i] ^= t;
+    unsigned h = 0;
+    for (int bit = bits - 1; bit >= 0; --bit)
+        for (int i = 0; i < 3; ++i) h = (h << 1) | ((X[i] >> bit) & 1u);
+    return h;
+}
+template <class T> __global__ void k_hilbert_keys(Dev<T> D, int f, int bits, unsigned* keys, int* idx) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= D.Npad) return;
+    idx[i] = i;
+    if (i >= D.N) { keys[i] = 1u << (3 * bits); return; }          // one past the largest cell key: padding sorts last
+    const double* X = frame_x(D, f);
+    int b[3];
+    for (int d = 0; d < 3; ++d) {
+        b[d] = (int)(X[d * D.Npad + i] * (double)D.P.inv_dx - 0.5);
+        b[d] = min(max(b[d], 0), D.P.n - 1);
+    }
+    keys[i] = hilbert_key_dev((unsigned)b[0], (unsigned)b[1], (unsigned)b[2], bits);
+}
+// frame f gathered through `order` (new slot i <- old slot order[i]) into `out`; v of the old frame kept in `vend`
+template <class T> __global__ void k_permute_frame(Dev<T> D, int f, const int* order, char* out, T* vend, const int* perm_old, int* perm_new) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= D.Npad) return;
+    const int Np = D.Npad, j = order[i];
+    const double* X = frame_x(D, f);
+    const T* R = frame_r(D, f);
+    double* Xo = reinterpret_cast<double*>(out);
+    T* Ro = reinterpret_cast<T*>(out + (size_t)3 * 8 * Np);
+    for (int d = 0; d < 3; ++d) Xo[d * Np + i] = X[d * Np + j];
+    for (int d = 0; d < 21; ++d) Ro[d * Np + i] = R[d * Np + j];
+    for (int d = 0; d < 3; ++d) vend[d * Np + i] = R[d * Np + i];          // old order, same slot
+    if (i < D.N) perm_new[i] = perm_old[j];
+}
+template <class T> static int resort_frame_t(plmpm_sim* s, int f, int epoch) {
+    Dev<T> D = make_dev<T>(s);
+    const int nb = s->Npad / 256;
+    int bits = 1;
+    while ((1 << bits) < s->n) ++bits;
+    hipLaunchKernelGGL((k_hilbert_keys<T>), dim3(nb), dim3(256), 0, s->stream, D, f, bits, s->skey[0], s->sidx[0]);
+    if (plmpm_sort_pairs(s->sort_tmp, s->sort_tmp_bytes, s->skey[0], s->skey[1], s->sidx[0], s->sidx[1], s->Npad, 3 * bits + 1, s->stream) != 0)
+        return fail("resort: device sort failed");
+    T* vend = (T*)(s->vend + (size_t)epoch * 3 * s->Npad * s->tsz);
+    hipLaunchKernelGGL((k_permute_frame<T>), dim3(nb), dim3(256), 0, s->stream, D, f, s->sidx[1], s->frame_tmp, vend,
+                       perm_of(s, s->frame_epoch[f]), perm_of(s, epoch));
+    HIPCHK(hipMemcpyAsync(s->state + (size_t)f * s->frame_bytes, s->frame_tmp, s->frame_bytes, hipMemcpyDeviceToDevice, s->stream));
+    s->frame_epoch[f] = epoch;
+    return 0;
+}
+// adjoint frame `which` from the storage order of epoch `from` to that of epoch `to`, through caller order (staging)
+template <class T> static int convert_adjoint_t(plmpm_sim* s, int which, int from, int to) {
+    if (from == to) return 0;
+    adj_io_t<T>(s, which, 0, 1, 1, 1, 1, from);
+    HIPCHK(hipMemsetAsync(s->adj[which], 0, (size_t)24 * s->Npad * s->tsz, s->stream));
+    adj_io_t<T>(s, which, 1, 1, 1, 1, 1, to);
+    s->adj_epoch[which] = to;
     return 0;
 }
 
@@ -788,6 +891,14 @@ int plmpm_create(const plmpm_config* cfg, const plmpm_primitive* prims, plmpm_ha
     s->ws.adjoint_bytes = align_up(2 * 24 * s->Npad * s->tsz, 256) + 3 * align_up(s->Npad * s->tsz, 256) + align_up((size_t)s->Npad * 4, 256);
     s->ws.grid_bytes = 4 * align_up(s->G * 4 * s->tsz, 256) + align_up((size_t)s->nblk * 4, 256) + 3 * align_up(s->G * s->tsz, 256);
     s->dist = s->cfg.slab_z0 > 0 || s->cfg.slab_z1 < cfg->n_grid || cfg->slab_halo > 0;
+    s->resort = cfg->resort_steps > 0 && !s->dist && cfg->substeps > 0;
+    s->n_epochs = s->resort ? s->F / (cfg->substeps * cfg->resort_steps) + 2 : 1;
+    s->frame_epoch.assign(s->F + 2, 0);
+    s->sort_tmp_bytes = s->resort ? plmpm_sort_temp_bytes(s->Npad) : 0;
+    s->ws.adjoint_bytes += align_up((size_t)3 * s->N * 8, 256);                      // material master copy
+    if (s->resort)
+        s->ws.adjoint_bytes += align_up((size_t)(s->n_epochs - 1) * s->Npad * 4, 256) + align_up((size_t)s->n_epochs * 3 * s->Npad * s->tsz, 256)
+                               + 4 * align_up((size_t)s->Npad * 4, 256) + align_up(s->sort_tmp_bytes, 256) + align_up(s->frame_bytes, 256);
     if (s->dist) s->ws.misc_bytes += 3 * align_up((size_t)(s->F + 1) * P1 * 4 * 8, 256);
     s->store = cfg->store_grid != 0;
     s->gstride = align_up(s->G * 4 * s->tsz, 256);
@@ -828,6 +939,15 @@ int plmpm_bind_workspace(plmpm_handle s, void* state, void* adjoint, void* grid,
     p = s->adjw + align_up(2 * 24 * s->Npad * s->tsz, 256);
     s->mu = take(s->Npad * s->tsz); s->lam = take(s->Npad * s->tsz); s->ys = take(s->Npad * s->tsz);
     s->perm_d = (int*)take((size_t)s->Npad * 4);
+    s->mats_master = (double*)take((size_t)3 * s->N * 8);
+    if (s->resort) {
+        s->perm_store = (int*)take((size_t)(s->n_epochs - 1) * s->Npad * 4);
+        s->vend = take((size_t)s->n_epochs * 3 * s->Npad * s->tsz);
+        for (int i = 0; i < 2; ++i) { s->skey[i] = (unsigned*)take((size_t)s->Npad * 4); s->sidx[i] = (int*)take((size_t)s->Npad * 4); }
+        s->sort_tmp = take(s->sort_tmp_bytes);
+        s->frame_tmp = take(s->frame_bytes);
+    }
+    REQUIRE((size_t)(p - s->adjw) <= s->ws.adjoint_bytes, "internal: adjoint workspace overflow");
     p = s->gridw;
     s->grid_in = take(s->G * 4 * s->tsz); s->grid_out = take(s->G * 4 * s->tsz);
     s->grid_out_adj = take(s->G * 4 * s->tsz); s->grid_in_adj = take(s->G * 4 * s->tsz);
@@ -863,6 +983,11 @@ int plmpm_bind_workspace(plmpm_handle s, void* state, void* adjoint, void* grid,
     std::vector<double> rot(F1 * P1 * 4, 0.0);
     for (size_t i = 0; i < F1 * P1; ++i) rot[4 * i] = 1.0;
     HIPCHK(hipMemcpyAsync(s->prot, rot.data(), rot.size() * 8, hipMemcpyHostToDevice, s->stream));
+    if (s->resort) {
+        // first use of the library sort loads its code object (~20 ms): pay that here, not in the first re-sorted step
+        if (plmpm_sort_pairs(s->sort_tmp, s->sort_tmp_bytes, s->skey[0], s->skey[1], s->sidx[0], s->sidx[1], s->Npad, 8, s->stream) != 0)
+            return fail("device sort unavailable");
+    }
     HIPCHK(hipStreamSynchronize(s->stream));
     s->bound = true;
     return 0;
@@ -881,10 +1006,11 @@ int plmpm_set_materials(plmpm_handle s, const double* mu, const double* lam, con
     NEED_BOUND(s);
     REQUIRE(mu && lam && ys, "null argument");
     size_t nb = (size_t)s->N * 8;
-    HIPCHK(hipMemcpyAsync(s->staging, mu, nb, hipMemcpyHostToDevice, s->stream));
-    HIPCHK(hipMemcpyAsync(s->staging + s->N, lam, nb, hipMemcpyHostToDevice, s->stream));
-    HIPCHK(hipMemcpyAsync(s->staging + 2 * (size_t)s->N, ys, nb, hipMemcpyHostToDevice, s->stream));
-    DISPATCH(s, set_materials_t, s);
+    HIPCHK(hipMemcpyAsync(s->mats_master, mu, nb, hipMemcpyHostToDevice, s->stream));
+    HIPCHK(hipMemcpyAsync(s->mats_master + s->N, lam, nb, hipMemcpyHostToDevice, s->stream));
+    HIPCHK(hipMemcpyAsync(s->mats_master + 2 * (size_t)s->N, ys, nb, hipMemcpyHostToDevice, s->stream));
+    s->have_mats = true;
+    DISPATCH(s, set_materials_t, s, s->mats_epoch);
     HIPCHK(hipStreamSynchronize(s->stream));
     return 0;
 }
@@ -942,6 +1068,8 @@ int plmpm_set_frame(plmpm_handle s, int frame, const double* x, const double* v,
         REQUIRE(x && v && F && C, "resort needs the full state (all of x, v, F, C)");
         compute_order(s, x);
         HIPCHK(hipMemcpyAsync(s->perm_d, s->perm.data(), N * 4, hipMemcpyHostToDevice, s->stream));
+        std::fill(s->frame_epoch.begin(), s->frame_epoch.end(), 0);          // a new episode: every frame in the reset order
+        if (s->have_mats) DISPATCH(s, set_materials_t, s, 0);
     }
     if (x) HIPCHK(hipMemcpyAsync(s->staging, x, N * 3 * 8, hipMemcpyHostToDevice, s->stream));
     if (v) HIPCHK(hipMemcpyAsync(s->staging + 3 * N, v, N * 3 * 8, hipMemcpyHostToDevice, s->stream));
@@ -971,6 +1099,7 @@ int plmpm_copy_frame(plmpm_handle s, int source, int target) {
     NEED_FRAME(s, target);
     size_t n16 = s->frame_bytes / 16;
     hipLaunchKernelGGL(k_copy_frame, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, s->stream, s->state, s->frame_bytes, source, target);
+    s->frame_epoch[target] = s->frame_epoch[source];
     if (s->P > 0) {
         HIPCHK(hipMemcpyAsync(s->ppos + (size_t)target * s->P * 3, s->ppos + (size_t)source * s->P * 3, (size_t)s->P * 3 * 8, hipMemcpyDeviceToDevice, s->stream));
         HIPCHK(hipMemcpyAsync(s->prot + (size_t)target * s->P * 4, s->prot + (size_t)source * s->P * 4, (size_t)s->P * 4 * 8, hipMemcpyDeviceToDevice, s->stream));
@@ -1071,7 +1200,9 @@ int plmpm_substep(plmpm_handle s, int frame) {
     NEED_BOUND(s);
     REQUIRE(frame >= 0 && frame < s->F, "substep: frame %d out of range", frame);
     launch_fk(s, frame, 1);
+    if (s->have_mats && s->mats_epoch != s->frame_epoch[frame]) DISPATCH(s, set_materials_t, s, s->frame_epoch[frame]);
     DISPATCH(s, substep_fwd, s, frame);
+    s->frame_epoch[frame + 1] = s->frame_epoch[frame];
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -1081,9 +1212,24 @@ int plmpm_step(plmpm_handle s, int first_frame, int n_substeps) {
     REQUIRE(first_frame >= 0 && n_substeps > 0 && first_frame + n_substeps <= s->F, "step: frames [%d,%d] exceed max_frames %d",
             first_frame, first_frame + n_substeps, s->F);
     launch_fk(s, first_frame, n_substeps);
+    // re-sort the step's first frame along the Hilbert curve (not the episode's first step: set_frame just sorted it)
+    const int span = std::max(s->cfg.substeps, 1) * std::max(s->cfg.resort_steps, 1);       // frames per storage order
+    const int epoch = first_frame / span;
+    if (s->resort && first_frame > 0 && n_substeps == s->cfg.substeps && first_frame % span == 0 && epoch < s->n_epochs &&
+        !s->prof_no_resort && s->frame_epoch[first_frame] != epoch) {
+        if (DISPATCH(s, resort_frame_t, s, first_frame, epoch)) return -1;
+    }
+    const int e = s->frame_epoch[first_frame];
+    if (s->have_mats && s->mats_epoch != e) DISPATCH(s, set_materials_t, s, e);
     if (s->store && n_substeps > 1) DISPATCH(s, step_fwd_fused, s, first_frame, n_substeps);
     else for (int f = first_frame; f < first_frame + n_substeps; ++f) DISPATCH(s, substep_fwd, s, f);
+    for (int f = first_frame + 1; f <= first_frame + n_substeps; ++f) s->frame_epoch[f] = e;
     HIPCHK(hipGetLastError());
+    return 0;
+}
+int plmpm_set_resort(plmpm_handle s, int on) {
+    REQUIRE(s, "null handle");
+    s->prof_no_resort = !on;
     return 0;
 }
 
@@ -1106,6 +1252,7 @@ int plmpm_grad_begin(plmpm_handle s, int last_frame) {
     }
     s->adj_frame[last_frame & 1] = last_frame;
     s->adj_frame[(last_frame + 1) & 1] = -1;
+    s->adj_epoch[0] = s->adj_epoch[1] = s->frame_epoch[last_frame];     // all zero: any order
     return 0;
 }
 
@@ -1124,6 +1271,7 @@ int plmpm_segment_carry(plmpm_handle s, int from_frame, int to_frame) {
     REQUIRE(s->adj_frame[from_frame & 1] == from_frame, "segment_carry: adjoint of frame %d is not resident", from_frame);
     if ((from_frame & 1) != (to_frame & 1))
         HIPCHK(hipMemcpyAsync(s->adj[to_frame & 1], s->adj[from_frame & 1], (size_t)24 * s->Npad * s->tsz, hipMemcpyDeviceToDevice, s->stream));
+    s->adj_epoch[to_frame & 1] = s->adj_epoch[from_frame & 1];
     s->adj_frame[to_frame & 1] = to_frame;
     s->adj_frame[(to_frame + 1) & 1] = -1;
     size_t P1 = std::max(s->P, 1), F1 = s->F + 1;
@@ -1147,10 +1295,20 @@ int plmpm_segment_carry(plmpm_handle s, int from_frame, int to_frame) {
     return 0;
 }
 
+// reverse of the substep that starts at `frame`: bring the incoming adjoint (of frame+1) and the materials into the
+// storage order of `frame`, then run it
+static int bwd_prepare(plmpm_sim* s, int frame) {
+    const int e = s->frame_epoch[frame], slot = (frame + 1) & 1;
+    if (s->adj_epoch[slot] != e && DISPATCH(s, convert_adjoint_t, s, slot, s->adj_epoch[slot], e)) return -1;
+    if (s->have_mats && s->mats_epoch != e) DISPATCH(s, set_materials_t, s, e);
+    s->adj_epoch[frame & 1] = e;
+    return 0;
+}
 int plmpm_substep_grad(plmpm_handle s, int frame) {
     NEED_BOUND(s);
     REQUIRE(frame >= 0 && frame < s->F, "substep_grad: frame %d out of range", frame);
     REQUIRE(s->adj_frame[(frame + 1) & 1] == frame + 1, "substep_grad(%d): adjoint of frame %d is not resident (call grad_begin / go in reverse order)", frame, frame + 1);
+    if (bwd_prepare(s, frame)) return -1;
     DISPATCH(s, substep_bwd, s, frame);
     HIPCHK(hipGetLastError());
     return 0;
@@ -1161,6 +1319,7 @@ int plmpm_step_grad(plmpm_handle s, int first_frame, int n_substeps, int step) {
     REQUIRE(first_frame >= 0 && n_substeps > 0 && first_frame + n_substeps <= s->F, "step_grad: bad frame range");
     for (int f = first_frame + n_substeps - 1; f >= first_frame; --f) {
         REQUIRE(s->adj_frame[(f + 1) & 1] == f + 1, "step_grad: adjoint of frame %d is not resident", f + 1);
+        if (bwd_prepare(s, f)) return -1;
         DISPATCH(s, substep_bwd, s, f);
     }
     if (s->P > 0)
@@ -1175,6 +1334,8 @@ int plmpm_add_frame_grad(plmpm_handle s, int frame, const double* xa, const doub
     NEED_FRAME(s, frame);
     REQUIRE(s->adj_frame[frame & 1] == frame, "add_frame_grad: adjoint of frame %d is not resident", frame);
     size_t N = s->N;
+    if (s->adj_epoch[frame & 1] != s->frame_epoch[frame] &&
+        DISPATCH(s, convert_adjoint_t, s, frame & 1, s->adj_epoch[frame & 1], s->frame_epoch[frame])) return -1;
     if (xa) HIPCHK(hipMemcpyAsync(s->staging, xa, N * 3 * 8, hipMemcpyHostToDevice, s->stream));
     if (va) HIPCHK(hipMemcpyAsync(s->staging + 3 * N, va, N * 3 * 8, hipMemcpyHostToDevice, s->stream));
     if (Fa) HIPCHK(hipMemcpyAsync(s->staging + 6 * N, Fa, N * 9 * 8, hipMemcpyHostToDevice, s->stream));
@@ -1296,6 +1457,8 @@ int plmpm_loss_backward_local(plmpm_handle s, int frame) {
     NEED_FRAME(s, frame);
     REQUIRE(s->have_target, "loss: no target density set");
     REQUIRE(s->adj_frame[frame & 1] == frame, "loss_backward: adjoint of frame %d is not resident", frame);
+    if (s->adj_epoch[frame & 1] != s->frame_epoch[frame] &&
+        DISPATCH(s, convert_adjoint_t, s, frame & 1, s->adj_epoch[frame & 1], s->frame_epoch[frame])) return -1;
     DISPATCH(s, loss_grad_t, s, frame);
     HIPCHK(hipGetLastError());
     return 0;

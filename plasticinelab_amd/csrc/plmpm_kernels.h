@@ -692,9 +692,9 @@ __global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_g2p_p2g(Dev<T> D, int
 }
 
 // ------------------------------------------------------------------------------------------------
-// g2p.grad: scatter grid_v_out.grad, x[f].grad partial -> adjoint frame `dst`
+// g2p.grad: scatter grid_v_out.grad, x[f].grad partial -> adjoint frame `dst`.  vnext: see below (nullptr = frame f+1)
 template <class T>
-__global__ __launch_bounds__(kBlock) void k_g2p_grad(Dev<T> D, int f, int src, int dst) {
+__global__ __launch_bounds__(kBlock) void k_g2p_grad(Dev<T> D, int f, int src, int dst, const T* vnext) {
     __shared__ int sred[32];
     __shared__ Vec4<T> tile[TileCap<T>::nodes];      // v_out values
     __shared__ Vec4<double> tile_a[TileCap<T>::nodes];    // v_out adjoint accumulation (f64, see k_p2g)
@@ -716,7 +716,8 @@ __global__ __launch_bounds__(kBlock) void k_g2p_grad(Dev<T> D, int f, int src, i
     const bool valid = sorted_finish(D, sl, p, x, base);
     PT_MARK(1);
     {
-        const T* R1 = frame_r(D, f + 1);
+        // v[f+1]: normally the stored frame; after a re-sort of frame f+1 the copy kept in this frame's particle order
+        const T* R1 = vnext ? vnext : frame_r(D, f + 1);
         const T* A1 = D.adj[src];
         T vn[3] = {T(0), T(0), T(0)}, xna[3] = {T(0), T(0), T(0)}, vna[3] = {T(0), T(0), T(0)}, Cna[9], xa[3];
         for (int d = 0; d < 9; ++d) Cna[d] = T(0);

@@ -7,6 +7,7 @@ engine; kernels run on torch's current HIP stream so that they order with
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional, Sequence
 
 import numpy as np
@@ -32,7 +33,7 @@ class Engine:
     def __init__(self, *, n_grid: int, n_particles: int, max_frames: int, substeps: int, dt: float, p_vol: float,
                  p_mass: float, gravity: Sequence[float], ground_friction: float, primitives: Sequence[dict] = (),
                  dtype: str = "float32", svd_grad_clamp: float = 1e-6, device: Optional[torch.device] = None,
-                 slab: Optional[Sequence[int]] = None, store_grid="auto", slab_halo: int = 0):
+                 slab: Optional[Sequence[int]] = None, store_grid="auto", slab_halo: int = 0, resort_steps: int = 4):
         self.lib = L.load()
         if not torch.cuda.is_available():
             raise L.EngineError("no ROCm device visible: the MPM engine has no CPU path")
@@ -50,6 +51,8 @@ class Engine:
             store_grid = max_frames * 8 * (8 if cfg.dtype == L.F64 else 4) * n_grid ** 3 <= 64 * 2 ** 30
         cfg.store_grid = int(bool(store_grid))
         cfg.slab_halo = int(slab_halo)
+        # re-sort the particles every so many env steps (single GPU); PLMPM_RESORT_STEPS overrides for experiments
+        cfg.resort_steps = int(os.environ.get("PLMPM_RESORT_STEPS", resort_steps))
         self.store_grid = bool(store_grid)
         parr = (L.Primitive * max(len(primitives), 1))()
         self.action_dims = []
@@ -134,6 +137,10 @@ class Engine:
         s = np.empty(8)
         L.check(self.lib.plmpm_get_primitive_grad(self.h, prim, f, _ptr(s)))
         return s
+
+    def set_resort(self, on):
+        """Switch the per-env-step re-sort off / on (optimizer/checkpoint.py keeps one order across segments)."""
+        L.check(self.lib.plmpm_set_resort(self.h, int(bool(on))))
 
     def add_primitive_grad(self, prim, f, grad8):
         g = np.zeros(8)
