@@ -100,6 +100,7 @@ struct plmpm_sim {
     std::vector<int> frame_epoch;
     int mats_epoch = 0;
     int adj_epoch[2] = {0, 0};
+    int steps_since_sort = 0;             // env steps since the order of the current frames was chosen
     size_t gstride = 0;
     std::vector<char> dirty;          // frame f holds a scattered grid that has not been consumed/cleared
     // optional per-kernel timing with HIP events on the launch stream (plmpm_profile_*)
@@ -892,7 +893,7 @@ int plmpm_create(const plmpm_config* cfg, const plmpm_primitive* prims, plmpm_ha
     s->ws.grid_bytes = 4 * align_up(s->G * 4 * s->tsz, 256) + align_up((size_t)s->nblk * 4, 256) + 3 * align_up(s->G * s->tsz, 256);
     s->dist = s->cfg.slab_z0 > 0 || s->cfg.slab_z1 < cfg->n_grid || cfg->slab_halo > 0;
     s->resort = cfg->resort_steps > 0 && !s->dist && cfg->substeps > 0;
-    s->n_epochs = s->resort ? s->F / (cfg->substeps * cfg->resort_steps) + 2 : 1;
+    s->n_epochs = s->resort ? s->F / (cfg->substeps * cfg->resort_steps) + 3 : 1;      // +2: the alternating pair of copy-mode episodes
     s->frame_epoch.assign(s->F + 2, 0);
     s->sort_tmp_bytes = s->resort ? plmpm_sort_temp_bytes(s->Npad) : 0;
     s->ws.adjoint_bytes += align_up((size_t)3 * s->N * 8, 256);                      // material master copy
@@ -1069,6 +1070,7 @@ int plmpm_set_frame(plmpm_handle s, int frame, const double* x, const double* v,
         compute_order(s, x);
         HIPCHK(hipMemcpyAsync(s->perm_d, s->perm.data(), N * 4, hipMemcpyHostToDevice, s->stream));
         std::fill(s->frame_epoch.begin(), s->frame_epoch.end(), 0);          // a new episode: every frame in the reset order
+        s->steps_since_sort = 0;
         if (s->have_mats) DISPATCH(s, set_materials_t, s, 0);
     }
     if (x) HIPCHK(hipMemcpyAsync(s->staging, x, N * 3 * 8, hipMemcpyHostToDevice, s->stream));
@@ -1214,11 +1216,18 @@ int plmpm_step(plmpm_handle s, int first_frame, int n_substeps) {
     launch_fk(s, first_frame, n_substeps);
     // re-sort the step's first frame along the Hilbert curve (not the episode's first step: set_frame just sorted it)
     const int span = std::max(s->cfg.substeps, 1) * std::max(s->cfg.resort_steps, 1);       // frames per storage order
-    const int epoch = first_frame / span;
-    if (s->resort && first_frame > 0 && n_substeps == s->cfg.substeps && first_frame % span == 0 && epoch < s->n_epochs &&
-        !s->prof_no_resort && s->frame_epoch[first_frame] != epoch) {
-        if (DISPATCH(s, resort_frame_t, s, first_frame, epoch)) return -1;
+    int epoch = first_frame / span;
+    bool sort_now = s->resort && first_frame > 0 && n_substeps == s->cfg.substeps && first_frame % span == 0 && epoch < s->n_epochs;
+    if (s->resort && first_frame == 0 && s->steps_since_sort >= s->cfg.resort_steps && s->n_epochs >= 3) {
+        // copy-mode episodes (Gym step(): every env step starts again at frame 0): same cadence, two alternating epochs
+        epoch = s->frame_epoch[0] == 1 ? 2 : 1;
+        sort_now = true;
     }
+    if (sort_now && !s->prof_no_resort && s->frame_epoch[first_frame] != epoch) {
+        if (DISPATCH(s, resort_frame_t, s, first_frame, epoch)) return -1;
+        s->steps_since_sort = 0;
+    }
+    ++s->steps_since_sort;
     const int e = s->frame_epoch[first_frame];
     if (s->have_mats && s->mats_epoch != e) DISPATCH(s, set_materials_t, s, e);
     if (s->store && n_substeps > 1) DISPATCH(s, step_fwd_fused, s, first_frame, n_substeps);

@@ -129,3 +129,30 @@ def test_checkpointed_gradient_equals_tape_gradient(dtype):
         assert abs(loss2 - loss) / abs(loss) < tol
         assert relerr(grad2, grad) < (1e-9 if dtype == "float64" else 1e-3)
         assert relerr(grad2, g["grad"]) < (1e-7 if dtype == "float64" else 1e-3)
+
+
+@pytest.mark.parametrize("mode", ["copy", "tape"])
+def test_resort_does_not_change_the_physics(mode, monkeypatch):
+    """The device re-sort of the storage order (cfg.resort_steps) only permutes where particles live: the trajectory
+    in caller order -- copy-mode Gym stepping, and tape-mode loss + action gradient across several re-sorts -- equals
+    the one of an engine that keeps the reset order, up to the summation order of the scatters (float64 engine)."""
+    from plasticinelab_amd.optimizer.solver import Solver
+    rng = np.random.default_rng(3)
+    out = {}
+    for R in ("0", "1"):
+        monkeypatch.setenv("PLMPM_RESORT_STEPS", R)
+        env = make_env("Move", 10 ** 9, "float64") if False else make_env_sub("Move", 3000, "float64")
+        acts = np.random.default_rng(5).uniform(-1, 1, (6, env.primitives.action_dim)) * 0.8
+        state0 = env.get_state()["state"]
+        if mode == "copy":
+            env.set_state(state0, 666.0, True)
+            for a in acts:
+                env.step(a)
+            st = env.simulator.get_state(0)
+            out[R] = (st[0], st[1], st[2], st[3])
+        else:
+            loss, grad = Solver(env, None, None, softness=666.0, horizon=len(acts)).forward(state0, acts)
+            out[R] = (np.array([loss]), grad)
+    for a, b in zip(out["0"], out["1"]):
+        assert relerr(a, b) < 1e-9
+    del rng
