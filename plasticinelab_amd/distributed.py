@@ -223,7 +223,11 @@ class SlabEngine:
 
     def loss_forward(self, f):
         g = self._loss_globals(f)
-        self._e.check_error()
+        # the error word is combined over the ranks before anyone raises: a rank that bailed out alone would leave
+        # the others waiting in their next exchange
+        flags = torch.tensor([float(self._e.error_flags())], dtype=torch.float64, device=self.comm.scalar_device)
+        self.comm.all_reduce_(flags, op=dist.ReduceOp.MAX)
+        self._e.check_error(int(flags.item()))
         return self._e.loss_finish(g)
 
     def loss_backward(self, f):

@@ -311,11 +311,16 @@ class Engine:
     def loss_backward_local(self, f):
         L.check(self.lib.plmpm_loss_backward_local(self.h, f))
 
-    def check_error(self):
+    def error_flags(self) -> int:
+        """Device error word (bit 0: a particle left this rank's z-slab + halo); cleared by the read."""
         e = C.c_int(0)
         L.check(self.lib.plmpm_check_error(self.h, C.byref(e)))
-        if e.value & 1:
-            raise L.EngineError("a particle left this rank's z-slab + halo (fixed ownership, no migration yet): "
+        return int(e.value)
+
+    def check_error(self, flags=None):
+        flags = self.error_flags() if flags is None else flags
+        if flags & 1:
+            raise L.EngineError("a particle left a rank's z-slab + halo (fixed ownership, no migration yet): "
                                 "raise slab_halo or use fewer ranks")
 
     def profile_enable(self, on=True):
