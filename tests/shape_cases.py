@@ -25,6 +25,15 @@ CASES = {
 }
 
 
+# every task family of the reference at its own v1 scene configuration (plb/envs/*.yml), subsampled; two env steps of
+# seeded actions, soft contact loss
+FAMILIES = ("Move", "TripleMove", "Rope", "Writer", "Torus", "Rollingpin", "Chopsticks", "Pinch", "Table", "Assembly")
+_ADIM = {"Move": 6, "TripleMove": 18, "Rope": 6, "Writer": 3, "Torus": 3, "Rollingpin": 3, "Chopsticks": 7, "Pinch": 3, "Table": 3,
+         "Assembly": 6}
+for _i, _f in enumerate(FAMILIES):
+    CASES[f"scene_{_f}"] = (_f, None, True, np.random.default_rng(100 + _i).uniform(-1, 1, (2, _ADIM[_f])) * 0.7)
+
+
 def case_cfg(name):
     from plasticinelab_amd.envs.scenes import load_scene
     kind, override, soft, acts = CASES[name]
