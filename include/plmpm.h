@@ -200,9 +200,11 @@ int plmpm_chain_grad(plmpm_handle h, int first_frame, int n_substeps, int step);
 int plmpm_halo_bytes(plmpm_handle h, int field, int za, int zb, size_t* bytes);
 /* device buffers laid out [comp][z - za][y][x] in the engine's scalar type */
 int plmpm_halo_pack(plmpm_handle h, int field, int frame, int za, int zb, void* dev_buf);
+/* adds the received planes; for PLMPM_HALO_GRID_IN every node that receives a non-zero value also marks its 4^3 block
+ * active, which merges the two ranks' block flags without a flag exchange */
 int plmpm_halo_unpack_add(plmpm_handle h, int field, int frame, int za, int zb, const void* dev_buf);
-/* block flags of `frame` (int32 per 4^3 block, z-major: planes [bz_a, bz_b) are contiguous) for OR-merging
- * with a neighbour's, and the primitive pose adjoints (double) for the cross-rank sum */
+/* block flags of `frame` (int32 per 4^3 block, z-major: planes [bz_a, bz_b) are contiguous; diagnostics), and the
+ * primitive pose adjoints (double) for the cross-rank sum */
 int plmpm_flags_region(plmpm_handle h, int frame, int bz_a, int bz_b, void** dev_ptr, size_t* count);
 int plmpm_pose_grad_region(plmpm_handle h, int first_frame, int n_frames, void** pos_adj, size_t* pos_count,
                            void** rot_adj, size_t* rot_count, void** gap_adj, size_t* gap_count);

@@ -1631,10 +1631,11 @@ int plmpm_halo_unpack_add(plmpm_handle s, int field, int frame, int za, int zb, 
     char* base; int nc;
     if (halo_field(s, field, frame, &base, &nc)) return -1;
     size_t tot = (size_t)nc * (zb - za) * s->n * s->n;
+    int* flags = field == PLMPM_HALO_GRID_IN ? s->fstore + (size_t)frame * s->nblk : nullptr;
     if (s->cfg.dtype == PLMPM_F64)
-        hipLaunchKernelGGL((k_halo_unpack_add<double>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s->stream, (double*)base, s->G, nc, s->n, s->nb, za, zb, (const double*)buf);
+        hipLaunchKernelGGL((k_halo_unpack_add<double>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s->stream, (double*)base, s->G, nc, s->n, s->nb, za, zb, (const double*)buf, flags);
     else
-        hipLaunchKernelGGL((k_halo_unpack_add<float>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s->stream, (float*)base, s->G, nc, s->n, s->nb, za, zb, (const float*)buf);
+        hipLaunchKernelGGL((k_halo_unpack_add<float>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s->stream, (float*)base, s->G, nc, s->n, s->nb, za, zb, (const float*)buf, flags);
     HIPCHK(hipGetLastError());
     return 0;
 }

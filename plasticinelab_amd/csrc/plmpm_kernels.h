@@ -959,7 +959,7 @@ __global__ void k_halo_pack(const T* src, size_t G, int ncomp, int n, int nb, in
     buf[i] = src[(size_t)c * G + node_index(nb, x, y, z)];
 }
 template <class T>
-__global__ void k_halo_unpack_add(T* dst, size_t G, int ncomp, int n, int nb, int za, int zb, const T* buf) {
+__global__ void k_halo_unpack_add(T* dst, size_t G, int ncomp, int n, int nb, int za, int zb, const T* buf, int* flags) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     size_t per = (size_t)(zb - za) * n * n;
     if (i >= per * ncomp) return;
@@ -967,7 +967,13 @@ __global__ void k_halo_unpack_add(T* dst, size_t G, int ncomp, int n, int nb, in
     size_t r = i - (size_t)c * per;
     int x = (int)(r % n), y = (int)((r / n) % n), z = za + (int)(r / ((size_t)n * n));
     T v = buf[i];
-    if (v != T(0)) dst[(size_t)c * G + node_index(nb, x, y, z)] += v;
+    if (v != T(0)) {
+        const int idx = node_index(nb, x, y, z);
+        dst[(size_t)c * G + idx] += v;
+        // a neighbour's particles reach this node: its block is active here too (this IS the merge of the two ranks'
+        // block flags -- no separate flag exchange)
+        if (flags) flags[idx >> 6] = 1;
+    }
 }
 
 // zero grid_in / flags of the active blocks (a stored frame that is scattered into again without a backward

@@ -167,19 +167,12 @@ class SlabEngine:
         return getattr(self._e, name)
 
     # ---- halos
-    def _halo(self, field, f, flags=False):
+    def _halo(self, field, f):
+        """Symmetric sum exchange of one halo field.  (The block flags of grid_in need no exchange of their own:
+        plmpm_halo_unpack_add marks the block of every node that receives a non-zero value.)"""
         e = self._e
-        fields = [(lambda za, zb: e.halo_pack(field, f, za, zb),
-                   lambda za, zb, buf: e.halo_unpack_add(field, f, za, zb, buf.to(e.device)))]
-        if flags:
-            def pack(za, zb):
-                return e.flags_view(f, za // 4, (zb + 3) // 4).clone()
-
-            def merge(za, zb, buf):
-                v = e.flags_view(f, za // 4, (zb + 3) // 4)
-                v.bitwise_or_(buf.to(v.device))
-            fields.append((pack, merge))
-        self.comm.exchange(*fields)
+        self.comm.exchange((lambda za, zb: e.halo_pack(field, f, za, zb),
+                            lambda za, zb, buf: e.halo_unpack_add(field, f, za, zb, buf.to(e.device))))
 
     # ---- hot path
     def step(self, first, n):
@@ -187,7 +180,7 @@ class SlabEngine:
         e.fk(first, n)
         for f in range(first, first + n):
             e.p2g(f)
-            self._halo(e.HALO_GRID_IN, f, flags=True)
+            self._halo(e.HALO_GRID_IN, f)
             e.grid_g2p(f)
 
     def substep(self, f):

@@ -68,6 +68,7 @@ class Engine:
             parr[i].lower_bound = (C.c_double * 3)(*p.get("lower_bound", (0.0, 0.0, 0.0)))
             parr[i].upper_bound = (C.c_double * 3)(*p.get("upper_bound", (1.0, 1.0, 1.0)))
             self.action_dims.append(parr[i].action_dim)
+        self._halo_counts = {}
         self.cfg, self.n_primitives = cfg, len(primitives)
         self.n_grid, self.n_particles, self.max_frames = n_grid, n_particles, max_frames
         self.dtype = "float64" if cfg.dtype == L.F64 else "float32"
@@ -259,10 +260,14 @@ class Engine:
 
     def halo_pack(self, field, f, za, zb):
         """Planes z in [za, zb) of a halo field as a dense device tensor [comp, zb-za, n, n]."""
-        nb = C.c_size_t()
-        L.check(self.lib.plmpm_halo_bytes(self.h, field, za, zb, C.byref(nb)))
+        key = (field, za, zb)
+        count = self._halo_counts.get(key)
+        if count is None:
+            nb = C.c_size_t()
+            L.check(self.lib.plmpm_halo_bytes(self.h, field, za, zb, C.byref(nb)))
+            count = self._halo_counts[key] = nb.value // (8 if self.dtype == "float64" else 4)
         n = self.n_grid
-        buf = torch.empty(nb.value // (8 if self.dtype == "float64" else 4), dtype=self.torch_dtype, device=self.device)
+        buf = torch.empty(count, dtype=self.torch_dtype, device=self.device)
         L.check(self.lib.plmpm_halo_pack(self.h, field, f, za, zb, C.c_void_p(buf.data_ptr())))
         return buf.view(-1, zb - za, n, n)
 
