@@ -695,22 +695,23 @@ __global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_g2p_p2g(Dev<T> D, int
 // g2p.grad: scatter grid_v_out.grad, x[f].grad partial -> adjoint frame `dst`.  vnext: see below (nullptr = frame f+1)
 template <class T>
 __global__ __launch_bounds__(kBlock) void k_g2p_grad(Dev<T> D, int f, int src, int dst, const T* vnext) {
-    __shared__ int sred[32];
-    __shared__ Vec4<T> tile[TileCap<T>::nodes];      // v_out values
-    __shared__ Vec4<double> tile_a[TileCap<T>::nodes];    // v_out adjoint accumulation (f64, see k_p2g)
+    // 960 nodes x (16 + 24) bytes = 37.5 KiB: four workgroups per CU (the kernel needs 126 VGPRs = 4 waves per SIMD)
+    constexpr int CAP = sizeof(T) == 4 ? 960 : 480;
+    __shared__ Vec4<T> tile[CAP];                    // v_out values
+    __shared__ double tile_a[CAP * 3];               // v_out adjoint accumulation (f64, see k_p2g)
     const double* X = frame_x(D, f);
     const int Np = D.Npad;
     int p, base[3];
     double x[3];
     PT_BEGIN();
-    const Tile tl = load_tile(D, f, TileCap<T>::nodes);             // stored by the scatter of this frame
+    const Tile tl = load_tile(D, f, CAP);                           // stored by the scatter of this frame
     SortLoad sl = sorted_begin(D, X);
     const int ex = tl.e[0], exy = tl.e[0] * tl.e[1], tn = exy * tl.e[2];
     if (tl.ok)
         for (int i = threadIdx.x; i < tn; i += kBlock) {
             int lz = i / exy, r = i - lz * exy, ly = r / ex, lx = r - ly * ex;
             tile[i] = D.grid_out[node_index(D.nb, tl.o[0] + lx, tl.o[1] + ly, tl.o[2] + lz)];
-            tile_a[i] = Vec4<double>{0.0, 0.0, 0.0, 0.0};
+            tile_a[3 * i] = 0.0; tile_a[3 * i + 1] = 0.0; tile_a[3 * i + 2] = 0.0;
         }
     PT_MARK(0);
     const bool valid = sorted_finish(D, sl, p, x, base);
@@ -738,11 +739,9 @@ __global__ __launch_bounds__(kBlock) void k_g2p_grad(Dev<T> D, int f, int src, i
                 },
                 [&](int i, int j, int l, const T* ga) {
                     T a0 = ga[0], a1 = ga[1], a2 = ga[2];
-                    if (PLB_ABLATE & 4) { if (a0 + a1 + a2 == T(-1e30)) tile_a[0].x = 1.0; return; }
                     seg_sum3(a0, a1, a2, sg);
-                    if (PLB_ABLATE & 1) { if (a0 + a1 + a2 == T(-1e30)) tile_a[0].x = 1.0; return; }
                     if (emitter) {
-                        double* q = reinterpret_cast<double*>(&tile_a[(oz + l) * exy + (oy + j) * ex + (ox + i)]);
+                        double* q = &tile_a[3 * ((oz + l) * exy + (oy + j) * ex + (ox + i))];
                         atomicAdd(q, (double)a0); atomicAdd(q + 1, (double)a1); atomicAdd(q + 2, (double)a2);
                     }
                 });
@@ -770,14 +769,14 @@ __global__ __launch_bounds__(kBlock) void k_g2p_grad(Dev<T> D, int f, int src, i
         }
     }
     PT_MARK(3);
-    if (tl.ok && !(PLB_ABLATE & 2)) {
+    if (tl.ok) {
         __syncthreads();
         for (int i = threadIdx.x; i < tn; i += kBlock) {
-            Vec4<double> a = tile_a[i];
-            if (a.x != 0.0 || a.y != 0.0 || a.z != 0.0) {
+            const double ax = tile_a[3 * i], ay = tile_a[3 * i + 1], az = tile_a[3 * i + 2];
+            if (ax != 0.0 || ay != 0.0 || az != 0.0) {
                 int lz = i / exy, r = i - lz * exy, ly = r / ex, lx = r - ly * ex;
                 int idx = node_index(D.nb, tl.o[0] + lx, tl.o[1] + ly, tl.o[2] + lz);
-                atomicAdd(&D.goa[0][idx], (T)a.x); atomicAdd(&D.goa[1][idx], (T)a.y); atomicAdd(&D.goa[2][idx], (T)a.z);
+                atomicAdd(&D.goa[0][idx], (T)ax); atomicAdd(&D.goa[1][idx], (T)ay); atomicAdd(&D.goa[2][idx], (T)az);
             }
         }
     }
