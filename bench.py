@@ -45,8 +45,8 @@ ALG = {
 HBM_PEAK_GBS = 8000.0          # MI355X spec (MI355X_MICROARCH.md); measured copy peak there: 6290 GB/s
 # HBM bytes per launch of the dominant kernel (k_g2p_p2g) on the DEFAULT workload, from the rocprofv3 PMC passes of this
 # very command committed as profiles/r01_pmc.txt: 2 x FETCH_SIZE (gfx950 correction of MI355X_MICROARCH.md, HBM
-# section) + WRITE_SIZE = 2 x 24 315.7 KB + 85 742.2 KB.  Reported as roofline.traffic only for that workload.
-PMC_TRAFFIC_BYTES = {"g2p_p2g": 2 * 24315.7e3 + 85742.2e3}
+# section) + WRITE_SIZE = 2 x 24 326.0 KB + 85 742.5 KB.  Reported as roofline.traffic only for that workload.
+PMC_TRAFFIC_BYTES = {"g2p_p2g": 2 * 24326.0e3 + 85742.5e3}
 
 
 def workload_cfg(n_particles=500_000, quality=2, max_steps=1024):
