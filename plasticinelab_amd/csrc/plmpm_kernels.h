@@ -9,9 +9,12 @@
 //                      grid_out_adj {v'_x, v'_y, v'_z}, are SoA: float atomics run at ~300 G/s on consecutive
 //                      addresses but ~80 G/s at a 16-byte stride (profiles/microbench/global_atomics.hip).
 //                      flags[block] marks blocks touched this substep.
-// Particles are stored cell-sorted (plmpm_set_frame(resort=1)), so a 256-thread workgroup's particles
-// cover a small box of cells: the scatter / gather kernels stage that box in LDS (tile path) and fall back
-// to direct global atomics when a workgroup's bounding box does not fit.
+// Particles are stored along the Hilbert curve of their cells (plmpm_set_frame(resort=1); re-sorted on the device
+// every cfg.resort_steps env steps), so a 256-thread workgroup's particles cover a small box of cells: the
+// scatter / gather kernels stage that box in LDS (tile path) and fall back to direct global atomics when a
+// workgroup's bounding box does not fit.  The box of every workgroup is kept per frame (Dev::tiles).  Inside a
+// wave, lanes are re-assigned by a DPP bitonic sort on the cell so that same-cell lanes are adjacent, their
+// contributions are pre-reduced with DPP row shifts and one lane per cell does the LDS atomics.
 #pragma once
 #include <hip/hip_runtime.h>
 #include "mpm_grid.h"
