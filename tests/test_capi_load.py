@@ -62,3 +62,19 @@ def test_product_never_imports_oracle():
                 src = open(os.path.join(dp, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+(oracle|tests)\b", src, flags=re.M), os.path.join(dp, f)
                 assert "host_emul" not in src or f in ("mpm_math.h", "mpm_grid.h"), os.path.join(dp, f)
+
+
+def test_integration_doc_structs_match_the_library_binding():
+    """The ctypes stub shown to reference maintainers in INTEGRATION.md declares the same struct layouts as the
+    binding that is actually shipped (plasticinelab_amd/_lib.py)."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    block = next(b for b in re.findall(r"```python\n(.*?)```", text, re.S) if "class Config" in b)
+    defs = block[block.index("class Config"):block.index("cfg = Config(")]
+    ns = {"C": ctypes}
+    exec(defs, ns)
+    for name in ("Config", "Primitive", "Workspace"):
+        a, b = ns[name], getattr(_lib, name)
+        assert ctypes.sizeof(a) == ctypes.sizeof(b), name
+        assert [(f[0], getattr(a, f[0]).offset) for f in a._fields_] == [(f[0], getattr(b, f[0]).offset) for f in b._fields_], name
