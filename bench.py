@@ -281,6 +281,11 @@ def main():
                            "traffic_unit": "bytes per launch (profiles/r01_pmc.txt)", "algorithmic_bytes": kernels[dom]["alg_MB"] * 1e6,
                            "active_nodes": nodes, "active_blocks": blocks,
                            "substep_alg_MB": alg_substep * 1e-6,
+                           # the lenient dense-grid byte count (every node of the n^3 grid, not only the
+                           # active ones) -- reported for reference, NOT what frac / substep_frac are computed from
+                           "substep_alg_MB_dense_grid": 4.0 * (150 * N + 57 * sim.n_grid ** 3) * 1e-6,
+                           "peak_achievable": 6290.0,      # measured copy peak quoted in MI355X_MICROARCH.md (GB/s)
+                           "substep_frac_of_achievable": (alg_substep / (sum_us * 1e-6)) / 6290e9,
                            "substep_kernel_sum_us": sum_us,
                            "substep_frac": (alg_substep / (sum_us * 1e-6)) / (HBM_PEAK_GBS * 1e9),
                            "kernels": kernels}
