@@ -192,6 +192,24 @@ template <class T> PLB_HD void shape_normal_local(int shape, const T* par, const
     }
 }
 
+// gradient of the Box distance (primitives.py:232-238) w.r.t. p, with Taichi's max/min adjoint routing:
+// g += scale * d sdf / d p
+template <class T> PLB_HD void box_sdf_grad(const T* par, const T* p, T scale, T* g) {
+    T q[3] = {t_abs(p[0]) - par[0], t_abs(p[1]) - par[1], t_abs(p[2]) - par[2]};
+    T e[3] = {t_max(q[0], T(0)), t_max(q[1], T(0)), t_max(q[2], T(0))};
+    T Le = len14(e[0], e[1], e[2]);
+    T qa[3];
+    for (int i = 0; i < 3; ++i) qa[i] = (T(0) < q[i]) ? scale * e[i] / Le : T(0);     // max(q_i, 0): to q_i iff 0 < q_i
+    T mm = t_max(q[1], q[2]);                        // max(q1, q2): to q1 iff q2 < q1, else to q2
+    T m3 = t_max(q[0], mm);                          // max(q0, mm): to q0 iff mm < q0, else to mm
+    if (m3 < T(0)) {                                 // min(m3, 0): to m3 iff m3 < 0
+        if (mm < q[0]) qa[0] += scale;
+        else if (q[2] < q[1]) qa[1] += scale;
+        else qa[2] += scale;
+    }
+    for (int i = 0; i < 3; ++i) g[i] += qa[i] * (p[i] > T(0) ? T(1) : (p[i] < T(0) ? T(-1) : T(0)));
+}
+
 // Reverse mode of (shape_sdf_local, shape_normal_local) w.r.t. the local point p: given the adjoints
 // da of the distance and na[3] of the normal, accumulate pa[3] += d<da*sdf + na.n>/dp.  Hand-derived for the
 // shapes the reference's tasks actually move (Capsule: writer.yml, Torus: torus.yml); min/max follow Taichi's
@@ -241,6 +259,63 @@ template <class T> PLB_HD bool shape_local_adj(int shape, const T* par, const T*
         // l = len14(x, z)
         xa += la * p[0] / l; za += la * p[2] / l;
         pa[0] += xa; pa[1] += q1a; pa[2] += za;
+        return true;
+    }
+    case SHAPE_CYLINDER: {                                // primitives.py:163-183 (h = radius, r = half height)
+        const T l = len14(p[0], p[2]);
+        const T d0 = l - par[0], d1 = t_abs(p[1]) - par[1];
+        // ---- normal
+        const T f = d0 > d1 ? T(1) : T(0);
+        const T ins = t_max(d0, d1) <= T(0) ? T(1) : T(0);
+        const T m0 = t_max(d0, T(0)) + ins * f, m1 = t_max(d1, T(0)) + ins * (T(1) - f);
+        const T L2 = len14(m0, m1);
+        const T n20 = m0 / L2, n21 = m1 / L2;
+        const T sgn = p[1] >= T(0) ? T(1) : T(-1);
+        const T x20 = p[0] / l, x21 = p[2] / l;
+        const T u[3] = {x20 * n20, n21 * sgn, x21 * n20};
+        const T L3 = len14(u[0], u[1], u[2]);
+        const T n[3] = {u[0] / L3, u[1] / L3, u[2] / L3};
+        const T nd = n[0] * na[0] + n[1] * na[1] + n[2] * na[2];
+        T ua[3];
+        for (int i = 0; i < 3; ++i) ua[i] = (na[i] - n[i] * nd) / L3;
+        const T x20a = ua[0] * n20, x21a = ua[2] * n20;
+        const T n20a = ua[0] * x20 + ua[2] * x21, n21a = ua[1] * sgn;
+        const T n2d = n20 * n20a + n21 * n21a;
+        const T m0a = (n20a - n20 * n2d) / L2, m1a = (n21a - n21 * n2d) / L2;
+        T d0a = (T(0) < d0) ? m0a : T(0), d1a = (T(0) < d1) ? m1a : T(0);           // max(d, 0): to d iff 0 < d
+        T xa = x20a / l, za = x21a / l;
+        T la = -(x20a * p[0] + x21a * p[2]) / (l * l);
+        // ---- distance: min(max(d0, d1), 0) + len14(max(d0, 0), max(d1, 0))
+        const T e0 = t_max(d0, T(0)), e1 = t_max(d1, T(0));
+        const T Le = len14(e0, e1);
+        if (T(0) < d0) d0a += da * e0 / Le;
+        if (T(0) < d1) d1a += da * e1 / Le;
+        if (t_max(d0, d1) < T(0)) { if (d1 < d0) d0a += da; else d1a += da; }       // min(mx, 0), max(d0, d1)
+        la += d0a;                                        // d0 = |l| - h, l > 0
+        xa += la * p[0] / l; za += la * p[2] / l;
+        pa[0] += xa; pa[2] += za;
+        pa[1] += d1a * (p[1] > T(0) ? T(1) : (p[1] < T(0) ? T(-1) : T(0)));
+        return true;
+    }
+    case SHAPE_BOX: {                                     // primitives.py:232-251: normal by central differences, d = 1e-4
+        const T d = T(1e-4);
+        T g[3], pp[3], pm[3];
+        for (int i = 0; i < 3; ++i) {
+            for (int k = 0; k < 3; ++k) { pp[k] = p[k]; pm[k] = p[k]; }
+            pp[i] += d; pm[i] -= d;
+            g[i] = (T(0.5) / d) * (shape_sdf_local(shape, par, pp) - shape_sdf_local(shape, par, pm));
+        }
+        const T Lg = len14(g[0], g[1], g[2]);
+        const T n[3] = {g[0] / Lg, g[1] / Lg, g[2] / Lg};
+        const T nd = n[0] * na[0] + n[1] * na[1] + n[2] * na[2];
+        for (int i = 0; i < 3; ++i) {
+            const T gia = (na[i] - n[i] * nd) / Lg * (T(0.5) / d);
+            for (int k = 0; k < 3; ++k) { pp[k] = p[k]; pm[k] = p[k]; }
+            pp[i] += d; pm[i] -= d;
+            box_sdf_grad(par, pp, gia, pa);
+            box_sdf_grad(par, pm, -gia, pa);
+        }
+        box_sdf_grad(par, p, da, pa);
         return true;
     }
     default: return false;

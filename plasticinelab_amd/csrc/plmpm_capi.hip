@@ -873,11 +873,7 @@ int plmpm_create(const plmpm_config* cfg, const plmpm_primitive* prims, plmpm_ha
             delete s;
             return fail("primitive %d: Chopsticks take a 7-dim action (3 linear, 3 angular, 1 grasp; primitives.py:92)", p);
         }
-        if (prims[p].action_dim > 0 && prims[p].shape != PLMPM_SPHERE && prims[p].shape != PLMPM_CAPSULE &&
-            prims[p].shape != PLMPM_TORUS && prims[p].shape != PLMPM_CHOPSTICKS) {
-            delete s;
-            return fail("movable primitive %d: pose adjoints exist for Sphere, Capsule, Torus and Chopsticks only (shape %d)", p, prims[p].shape);
-        }
+        if (prims[p].shape < PLMPM_SPHERE || prims[p].shape > PLMPM_CHOPSTICKS) { delete s; return fail("primitive %d: unknown shape %d", p, prims[p].shape); }
         s->act_ofs[p + 1] = s->act_ofs[p] + prims[p].action_dim;
     }
     s->act_total = s->act_ofs[s->P];

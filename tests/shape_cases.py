@@ -17,6 +17,9 @@ CASES = {
     "capsule_soft": ("tilted", ("Capsule", dict(h=0.06, r=0.03)), True, _ACT6),
     "torus_hard": ("tilted", ("Torus", dict(tx=0.05, ty=0.02)), False, _ACT6),
     "torus_soft": ("tilted", ("Torus", dict(tx=0.05, ty=0.02)), True, _ACT6),
+    # no reference task moves a Cylinder or a Box; SURVEY 8f rank 2 lists their adjoints all the same
+    "cylinder_soft": ("tilted", ("Cylinder", dict(h=0.05, r=0.04)), True, _ACT6),
+    "box_soft": ("tilted", ("Box", dict(size=(0.04, 0.03, 0.05))), True, _ACT6),
     "rollingpin": ("Rollingpin", None, True, np.array([[0.8, -0.5, -0.6], [0.6, 0.4, -0.3]])),
     # gap opened in step 1 so that the minimal-gap clamp is inactive, closed in steps 2-3
     "chopsticks": ("Chopsticks", None, True, np.array([[0.6, -0.2, -0.2, 0.5, -0.4, 0.3, -0.8],

@@ -96,10 +96,12 @@ def test_static_cylinder_contact_forward(case):
         assert relerr(x, y.numpy()) < 1e-11
 
 
-@pytest.mark.parametrize("shape,kw", [("Capsule", dict(h=0.06, r=0.03)), ("Torus", dict(tx=0.05, ty=0.02))])
+@pytest.mark.parametrize("shape,kw", [("Capsule", dict(h=0.06, r=0.03)), ("Torus", dict(tx=0.05, ty=0.02)),
+                                      ("Cylinder", dict(h=0.05, r=0.04)), ("Box", dict(size=(0.04, 0.03, 0.05)))])
 def test_capsule_torus_pose_adjoints(shape, kw):
-    """Movable Capsule (writer.yml) / Torus (torus.yml): tilted, 6-dof actions so that position AND rotation
-    adjoints at frames f and f+1 are exercised; hand-derived sdf-gradient / normal-Jacobian vs oracle autograd."""
+    """Movable Capsule (writer.yml) / Torus (torus.yml) -- and Cylinder / Box, which no reference task moves but
+    SURVEY 8f rank 2 lists: tilted, 6-dof actions so that position AND rotation adjoints at frames f and f+1 are
+    exercised; hand-derived sdf-gradient / normal-Jacobian vs oracle autograd."""
     torch.manual_seed(0)
     cfg, sim, prims, x0 = oracle_scene("Move", 1, n_particles=1500)
     rot = np.array([0.9, 0.2, -0.3, 0.25]); rot /= np.linalg.norm(rot)
