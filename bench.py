@@ -95,6 +95,9 @@ def _target(x_all, sim):
     return mass_grid(np.clip(x_all + np.array([0.03, 0.0, 0.02]), 0.03, 0.97), sim.n_grid, sim.p_mass)
 
 
+XY_MARGIN = 12      # node layers around the body's xy bounding box that the halo planes cover (the rest is empty)
+
+
 def build_env(args, device, rank=0, world=1, slabs=False):
     from plasticinelab_amd.engine.taichi_env import TaichiEnv
     sub = int(2e-3 // (0.5e-4 / (args.quality * 0.5)))
@@ -105,9 +108,11 @@ def build_env(args, device, rank=0, world=1, slabs=False):
         n = int(128 * args.quality * 0.5)
         span = int(0.31 * n) + 3
         halo = max(2, min(4, span // (2 * world)))
-        env, layout, _ = make_slab_env(cfg, rank, world, halo=halo, compute_dtype=args.dtype, device=device, target_fn=_target)
+        env, layout, _ = make_slab_env(cfg, rank, world, halo=halo, compute_dtype=args.dtype, device=device, target_fn=_target,
+                                       xy_margin=XY_MARGIN)
         env.loss.set_weights(10, 10, 1, False)
-        return env, f"{world} z-slabs {list(layout.bounds)}, halo {halo} layers, RCCL sum exchange per substep"
+        return env, (f"{world} z-slabs {list(layout.bounds)}, halo {halo} layers (xy window: body + {XY_MARGIN}), "
+                     "RCCL sum exchange per substep")
     env = TaichiEnv(cfg, compute_dtype=args.dtype, device=device)
     env.initialize()
     env.loss.load_target_density(grids=_target(env.init_particles, env.simulator))

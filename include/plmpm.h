@@ -198,11 +198,27 @@ int plmpm_grad_gather(plmpm_handle h, int frame);                           /* g
 int plmpm_chain_grad(plmpm_handle h, int first_frame, int n_substeps, int step);   /* fk.grad + set_velocity.grad */
 /* element size in bytes of the engine's scalar type, and the size of a halo buffer for planes [za, zb) */
 int plmpm_halo_bytes(plmpm_handle h, int field, int za, int zb, size_t* bytes);
-/* device buffers laid out [comp][z - za][y][x] in the engine's scalar type */
+/* device buffers laid out [comp][z - za][y - y0][x - x0] (the halo window) in the engine's scalar type */
 int plmpm_halo_pack(plmpm_handle h, int field, int frame, int za, int zb, void* dev_buf);
 /* adds the received planes; for PLMPM_HALO_GRID_IN every node that receives a non-zero value also marks its 4^3 block
  * active, which merges the two ranks' block flags without a flag exchange */
 int plmpm_halo_unpack_add(plmpm_handle h, int field, int frame, int za, int zb, const void* dev_buf);
+/* Only the xy window [x0, x1) x [y0, y1) of the halo planes travels (default: whole planes); both sides of a face
+ * must use the same window.  Set it before sizing buffers with plmpm_halo_bytes.  A particle whose stencil leaves
+ * the window raises PLMPM_ERR_HALO exactly like one that leaves slab + halo in z. */
+int plmpm_set_halo_window(plmpm_handle h, int x0, int x1, int y0, int y1);
+/* One call each side of the exchange, for the per-substep loop (launch and issue latency, not bandwidth, bound the
+ * slab path at 128^3); both faces are packed / unpacked by one kernel launch:
+ *   plmpm_slab_pre : field GRID_IN -> plmpm_p2g(frame), GRID_OUT_ADJ -> plmpm_grad_scatter(frame); then
+ *                    plmpm_halo_pack of planes [za[i], zb[i]) into send[i] for every face i (n_faces <= 2)
+ *   plmpm_slab_post: plmpm_halo_unpack_add of recv[i] for every face; then plmpm_grid_g2p / plmpm_grad_gather
+ * chain (GRID_IN only): slab_post(frame, chain=1) leaves g2p(frame) pending, and the caller's next library call
+ * must be slab_pre(frame + 1, chain=1), which runs it fused with p2g(frame + 1) in one kernel (as plmpm_step does
+ * on one GPU).  The last substep of an env step passes chain=0. */
+int plmpm_slab_pre(plmpm_handle h, int field, int frame, int chain, int n_faces, const int* za, const int* zb,
+                   void* const* send);
+int plmpm_slab_post(plmpm_handle h, int field, int frame, int chain, int n_faces, const int* za, const int* zb,
+                    const void* const* recv);
 /* block flags of `frame` (int32 per 4^3 block, z-major: planes [bz_a, bz_b) are contiguous; diagnostics), and the
  * primitive pose adjoints (double) for the cross-rank sum */
 int plmpm_flags_region(plmpm_handle h, int frame, int bz_a, int bz_b, void** dev_ptr, size_t* count);

@@ -88,6 +88,9 @@ SYMBOLS = {
     "plmpm_halo_bytes": (_I, [_P, _I, _I, _I, C.POINTER(C.c_size_t)]),
     "plmpm_halo_pack": (_I, [_P, _I, _I, _I, _I, _P]),
     "plmpm_halo_unpack_add": (_I, [_P, _I, _I, _I, _I, _P]),
+    "plmpm_set_halo_window": (_I, [_P, _I, _I, _I, _I]),
+    "plmpm_slab_pre": (_I, [_P, _I, _I, _I, _I, _P, _P, _P]),
+    "plmpm_slab_post": (_I, [_P, _I, _I, _I, _I, _P, _P, _P]),
     "plmpm_flags_region": (_I, [_P, _I, _I, _I, C.POINTER(_P), C.POINTER(C.c_size_t)]),
     "plmpm_pose_grad_region": (_I, [_P, _I, _I, C.POINTER(_P), C.POINTER(C.c_size_t), C.POINTER(_P), C.POINTER(C.c_size_t),
                                     C.POINTER(_P), C.POINTER(C.c_size_t)]),

@@ -66,6 +66,8 @@ struct plmpm_sim {
     // multi-GPU: pose adjoints produced by this rank's nodes/particles accumulate in *_l, get summed over
     // ranks by the host and are then merged into the global ppos_a/prot_a the kinematics chain reads
     bool dist = false;
+    int win[4] = {0, 0, 0, 0};        // xy window [x0, x1) x [y0, y1) of the halo planes that travel (default: whole planes)
+    int g2p_deferred = -1;            // slab path: frame whose g2p waits to run fused with the next frame's p2g
     double *ppos_l = nullptr, *prot_l = nullptr, *pgap_l = nullptr;
     // host state
     std::vector<int32_t> perm;
@@ -155,6 +157,10 @@ template <class T> static Dev<T> make_dev(const plmpm_sim* s, int frame = -1) {
     D.zlo = c.slab_z0 - c.slab_halo; D.zhi = c.slab_z1 + c.slab_halo;
     if (c.slab_z0 <= 0) D.zlo = -(1 << 20);
     if (c.slab_z1 >= c.n_grid) D.zhi = 1 << 20;
+    for (int d = 0; d < 2; ++d) {
+        D.wlo[d] = s->win[2 * d] <= 0 ? -(1 << 20) : s->win[2 * d];
+        D.whi[d] = s->win[2 * d + 1] >= c.n_grid ? (1 << 20) : s->win[2 * d + 1];
+    }
     D.err = s->err_d;
     D.frame_bytes = s->frame_bytes;
     D.state = s->state;
@@ -661,10 +667,19 @@ template <class T> static int phase_p2g(plmpm_sim* s, int f) {
     s->dirty[f] = 1;
     return 0;
 }
-template <class T> static int phase_grid_g2p(plmpm_sim* s, int f) {
+template <class T> static int phase_grid_g2p(plmpm_sim* s, int f, bool defer_g2p = false) {
     Dev<T> D = make_dev<T>(s, f);
     LAUNCH(s, K_GRID_OP, (k_grid_op<T, false>), dim3(nwg_grid(s)), D, f);
-    LAUNCH(s, K_G2P, (k_g2p<T>), dim3(nblocks_particles(s)), D, f);
+    if (!defer_g2p) LAUNCH(s, K_G2P, (k_g2p<T>), dim3(nblocks_particles(s)), D, f);
+    return 0;
+}
+// g2p(f-1), deferred by the previous phase_grid_g2p, fused with p2g(f) exactly as in step_fwd_fused
+template <class T> static int phase_g2p_p2g(plmpm_sim* s, int f) {
+    Dev<T> D = make_dev<T>(s, f);
+    if (s->dirty[f]) LAUNCHG_CLEAR(s, D);
+    const Vec4<T>* vprev = (const Vec4<T>*)(s->vstore + (size_t)(f - 1) * s->gstride);
+    LAUNCH(s, K_G2P_P2G, (k_g2p_p2g<T>), dim3(nblocks_particles(s)), D, f, vprev);
+    s->dirty[f] = 1;
     return 0;
 }
 template <class T> static int phase_grad_scatter(plmpm_sim* s, int f) {
@@ -879,6 +894,7 @@ int plmpm_create(const plmpm_config* cfg, const plmpm_primitive* prims, plmpm_ha
     s->act_total = s->act_ofs[s->P];
     s->N = cfg->n_particles;
     s->Npad = (int)align_up(s->N, kBlock);
+    s->win[1] = s->win[3] = cfg->n_grid;
     s->n = cfg->n_grid; s->nb = s->n / 4; s->nblk = s->nb * s->nb * s->nb; s->G = (size_t)s->n * s->n * s->n;
     s->F = cfg->max_frames;
     s->tsz = cfg->dtype == PLMPM_F64 ? 8 : 4;
@@ -996,7 +1012,11 @@ int plmpm_set_stream(plmpm_handle s, void* hip_stream) {
     return 0;
 }
 
-#define NEED_BOUND(s) REQUIRE((s) && (s)->bound, "workspace not bound")
+#define NEED_BOUND(s)                                                                                             \
+    do {                                                                                                          \
+        REQUIRE((s) && (s)->bound, "workspace not bound");                                                        \
+        REQUIRE((s)->g2p_deferred < 0, "frame %d's g2p is deferred: call plmpm_slab_pre(frame + 1, chain = 1) next", (s)->g2p_deferred); \
+    } while (0)
 #define NEED_FRAME(s, f) REQUIRE((f) >= 0 && (f) <= (s)->F, "frame %d out of range [0,%d]", (f), (s)->F)
 
 int plmpm_set_materials(plmpm_handle s, const double* mu, const double* lam, const double* ys) {
@@ -1602,37 +1622,79 @@ static int halo_field(plmpm_sim* s, int field, int frame, char** base, int* ncom
     else return fail("unknown halo field %d", field);
     return 0;
 }
+static inline int halo_ncomp(int field) { return field == PLMPM_HALO_GRID_IN ? 4 : (field == PLMPM_HALO_GRID_OUT_ADJ ? 3 : 1); }
+static inline size_t halo_plane_nodes(const plmpm_sim* s) { return (size_t)(s->win[1] - s->win[0]) * (s->win[3] - s->win[2]); }
+int plmpm_set_halo_window(plmpm_handle s, int x0, int x1, int y0, int y1) {
+    REQUIRE(s, "null handle");
+    REQUIRE(0 <= x0 && x0 < x1 && x1 <= s->n && 0 <= y0 && y0 < y1 && y1 <= s->n, "halo window [%d,%d) x [%d,%d) outside the %d^2 plane", x0, x1, y0, y1, s->n);
+    s->win[0] = x0; s->win[1] = x1; s->win[2] = y0; s->win[3] = y1;
+    return 0;
+}
 int plmpm_halo_bytes(plmpm_handle s, int field, int za, int zb, size_t* bytes) {
     REQUIRE(s && bytes && za >= 0 && zb <= s->n && za < zb, "halo_bytes: bad plane range [%d,%d)", za, zb);
-    int nc = field == PLMPM_HALO_GRID_IN ? 4 : (field == PLMPM_HALO_GRID_OUT_ADJ ? 3 : 1);
-    *bytes = (size_t)nc * (zb - za) * s->n * s->n * s->tsz;
+    *bytes = (size_t)halo_ncomp(field) * (zb - za) * halo_plane_nodes(s) * s->tsz;
+    return 0;
+}
+// pack (dir 0) or unpack-add (dir 1) every face in one launch
+static int halo_faces(plmpm_sim* s, int dir, int field, int frame, int n_faces, const int* za, const int* zb, void* const* bufs) {
+    REQUIRE(n_faces >= 0 && n_faces <= 2, "a z-slab has at most 2 faces (got %d)", n_faces);
+    if (n_faces == 0) return 0;
+    char* base; int nc;
+    if (halo_field(s, field, frame, &base, &nc)) return -1;
+    HaloFaces H;
+    memset(&H, 0, sizeof H);
+    H.n_faces = n_faces;
+    H.x0 = s->win[0]; H.x1 = s->win[1]; H.y0 = s->win[2]; H.y1 = s->win[3];
+    size_t most = 0;
+    for (int i = 0; i < n_faces; ++i) {
+        REQUIRE(bufs[i] && za[i] >= 0 && zb[i] <= s->n && za[i] < zb[i], "halo: bad plane range [%d,%d)", za[i], zb[i]);
+        H.za[i] = za[i]; H.zb[i] = zb[i]; H.buf[i] = bufs[i];
+        most = std::max(most, (size_t)nc * (zb[i] - za[i]) * halo_plane_nodes(s));
+    }
+    const dim3 grid((unsigned)((most + 255) / 256), (unsigned)n_faces);
+    int* flags = field == PLMPM_HALO_GRID_IN ? s->fstore + (size_t)frame * s->nblk : nullptr;
+    if (s->cfg.dtype == PLMPM_F64) {
+        if (dir == 0) hipLaunchKernelGGL((k_halo_pack<double>), grid, dim3(256), 0, s->stream, (const double*)base, s->G, nc, s->nb, H);
+        else hipLaunchKernelGGL((k_halo_unpack_add<double>), grid, dim3(256), 0, s->stream, (double*)base, s->G, nc, s->nb, H, flags);
+    } else {
+        if (dir == 0) hipLaunchKernelGGL((k_halo_pack<float>), grid, dim3(256), 0, s->stream, (const float*)base, s->G, nc, s->nb, H);
+        else hipLaunchKernelGGL((k_halo_unpack_add<float>), grid, dim3(256), 0, s->stream, (float*)base, s->G, nc, s->nb, H, flags);
+    }
+    HIPCHK(hipGetLastError());
     return 0;
 }
 int plmpm_halo_pack(plmpm_handle s, int field, int frame, int za, int zb, void* buf) {
     NEED_BOUND(s);
-    REQUIRE(buf && za >= 0 && zb <= s->n && za < zb, "halo_pack: bad plane range [%d,%d)", za, zb);
-    char* base; int nc;
-    if (halo_field(s, field, frame, &base, &nc)) return -1;
-    size_t tot = (size_t)nc * (zb - za) * s->n * s->n;
-    if (s->cfg.dtype == PLMPM_F64)
-        hipLaunchKernelGGL((k_halo_pack<double>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s->stream, (const double*)base, s->G, nc, s->n, s->nb, za, zb, (double*)buf);
-    else
-        hipLaunchKernelGGL((k_halo_pack<float>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s->stream, (const float*)base, s->G, nc, s->n, s->nb, za, zb, (float*)buf);
-    HIPCHK(hipGetLastError());
-    return 0;
+    return halo_faces(s, 0, field, frame, 1, &za, &zb, &buf);
 }
 int plmpm_halo_unpack_add(plmpm_handle s, int field, int frame, int za, int zb, const void* buf) {
     NEED_BOUND(s);
-    REQUIRE(buf && za >= 0 && zb <= s->n && za < zb, "halo_unpack_add: bad plane range [%d,%d)", za, zb);
-    char* base; int nc;
-    if (halo_field(s, field, frame, &base, &nc)) return -1;
-    size_t tot = (size_t)nc * (zb - za) * s->n * s->n;
-    int* flags = field == PLMPM_HALO_GRID_IN ? s->fstore + (size_t)frame * s->nblk : nullptr;
-    if (s->cfg.dtype == PLMPM_F64)
-        hipLaunchKernelGGL((k_halo_unpack_add<double>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s->stream, (double*)base, s->G, nc, s->n, s->nb, za, zb, (const double*)buf, flags);
-    else
-        hipLaunchKernelGGL((k_halo_unpack_add<float>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s->stream, (float*)base, s->G, nc, s->n, s->nb, za, zb, (const float*)buf, flags);
+    void* b = const_cast<void*>(buf);
+    return halo_faces(s, 1, field, frame, 1, &za, &zb, &b);
+}
+int plmpm_slab_pre(plmpm_handle s, int field, int frame, int chain, int n_faces, const int* za, const int* zb, void* const* send) {
+    REQUIRE(field == PLMPM_HALO_GRID_IN || field == PLMPM_HALO_GRID_OUT_ADJ, "slab_pre: field %d has no substep phase", field);
+    REQUIRE(n_faces >= 0 && (n_faces == 0 || (za && zb && send)), "slab_pre: bad face list");
+    if (chain) {
+        REQUIRE(s && s->bound && field == PLMPM_HALO_GRID_IN, "slab_pre: only the forward phase chains");
+        REQUIRE(frame >= 1 && frame < s->F && s->g2p_deferred == frame - 1, "slab_pre(%d, chain): frame %d's g2p was not deferred (deferred: %d)", frame, frame - 1, s->g2p_deferred);
+        s->g2p_deferred = -1;
+        DISPATCH(s, phase_g2p_p2g, s, frame);
+        HIPCHK(hipGetLastError());
+    } else if (field == PLMPM_HALO_GRID_IN ? plmpm_p2g(s, frame) : plmpm_grad_scatter(s, frame)) return -1;
+    return halo_faces(s, 0, field, frame, n_faces, za, zb, send);
+}
+int plmpm_slab_post(plmpm_handle s, int field, int frame, int chain, int n_faces, const int* za, const int* zb, const void* const* recv) {
+    NEED_BOUND(s);
+    REQUIRE(field == PLMPM_HALO_GRID_IN || field == PLMPM_HALO_GRID_OUT_ADJ, "slab_post: field %d has no substep phase", field);
+    REQUIRE(n_faces >= 0 && (n_faces == 0 || (za && zb && recv)), "slab_post: bad face list");
+    REQUIRE(!chain || (field == PLMPM_HALO_GRID_IN && frame + 1 < s->F), "slab_post: only a forward phase with a successor chains");
+    if (halo_faces(s, 1, field, frame, n_faces, za, zb, const_cast<void* const*>(recv))) return -1;
+    if (field == PLMPM_HALO_GRID_OUT_ADJ) return plmpm_grad_gather(s, frame);
+    REQUIRE(s->store && frame >= 0 && frame < s->F, "slab_post: bad call");
+    DISPATCH(s, phase_grid_g2p, s, frame, chain != 0);
     HIPCHK(hipGetLastError());
+    if (chain) s->g2p_deferred = frame;
     return 0;
 }
 int plmpm_flags_region(plmpm_handle s, int frame, int bz_a, int bz_b, void** dev_ptr, size_t* count) {

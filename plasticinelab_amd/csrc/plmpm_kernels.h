@@ -80,6 +80,7 @@ template <class T> struct Dev {
     int nprim;
     int z0, z1;                      // owned z-slab (nodes): pose adjoints / loss sums only count these
     int zlo, zhi;                    // stencil bases of this rank's particles must satisfy zlo <= z, z + 2 < zhi
+    int wlo[2], whi[2];              // ... and, in x and y, stay inside the window of the halo planes that travel
     int* err;                        // device error word (bit 0: a particle left the slab + halo)
     size_t frame_bytes;
     char* state;                     // particle frames
@@ -146,6 +147,12 @@ template <class T, class Body> __device__ __forceinline__ void for_each_active_b
         for (unsigned long long r = m; r; r &= r - 1, ++rank)
             if ((rank & (kBlock / 64 - 1)) == wave) body(b0 + (__ffsll((long long)r) - 1) * G);
     }
+}
+
+// multi-GPU: the 3-wide stencil at `base` must stay inside slab + halo in z and inside the exchanged window in x, y
+template <class T> __device__ __forceinline__ bool outside_halo_reach(const Dev<T>& D, const int* base) {
+    return base[2] < D.zlo || base[2] + 2 >= D.zhi || base[0] < D.wlo[0] || base[0] + 2 >= D.whi[0] ||
+           base[1] < D.wlo[1] || base[1] + 2 >= D.whi[1];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -424,7 +431,7 @@ __global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_p2g(Dev<T> D, int f) 
     int p, base[3];
     double x[3];
     const bool valid = load_sorted_particle(D, X, p, x, base);
-    if (WRITE_F && valid && (base[2] < D.zlo || base[2] + 2 >= D.zhi)) atomicOr(D.err, 1);
+    if (WRITE_F && valid && outside_halo_reach(D, base)) atomicOr(D.err, 1);
     Tile tl = block_tile(base, valid, sred, TileCap<T>::nodes);
     store_tile(D, f, tl);
     const int tn = tl.e[0] * tl.e[1] * tl.e[2];
@@ -627,7 +634,7 @@ __global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_g2p_p2g(Dev<T> D, int
     // ---------------- p2g(f): scatter
     int base[3];
     for (int d = 0; d < 3; ++d) base[d] = (int)(x[d] * (double)D.P.inv_dx - 0.5);
-    if (valid && (base[2] < D.zlo || base[2] + 2 >= D.zhi)) atomicOr(D.err, 1);
+    if (valid && outside_halo_reach(D, base)) atomicOr(D.err, 1);
     __syncthreads();                                                     // everyone is done reading tile_v
     Tile tl = block_tile(base, valid, sred, TileCap<T>::nodes);
     store_tile(D, f, tl);
@@ -918,6 +925,7 @@ __global__ __launch_bounds__(kBlock) void k_grid_mass(Dev<T> D, int f, T* gm) {
     const bool valid = load_sorted_particle(D, X, p, x, base);
     T fx[3], w[3][3];
     stencil<T, double>(x, D.P.inv_dx, base, fx, w, nullptr);
+    if (valid && outside_halo_reach(D, base)) atomicOr(D.err, 1);
     Tile tl = block_tile(base, valid, sred, TileCap<T>::nodes * 4);
     const int ex = tl.e[0], exy = tl.e[0] * tl.e[1], tn = exy * tl.e[2];
     if (tl.ok) {
@@ -948,29 +956,39 @@ __global__ __launch_bounds__(kBlock) void k_grid_mass(Dev<T> D, int f, T* gm) {
     }
 }
 
-// z-slab halo: node planes z in [za, zb) of `ncomp` SoA component arrays (stride G) <-> a dense buffer
-// laid out [comp][z - za][y][x].  Unpack adds (symmetric sum exchange).
+// z-slab halo: node planes z in [za, zb), restricted to the xy window [x0, x1) x [y0, y1), of `ncomp` SoA component
+// arrays (stride G) <-> a dense buffer laid out [comp][z - za][y - y0][x - x0].  Unpack adds (symmetric sum
+// exchange).  Both faces of a slab go in one launch (blockIdx.y = face).
+struct HaloFaces {
+    int n_faces;
+    int za[2], zb[2];
+    void* buf[2];
+    int x0, x1, y0, y1;
+};
 template <class T>
-__global__ void k_halo_pack(const T* src, size_t G, int ncomp, int n, int nb, int za, int zb, T* buf) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    size_t per = (size_t)(zb - za) * n * n;
+__global__ void k_halo_pack(const T* src, size_t G, int ncomp, int nb, HaloFaces H) {
+    const int fc = blockIdx.y, wx = H.x1 - H.x0, wy = H.y1 - H.y0;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t per = (size_t)(H.zb[fc] - H.za[fc]) * wy * wx;
     if (i >= per * ncomp) return;
-    int c = (int)(i / per);
-    size_t r = i - (size_t)c * per;
-    int x = (int)(r % n), y = (int)((r / n) % n), z = za + (int)(r / ((size_t)n * n));
-    buf[i] = src[(size_t)c * G + node_index(nb, x, y, z)];
+    const int c = (int)(i / per);
+    const size_t r = i - (size_t)c * per;
+    const int x = H.x0 + (int)(r % wx), y = H.y0 + (int)((r / wx) % wy), z = H.za[fc] + (int)(r / ((size_t)wx * wy));
+    ((T*)H.buf[fc])[i] = src[(size_t)c * G + node_index(nb, x, y, z)];
 }
 template <class T>
-__global__ void k_halo_unpack_add(T* dst, size_t G, int ncomp, int n, int nb, int za, int zb, const T* buf, int* flags) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    size_t per = (size_t)(zb - za) * n * n;
+__global__ void k_halo_unpack_add(T* dst, size_t G, int ncomp, int nb, HaloFaces H, int* flags) {
+    const int fc = blockIdx.y, wx = H.x1 - H.x0, wy = H.y1 - H.y0;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t per = (size_t)(H.zb[fc] - H.za[fc]) * wy * wx;
     if (i >= per * ncomp) return;
-    int c = (int)(i / per);
-    size_t r = i - (size_t)c * per;
-    int x = (int)(r % n), y = (int)((r / n) % n), z = za + (int)(r / ((size_t)n * n));
-    T v = buf[i];
+    const int c = (int)(i / per);
+    const size_t r = i - (size_t)c * per;
+    const int x = H.x0 + (int)(r % wx), y = H.y0 + (int)((r / wx) % wy), z = H.za[fc] + (int)(r / ((size_t)wx * wy));
+    const T v = ((const T*)H.buf[fc])[i];
     if (v != T(0)) {
         const int idx = node_index(nb, x, y, z);
+        // the two faces of a slab are >= 2*halo planes apart, so no two threads of this launch add to the same node
         dst[(size_t)c * G + idx] += v;
         // a neighbour's particles reach this node: its block is active here too (this IS the merge of the two ranks'
         // block flags -- no separate flag exchange)

@@ -89,6 +89,23 @@ class SlabLayout:
         return cls(n_grid, tuple(faces), halo)
 
 
+@dataclass
+class HaloFace:
+    nbr: int
+    za: int
+    zb: int
+    send: torch.Tensor
+    recv: torch.Tensor
+    wire_send: torch.Tensor          # = send / recv unless the backend wants host memory
+    wire_recv: torch.Tensor
+
+
+@dataclass
+class HaloPlan:
+    faces: List[HaloFace]
+    ops: list
+
+
 class HaloComm:
     """Symmetric sum exchange with the z-neighbours through ``torch.distributed`` point-to-point ops."""
 
@@ -103,7 +120,8 @@ class HaloComm:
 
     def exchange(self, *fields):
         """fields: (pack, unpack_add) pairs, ``pack(za, zb) -> tensor`` and ``unpack_add(za, zb, tensor)``.
-        All fields of all faces travel in ONE batch of point-to-point ops (one latency per substep phase)."""
+        All fields of all faces travel in ONE batch of point-to-point ops (one latency per substep phase).
+        General-purpose form (fresh buffers every call); the per-substep hot path uses ``plan`` / ``run``."""
         faces = self.layout.faces(self.rank)
         if not faces:
             return
@@ -119,6 +137,37 @@ class HaloComm:
             req.wait()
         for za, zb, r, _s, unpack_add in work:
             unpack_add(za, zb, r)
+
+    def plan(self, pack) -> "HaloPlan":
+        """Persistent buffers and point-to-point op list of one halo field: ``pack(za, zb)`` returns the face's first
+        message, whose storage becomes the face's send buffer for the rest of the run.  Built once per field so that
+        a substep costs two kernel launches per face and one ``batch_isend_irecv`` -- no allocation, no op
+        construction (the host issue rate, not the link, bounds the slab path at 128^3)."""
+        faces, ops = [], []
+        for nbr, za, zb in self.layout.faces(self.rank):
+            send = pack(za, zb).contiguous()
+            recv = torch.empty_like(send)
+            if self.stage_host and send.is_cuda:
+                ws, wr = (torch.empty(send.shape, dtype=send.dtype, pin_memory=True) for _ in range(2))
+            else:
+                ws, wr = send, recv
+            faces.append(HaloFace(nbr, za, zb, send, recv, ws, wr))
+            ops.append(dist.P2POp(dist.isend, ws, nbr, self.group))
+            ops.append(dist.P2POp(dist.irecv, wr, nbr, self.group))
+        return HaloPlan(faces, ops)
+
+    def run(self, plan: "HaloPlan"):
+        """Send every face's ``send`` buffer, receive into its ``recv`` buffer."""
+        if not plan.faces:
+            return
+        for fc in plan.faces:
+            if fc.wire_send is not fc.send:
+                fc.wire_send.copy_(fc.send)                      # synchronous device -> pinned host copy
+        for req in dist.batch_isend_irecv(plan.ops):
+            req.wait()
+        for fc in plan.faces:
+            if fc.wire_recv is not fc.recv:
+                fc.recv.copy_(fc.wire_recv, non_blocking=True)   # ordered on the engine's stream before the unpack
 
     def all_reduce_(self, t: torch.Tensor, op=dist.ReduceOp.SUM):
         if self.layout.world == 1:
@@ -158,10 +207,11 @@ class SlabEngine:
     """Proxy around one rank's ``Engine`` that turns ``step`` / ``step_grad`` / ``loss_*`` into the phase-split,
     halo-exchanging versions.  ``MPMSimulator``, ``Loss`` and ``Tape`` work on it unchanged."""
 
-    def __init__(self, engine, layout: SlabLayout, rank: int, group=None):
+    def __init__(self, engine, layout: SlabLayout, rank: int, group=None, comm: Optional[HaloComm] = None):
         self._e, self.layout, self.rank = engine, layout, rank
-        self.comm = HaloComm(layout, rank, group)
+        self.comm = comm if comm is not None else HaloComm(layout, rank, group)
         self.soft_contact = False
+        self._plans = {}                           # halo field -> HaloPlan (persistent buffers, built on first use)
 
     def __getattr__(self, name):                   # everything not overridden goes straight to the engine
         return getattr(self._e, name)
@@ -171,17 +221,40 @@ class SlabEngine:
         """Symmetric sum exchange of one halo field.  (The block flags of grid_in need no exchange of their own:
         plmpm_halo_unpack_add marks the block of every node that receives a non-zero value.)"""
         e = self._e
-        self.comm.exchange((lambda za, zb: e.halo_pack(field, f, za, zb),
-                            lambda za, zb, buf: e.halo_unpack_add(field, f, za, zb, buf.to(e.device))))
+        plan = self._plans.get(field)
+        if plan is None:
+            plan = self._plans[field] = self.comm.plan(lambda za, zb: e.halo_pack(field, f, za, zb))
+        else:
+            for fc in plan.faces:
+                e.halo_pack(field, f, fc.za, fc.zb, out=fc.send)
+        self.comm.run(plan)
+        for fc in plan.faces:
+            e.halo_unpack_add(field, f, fc.za, fc.zb, fc.recv)
+
+    def _phase(self, field, f, pre, post, chain_in=False, chain_out=False):
+        """One exchange-split phase of a substep: pre(f) | halo sum exchange of ``field`` | post(f).  After the first
+        call the face buffers are persistent and each side of the exchange is ONE library call (two kernel launches
+        before the exchange, two after).  Returns whether g2p(f) was left pending for the next phase (``chain_out``
+        honoured)."""
+        e = self._e
+        plan = self._plans.get(field)
+        if plan is None:
+            pre(f)
+            self._halo(field, f)                # builds the plan
+            post(f)
+            return False
+        e.slab_pre(field, f, plan.faces, chain=chain_in)
+        self.comm.run(plan)
+        e.slab_post(field, f, plan.faces, chain=chain_out)
+        return chain_out
 
     # ---- hot path
     def step(self, first, n):
         e = self._e
         e.fk(first, n)
+        pending = False                         # g2p(f - 1) deferred: it runs fused with p2g(f), as on one GPU
         for f in range(first, first + n):
-            e.p2g(f)
-            self._halo(e.HALO_GRID_IN, f)
-            e.grid_g2p(f)
+            pending = self._phase(e.HALO_GRID_IN, f, e.p2g, e.grid_g2p, chain_in=pending, chain_out=f + 1 < first + n)
 
     def substep(self, f):
         self.step(f, 1)
@@ -189,9 +262,7 @@ class SlabEngine:
     def step_grad(self, first, n, step):
         e = self._e
         for f in range(first + n - 1, first - 1, -1):
-            e.grad_scatter(f)
-            self._halo(e.HALO_GRID_OUT_ADJ, f)
-            e.grad_gather(f)
+            self._phase(e.HALO_GRID_OUT_ADJ, f, e.grad_scatter, e.grad_gather)
         for view in e.pose_grad_views(first, n + 1):      # position, rotation, (Chopsticks) gap adjoints
             self.comm.all_reduce_(view)
         e.chain_grad(first, n, step)
@@ -233,10 +304,15 @@ class SlabEngine:
 
 
 def make_slab_env(cfg, rank: int, world: int, *, halo: int = 4, compute_dtype=None, device=None, group=None,
-                  target_fn: Optional[Callable] = None, particles: Optional[np.ndarray] = None):
+                  target_fn: Optional[Callable] = None, particles: Optional[np.ndarray] = None,
+                  layout: Optional[SlabLayout] = None, comm: Optional[HaloComm] = None,
+                  xy_margin: Optional[int] = None):
     """Build this rank's ``TaichiEnv`` over its slab of the scene in ``cfg`` (every rank samples the same seed-0
     particle cloud and keeps its own part).  ``target_fn(all_particles, sim) -> (n,n,n) grid`` may supply the loss
-    target.  Returns (env, layout, owned_index)."""
+    target.  ``xy_margin`` (node layers) shrinks the exchanged halo planes to the xy bounding box of the whole
+    particle cloud at reset plus that margin -- a body that moves further than the margin raises, like one that
+    drifts out of its slab; ``None`` sends whole planes.  ``layout`` / ``comm`` override the balanced cut and the torch.distributed communicator (measurement
+    tools: profiles/tools/slab_host_cost.py).  Returns (env, layout, owned_index)."""
     from .engine import taichi_env as te
     from .engine.losses import Loss
     from .engine.mpm_simulator import MPMSimulator
@@ -249,7 +325,8 @@ def make_slab_env(cfg, rank: int, world: int, *, halo: int = 4, compute_dtype=No
         colors = np.zeros(len(x_all), np.int32)
     quality = cfg.SIMULATOR.quality * 0.5
     n_grid = int(128 * quality)
-    layout = SlabLayout.balanced(x_all, n_grid, world, halo)
+    if layout is None:
+        layout = SlabLayout.balanced(x_all, n_grid, world, halo)
     owner = layout.owner_of(SlabLayout.stencil_base_z(x_all, n_grid))
     mine = np.nonzero(owner == rank)[0]
     if len(mine) == 0:
@@ -268,7 +345,12 @@ def make_slab_env(cfg, rank: int, world: int, *, halo: int = 4, compute_dtype=No
     sim = MPMSimulator(cfg.SIMULATOR, env.primitives, compute_dtype=compute_dtype, device=device,
                        slab=(z0, z1), slab_halo=layout.halo if world > 1 else 0)
     if world > 1:
-        sim.engine = SlabEngine(sim.engine, layout, rank, group)
+        if xy_margin is not None:
+            b = (x_all[:, :2] * n_grid - 0.5).astype(np.int64)           # stencil bases, same on every rank
+            lo = np.maximum(b.min(0) - int(xy_margin), 0)
+            hi = np.minimum(b.max(0) + 3 + int(xy_margin), n_grid)
+            sim.engine.set_halo_window(lo[0], hi[0], lo[1], hi[1])
+        sim.engine = SlabEngine(sim.engine, layout, rank, group, comm)
         env.primitives._bind(sim.engine)
     env.simulator = sim
     env.renderer = None

@@ -69,6 +69,8 @@ class Engine:
             parr[i].upper_bound = (C.c_double * 3)(*p.get("upper_bound", (1.0, 1.0, 1.0)))
             self.action_dims.append(parr[i].action_dim)
         self._halo_counts = {}
+        self._halo_window = (0, n_grid, 0, n_grid)
+        self._face_cache = {}
         self.cfg, self.n_primitives = cfg, len(primitives)
         self.n_grid, self.n_particles, self.max_frames = n_grid, n_particles, max_frames
         self.dtype = "float64" if cfg.dtype == L.F64 else "float32"
@@ -258,22 +260,56 @@ class Engine:
     def torch_dtype(self):
         return torch.float64 if self.dtype == "float64" else torch.float32
 
-    def halo_pack(self, field, f, za, zb):
-        """Planes z in [za, zb) of a halo field as a dense device tensor [comp, zb-za, n, n]."""
+    def halo_pack(self, field, f, za, zb, out=None):
+        """Planes z in [za, zb) of a halo field as a dense device tensor [comp, zb-za, n, n]; ``out`` (a tensor this
+        method returned earlier for the same field and planes) is refilled in place instead of allocating."""
+        if out is not None:
+            L.check(self.lib.plmpm_halo_pack(self.h, field, f, za, zb, C.c_void_p(out.data_ptr())))
+            return out
         key = (field, za, zb)
         count = self._halo_counts.get(key)
         if count is None:
             nb = C.c_size_t()
             L.check(self.lib.plmpm_halo_bytes(self.h, field, za, zb, C.byref(nb)))
             count = self._halo_counts[key] = nb.value // (8 if self.dtype == "float64" else 4)
-        n = self.n_grid
+        x0, x1, y0, y1 = self._halo_window
         buf = torch.empty(count, dtype=self.torch_dtype, device=self.device)
         L.check(self.lib.plmpm_halo_pack(self.h, field, f, za, zb, C.c_void_p(buf.data_ptr())))
-        return buf.view(-1, zb - za, n, n)
+        return buf.view(-1, zb - za, y1 - y0, x1 - x0)
+
+    def set_halo_window(self, x0, x1, y0, y1):
+        """Only nodes x in [x0, x1), y in [y0, y1) of the halo planes travel (default: whole planes); the same on
+        every rank.  Particles whose stencil leaves the window raise like those that leave slab + halo."""
+        L.check(self.lib.plmpm_set_halo_window(self.h, int(x0), int(x1), int(y0), int(y1)))
+        self._halo_window = (int(x0), int(x1), int(y0), int(y1))
+        self._halo_counts.clear()
+        self._face_cache.clear()
 
     def halo_unpack_add(self, field, f, za, zb, buf):
         buf = buf.contiguous()
         L.check(self.lib.plmpm_halo_unpack_add(self.h, field, f, za, zb, C.c_void_p(buf.data_ptr())))
+
+    def _face_args(self, field, faces, which):
+        key = (field, which, id(faces))
+        c = self._face_cache.get(key)
+        if c is None:
+            nf = len(faces)
+            c = self._face_cache[key] = ((C.c_int * nf)(*[fc.za for fc in faces]), (C.c_int * nf)(*[fc.zb for fc in faces]),
+                                         (C.c_void_p * nf)(*[getattr(fc, which).data_ptr() for fc in faces]), nf, faces)
+        return c
+
+    def slab_pre(self, field, f, faces, chain=False):
+        """p2g (GRID_IN) or grad_scatter (GRID_OUT_ADJ) of frame f, then pack every face into its ``send`` buffer.
+        ``faces``: the persistent list of a HaloPlan (objects with za, zb, send, recv).  ``chain``: the previous
+        ``slab_post(f - 1, chain=True)`` left g2p(f - 1) pending; it runs fused with this p2g."""
+        za, zb, ptr, nf, _ = self._face_args(field, faces, "send")
+        L.check(self.lib.plmpm_slab_pre(self.h, field, f, int(chain), nf, za, zb, ptr))
+
+    def slab_post(self, field, f, faces, chain=False):
+        """unpack-add every face's ``recv`` buffer, then grid_g2p (GRID_IN) or grad_gather (GRID_OUT_ADJ).
+        ``chain``: leave g2p(f) to the next ``slab_pre(f + 1, chain=True)``, which must be the next engine call."""
+        za, zb, ptr, nf, _ = self._face_args(field, faces, "recv")
+        L.check(self.lib.plmpm_slab_post(self.h, field, f, int(chain), nf, za, zb, ptr))
 
     def _view(self, ptr, count, dtype):
         """torch view of engine-owned device memory (inside one of the bound workspaces)."""

@@ -1,0 +1,109 @@
+"""Host issue cost of the z-slab path, measured on ONE GPU with a loop-back exchange.
+
+The slab engine is built for a middle rank of a 3-rank layout (two faces, like every interior rank of an N-GPU run)
+and its communicator is replaced by one that copies each face's send buffer into its receive buffer -- same kernel
+sequence and Python / ctypes work per substep as a real run, no RCCL.  The numbers printed are
+  issue us/substep : host time to enqueue K env steps forward + reverse, stream not waited on
+  wall  us/substep : the same with the final synchronize
+so that `issue` is the floor any N >= 2 run pays per substep before communication latency.
+
+    python profiles/tools/slab_host_cost.py [--steps K] [--particles N]
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import bench  # noqa: E402
+from plasticinelab_amd import distributed as D  # noqa: E402
+
+
+class LoopbackComm(D.HaloComm):
+    def __init__(self, layout, rank):
+        self.layout, self.rank, self.group = layout, rank, None
+        self.stage_host = False
+        self.scalar_device = torch.device("cuda", torch.cuda.current_device())
+
+    def plan(self, pack):
+        faces = []
+        for nbr, za, zb in self.layout.faces(self.rank):
+            s = pack(za, zb).contiguous()
+            faces.append(D.HaloFace(nbr, za, zb, s, torch.empty_like(s), s, s))
+        return D.HaloPlan(faces, [])
+
+    def run(self, plan):
+        for fc in plan.faces:
+            fc.recv.copy_(fc.send, non_blocking=True)
+            fc.recv.mul_(0.0)                       # add zeros: the physics stays that of the single-GPU run
+
+    def all_reduce_(self, t, op=None):
+        return t
+
+    def reduce_loss_record(self, rec, soft_contact, phase):
+        return rec
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--particles", type=int, default=500_000)
+    ap.add_argument("--quality", type=float, default=2)
+    ap.add_argument("--dtype", default="float32")
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--world", type=int, default=0, help="emulate the middle rank of a balanced N-slab cut (0: one rank owns all)")
+    ap.add_argument("--xy-margin", type=int, default=None)
+    ap.add_argument("--profile", action="store_true", help="cProfile one rollout (top functions by own time)")
+    args = ap.parse_args()
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    sub = int(2e-3 // (0.5e-4 / (args.quality * 0.5)))
+    cfg = bench.workload_cfg(args.particles, args.quality, max_steps=max(args.steps, 1) * sub + 1)
+    n = int(128 * args.quality * 0.5)
+    # interior-rank geometry: rank 1 of 3 owns the whole body and has two faces just outside it
+    layout = D.SlabLayout(n, (0, int(0.31 * n), int(0.70 * n), n), 2)
+    rank, world = 1, 3
+    if args.world > 1:                                   # the real cut bench.py would make, seen from a middle rank
+        from plasticinelab_amd.engine.shapes import Shapes
+        x_all, _ = Shapes(cfg.SHAPES).get()
+        world, rank = args.world, args.world // 2
+        halo = max(2, min(4, (int(0.31 * n) + 3) // (2 * world)))
+        layout = D.SlabLayout.balanced(x_all, n, world, halo)
+    env, _, mine = D.make_slab_env(cfg, rank, world, compute_dtype=args.dtype, device=dev, target_fn=bench._target,
+                                   layout=layout, comm=LoopbackComm(layout, rank), xy_margin=args.xy_margin)
+    print(f"rank {rank}/{world}: slab {layout.slab(rank)}, halo {layout.halo}, {len(mine)} particles, "
+          f"window {env.simulator.engine._halo_window}")
+    env.loss.set_weights(10, 10, 1, False)
+    sim = env.simulator
+    state0 = env.get_state()["state"]
+    acts = bench.seeded_actions(args.steps, env.primitives.action_dim)
+    sub = sim.substeps
+    for timed in (False, True, True):
+        env.set_state(state0, 666.0, False)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        bench.rollout(env, acts)
+        t1 = time.perf_counter()
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        if timed:
+            k = args.steps * sub
+            print(f"issue {1e6 * (t1 - t0) / k:7.1f} us/substep   wall {1e6 * (t2 - t0) / k:7.1f} us/substep   "
+                  f"({k} fwd+bwd substeps)")
+    if args.profile:
+        import cProfile
+        import pstats
+        env.set_state(state0, 666.0, False)
+        pr = cProfile.Profile()
+        pr.enable()
+        bench.rollout(env, acts)
+        pr.disable()
+        torch.cuda.synchronize()
+        pstats.Stats(pr).sort_stats("tottime").print_stats(22)
+
+
+if __name__ == "__main__":
+    main()

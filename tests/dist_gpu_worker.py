@@ -14,6 +14,7 @@ sys.path.insert(0, ROOT)
 
 def main():
     out_path, dtype, halo = sys.argv[1], sys.argv[2], int(sys.argv[3])
+    xy_margin = None if len(sys.argv) < 5 or sys.argv[4] == "none" else int(sys.argv[4])
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -29,7 +30,7 @@ def main():
     x_all, _ = Shapes(cfg.SHAPES).get()
     n = int(g["n_particles"])
     sub = np.ascontiguousarray(x_all[::len(x_all) // n][:n])
-    env, layout, mine = make_slab_env(cfg, rank, world, halo=halo, compute_dtype=dtype, particles=sub,
+    env, layout, mine = make_slab_env(cfg, rank, world, halo=halo, compute_dtype=dtype, particles=sub, xy_margin=xy_margin,
                                       target_fn=lambda x, sim: sparse_target("Move3D-v1"))
     env.loss.set_weights(10, 10, 1, False)
     solver = Solver(env, None, None, softness=666.0, horizon=len(g["actions"]))

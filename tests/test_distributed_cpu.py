@@ -67,13 +67,25 @@ class ToyEngine:
     def chain_grad(self, first, n, step):
         self.calls.append(("chain_grad", first, n, step, float(self.pos_l[first:first + n + 1].sum())))
 
-    def halo_pack(self, field, f, za, zb):
+    def halo_pack(self, field, f, za, zb, out=None):
         src = {0: self.gin.get(f), 1: self.goa, 2: getattr(self, "lm", None)}[field]
+        if out is not None:
+            return out.copy_(src[:, za:zb])
         return src[:, za:zb].clone()
 
     def halo_unpack_add(self, field, f, za, zb, buf):
         src = {0: self.gin.get(f), 1: self.goa, 2: getattr(self, "lm", None)}[field]
         src[:, za:zb] += buf
+
+    def slab_pre(self, field, f, faces, chain=False):
+        (self.p2g if field == 0 else self.grad_scatter)(f)
+        for fc in faces:
+            self.halo_pack(field, f, fc.za, fc.zb, out=fc.send)
+
+    def slab_post(self, field, f, faces, chain=False):
+        for fc in faces:
+            self.halo_unpack_add(field, f, fc.za, fc.zb, fc.recv)
+        (self.grid_g2p if field == 0 else self.grad_gather)(f)      # (the toy g2p has nothing to fuse with)
 
     def flags_view(self, f, bza, bzb):
         m = (N // 4) ** 2

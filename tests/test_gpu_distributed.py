@@ -21,8 +21,9 @@ def free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("dtype,world,halo", [("float64", 2, 3), ("float32", 2, 3), ("float64", 3, 2)])
-def test_slab_ranks_match_single_rank(tmp_path, dtype, world, halo):
+# xy_margin: whole halo planes travel (None) or only the body's xy bounding box + that many node layers
+@pytest.mark.parametrize("dtype,world,halo,xy_margin", [("float64", 2, 3, None), ("float32", 2, 3, 8), ("float64", 3, 2, 6)])
+def test_slab_ranks_match_single_rank(tmp_path, dtype, world, halo, xy_margin):
     g = np.load(os.path.join(GOLDEN, "rollout_small.npz"))
     out = str(tmp_path / "r")
     port = free_port()
@@ -30,7 +31,8 @@ def test_slab_ranks_match_single_rank(tmp_path, dtype, world, halo):
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    HSA_ENABLE_IPC_MODE_LEGACY="0")
-        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_gpu_worker.py"), out, dtype, str(halo)],
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_gpu_worker.py"), out, dtype, str(halo),
+                                       "none" if xy_margin is None else str(xy_margin)],
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     logs = [p.communicate(timeout=600)[0].decode() for p in procs]
     for p, lg in zip(procs, logs):
