@@ -403,6 +403,8 @@ template <class T> PLB_HD bool collide_eval(const PrimT<T>& pr, T softness, T dt
 // adjoint of one collide.  v: velocity before this collide; vn_a: adjoint of its output.
 // Writes v_a; accumulates pose adjoints into pa (only for movable Spheres -- other movable
 // shapes need d sdf/d pose, d normal/d pose, which are not derived yet).
+template <class T> PLB_HD void collide_grad_from(const PrimT<T>& pr, T softness, T dt, const double* gp,
+                                                 const CollideTmp<T>& c, const T* vn_a, T* v_a, PoseAdj<T>* pa);
 template <class T> PLB_HD bool collide_grad(const PrimT<T>& pr, T softness, T dt, const double* gp, const T* v,
                                             const T* vn_a, T* v_a, PoseAdj<T>* pa) {
     CollideTmp<T> c;
@@ -411,6 +413,12 @@ template <class T> PLB_HD bool collide_grad(const PrimT<T>& pr, T softness, T dt
         for (int i = 0; i < 3; ++i) v_a[i] = vn_a[i];
         return false;
     }
+    collide_grad_from(pr, softness, dt, gp, c, vn_a, v_a, pa);
+    return true;
+}
+// the adjoint proper, from the intermediates `c` of a collide_eval that hit
+template <class T> PLB_HD void collide_grad_from(const PrimT<T>& pr, T softness, T dt, const double* gp,
+                                                 const CollideTmp<T>& c, const T* vn_a, T* v_a, PoseAdj<T>* pa) {
     T m = c.e < T(0) ? T(0) : c.e;
     T cva[3], iva[3], g2a[3], gvta[3], Da[3] = {T(0), T(0), T(0)};
     T infla = T(0);
@@ -442,14 +450,14 @@ template <class T> PLB_HD bool collide_grad(const PrimT<T>& pr, T softness, T dt
     if (c.nc < T(0)) nca += mna;
     for (int i = 0; i < 3; ++i) { iva[i] += nca * c.D[i]; Da[i] += nca * c.iv[i]; }
     for (int i = 0; i < 3; ++i) { v_a[i] = iva[i]; cva[i] -= iva[i]; }
-    if (!pa || !pr.movable) return true;
+    if (!pa || !pr.movable) return;
     // ---- pose adjoints
     // influence = min(exp(-dist*soft), 1): adjoint to the exp iff exp < 1
     double dista = 0.0;
-    T ex = t_exp((T)(-c.dist * (double)softness));
-    if (ex < T(1)) dista = -(double)softness * (double)ex * (double)infla;
+    if (c.infl < T(1)) dista = -(double)softness * (double)c.infl * (double)infla;     // infl = exp(..) when < 1
     // collider velocity
-    double npa[3] = {(double)cva[0] / (double)dt, (double)cva[1] / (double)dt, (double)cva[2] / (double)dt};
+    const double inv_dt = 1.0 / (double)dt;
+    double npa[3] = {(double)cva[0] * inv_dt, (double)cva[1] * inv_dt, (double)cva[2] * inv_dt};
     for (int i = 0; i < 3; ++i) pa->pos1[i] += npa[i];
     qrot_adj_q(pr.rot1, c.rel, npa, pa->rot1);
     double cr1[4], rela[3];
@@ -459,12 +467,12 @@ template <class T> PLB_HD bool collide_grad(const PrimT<T>& pr, T softness, T dt
     if (pr.shape == SHAPE_SPHERE) {
         // dist = len14(gp - c) - r ; D = (gp - c)/len14
         double d[3] = {gp[0] - pr.pos[0], gp[1] - pr.pos[1], gp[2] - pr.pos[2]};
-        double L = len14(d[0], d[1], d[2]);
-        double Dd[3] = {d[0] / L, d[1] / L, d[2] / L};
+        double iL = 1.0 / len14(d[0], d[1], d[2]);
+        double Dd[3] = {d[0] * iL, d[1] * iL, d[2] * iL};
         double Dad[3] = {(double)Da[0], (double)Da[1], (double)Da[2]};
         double dD = dot3(Dad, Dd);
         for (int i = 0; i < 3; ++i) {
-            double da = dista * d[i] / L + (Dad[i] - Dd[i] * dD) / L;   // adjoint of d = gp - c
+            double da = dista * Dd[i] + (Dad[i] - Dd[i] * dD) * iL;     // adjoint of d = gp - c
             pa->pos[i] -= da;
         }
     } else {
@@ -478,7 +486,6 @@ template <class T> PLB_HD bool collide_grad(const PrimT<T>& pr, T softness, T dt
         shape_local_adj(pr.shape, pr.par, c.rel, dista, nla, loca, &pa->gap);
         inv_trans_adj(gp, pr.pos, pr.rot, c.iq, loca, pa->pos, pa->rot);
     }
-    return true;
 }
 
 // ------------------------------------------------------------------ box boundary (mpm_simulator.py:200-219)
@@ -558,13 +565,17 @@ PLB_HD void grid_node_bwd(const SimP<T>& P, const int* I, T m, const T* mv, int 
     T v0[3] = {inv * mv[0] + P.grav[0], inv * mv[1] + P.grav[1], inv * mv[2] + P.grav[2]};
     double gp[3] = {I[0] / (double)P.n, I[1] / (double)P.n, I[2] / (double)P.n};
     T a[3] = {T(0), T(0), T(0)};
+    // the LAST primitive the node touches keeps its collide intermediates from the forward sweep, so the common case
+    // (a node in contact with one manipulator) evaluates the double-precision geometry once, not three times
+    int last = -1;
+    CollideTmp<T> cl;
     if (live) {
         // forward to the state after all collides
         T vc[3] = {v0[0], v0[1], v0[2]};
         for (int p = 0; p < nprim; ++p) {
             CollideTmp<T> c;
             T vn[3];
-            if (collide_eval(prims[p], P.softness, P.dt, gp, vc, c, vn)) { vc[0] = vn[0]; vc[1] = vn[1]; vc[2] = vn[2]; }
+            if (collide_eval(prims[p], P.softness, P.dt, gp, vc, c, vn)) { vc[0] = vn[0]; vc[1] = vn[1]; vc[2] = vn[2]; cl = c; last = p; }
         }
         // boundary stages
         T vb0[3] = {vc[0], vc[1], vc[2]}, vb1[3], vb2[3];
@@ -576,20 +587,25 @@ PLB_HD void grid_node_bwd(const SimP<T>& P, const int* I, T m, const T* mv, int 
         boundary_axis_grad(P, I, 1, vb1, a);
         boundary_axis_grad(P, I, 0, vb0, a);
     }
-    // collides in reverse; the velocity entering collide p is recomputed from v0
+    // collides in reverse; primitives after `last` did not touch the node, `last` reuses its intermediates, and for
+    // the ones before it (a node between two manipulators) the velocity entering the collide is recomputed from v0
     for (int p = nprim - 1; p >= 0; --p) {
         PoseAdj<T> pa;
         pa.zero();
         bool hit = false;
-        if (live) {
-            T vin[3] = {v0[0], v0[1], v0[2]};
+        CollideTmp<T> c;
+        if (live && p == last) { c = cl; hit = true; }
+        else if (live && p < last) {
+            T vin[3] = {v0[0], v0[1], v0[2]}, vn[3];
             for (int q = 0; q < p; ++q) {
-                CollideTmp<T> c;
-                T vn[3];
-                if (collide_eval(prims[q], P.softness, P.dt, gp, vin, c, vn)) { vin[0] = vn[0]; vin[1] = vn[1]; vin[2] = vn[2]; }
+                CollideTmp<T> cq;
+                if (collide_eval(prims[q], P.softness, P.dt, gp, vin, cq, vn)) { vin[0] = vn[0]; vin[1] = vn[1]; vin[2] = vn[2]; }
             }
+            hit = collide_eval(prims[p], P.softness, P.dt, gp, vin, c, vn);
+        }
+        if (hit) {
             T va[3];
-            hit = collide_grad(prims[p], P.softness, P.dt, gp, vin, a, va, &pa);
+            collide_grad_from(prims[p], P.softness, P.dt, gp, c, a, va, &pa);
             a[0] = va[0]; a[1] = va[1]; a[2] = va[2];
         }
         sink(p, pa, hit && prims[p].movable);

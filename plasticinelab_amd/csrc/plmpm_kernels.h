@@ -797,7 +797,7 @@ __global__ __launch_bounds__(kBlock) void k_g2p_grad(Dev<T> D, int f, int src, i
 // ------------------------------------------------------------------------------------------------
 // grid_op.grad over active blocks: grid_out_adj -> grid_in_adj, pose adjoints; clears grid_out_adj
 template <class T>
-__global__ __launch_bounds__(kBlock) void k_grid_op_grad(Dev<T> D, int f) {
+__global__ __launch_bounds__(kBlock, 2) void k_grid_op_grad(Dev<T> D, int f) {
     __shared__ PrimT<T> sp[kMaxPrim];
     __shared__ double sacc[kMaxPrim * 15];
     __shared__ int shit;
@@ -825,12 +825,8 @@ __global__ __launch_bounds__(kBlock) void k_grid_op_grad(Dev<T> D, int f) {
             for (int d = 0; d < 4; ++d) { vals[3 + d] = h ? pa.rot[d] : 0.0; vals[10 + d] = h ? pa.rot1[d] : 0.0; }
             vals[14] = h ? pa.gap : 0.0;
             const int nc = sp[q].shape == SHAPE_CHOPSTICKS ? 15 : 14;
-            for (int c = 0; c < nc; ++c) {
-                double v = vals[c];
-                for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-                vals[c] = v;
-            }
-            if (lane == 0) {
+            for (int c = 0; c < nc; ++c) vals[c] = wave_sum_to_lane63(vals[c]);
+            if (lane == 63) {
                 double* o = &sacc[q * 15];
                 for (int c = 0; c < nc; ++c) atomicAdd(&o[c], vals[c]);
                 shit = 1;
