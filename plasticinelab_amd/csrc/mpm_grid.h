@@ -554,7 +554,9 @@ PLB_HD bool grid_node_fwd(const SimP<T>& P, const int* I, T m, const T* mv, int 
 // grid_op adjoint for one node.  vout_a: adjoint of grid_v_out.  Outputs m_a, mv_a.  sink(p, PoseAdj, hit) is
 // called for EVERY primitive by EVERY caller (hit = false, zero adjoint when the node does not touch it), so a
 // GPU sink may use wave-wide collectives.
-template <class T, class Sink>
+// POSE = false leaves the pose adjoints out (sink still gets `hit`): the GPU path computes them off the critical
+// path, for the few blocks that touch a manipulator.
+template <class T, bool POSE = true, class Sink>
 PLB_HD void grid_node_bwd(const SimP<T>& P, const int* I, T m, const T* mv, int nprim, const PrimT<T>* prims,
                           const T* vout_a, T* m_a, T* mv_a, Sink&& sink) {
     *m_a = T(0); mv_a[0] = mv_a[1] = mv_a[2] = T(0);
@@ -567,6 +569,8 @@ PLB_HD void grid_node_bwd(const SimP<T>& P, const int* I, T m, const T* mv, int 
     T a[3] = {T(0), T(0), T(0)};
     // the LAST primitive the node touches keeps its collide intermediates from the forward sweep, so the common case
     // (a node in contact with one manipulator) evaluates the double-precision geometry once, not three times
+    // (not in the POSE pass, which runs off the critical path and is short of registers)
+    constexpr bool KEEP = !POSE;
     int last = -1;
     CollideTmp<T> cl;
     if (live) {
@@ -575,7 +579,10 @@ PLB_HD void grid_node_bwd(const SimP<T>& P, const int* I, T m, const T* mv, int 
         for (int p = 0; p < nprim; ++p) {
             CollideTmp<T> c;
             T vn[3];
-            if (collide_eval(prims[p], P.softness, P.dt, gp, vc, c, vn)) { vc[0] = vn[0]; vc[1] = vn[1]; vc[2] = vn[2]; cl = c; last = p; }
+            if (collide_eval(prims[p], P.softness, P.dt, gp, vc, c, vn)) {
+                vc[0] = vn[0]; vc[1] = vn[1]; vc[2] = vn[2];
+                if (KEEP) { cl = c; last = p; }
+            }
         }
         // boundary stages
         T vb0[3] = {vc[0], vc[1], vc[2]}, vb1[3], vb2[3];
@@ -594,8 +601,8 @@ PLB_HD void grid_node_bwd(const SimP<T>& P, const int* I, T m, const T* mv, int 
         pa.zero();
         bool hit = false;
         CollideTmp<T> c;
-        if (live && p == last) { c = cl; hit = true; }
-        else if (live && p < last) {
+        if (KEEP && live && p == last) { c = cl; hit = true; }
+        else if (live && (!KEEP || p < last)) {
             T vin[3] = {v0[0], v0[1], v0[2]}, vn[3];
             for (int q = 0; q < p; ++q) {
                 CollideTmp<T> cq;
@@ -605,7 +612,7 @@ PLB_HD void grid_node_bwd(const SimP<T>& P, const int* I, T m, const T* mv, int 
         }
         if (hit) {
             T va[3];
-            collide_grad_from(prims[p], P.softness, P.dt, gp, c, a, va, &pa);
+            collide_grad_from(prims[p], P.softness, P.dt, gp, c, a, va, POSE ? &pa : nullptr);
             a[0] = va[0]; a[1] = va[1]; a[2] = va[2];
         }
         sink(p, pa, hit && prims[p].movable);

@@ -82,6 +82,7 @@ struct plmpm_sim {
     char* gstore = nullptr;      // grid_m / grid_v_in per frame (SoA, 4 comps)
     char* vstore = nullptr;      // grid_v_out per frame (AoS T4)
     int* fstore = nullptr;
+    int* contact = nullptr;      // [0] = n, [1..n]: blocks whose pose adjoints k_grid_op_grad left to the k_p2g_grad launch
     int* tiles = nullptr;        // per-frame stencil boxes of the particle workgroups: [(F+1)][Npad/256][8]
     // Per-env-step storage order ("epochs").  Epoch 0 is the order chosen at reset (perm_d).  With cfg.resort_steps,
     // plmpm_step re-sorts the step's first frame along the Hilbert curve before it starts (epoch = step index); the
@@ -174,6 +175,7 @@ template <class T> static Dev<T> make_dev(const plmpm_sim* s, int frame = -1) {
     D.grid_in_adj = (Vec4<T>*)s->grid_in_adj;
     D.flags = framed ? s->fstore + (size_t)frame * s->nblk : s->flags;
     D.tiles = s->tiles;
+    D.contact = s->contact;
     D.trace = (unsigned long long*)s->staging;      // profiling builds only (needs N * 24 * 8 >= 3 * 16384 * 128 bytes)
     D.ppos = s->ppos; D.prot = s->prot; D.pgap = s->pgap;
     D.ppos_a = s->dist ? s->ppos_l : s->ppos_a;
@@ -605,6 +607,12 @@ static ChainBufs chain_bufs(const plmpm_sim* s) {
     return B;
 }
 static inline int nblocks_particles(const plmpm_sim* s) { return s->Npad / kBlock; }
+#ifndef PLB_POSE_WG
+#define PLB_POSE_WG 16
+#endif
+// workgroups at the head of every k_p2g_grad launch that finish grid_op.grad's pose adjoints (64 waves: the blocks in
+// contact with a manipulator number a few dozen)
+constexpr int kPoseWG = PLB_POSE_WG;
 static inline int nblocks_grid(const plmpm_sim* s) { return (s->nblk + (kBlock / 64) - 1) / (kBlock / 64); }
 // persistent grid kernels: a fixed number of workgroups, each striding over its share of the block flags
 static inline int nwg_grid(const plmpm_sim* s) { return std::min(nblocks_grid(s), kGridWG); }
@@ -634,7 +642,7 @@ template <class T> static int substep_bwd(plmpm_sim* s, int f) {
     }
     LAUNCH(s, K_G2P_GRAD, (k_g2p_grad<T>), dim3(nblocks_particles(s)), D, f, src, dst, vnext);
     LAUNCH(s, K_GRID_OP_GRAD, (k_grid_op_grad<T>), dim3(nwg_grid(s)), D, f);
-    LAUNCH(s, K_P2G_GRAD, (k_p2g_grad<T>), dim3(nblocks_particles(s)), D, f, src, dst);
+    LAUNCH(s, K_P2G_GRAD, (k_p2g_grad<T>), dim3(nblocks_particles(s) + kPoseWG), D, f, src, dst, kPoseWG);
     if (s->store) s->dirty[f] = 0;           // k_grid_op_grad left grid_in / flags of this frame clean
     s->adj_frame[dst] = f;
     return 0;
@@ -690,7 +698,7 @@ template <class T> static int phase_grad_scatter(plmpm_sim* s, int f) {
 template <class T> static int phase_grad_gather(plmpm_sim* s, int f) {
     Dev<T> D = make_dev<T>(s, f);
     LAUNCH(s, K_GRID_OP_GRAD, (k_grid_op_grad<T>), dim3(nwg_grid(s)), D, f);
-    LAUNCH(s, K_P2G_GRAD, (k_p2g_grad<T>), dim3(nblocks_particles(s)), D, f, (f + 1) & 1, f & 1);
+    LAUNCH(s, K_P2G_GRAD, (k_p2g_grad<T>), dim3(nblocks_particles(s) + kPoseWG), D, f, (f + 1) & 1, f & 1, kPoseWG);
     s->dirty[f] = 0;
     s->adj_frame[f & 1] = f;
     return 0;
@@ -916,7 +924,7 @@ int plmpm_create(const plmpm_config* cfg, const plmpm_primitive* prims, plmpm_ha
     s->store = cfg->store_grid != 0;
     s->gstride = align_up(s->G * 4 * s->tsz, 256);
     if (s->store) s->ws.grid_bytes += 2 * (size_t)s->F * s->gstride + align_up((size_t)s->F * s->nblk * 4, 256);
-    s->ws.grid_bytes += align_up((size_t)(s->F + 1) * (s->Npad / kBlock) * 8 * 4, 256);
+    s->ws.grid_bytes += align_up((size_t)(s->F + 1) * (s->Npad / kBlock) * 8 * 4, 256) + align_up((size_t)(s->nblk + 1) * 4, 256);
     s->dirty.assign(s->F + 1, 0);
     s->ws.misc_bytes = 2 * align_up((size_t)(s->F + 1) * P1 * 7 * 8, 256) + 2 * align_up((size_t)(s->F + 1) * P1 * 8 * 8, 256)  // poses(+adj), padded
                        + 4 * align_up((size_t)(s->F + 1) * P1 * 3 * 8, 256)                       // v,w (+adj)
@@ -972,6 +980,7 @@ int plmpm_bind_workspace(plmpm_handle s, void* state, void* adjoint, void* grid,
         s->fstore = (int*)take((size_t)s->F * s->nblk * 4);
     }
     s->tiles = (int*)take((size_t)(s->F + 1) * (s->Npad / kBlock) * 8 * 4);
+    s->contact = (int*)take((size_t)(s->nblk + 1) * 4);
     REQUIRE((size_t)(p - s->gridw) <= s->ws.grid_bytes, "internal: grid workspace overflow");
     p = s->miscw;
     size_t P1 = std::max(s->P, 1), F1 = s->F + 1;

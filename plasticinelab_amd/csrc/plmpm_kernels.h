@@ -30,7 +30,7 @@ constexpr int kBlock = 256;          // threads per workgroup in particle kernel
 #define PLB_P2G_WAVES 4
 #endif
 #ifndef PLB_P2G_GRAD_WAVES
-#define PLB_P2G_GRAD_WAVES 1
+#define PLB_P2G_GRAD_WAVES 2
 #endif
 constexpr int kMaxPrim = 8;
 constexpr int kGridWG = 512;         // workgroups of the persistent grid kernels (4 waves each, one wave per block)
@@ -91,6 +91,7 @@ template <class T> struct Dev {
     Vec4<T>*grid_out, *grid_in_adj;  // AoS
     int* flags;
     int* tiles;                      // [(F+1)][workgroups][8]: stencil box of each 256-particle workgroup, per frame
+    int* contact;                    // [0] = n, [1..n] = blocks whose pose adjoints are still due (grid_op.grad -> p2g.grad)
     unsigned long long* trace;       // profiling builds only
     // primitives (double): pos[(F+1)][P][3], rot[(F+1)][P][4], gap[(F+1)][P] (Chopsticks) and adjoints
     const double *ppos, *prot, *pgap;
@@ -359,8 +360,8 @@ template <class T> __device__ __forceinline__ void store_tile(const Dev<T>& D, i
         q[threadIdx.x] = threadIdx.x < 3 ? t.o[threadIdx.x] : t.e[threadIdx.x - 3];
     }
 }
-template <class T> __device__ __forceinline__ Tile load_tile(const Dev<T>& D, int f, int cap) {
-    const int* q = D.tiles + ((size_t)f * gridDim.x + blockIdx.x) * 8;
+template <class T> __device__ __forceinline__ Tile load_tile(const Dev<T>& D, int f, int cap, int wg = blockIdx.x, int nwg = gridDim.x) {
+    const int* q = D.tiles + ((size_t)f * nwg + wg) * 8;
     Tile t;
     int nodes = 1;
     for (int d = 0; d < 3; ++d) { t.o[d] = q[d]; t.e[d] = q[3 + d]; nodes *= t.e[d]; }
@@ -714,6 +715,7 @@ __global__ __launch_bounds__(kBlock) void k_g2p_grad(Dev<T> D, int f, int src, i
     int p, base[3];
     double x[3];
     PT_BEGIN();
+    if (blockIdx.x == 0 && threadIdx.x == 0) D.contact[0] = 0;     // the list k_grid_op_grad(f) is about to fill
     const Tile tl = load_tile(D, f, CAP);                           // stored by the scatter of this frame
     SortLoad sl = sorted_begin(D, X);
     const int ex = tl.e[0], exy = tl.e[0] * tl.e[1], tn = exy * tl.e[2];
@@ -795,30 +797,27 @@ __global__ __launch_bounds__(kBlock) void k_g2p_grad(Dev<T> D, int f, int src, i
 }
 
 // ------------------------------------------------------------------------------------------------
-// grid_op.grad over active blocks: grid_out_adj -> grid_in_adj, pose adjoints; clears grid_out_adj
-template <class T>
-__global__ __launch_bounds__(kBlock, 2) void k_grid_op_grad(Dev<T> D, int f) {
-    __shared__ PrimT<T> sp[kMaxPrim];
-    __shared__ double sacc[kMaxPrim * 15];
-    __shared__ int shit;
-    load_prims(D, f, sp);
-    if (threadIdx.x < kMaxPrim * 15) sacc[threadIdx.x] = 0.0;
-    if (threadIdx.x == 0) shit = 0;
-    __syncthreads();
-    const int lane = threadIdx.x & 63;
-    for_each_active_block(D, [&](int blk) {
-        const int idx = (blk << 6) | lane;
-        const int bx = blk % D.nb, by = (blk / D.nb) % D.nb, bz = blk / (D.nb * D.nb);
-        int I[3] = {(bx << 2) | (lane & 3), (by << 2) | ((lane >> 2) & 3), (bz << 2) | (lane >> 4)};
-        T gm = D.gin[0][idx];
-        T mv[3] = {D.gin[1][idx], D.gin[2][idx], D.gin[3][idx]};
-        T va[3] = {D.goa[0][idx], D.goa[1][idx], D.goa[2][idx]}, ma, mva[3];
-        const bool owned = I[2] >= D.z0 && I[2] < D.z1;     // halo nodes are computed on two ranks: count once
-        grid_node_bwd<T>(D.P, I, gm, mv, D.nprim, sp, va, &ma, mva, [&](int q, const PoseAdj<T>& pa, bool hit) {
-            // every lane of the wave gets here for every primitive: sum the 15 pose-adjoint components across the
-            // wave (DPP scans) and let one lane touch LDS (64 lanes hitting the same 14 addresses with
-            // ds_add_f64 serialise badly)
-            const bool h = hit && owned;
+// grid_op.grad: grid_out_adj -> grid_in_adj, pose adjoints; clears grid_out_adj, grid_in and the block flag.
+// One wave, one 4^3 block.  POSE = false computes the velocity adjoint only and returns true when an owned node of
+// the block touches a movable primitive: its pose adjoints are then still due and the block's inputs are left in
+// place for the POSE = true pass, which clears them.
+template <class T, bool POSE>
+__device__ __forceinline__ bool grid_block_bwd(const Dev<T>& D, int blk, int lane, const PrimT<T>* sp, double* sacc, int* shit) {
+    const int idx = (blk << 6) | lane;
+    const int bx = blk % D.nb, by = (blk / D.nb) % D.nb, bz = blk / (D.nb * D.nb);
+    int I[3] = {(bx << 2) | (lane & 3), (by << 2) | ((lane >> 2) & 3), (bz << 2) | (lane >> 4)};
+    T gm = D.gin[0][idx];
+    T mv[3] = {D.gin[1][idx], D.gin[2][idx], D.gin[3][idx]};
+    T va[3] = {D.goa[0][idx], D.goa[1][idx], D.goa[2][idx]}, ma, mva[3];
+    const bool owned = I[2] >= D.z0 && I[2] < D.z1;     // halo nodes are computed on two ranks: count once
+    bool due = false;
+    grid_node_bwd<T, POSE>(D.P, I, gm, mv, D.nprim, sp, va, &ma, mva, [&](int q, const PoseAdj<T>& pa, bool hit) {
+        // every lane of the wave gets here for every primitive: sum the 15 pose-adjoint components across the
+        // wave (DPP scans) and let one lane touch LDS (64 lanes hitting the same 14 addresses with
+        // ds_add_f64 serialise badly)
+        const bool h = hit && owned;
+        if constexpr (!POSE) { due |= h; return; }
+        else {
             if (!__any(h)) return;
             double vals[15];
             for (int d = 0; d < 3; ++d) { vals[d] = h ? pa.pos[d] : 0.0; vals[7 + d] = h ? pa.pos1[d] : 0.0; }
@@ -829,16 +828,50 @@ __global__ __launch_bounds__(kBlock, 2) void k_grid_op_grad(Dev<T> D, int f) {
             if (lane == 63) {
                 double* o = &sacc[q * 15];
                 for (int c = 0; c < nc; ++c) atomicAdd(&o[c], vals[c]);
-                shit = 1;
+                *shit = 1;
             }
-        });
-        D.grid_in_adj[idx] = Vec4<T>{ma, mva[0], mva[1], mva[2]};
+        }
+    });
+    const bool defer = !POSE && __any(due);
+    if (!POSE) D.grid_in_adj[idx] = Vec4<T>{ma, mva[0], mva[1], mva[2]};
+    if (!defer) {
         D.goa[0][idx] = T(0); D.goa[1][idx] = T(0); D.goa[2][idx] = T(0);
         // this frame's grid is consumed: leave grid_in / flags clean for the next scatter into them.  grid_in_adj
         // is never cleared -- p2g.grad only reads nodes of active blocks, which are all rewritten every substep.
         D.gin[0][idx] = T(0); D.gin[1][idx] = T(0); D.gin[2][idx] = T(0); D.gin[3][idx] = T(0);
         if (lane == 0) D.flags[blk] = 0;
+    }
+    return defer;
+}
+
+// Persistent over the active blocks.  The double-precision pose adjoints of the blocks in contact (a few dozen waves,
+// several microseconds each: the whole tail of this kernel when done here) are handed to spare workgroups of the
+// p2g.grad launch that follows, through D.contact.
+template <class T>
+__global__ __launch_bounds__(kBlock) void k_grid_op_grad(Dev<T> D, int f) {
+    __shared__ PrimT<T> sp[kMaxPrim];
+    load_prims(D, f, sp);
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    for_each_active_block(D, [&](int blk) {
+        if (grid_block_bwd<T, false>(D, blk, lane, sp, nullptr, nullptr) && lane == 0)
+            D.contact[1 + atomicAdd(&D.contact[0], 1)] = blk;
     });
+}
+
+// the pose-adjoint workgroups of the p2g.grad launch: blocks listed in D.contact, one wave each
+template <class T>
+__device__ __forceinline__ void pose_adjoint_blocks(const Dev<T>& D, int f, int wg, int nwg) {
+    __shared__ PrimT<T> sp[kMaxPrim];
+    __shared__ double sacc[kMaxPrim * 15];
+    __shared__ int shit;
+    load_prims(D, f, sp);
+    if (threadIdx.x < kMaxPrim * 15) sacc[threadIdx.x] = 0.0;
+    if (threadIdx.x == 0) shit = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, count = D.contact[0];
+    for (int i = wg * (kBlock / 64) + (threadIdx.x >> 6); i < count; i += nwg * (kBlock / 64))
+        grid_block_bwd<T, true>(D, D.contact[1 + i], lane, sp, sacc, &shit);
     __syncthreads();
     if (shit && threadIdx.x < D.nprim * 15) {
         int q = threadIdx.x / 15, c = threadIdx.x % 15;
@@ -857,15 +890,19 @@ __global__ __launch_bounds__(kBlock, 2) void k_grid_op_grad(Dev<T> D, int f) {
 // ------------------------------------------------------------------------------------------------
 // p2g.grad + svd_grad + compute_F_tmp.grad: gather grid_in_adj, finish adjoint frame `dst`
 template <class T>
-__global__ __launch_bounds__(kBlock, PLB_P2G_GRAD_WAVES) void k_p2g_grad(Dev<T> D, int f, int src, int dst) {
+__global__ __launch_bounds__(kBlock, PLB_P2G_GRAD_WAVES) void k_p2g_grad(Dev<T> D, int f, int src, int dst, int npose) {
     __shared__ Vec4<T> tile[TileCap<T>::nodes];
-    const int p = blockIdx.x * kBlock + threadIdx.x;
+    // the first `npose` workgroups finish grid_op.grad (pose adjoints of the blocks in contact) under cover of the
+    // particle workgroups
+    const int chunk = (int)blockIdx.x - npose;
+    if (chunk < 0) { pose_adjoint_blocks(D, f, (int)blockIdx.x, npose); return; }
+    const int p = chunk * kBlock + threadIdx.x;
     const bool valid = p < D.N;
     const double* X = frame_x(D, f);
     const T* R = frame_r(D, f);
     const int Np = D.Npad;
     PT_BEGIN();
-    const Tile tl = load_tile(D, f, TileCap<T>::nodes);             // stored by the scatter of this frame
+    const Tile tl = load_tile(D, f, TileCap<T>::nodes, chunk, (int)gridDim.x - npose);   // stored by the scatter of this frame
     double x[3] = {0.5, 0.5, 0.5};
     if (valid) { x[0] = X[p]; x[1] = X[Np + p]; x[2] = X[2 * Np + p]; }
     const int ex = tl.e[0], exy = tl.e[0] * tl.e[1], tn = exy * tl.e[2];
