@@ -253,7 +253,8 @@ def main():
         "metric": "MPM substeps/sec (fwd+bwd)", "value": value, "unit": "substeps/s", "n_gpus": world,
         "steps": K, "warmup": W, "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True, "scaling": "strong" if slabs else "weak",
         "vs_baseline": None, "dtype": "f32" if args.dtype == "float32" else "f64", "data": "synthetic",
-        "config": {"workload": "config3_cube128", "n_grid": sim.n_grid,
+        "config": {"workload": ("config3_cube128" if (args.particles, args.quality) == (500_000, 2)
+                                else f"cube{sim.n_grid}_{args.particles}p"), "n_grid": sim.n_grid,
                    "n_particles": args.particles if slabs else sim.n_particles,
                    "substeps_per_step": sub, "primitives": 2, "positions": "f64", "loss": "sdf+density+hard contact",
                    "parallelism": parallelism},
