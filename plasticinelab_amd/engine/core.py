@@ -353,7 +353,7 @@ class Engine:
         L.check(self.lib.plmpm_loss_backward_local(self.h, f))
 
     def error_flags(self) -> int:
-        """Device error word (bit 0: a particle left this rank's z-slab + halo); cleared by the read."""
+        """Device error word (bit 0: a particle left this rank's z-slab + halo or the halo window); cleared by the read."""
         e = C.c_int(0)
         L.check(self.lib.plmpm_check_error(self.h, C.byref(e)))
         return int(e.value)
@@ -361,8 +361,8 @@ class Engine:
     def check_error(self, flags=None):
         flags = self.error_flags() if flags is None else flags
         if flags & 1:
-            raise L.EngineError("a particle left a rank's z-slab + halo (fixed ownership, no migration yet): "
-                                "raise slab_halo or use fewer ranks")
+            raise L.EngineError("a particle left a rank's z-slab + halo, or the xy window of the exchanged halo planes "
+                                "(fixed ownership, no migration yet): raise slab_halo / xy_margin or use fewer ranks")
 
     def profile_enable(self, on=True):
         L.check(self.lib.plmpm_profile_enable(self.h, int(on)))

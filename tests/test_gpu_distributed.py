@@ -48,3 +48,39 @@ def test_slab_ranks_match_single_rank(tmp_path, dtype, world, halo, xy_margin):
         x[r["mine"]] = r["x"]; v[r["mine"]] = r["v"]
     assert relerr(x, g["x_final"]) < xtol
     assert relerr(v, g["v_final"]) < (1e-8 if dtype == "float64" else 2e-3)
+
+
+def test_leaving_the_slab_or_the_halo_window_raises():
+    """Fixed ownership: a stencil outside slab + halo in z, or outside the exchanged xy window, sets the error word
+    (Engine.check_error raises); inside both it does not."""
+    from plasticinelab_amd._lib import EngineError
+    from plasticinelab_amd.engine.core import Engine
+    from tests import emul
+    from tests.util import O, oracle_scene
+    from tests.gpu_util import load_state
+    _, sim, prims, x0 = oracle_scene("Move", 1, n_particles=1500)
+    n = sim.n_grid
+    b = (x0 * n - 0.5).astype(np.int64)
+    lo, hi = b.min(0), b.max(0) + 3                     # node box of all stencils
+    plist = [dict(shape=p.shape, action_dim=p.action_dim, params=emul.prim_par(p), friction=p.friction,
+                  action_scale=p.action_scale, lower_bound=p.lower_bound, upper_bound=p.upper_bound) for p in prims]
+
+    def flags(slab, window):
+        eng = Engine(n_grid=n, n_particles=sim.n_particles, max_frames=sim.substeps + 1, substeps=sim.substeps, dt=sim.dt,
+                     p_vol=sim.p_vol, p_mass=sim.p_mass, gravity=sim.gravity, ground_friction=sim.ground_friction,
+                     primitives=plist, dtype="float32", slab=slab, slab_halo=2, store_grid=True)
+        if window is not None:
+            eng.set_halo_window(*window)
+        load_state(eng, 0, O.init_state(x0), O.materials(sim), O.init_poses(prims))
+        eng.set_action(0, sim.substeps, np.zeros(sum(p.action_dim for p in prims)))
+        eng.fk(0, 1)
+        eng.p2g(0)
+        return eng
+
+    inside = (int(lo[2]), int(hi[2]))
+    assert flags(inside, None).error_flags() == 0
+    assert flags(inside, (max(int(lo[0]) - 2, 0), int(hi[0]) + 2, max(int(lo[1]) - 2, 0), int(hi[1]) + 2)).error_flags() == 0
+    assert flags(inside, (int(lo[0]) + 3, int(hi[0]) + 2, 0, n)).error_flags() & 1         # x window cuts the body
+    assert flags(inside, (0, n, max(int(lo[1]) - 2, 0), int(hi[1]) - 3)).error_flags() & 1         # y window cuts the body
+    with pytest.raises(EngineError, match="z-slab"):
+        flags((int(lo[2]) + 4, int(hi[2])), None).check_error()                            # slab + halo 2 misses 2 layers
