@@ -242,6 +242,10 @@ int plmpm_debug_counters(plmpm_handle h, int* out4);
 /* ---- introspection ------------------------------------------------------------------------- */
 /* number of grid nodes with mass > 0 and number of active 4^3 blocks after the last forward substep */
 int plmpm_grid_stats(plmpm_handle h, int frame, int64_t* active_nodes, int64_t* active_blocks);
+/* diagnostics: the stencil bounding box (origin node x,y,z, extent x,y,z) of every 256-particle workgroup of a frame
+ * that has been scattered, as the kernels stage it in LDS; out = int32[n_workgroups][6] (out may be NULL to query
+ * n_workgroups).  A box of more than 1024 (fp32) / 512 (fp64) nodes takes the slow global-memory path. */
+int plmpm_tile_boxes(plmpm_handle h, int frame, int32_t* out, int max_workgroups, int* n_workgroups);
 /* per-kernel timing with HIP events recorded on the launch stream, around every hot-path kernel.
  * enable(1) starts collecting; read() synchronises, returns summed milliseconds and launch counts for
  * the plmpm_profile_kernel_count() kernel classes and resets the collection. */

@@ -78,6 +78,7 @@ SYMBOLS = {
     "plmpm_get_grid_mass": (_I, [_P, _I, _P]),
     "plmpm_loss_get_target_sdf": (_I, [_P, _P]),
     "plmpm_grid_stats": (_I, [_P, _I, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "plmpm_tile_boxes": (_I, [_P, _I, _P, _I, C.POINTER(C.c_int)]),
     "plmpm_get_order": (_I, [_P, _P]),
     "plmpm_fk": (_I, [_P, _I, _I]),
     "plmpm_p2g": (_I, [_P, _I]),

@@ -1566,6 +1566,21 @@ int plmpm_grid_stats(plmpm_handle s, int frame, int64_t* active_nodes, int64_t* 
     return 0;
 }
 
+int plmpm_tile_boxes(plmpm_handle s, int frame, int32_t* out, int max_workgroups, int* n_workgroups) {
+    NEED_BOUND(s);
+    NEED_FRAME(s, frame);
+    const int nwg = nblocks_particles(s);
+    if (n_workgroups) *n_workgroups = nwg;
+    if (!out) return 0;
+    REQUIRE(max_workgroups >= nwg, "tile_boxes: room for %d workgroups, need %d", max_workgroups, nwg);
+    std::vector<int> h((size_t)nwg * 8);
+    HIPCHK(hipMemcpyAsync(h.data(), s->tiles + (size_t)frame * nwg * 8, h.size() * 4, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    for (int w = 0; w < nwg; ++w)
+        for (int k = 0; k < 6; ++k) out[w * 6 + k] = h[(size_t)w * 8 + k];
+    return 0;
+}
+
 int plmpm_fk(plmpm_handle s, int first_frame, int n_substeps) {
     NEED_BOUND(s);
     REQUIRE(first_frame >= 0 && n_substeps > 0 && first_frame + n_substeps <= s->F, "fk: bad frame range");

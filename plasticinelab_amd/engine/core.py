@@ -230,6 +230,14 @@ class Engine:
         L.check(self.lib.plmpm_grid_stats(self.h, f, C.byref(a), C.byref(b)))
         return a.value, b.value
 
+    def tile_boxes(self, f):
+        """(n_workgroups, 6) int32: stencil box origin + extent of each 256-particle workgroup of a scattered frame."""
+        n = C.c_int(0)
+        L.check(self.lib.plmpm_tile_boxes(self.h, f, None, 0, C.byref(n)))
+        out = np.zeros((n.value, 6), np.int32)
+        L.check(self.lib.plmpm_tile_boxes(self.h, f, _ptr(out), n.value, C.byref(n)))
+        return out
+
     def order(self):
         p = np.empty(self.n_particles, np.int32)
         L.check(self.lib.plmpm_get_order(self.h, _ptr(p)))

@@ -1,5 +1,8 @@
 import sys, ctypes as C, numpy as np, torch
 sys.path.insert(0, '/root/repo')
+import os
+import plasticinelab_amd._lib as L
+L.LIB_PATH = os.environ.get('EXP_LIB', L.LIB_PATH)      # a -DPLB_PHASE_TIMING build of libplmpm.so
 import bench
 class A: pass
 args = A(); args.particles = 500_000; args.quality = 2; args.steps = 2; args.warmup = 1; args.dtype = 'float32'
