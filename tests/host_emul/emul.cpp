@@ -140,8 +140,12 @@ template <class T> static int substep_grad_t(const emul_cfg& c, const emul_prim*
     for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) for (int k = 0; k < n; ++k) {
         size_t I = g.idx(i, j, k);
         int Iv[3] = {i, j, k};
-        T ma, mva[3];
-        grid_node_bwd<T>(P, Iv, g.m[I], &g.mv[3 * I], (int)prims.size(), prims.data(), &vout_a[3 * I], &ma, mva,
+        T ma, mva[3], ma2, mva2[3];
+        // as on the GPU: the velocity adjoint comes from the POSE = false pass (k_grid_op_grad), the pose adjoints
+        // from the POSE = true pass that the spare workgroups of k_p2g_grad run on the blocks in contact
+        grid_node_bwd<T, false>(P, Iv, g.m[I], &g.mv[3 * I], (int)prims.size(), prims.data(), &vout_a[3 * I], &ma, mva,
+            [&](int, const PoseAdj<T>&, bool) {});
+        grid_node_bwd<T, true>(P, Iv, g.m[I], &g.mv[3 * I], (int)prims.size(), prims.data(), &vout_a[3 * I], &ma2, mva2,
             [&](int p, const PoseAdj<T>& pa, bool hit) {
                 if (!hit) return;
                 double* o = &padj[(size_t)p * 15];
