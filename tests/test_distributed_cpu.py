@@ -36,6 +36,7 @@ class ToyEngine:
         self.pos_l = torch.zeros(64, dtype=torch.float64)
         self.rot_l = torch.zeros(64, dtype=torch.float64)
         self.calls = []
+        self.pending = None
 
     def fk(self, first, n):
         self.calls.append(("fk", first, n))
@@ -78,14 +79,25 @@ class ToyEngine:
         src[:, za:zb] += buf
 
     def slab_pre(self, field, f, faces, chain=False):
+        if chain:                                       # g2p(f - 1) was deferred: it runs with this p2g, as in the library
+            assert field == 0 and self.pending == f - 1, (field, f, self.pending)
+            self.grid_g2p(f - 1)
+            self.pending = None
+        else:
+            assert self.pending is None
         (self.p2g if field == 0 else self.grad_scatter)(f)
         for fc in faces:
             self.halo_pack(field, f, fc.za, fc.zb, out=fc.send)
+        self.calls.append(("slab_pre", field, f, bool(chain)))
 
     def slab_post(self, field, f, faces, chain=False):
         for fc in faces:
             self.halo_unpack_add(field, f, fc.za, fc.zb, fc.recv)
-        (self.grid_g2p if field == 0 else self.grad_gather)(f)      # (the toy g2p has nothing to fuse with)
+        if field == 0 and chain:
+            self.pending = f                            # plmpm_slab_post(chain=1): grid_op only, g2p left pending
+        else:
+            (self.grid_g2p if field == 0 else self.grad_gather)(f)
+        self.calls.append(("slab_post", field, f, bool(chain)))
 
     def flags_view(self, f, bza, bzb):
         m = (N // 4) ** 2
@@ -139,17 +151,24 @@ def _world(rank, world, port, bz_all, w_all, out):
         eng = SlabEngine(toy, layout, rank) if world > 1 else None
         if world == 1:
             # reference semantics without any exchange
-            toy.fk(0, 2)
-            for f in (0, 1):
+            toy.fk(0, 3)
+            for f in (0, 1, 2):
                 toy.p2g(f); toy.grid_g2p(f)
-            for f in (1, 0):
+            for f in (2, 1, 0):
                 toy.grad_scatter(f); toy.grad_gather(f)
-            toy.chain_grad(0, 2, 0)
-            toy.loss_scatter(2); rec = toy.loss_partials(2, 0); info = toy.loss_finish(rec)
+            toy.chain_grad(0, 3, 0)
+            toy.loss_scatter(3); rec = toy.loss_partials(3, 0); info = toy.loss_finish(rec)
         else:
-            eng.step(0, 2)
-            eng.step_grad(0, 2, 0)
-            info = eng.loss_forward(2)
+            eng.step(0, 3)
+            assert toy.pending is None
+            eng.step_grad(0, 3, 0)
+            info = eng.loss_forward(3)
+            # substep 0 built the plans through the unfused calls; after that one library call each side of the
+            # exchange, with g2p(1) deferred into the p2g of substep 2
+            fwd = [c for c in toy.calls if c[0].startswith("slab_") and c[1] == 0]
+            assert fwd == [("slab_pre", 0, 1, False), ("slab_post", 0, 1, True), ("slab_pre", 0, 2, True), ("slab_post", 0, 2, False)], fwd
+            bwd = [c for c in toy.calls if c[0].startswith("slab_") and c[1] == 1]
+            assert [c[2] for c in bwd] == [1, 1, 0, 0] and not any(c[3] for c in bwd), bwd
         out[rank] = dict(mine=mine, read=toy.read, adj=toy.adj_read, flags={f: toy.flags[f].numpy().copy() for f in toy.flags},
                          chain=[c for c in toy.calls if c[0] == "chain_grad"], info=info,
                          bounds=layout.bounds, order=[c[0] for c in toy.calls])
@@ -187,7 +206,7 @@ def test_ranks_equal_one_rank(WORLD):
     one = run(1, bz, w)[0]
     two = run(WORLD, bz, w)
     assert two[0]["bounds"] == two[1]["bounds"] and sum(len(two[r]["mine"]) for r in range(WORLD)) == 40
-    for f in (0, 1):
+    for f in (0, 1, 2):
         got = np.empty(40); adj = np.empty(40)
         for r in range(WORLD):
             got[two[r]["mine"]] = two[r]["read"][f]
