@@ -46,9 +46,15 @@ class Engine:
         cfg.gravity = (C.c_double * 3)(*[float(g) for g in gravity])
         cfg.ground_friction, cfg.svd_grad_clamp = float(ground_friction), float(svd_grad_clamp)
         cfg.slab_z0, cfg.slab_z1 = (0, n_grid) if slab is None else (int(slab[0]), int(slab[1]))
-        if store_grid == "auto":       # per-frame grid_m/grid_v_in: worth it while it stays a modest slice of 288 GB
-            # grid_m/grid_v_in + grid_v_out of every frame: 8 scalars per node
-            store_grid = max_frames * 8 * (8 if cfg.dtype == L.F64 else 4) * n_grid ** 3 <= 64 * 2 ** 30
+        if store_grid == "auto":
+            # grid_m/grid_v_in + grid_v_out of every frame (8 scalars per node) stay resident -- no forward recompute in
+            # substep_grad, fused g2p+p2g forward: 1.45x the substep rate -- while they take at most 40 % of the HBM
+            # and, with the particle frames, at most 70 % (288 GB on an MI355X: 128^3 rollouts of up to ~1700 frames)
+            tsz = 8 if cfg.dtype == L.F64 else 4
+            grid_b = max_frames * 8 * tsz * n_grid ** 3
+            state_b = (max_frames + 1) * (n_particles + 255) // 256 * 256 * (24 + 21 * tsz)
+            hbm = torch.cuda.get_device_properties(self.device).total_memory
+            store_grid = grid_b <= 0.40 * hbm and grid_b + state_b <= 0.70 * hbm
         cfg.store_grid = int(bool(store_grid))
         cfg.slab_halo = int(slab_halo)
         # re-sort the particles every so many env steps (single GPU); PLMPM_RESORT_STEPS overrides for experiments
