@@ -1,5 +1,9 @@
+"""Summary of gpurun_out/trace.npy (wave_trace_run.py): per kernel the wave lifetimes, mean cycles per phase, the
+longest-lived waves and one SIMD's timeline."""
+import os
 import numpy as np
-t=np.load('/root/repo/gpurun_out/trace.npy')
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+t=np.load(os.path.join(ROOT, 'gpurun_out', 'trace.npy'))
 for ki,name,marks in ((1,'g2p_grad',['tilefill','sort','adj+barrier','loop','flush','Xarrived']),(2,'p2g_grad',['-','fill','compute','store']),(0,'g2p_p2g',['fill issued','sort+E+barrier','gather+store','bbox2+zero','const+scatter','flush'])):
     a=t[ki][:7944].astype(np.int64)
     a=a[a[:,0]>0]

@@ -1,6 +1,8 @@
-import sys, ctypes as C, numpy as np, torch
-sys.path.insert(0, '/root/repo')
-import os
+"""Per-wave phase trace of the three big particle kernels (needs a -DPLB_PHASE_TIMING build of libplmpm.so, passed
+as EXP_LIB=...): runs the benchmark rollout and dumps the trace rows to gpurun_out/trace.npy."""
+import os, sys, ctypes as C, numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
 import plasticinelab_amd._lib as L
 L.LIB_PATH = os.environ.get('EXP_LIB', L.LIB_PATH)      # a -DPLB_PHASE_TIMING build of libplmpm.so
 import bench
@@ -20,4 +22,5 @@ n = 3 * 16384 * 16
 buf = (C.c_ulonglong * n)()
 lib.plmpm_debug_trace.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
 lib.plmpm_debug_trace(sim.engine.h, buf, n)
-np.save('/root/repo/gpurun_out/trace.npy', np.array(buf, dtype=np.uint64).reshape(3, 16384, 16))
+os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
+np.save(os.path.join(ROOT, 'gpurun_out', 'trace.npy'), np.array(buf, dtype=np.uint64).reshape(3, 16384, 16))
