@@ -219,3 +219,42 @@ def test_chopsticks_kinematics_and_adjoint():
         for a, b in zip(got, gs):
             b = 0.0 if b is None else b.numpy()
             assert np.allclose(a, b, rtol=1e-12, atol=1e-13)
+
+
+def test_node_between_two_manipulators():
+    """Two overlapping spheres pressed into the same corner of the body: nodes in contact with BOTH exercise the branch
+    of grid_node_bwd that recomputes the velocity entering the earlier collide (the later one reuses its forward
+    intermediates), in the velocity-only pass and in the pose pass."""
+    torch.manual_seed(1)
+    cfg, sim, prims0, x0 = oracle_scene("Move", 1, n_particles=1500)
+    top = x0[np.argmax(x0[:, 1])]
+    c = np.array([top[0], top[1] + 0.025, top[2]])
+    prims = [O.PrimCfg(shape="Sphere", radius=0.04, init_pos=tuple(c + d), friction=0.9, action_dim=3, action_scale=(0.01,) * 3)
+             for d in (np.array([-0.008, 0.0, 0.0]), np.array([0.008, 0.004, 0.0]))]
+    state, mats, poses = O.init_state(x0), O.materials(sim), O.init_poses(prims)
+    a = torch.tensor([0.3, -0.8, 0.1, -0.2, -0.9, 0.2], dtype=O.DT)
+    vel = [O.set_velocity(p, a[3 * k:3 * k + 3], sim.substeps) for k, p in enumerate(prims)]
+    nxt = [O.forward_kinematics(p, pos, r, v, w) for p, (pos, r), (v, w) in zip(prims, poses, vel)]
+    # both spheres must reach the same nodes, or the test checks nothing
+    n = sim.n_grid
+    gp = torch.stack(torch.meshgrid(*[torch.arange(n, dtype=O.DT) / n] * 3, indexing="ij"), -1).reshape(-1, 3)
+    near = [(torch.linalg.norm(gp - pos, dim=1) - 0.04) < 0.0 for pos, _ in poses]
+    assert int((near[0] & near[1]).sum()) > 20
+    sin = tuple(t.clone().requires_grad_(True) for t in state)
+    pin = [(p.clone().requires_grad_(True), r.clone().requires_grad_(True)) for p, r in poses]
+    nin = [(p.clone().requires_grad_(True), r.clone().requires_grad_(True)) for p, r in nxt]
+    out = O.substep(sim, prims, 666.0, sin, mats, pin, nin)
+    cot = [torch.randn_like(t) for t in out]
+    inputs = list(sin) + [t for pr in pin for t in pr] + [t for pr in nin for t in pr]
+    gs = torch.autograd.grad(sum((o * c).sum() for o, c in zip(out, cot)), inputs, allow_unused=True)
+    gs = [torch.zeros_like(t) if g is None else g for g, t in zip(gs, inputs)]
+    ec = emul.make_cfg(sim, len(prims), 666.0)
+    pa = emul.make_prims(prims, [(p.numpy(), r.numpy()) for p, r in poses], [(p.numpy(), r.numpy()) for p, r in nxt])
+    st, mt = [t.numpy() for t in state], [t.numpy() for t in mats]
+    (xa, va, Ca, Fa), pose = emul.substep_grad(ec, pa, st, mt, out[1].detach().numpy(), [c.numpy() for c in cot])
+    for u, g in zip((xa, va, Ca, Fa), gs[:4]):
+        assert relerr(u, g.numpy()) < 1e-10
+    P = len(prims)
+    for k in range(P):
+        ref = np.concatenate([gs[4 + 2 * k].numpy(), gs[5 + 2 * k].numpy(), gs[4 + 2 * P + 2 * k].numpy(), gs[5 + 2 * P + 2 * k].numpy()])
+        assert np.abs(ref[:3]).max() > 0 and relerr(pose[k][:14], ref) < 1e-10
