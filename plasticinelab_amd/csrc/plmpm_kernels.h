@@ -890,7 +890,7 @@ __device__ __forceinline__ void pose_adjoint_blocks(const Dev<T>& D, int f, int 
 // ------------------------------------------------------------------------------------------------
 // p2g.grad + svd_grad + compute_F_tmp.grad: gather grid_in_adj, finish adjoint frame `dst`
 template <class T>
-__global__ __launch_bounds__(kBlock, PLB_P2G_GRAD_WAVES) void k_p2g_grad(Dev<T> D, int f, int src, int dst, int npose) {
+__global__ __launch_bounds__(kBlock, sizeof(T) == 4 ? PLB_P2G_GRAD_WAVES : 1) void k_p2g_grad(Dev<T> D, int f, int src, int dst, int npose) {
     __shared__ Vec4<T> tile[TileCap<T>::nodes];
     // the first `npose` workgroups finish grid_op.grad (pose adjoints of the blocks in contact) under cover of the
     // particle workgroups
