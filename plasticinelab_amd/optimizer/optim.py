@@ -1,72 +1,85 @@
-"""numpy optimisers over an action sequence; same update rules and config keys as
-/root/reference/plb/optimizer/optim.py:5-77."""
+"""First-order optimisers over a flat or (horizon, action_dim) numpy parameter array.
+
+Public surface as in the reference (/root/reference/plb/optimizer/optim.py:5-77): ``Adam(parameters, cfg, **kw)`` /
+``Momentum(...)``, config keys ``lr, bounds, type`` (+ ``momentum`` / ``beta_1, beta_2, epsilon``), and
+``step(grads) -> new parameters`` which updates ``parameters`` in place and clips to ``bounds``.  The implementation
+is organised around one hook, ``direction(g, t)``: the (bias-corrected) descent direction for gradient ``g`` at
+update count ``t``; running statistics live in ``self.state``.
+"""
 from __future__ import annotations
+
+from typing import Dict
 
 import numpy as np
 
 from ..config import CfgNode
 
+_BASE_KEYS = {"lr": 0.1, "bounds": (-1.0, 1.0), "type": ""}
+
 
 class Optimizer:
-    defaults = {"lr": 0.1, "bounds": (-1.0, 1.0), "type": ""}
+    extra_keys: Dict[str, float] = {}
 
     def __init__(self, parameters: np.ndarray, cfg=None, **kwargs):
         self.cfg = CfgNode(dict(self.default_config()))
-        if cfg is not None:
-            self.cfg.merge(dict(cfg), strict=False)
-        self.cfg.merge(kwargs, strict=False)
-        self.lr = self.cfg.lr
-        self.bounds = self.cfg.bounds
+        for source in (cfg, kwargs):
+            if source:
+                self.cfg.merge(dict(source), strict=False)
         self.parameters = parameters
-        self.initialize()
+        self.state: Dict[str, np.ndarray] = {}
+        self.updates = 0
 
     @classmethod
-    def default_config(cls):
-        out = {}
-        for k in reversed(cls.__mro__):
-            out.update(getattr(k, "defaults", {}))
-        return out
+    def default_config(cls) -> dict:
+        return {**_BASE_KEYS, **cls.extra_keys}
 
-    def initialize(self):
+    # the two knobs the solvers read back
+    @property
+    def lr(self):
+        return self.cfg.lr
+
+    @property
+    def bounds(self):
+        return tuple(self.cfg.bounds)
+
+    def _stat(self, name: str) -> np.ndarray:
+        """Running statistic ``name`` (float64, shaped like the parameters, zero at first use)."""
+        if name not in self.state:
+            self.state[name] = np.zeros(self.parameters.shape, np.float64)
+        return self.state[name]
+
+    def direction(self, g: np.ndarray, t: int) -> np.ndarray:
         raise NotImplementedError
 
-    def _step(self, grads):
-        raise NotImplementedError
-
-    def step(self, grads):
-        assert grads.shape == self.parameters.shape
-        self.parameters[:] = self._step(grads).clip(*self.bounds)
-        return self.parameters.copy()
+    def step(self, grads) -> np.ndarray:
+        g = np.asarray(grads, np.float64)
+        if g.shape != self.parameters.shape:
+            raise AssertionError(f"gradient shape {g.shape} != parameter shape {self.parameters.shape}")
+        lo, hi = self.bounds
+        np.clip(self.parameters - self.lr * self.direction(g, self.updates), lo, hi, out=self.parameters)
+        self.updates += 1
+        return np.array(self.parameters)
 
 
 class Momentum(Optimizer):
-    defaults = {"momentum": 0.9}
+    """Exponential moving average of the gradient (weight ``momentum`` on the past)."""
+    extra_keys = {"momentum": 0.9}
 
-    def initialize(self):
-        self.momentum_buffer = np.zeros_like(self.parameters, dtype=np.float64)
-        self.momentum = self.cfg.momentum
-
-    def _step(self, grads):
-        g = self.momentum_buffer * self.momentum + grads * (1 - self.momentum)
-        self.momentum_buffer[:] = g
-        return self.parameters - self.lr * g
+    def direction(self, g, t):
+        avg = self._stat("avg")
+        avg *= self.cfg.momentum
+        avg += (1.0 - self.cfg.momentum) * g
+        return avg
 
 
 class Adam(Optimizer):
-    defaults = {"beta_1": 0.9, "beta_2": 0.999, "epsilon": 1e-8}
+    """Adam with bias correction; ``epsilon`` is added to the root of the corrected second moment."""
+    extra_keys = {"beta_1": 0.9, "beta_2": 0.999, "epsilon": 1e-8}
 
-    def initialize(self):
-        self.momentum_buffer = np.zeros_like(self.parameters, dtype=np.float64)
-        self.v_buffer = np.zeros_like(self.momentum_buffer)
-        self.iter = 0
-
-    def _step(self, grads):
-        b1, b2, eps = self.cfg.beta_1, self.cfg.beta_2, self.cfg.epsilon
-        g = grads.reshape(self.parameters.shape)
-        m = b1 * self.momentum_buffer + (1 - b1) * g
-        v = b2 * self.v_buffer + (1 - b2) * (g * g)
-        self.momentum_buffer[:], self.v_buffer[:] = m, v
-        m_hat = m / (1 - b1 ** (self.iter + 1))
-        v_hat = v / (1 - b2 ** (self.iter + 1))
-        self.iter += 1
-        return self.parameters - (self.lr * m_hat) / (np.sqrt(v_hat) + eps)
+    def direction(self, g, t):
+        first, second = self._stat("first"), self._stat("second")
+        for stat, beta, sample in ((first, self.cfg.beta_1, g), (second, self.cfg.beta_2, g * g)):
+            stat *= beta
+            stat += (1.0 - beta) * sample
+        unbias = [1.0 - beta ** (t + 1) for beta in (self.cfg.beta_1, self.cfg.beta_2)]
+        return (first / unbias[0]) / (np.sqrt(second / unbias[1]) + self.cfg.epsilon)
