@@ -8,7 +8,9 @@ the same attributes (including a real yacs node) is accepted by the engine.
 """
 from __future__ import annotations
 
+import ast
 import copy
+import operator
 from typing import Any, Iterable, Mapping, Optional
 
 import yaml
@@ -64,13 +66,43 @@ def _wrap(v):
     return v
 
 
+_BIN_OPS = {ast.Add: operator.add, ast.Sub: operator.sub, ast.Mult: operator.mul, ast.Div: operator.truediv,
+            ast.FloorDiv: operator.floordiv, ast.Mod: operator.mod, ast.Pow: operator.pow,
+            ast.LShift: operator.lshift, ast.RShift: operator.rshift, ast.BitOr: operator.or_,
+            ast.BitAnd: operator.and_, ast.BitXor: operator.xor}
+_UN_OPS = {ast.UAdd: operator.pos, ast.USub: operator.neg, ast.Invert: operator.invert}
+
+
+def _arith(node):
+    """Numbers, tuples / lists of them and arithmetic on them -- nothing else (no names, calls, attributes)."""
+    if isinstance(node, ast.Expression):
+        return _arith(node.body)
+    if isinstance(node, ast.Constant) and isinstance(node.value, (int, float, bool)) or \
+            isinstance(node, ast.Constant) and node.value is None:
+        return node.value
+    if isinstance(node, ast.Tuple):
+        return tuple(_arith(e) for e in node.elts)
+    if isinstance(node, ast.List):
+        return [_arith(e) for e in node.elts]
+    if isinstance(node, ast.BinOp) and type(node.op) in _BIN_OPS:
+        a, b = _arith(node.left), _arith(node.right)
+        if isinstance(node.op, ast.Pow) and abs(b) > 64:
+            raise ValueError("exponent too large")
+        return _BIN_OPS[type(node.op)](a, b)
+    if isinstance(node, ast.UnaryOp) and type(node.op) in _UN_OPS:
+        return _UN_OPS[type(node.op)](_arith(node.operand))
+    raise ValueError(f"not plain arithmetic: {ast.dump(node)}")
+
+
 def as_value(v):
     """Scene files carry tuples and arithmetic as strings, e.g. ``(0.5, 0.5, 0.5)``
     or ``0.2049/2`` or ``127<<16``; the reference ``eval``s them
-    (shape_maker.py:23).  Evaluate with no builtins."""
+    (shape_maker.py:23).  Here they go through a small arithmetic evaluator over the
+    parsed expression (numbers, tuples, + - * / // % ** << >> | & ^): a scene file
+    cannot run code.  Anything else is returned unchanged, as a string."""
     if isinstance(v, str):
         try:
-            return eval(v, {"__builtins__": {}}, {})
+            return _arith(ast.parse(v.strip(), mode="eval"))
         except Exception:
             return v
     return v

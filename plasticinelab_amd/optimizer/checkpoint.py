@@ -19,7 +19,19 @@ def forward_checkpointed(env, init_state, actions, segment: int, softness: float
     H, T, sub = len(actions), int(segment), sim.substeps
     if T * sub >= sim.max_steps:
         raise ValueError(f"segment of {T} steps needs {T * sub + 1} frames, simulator has max_steps={sim.max_steps}")
-    env.set_state(init_state, softness, False)          # sorts the storage order once; it is kept for all segments
+    env.set_state(init_state, softness, False)          # sorts the storage order once ...
+    # ... and it is kept for all segments: every segment reuses frames 0..T*sub, so a per-step re-sort would hand
+    # out the same epoch numbers (and overwrite their permutations) while adjoints still carry those labels
+    eng.set_resort(False)
+    try:
+        return _forward_checkpointed(env, init_state, actions, T, H, sub)
+    finally:
+        eng.set_resort(True)
+
+
+def _forward_checkpointed(env, init_state, actions, T, H, sub):
+    sim, loss = env.simulator, env.loss
+    eng = sim.engine
     loss.clear_loss()
     checkpoints, total = {}, 0.0
     for i in range(H):

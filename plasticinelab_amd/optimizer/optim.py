@@ -33,14 +33,32 @@ class Optimizer:
     def default_config(cls) -> dict:
         return {**_BASE_KEYS, **cls.extra_keys}
 
-    # the two knobs the solvers read back
+    # the two knobs the solvers read back -- and may set (an lr schedule writes ``optim.lr = ...`` in the
+    # reference, where they are plain attributes: optim.py:12-13); both write through to ``cfg``
     @property
     def lr(self):
         return self.cfg.lr
 
+    @lr.setter
+    def lr(self, value):
+        self.cfg.lr = float(value)
+
     @property
     def bounds(self):
         return tuple(self.cfg.bounds)
+
+    @bounds.setter
+    def bounds(self, value):
+        lo, hi = value
+        self.cfg.bounds = (float(lo), float(hi))
+
+    @property
+    def iter(self):                                  # reference name of the update counter (optim.py:36,60)
+        return self.updates
+
+    @iter.setter
+    def iter(self, value):
+        self.updates = int(value)
 
     def _stat(self, name: str) -> np.ndarray:
         """Running statistic ``name`` (float64, shaped like the parameters, zero at first use)."""
@@ -65,6 +83,10 @@ class Momentum(Optimizer):
     """Exponential moving average of the gradient (weight ``momentum`` on the past)."""
     extra_keys = {"momentum": 0.9}
 
+    @property
+    def momentum_buffer(self):                       # reference attribute (optim.py:37)
+        return self._stat("avg")
+
     def direction(self, g, t):
         avg = self._stat("avg")
         avg *= self.cfg.momentum
@@ -75,6 +97,14 @@ class Momentum(Optimizer):
 class Adam(Optimizer):
     """Adam with bias correction; ``epsilon`` is added to the root of the corrected second moment."""
     extra_keys = {"beta_1": 0.9, "beta_2": 0.999, "epsilon": 1e-8}
+
+    @property
+    def momentum_buffer(self):                       # reference attributes (optim.py:61-62)
+        return self._stat("first")
+
+    @property
+    def v_buffer(self):
+        return self._stat("second")
 
     def direction(self, g, t):
         first, second = self._stat("first"), self._stat("second")

@@ -152,6 +152,60 @@ def make_rollout_shapes():
     np.savez_compressed(os.path.join(HERE, "rollout_shapes.npz"), **out)
 
 
+def _target_sdf(tgt, dx):
+    import ctypes
+    lib = ctypes.CDLL(os.path.join(ROOT, "oracle", "libplb_oracle_c.so"))
+    n = tgt.shape[0]
+    sdf = np.empty((n, n, n)); npn = np.empty((n, n, n, 3))
+    lib.plb_oracle_target_sdf.restype = ctypes.c_int
+    lib.plb_oracle_target_sdf(np.ascontiguousarray(tgt).ctypes.data_as(ctypes.c_void_p), ctypes.c_int(n),
+                              ctypes.c_double(dx), ctypes.c_double(1000.0), ctypes.c_int(2 * n),
+                              sdf.ctypes.data_as(ctypes.c_void_p), npn.ctypes.data_as(ctypes.c_void_p))
+    return sdf
+
+
+def make_gym():
+    """The Gym surface (plb/envs/env.py:28-57) on Move-v1 as the ORACLE computes it: 50 copy-mode env steps with
+    seeded actions; per step the reward (loss.py:288-298: start_loss - step loss), the loss terms and the IoU, and
+    the 1214-long observation (200 particles x (x, v) + 2 x 7 manipulator state) after steps 1, 25 and 50."""
+    import torch
+    from tests.util import O, oracle_scene, sparse_target
+    cfg, sim, prims, x0 = oracle_scene("Move", 1)
+    tgt = sparse_target("Move3D-v1")
+    sdf = _target_sdf(tgt, sim.dx)
+    td, ts = torch.as_tensor(tgt.reshape(-1)), torch.as_tensor(sdf.reshape(-1))
+    H, A = 50, sum(p.action_dim for p in prims)
+    actions = np.random.default_rng(7).uniform(-1, 1, (H, A)) * 0.6
+    lcfg = O.LossCfg()
+    state, mats, poses = O.init_state(x0), O.materials(sim), O.init_poses(prims)
+
+    def obs(state, poses):
+        x, v = state[0].numpy(), state[1].numpy()
+        k = len(x) // 200
+        s = np.concatenate([np.concatenate([t.numpy().reshape(-1) for t in po]) for po in poses])
+        return np.concatenate((np.concatenate((x[::k], v[::k]), axis=-1).reshape(-1), s))
+
+    out = {"actions": actions, "obs_0": obs(state, poses)}
+    with torch.no_grad():
+        l0, parts0 = O.compute_loss(sim, lcfg, prims, state[0], poses, td, ts)
+        out["start_loss"] = np.array(float(l0))
+        out["init_iou"] = np.array(float(O.iou(parts0["grid_m"], td)))
+        rewards, terms = [], []
+        t = time.time()
+        for i in range(H):
+            state, poses = O.env_step(sim, prims, 666.0, state, mats, poses, torch.as_tensor(actions[i], dtype=O.DT))
+            l, parts = O.compute_loss(sim, lcfg, prims, state[0], poses, td, ts)
+            rewards.append(float(l0) - float(l))
+            terms.append([float(l), float(parts["sdf_loss"]), float(parts["density_loss"]), float(parts["contact_loss"]),
+                          float(O.iou(parts["grid_m"], td))])
+            if i + 1 in (1, 25, 50):
+                out[f"obs_{i + 1}"] = obs(state, poses)
+        print("gym rollout", time.time() - t, "s; reward[0], reward[-1] =", rewards[0], rewards[-1])
+    out["rewards"] = np.array(rewards)
+    out["terms"] = np.array(terms)
+    np.savez_compressed(os.path.join(HERE, "gym_move_v1.npz"), **out)
+
+
 if __name__ == "__main__":
     for what in sys.argv[1:]:
         globals()[f"make_{what}"]()

@@ -2,8 +2,8 @@
 Primitives.get_grad) against oracle-generated golden vectors (tests/golden/rollout_*.npz).
 
 Tolerances (max-norm relative):  float64 engine: loss 1e-10, action gradient 1e-7;
-float32 engine: loss 1e-5, action gradient 1e-3 on the 3-step case (BASELINE's 1e-4 target is
-checked, and reported, on the full Move-v1 config in test_gpu_move_v1)."""
+float32 engine: loss 1e-5, action gradient 1e-4 (BASELINE.json north_star: "within 1e-4 relative fp32"),
+on the 3-step cases and on the full Move-v1 config (test_gpu_move_v1)."""
 import os
 
 import numpy as np
@@ -70,7 +70,8 @@ def test_small_rollout_matches_oracle(tag, dtype):
     env = make_env_sub("Move", int(g["n_particles"]), dtype, soft_contact=bool(g["soft_contact"]))
     state0 = env.get_state()["state"]
     loss, grad = run_forward(env, g["actions"], state0)
-    ltol, gtol = (1e-10, 1e-7) if dtype == "float64" else (1e-5, 1e-3)
+    ltol, gtol = (1e-10, 1e-7) if dtype == "float64" else (1e-5, 1e-4)
+    print(f"\n[{tag} {dtype}] loss rel {abs(loss - float(g['loss'])) / abs(float(g['loss'])):.3e}; grad max-rel err {relerr(grad, g['grad']):.3e}")
     assert abs(loss - float(g["loss"])) / abs(float(g["loss"])) < ltol
     assert relerr(grad, g["grad"]) < gtol
     # final particle state of the rollout
@@ -97,7 +98,7 @@ def test_gpu_move_v1(dtype):
     lerr = abs(loss - float(g["loss"])) / abs(float(g["loss"]))
     gerr = relerr(grad, g["grad"])
     print(f"\n[move_v1 {dtype}] loss {loss:.12g} (oracle {float(g['loss']):.12g}) rel {lerr:.3e}; grad max-rel err {gerr:.3e}")
-    ltol, gtol = (1e-9, 1e-6) if dtype == "float64" else (1e-5, 1e-3)
+    ltol, gtol = (1e-9, 1e-6) if dtype == "float64" else (1e-5, 1e-4)       # north_star: 1e-4 relative fp32
     assert lerr < ltol
     assert gerr < gtol
 
@@ -127,8 +128,27 @@ def test_checkpointed_gradient_equals_tape_gradient(dtype):
         loss2, grad2 = forward_checkpointed(env, state0, g["actions"], seg)
         tol = 1e-11 if dtype == "float64" else 2e-5
         assert abs(loss2 - loss) / abs(loss) < tol
-        assert relerr(grad2, grad) < (1e-9 if dtype == "float64" else 1e-3)
-        assert relerr(grad2, g["grad"]) < (1e-7 if dtype == "float64" else 1e-3)
+        assert relerr(grad2, grad) < (1e-9 if dtype == "float64" else 1e-4)
+        assert relerr(grad2, g["grad"]) < (1e-7 if dtype == "float64" else 1e-4)
+
+
+@pytest.mark.parametrize("segment", [4, 8, 12])
+def test_checkpointed_gradient_long_horizon(segment):
+    """Segments of >= 2 x resort_steps env steps over a horizon of >= 3 segments: the per-step device re-sort must
+    stay off inside forward_checkpointed (every segment reuses the same frames, so re-sort epochs would collide and
+    adjoints would be applied in the wrong particle order -- round-1 advisor finding)."""
+    from plasticinelab_amd.optimizer.checkpoint import forward_checkpointed
+    env = make_env_sub("Move", 2000, "float64")
+    H = 3 * segment
+    acts = np.random.default_rng(11).uniform(-1, 1, (H, env.primitives.action_dim)) * 0.5
+    state0 = env.get_state()["state"]
+    loss, grad = run_forward(env, acts, state0)             # stored trajectory, re-sorted every 4 env steps
+    loss2, grad2 = forward_checkpointed(env, state0, acts, segment)
+    assert abs(loss2 - loss) / abs(loss) < 1e-10
+    assert relerr(grad2, grad) < 1e-8
+    # the engine re-sorts again afterwards (set_resort restored)
+    loss3, grad3 = run_forward(env, acts, state0)
+    assert abs(loss3 - loss) / abs(loss) < 1e-10 and relerr(grad3, grad) < 1e-8
 
 
 @pytest.mark.parametrize("mode", ["copy", "tape"])
