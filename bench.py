@@ -14,10 +14,11 @@ with 500 000 seed-0 uniform particles (~8 per cell), sigma_y = 200, two Sphere m
 touching opposite faces, seeded actions, own target grid (the cube's mass grid shifted by a few cells).
 
 Prints ONE JSON line (rank 0).  N > 1: one process per GPU; the SAME total workload is cut into z-slabs
-(plasticinelab_amd/distributed.py: fixed particle ownership, symmetric halo sum exchange over RCCL each substep,
-forward and adjoint) -> "scaling": "strong".  If the slab path cannot run (body too thin for N slabs, a particle
-drifting past the halo, an RCCL error) the bench falls back to N independent replicas of the workload
-("scaling": "weak") and says so in config.parallelism.
+(plasticinelab_amd/distributed.py: windowed grids, zero-copy block-plane halo sum exchange over RCCL each substep
+forward and adjoint, particle migration every env step) -> "scaling": "strong".  If the slab path cannot run (body
+too thin for N slabs of >= 8 layers -- config 3's cube spans 40 layers, so at most 5 ranks --, a particle leaving the
+grid window, an RCCL error) the bench falls back to N independent replicas of the workload ("scaling": "weak") and
+says so in config.parallelism.
 """
 from __future__ import annotations
 
@@ -42,11 +43,24 @@ ALG = {
     "grid_op_grad": (0, 11), "p2g_grad": (54, 4), "clear_active": (0, 0),
     "g2p_p2g": (51, 7),        # g2p(f-1) + p2g(f) fused
 }
-HBM_PEAK_GBS = 8000.0          # MI355X spec (MI355X_MICROARCH.md); measured copy peak there: 6290 GB/s
-# HBM bytes per launch of the dominant kernel (k_g2p_p2g) on the DEFAULT workload, from the rocprofv3 PMC passes of this
-# very command committed as profiles/r01_pmc.txt: 2 x FETCH_SIZE (gfx950 correction of MI355X_MICROARCH.md, HBM
-# section) + WRITE_SIZE = 2 x 24 326.0 KB + 85 742.5 KB.  Reported as roofline.traffic only for that workload.
-PMC_TRAFFIC_BYTES = {"g2p_p2g": 2 * 24326.0e3 + 85742.5e3}
+HBM_PEAK_GBS = 8000.0          # MI355X spec (MI355X_MICROARCH.md); the copy / read rates this box reaches are measured live
+PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc.json")
+
+
+def pmc_traffic(kernel, workload, dtype):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/r02_pmc.json, written by
+    profiles/tools/pmc_summary.py from separate --pmc FETCH_SIZE / WRITE_SIZE runs of this very command: 2 x
+    FETCH_SIZE + WRITE_SIZE, the gfx950 correction of MI355X_MICROARCH.md's HBM section).  None when the file is
+    missing or was taken on another workload / dtype -- a stale number is worse than none."""
+    try:
+        with open(PMC_FILE) as f:
+            d = json.load(f)
+        if d.get("workload") != workload or d.get("dtype") != dtype:
+            return None, None
+        k = d["kernels"].get(kernel)
+        return (None, None) if k is None else (float(k["hbm_bytes_per_launch"]), d.get("source"))
+    except (OSError, ValueError, KeyError):
+        return None, None
 
 
 def workload_cfg(n_particles=500_000, quality=2, max_steps=1024):
@@ -95,7 +109,7 @@ def _target(x_all, sim):
     return mass_grid(np.clip(x_all + np.array([0.03, 0.0, 0.02]), 0.03, 0.97), sim.n_grid, sim.p_mass)
 
 
-XY_MARGIN = 12      # node layers around the body's xy bounding box that the halo planes cover (the rest is empty)
+XY_MARGIN = 24      # node layers around the body's bounding box that a rank's grid window covers (the rest is never touched)
 
 
 def build_env(args, device, rank=0, world=1, slabs=False):
@@ -104,15 +118,15 @@ def build_env(args, device, rank=0, world=1, slabs=False):
     frames = max(args.steps, args.warmup, 1) * sub + 1
     cfg = workload_cfg(args.particles, args.quality, max_steps=frames)
     if slabs:
+        import torch.distributed as dist
         from plasticinelab_amd.distributed import make_slab_env
-        n = int(128 * args.quality * 0.5)
-        span = int(0.31 * n) + 3
-        halo = max(2, min(4, span // (2 * world)))
-        env, layout, _ = make_slab_env(cfg, rank, world, halo=halo, compute_dtype=args.dtype, device=device, target_fn=_target,
-                                       xy_margin=XY_MARGIN)
+        env, layout, _ = make_slab_env(cfg, rank, world, compute_dtype=args.dtype, device=device, target_fn=_target,
+                                       xy_margin=XY_MARGIN, migrate_every=1)
         env.loss.set_weights(10, 10, 1, False)
-        return env, (f"{world} z-slabs {list(layout.bounds)}, halo {halo} layers (xy window: body + {XY_MARGIN}), "
-                     "RCCL sum exchange per substep")
+        backend = dist.get_backend()
+        return env, (f"{world} z-slabs {list(layout.bounds)}, grid window = body + {XY_MARGIN} layers, zero-copy halo of one 4^3 block "
+                     f"plane per face side summed over {'RCCL' if backend == 'nccl' else backend} each substep (fwd + adjoint), "
+                     "particle migration every env step")
     env = TaichiEnv(cfg, compute_dtype=args.dtype, device=device)
     env.initialize()
     env.loss.load_target_density(grids=_target(env.init_particles, env.simulator))
@@ -261,15 +275,25 @@ def main():
         "final_loss": float(loss),
     }
 
-    if rank == 0 and not args.no_roofline and world == 1:
-        # per-kernel durations, measured live with HIP events on the launch stream over the same K-step rollout
+    workload = out["config"]["workload"]
+    if not args.no_roofline:
+        # per-kernel durations, measured live with HIP events on the launch stream over the same K-step rollout.  N > 1:
+        # every rank replays the rollout (it contains the exchanges); the reported kernels are rank 0's, their algorithmic
+        # bytes those of rank 0's launches (its particles, its active nodes), the job-level fraction uses the whole
+        # workload's bytes against N x the per-GPU peak.
         env.set_state(state0, 666.0, False)
         nodes, blocks = sim.engine.grid_stats(0)
         sim.engine.profile_enable(True)
         rollout(env, acts)
         prof = sim.engine.profile_read()
         sim.engine.profile_enable(False)
-        N = sim.n_particles
+        N = sim.n_particles                                   # this rank's particles (at reset)
+        tot = torch.tensor([float(N), float(nodes)], dtype=torch.float64, device=red_dev)
+        if dist is not None:
+            dist.all_reduce(tot)                              # halo nodes are active on both neighbours: counted twice, as they are swept twice
+        if slabs is False and world > 1:
+            tot /= world                                      # replicas: every rank holds the whole workload
+    if rank == 0 and not args.no_roofline:
         kernels = {}
         for name, (ms, cnt) in prof.items():
             if cnt == 0:
@@ -279,23 +303,32 @@ def main():
             kernels[name] = {"avg_us": 1e3 * avg, "launches": cnt, "alg_MB": 4e-6 * (cN * N + cA * nodes),
                              "GBps": 4e-9 * (cN * N + cA * nodes) / (1e-3 * avg) if avg > 0 else 0.0}
         dom = max(kernels, key=lambda k: kernels[k]["avg_us"] * kernels[k]["launches"])
-        alg_substep = 4.0 * (150 * N + 57 * nodes)
+        alg_substep = 4.0 * (150 * N + 57 * nodes)            # this rank's share
+        alg_unit = 4.0 * (150 * float(tot[0]) + 57 * float(tot[1]))     # bytes of one substep as counted in `value`
         sum_us = sum(v["avg_us"] * v["launches"] for v in kernels.values()) / (K * sub)     # per fwd+bwd substep
+        copy_gbs, read_gbs = sim.engine.measure_hbm()
+        traffic, traffic_src = pmc_traffic(dom, workload, out["dtype"]) if world == 1 else (None, None)
         out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": kernels[dom]["GBps"], "peak": HBM_PEAK_GBS,
                            "unit": "GB/s", "frac": kernels[dom]["GBps"] / HBM_PEAK_GBS,
-                           "traffic": (PMC_TRAFFIC_BYTES.get(dom) if (args.particles, args.quality, args.dtype) == (500_000, 2, "float32") else None),
-                           "traffic_unit": "bytes per launch (profiles/r01_pmc.txt)", "algorithmic_bytes": kernels[dom]["alg_MB"] * 1e6,
+                           "traffic": traffic, "traffic_unit": "HBM bytes per launch", "traffic_source": traffic_src,
+                           "algorithmic_bytes": kernels[dom]["alg_MB"] * 1e6,
+                           "scope": "single GPU" if world == 1 else f"rank 0 of {world} ({N} particles, {nodes} active nodes)",
                            "active_nodes": nodes, "active_blocks": blocks,
                            "substep_alg_MB": alg_substep * 1e-6,
                            # the lenient dense-grid byte count (every node of the n^3 grid, not only the
                            # active ones) -- reported for reference, NOT what frac / substep_frac are computed from
-                           "substep_alg_MB_dense_grid": 4.0 * (150 * N + 57 * sim.n_grid ** 3) * 1e-6,
-                           "peak_achievable": 6290.0,      # measured copy peak quoted in MI355X_MICROARCH.md (GB/s)
-                           "substep_frac_of_achievable": (alg_substep / (sum_us * 1e-6)) / 6290e9,
+                           "substep_alg_MB_dense_grid": 4.0 * (150 * float(tot[0]) + 57 * sim.n_grid ** 3) * 1e-6,
+                           # the roofs this very box reaches, measured just now with the library's 16 B / lane kernels
+                           "peak_measured_copy": copy_gbs, "peak_measured_read": read_gbs,
                            "substep_kernel_sum_us": sum_us,
                            "substep_frac": (alg_substep / (sum_us * 1e-6)) / (HBM_PEAK_GBS * 1e9),
+                           "substep_frac_of_measured_read": (alg_substep / (sum_us * 1e-6)) / (read_gbs * 1e9),
+                           # whole job, wall clock: the workload's algorithmic bytes per fwd+bwd substep x substeps/s
+                           # against n_gpus x the spec peak
+                           "job_alg_MB_per_substep": alg_unit * 1e-6,
+                           "job_frac": alg_unit * value / (world * HBM_PEAK_GBS * 1e9),
                            "kernels": kernels}
-    if rank == 0 and not args.no_cpu_baseline and world == 1:
+    if rank == 0 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args, env)
     if rank == 0:
         print(json.dumps(out))

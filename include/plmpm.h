@@ -72,6 +72,17 @@ typedef struct plmpm_config {
      * I/O stays in caller order and the reverse sweep converts the adjoint frame at those boundaries.  Single-GPU
      * engines only (ignored for slabs).  0: the order chosen at reset is kept for the whole episode. */
     int32_t resort_steps;
+    /* Grid window: only the box of nodes [grid_lo[d], grid_hi[d]) per axis -- rounded outwards to whole 4^3 blocks -- is
+     * allocated, stored per frame and swept by the grid kernels (all zero = the whole n^3 grid, the reference's
+     * layout).  Results are those of the full grid as long as every particle's stencil stays inside the window; one
+     * that leaves it raises PLMPM_ERR_HALO in plmpm_check_error (its accesses are clamped into the window, so the
+     * run stays memory-safe).  This is what lets a 512^3 rank keep per-frame grids: the per-frame store costs
+     * 32 B x window nodes instead of 32 B x n^3. */
+    int32_t grid_lo[3], grid_hi[3];
+    /* rows every particle frame has room for (>= n_particles; 0 = n_particles).  Slab engines gain and lose
+     * particles by migration (plmpm_migrate_*), so their frames are sized with head-room. */
+    int32_t particle_capacity;
+    int32_t reserved0;
 } plmpm_config;
 
 /* One rigid manipulator; mirrors Primitive.default_config + per-shape params
@@ -128,6 +139,11 @@ int plmpm_get_primitive_state(plmpm_handle h, int prim, int frame, double* state
 int plmpm_set_resort(plmpm_handle h, int on);
 /* Primitives.set_softness (primitives.py:303-305) */
 int plmpm_set_softness(plmpm_handle h, double softness);
+/* Primitive.sdf (primive_base.py:57-60; Sphere primitives.py:22-24, ...): signed distance of n host points (n,3) to
+ * primitive `prim` at its pose of `frame` */
+int plmpm_primitive_sdf(plmpm_handle h, int prim, int frame, const double* points, int n, double* out);
+/* Primitive.set_velocity (primive_base.py:184-192): refill v, w of env step `step`'s frames from action_buffer[step] */
+int plmpm_set_velocity(plmpm_handle h, int prim, int step, int n_substeps);
 
 /* ---- actions ----------------------------------------------------------------------------- */
 /* Primitives.set_action (primitives.py:289-293) -> per primitive no_grad_set_action_kernel +
@@ -180,48 +196,69 @@ int plmpm_loss_forward(plmpm_handle h, int frame, double* out6);
 int plmpm_loss_backward(plmpm_handle h, int frame);
 /* compute_grid_m_kernel (mpm_simulator.py:382-392) -> host (n,n,n) float64 */
 int plmpm_get_grid_mass(plmpm_handle h, int frame, double* out);
-/* target_sdf as computed by plmpm_loss_set_target, host (n,n,n) float64 */
+/* target_sdf as computed by plmpm_loss_set_target, host (n,n,n) float64 (nodes outside the grid window read 0) */
 int plmpm_loss_get_target_sdf(plmpm_handle h, double* out);
+/* Loss.min_dist / Loss.dist_norm per primitive after the last loss evaluation (loss.py:116-135); either may be NULL */
+int plmpm_loss_contact_scalars(plmpm_handle h, double* min_dist, double* dist_norm);
 
 /* ---- multi-GPU building blocks (z-slab decomposition; the host side exchanges halos with RCCL) ------------
  * The forward substep is p2g | halo sum-exchange of grid_m,grid_v_in | grid_op + g2p, the reverse
- * grid_op(recompute) + g2p.grad | halo sum-exchange of grid_v_out.grad | grid_op.grad + p2g.grad.  These split
- * plmpm_substep / plmpm_substep_grad at the exchange points.  Requires store_grid = 1. */
+ * g2p.grad | halo sum-exchange of grid_v_out.grad | grid_op.grad + p2g.grad.  These split
+ * plmpm_substep / plmpm_substep_grad at the exchange points.  Requires store_grid = 1.
+ *
+ * Halos are ZERO-COPY: slab faces sit on multiples of 4, the grid is stored in 4^3 blocks with the z block index
+ * slowest, so the block planes around a face are one contiguous range per SoA component.  The host sends those
+ * ranges straight out of the grid arrays (plmpm_halo_region) and receives the neighbour's copy into a buffer it
+ * registers once (plmpm_halo_set_recv); grid_op / grid_op.grad add the received values on first touch.  No pack or
+ * unpack kernels: a fwd+bwd substep is the same 5 launches as on one GPU. */
 enum plmpm_halo_field { PLMPM_HALO_GRID_IN = 0 /* 4 comps */, PLMPM_HALO_GRID_OUT_ADJ = 1 /* 3 comps */,
                         PLMPM_HALO_LOSS_MASS = 2 /* 1 comp */ };
 #define PLMPM_ERR_HALO 1
 int plmpm_fk(plmpm_handle h, int first_frame, int n_substeps);              /* forward_kinematics chain only */
-int plmpm_p2g(plmpm_handle h, int frame);
-int plmpm_grid_g2p(plmpm_handle h, int frame);
-int plmpm_grad_scatter(plmpm_handle h, int frame);                          /* grid_op recompute + g2p.grad */
-int plmpm_grad_gather(plmpm_handle h, int frame);                           /* grid_op.grad + p2g.grad + clear */
+/* chain = 1: g2p(frame - 1), left pending by plmpm_grid_g2p(frame - 1, chain = 1), runs fused with p2g(frame) in one
+ * kernel (as plmpm_step does on one GPU) */
+int plmpm_p2g(plmpm_handle h, int frame, int chain);
+/* grid_op(frame) -- adding the halo planes registered for PLMPM_HALO_GRID_IN -- then g2p(frame); chain = 1 leaves the
+ * g2p to the next plmpm_p2g(frame + 1, chain = 1), which must be the next call.  The last substep of an env step
+ * passes chain = 0. */
+int plmpm_grid_g2p(plmpm_handle h, int frame, int chain);
+int plmpm_grad_scatter(plmpm_handle h, int frame);                          /* g2p.grad */
+int plmpm_grad_gather(plmpm_handle h, int frame);                           /* grid_op.grad (+ halo planes) + p2g.grad + clear */
 int plmpm_chain_grad(plmpm_handle h, int first_frame, int n_substeps, int step);   /* fk.grad + set_velocity.grad */
-/* element size in bytes of the engine's scalar type, and the size of a halo buffer for planes [za, zb) */
-int plmpm_halo_bytes(plmpm_handle h, int field, int za, int zb, size_t* bytes);
-/* device buffers laid out [comp][z - za][y - y0][x - x0] (the halo window) in the engine's scalar type */
-int plmpm_halo_pack(plmpm_handle h, int field, int frame, int za, int zb, void* dev_buf);
-/* adds the received planes; for PLMPM_HALO_GRID_IN every node that receives a non-zero value also marks its 4^3 block
- * active, which merges the two ranks' block flags without a flag exchange */
-int plmpm_halo_unpack_add(plmpm_handle h, int field, int frame, int za, int zb, const void* dev_buf);
-/* Only the xy window [x0, x1) x [y0, y1) of the halo planes travels (default: whole planes); both sides of a face
- * must use the same window.  Set it before sizing buffers with plmpm_halo_bytes.  A particle whose stencil leaves
- * the window raises PLMPM_ERR_HALO exactly like one that leaves slab + halo in z. */
-int plmpm_set_halo_window(plmpm_handle h, int x0, int x1, int y0, int y1);
-/* One call each side of the exchange, for the per-substep loop (launch and issue latency, not bandwidth, bound the
- * slab path at 128^3); both faces are packed / unpacked by one kernel launch:
- *   plmpm_slab_pre : field GRID_IN -> plmpm_p2g(frame), GRID_OUT_ADJ -> plmpm_grad_scatter(frame); then
- *                    plmpm_halo_pack of planes [za[i], zb[i]) into send[i] for every face i (n_faces <= 2)
- *   plmpm_slab_post: plmpm_halo_unpack_add of recv[i] for every face; then plmpm_grid_g2p / plmpm_grad_gather
- * chain (GRID_IN only): slab_post(frame, chain=1) leaves g2p(frame) pending, and the caller's next library call
- * must be slab_pre(frame + 1, chain=1), which runs it fused with p2g(frame + 1) in one kernel (as plmpm_step does
- * on one GPU).  The last substep of an env step passes chain=0. */
-int plmpm_slab_pre(plmpm_handle h, int field, int frame, int chain, int n_faces, const int* za, const int* zb,
-                   void* const* send);
-int plmpm_slab_post(plmpm_handle h, int field, int frame, int chain, int n_faces, const int* za, const int* zb,
-                    const void* const* recv);
-/* block flags of `frame` (int32 per 4^3 block, z-major: planes [bz_a, bz_b) are contiguous; diagnostics), and the
- * primitive pose adjoints (double) for the cross-rank sum */
-int plmpm_flags_region(plmpm_handle h, int frame, int bz_a, int bz_b, void** dev_ptr, size_t* count);
+/* origin node and extent in 4^3 blocks of the allocated grid window (cfg.grid_lo / grid_hi after rounding) */
+int plmpm_grid_window(plmpm_handle h, int32_t* origin3, int32_t* blocks3);
+/* component `comp` of block planes [bz_a, bz_b) (absolute block-plane indices, node z / 4) of a halo field: one
+ * contiguous device range of `count` scalars of the engine's type.  Both sides of a face must use the same xy window. */
+int plmpm_halo_region(plmpm_handle h, int field, int frame, int comp, int bz_a, int bz_b, void** dev_ptr, size_t* count);
+/* where the neighbours' copies arrive: recv[i] holds [ncomp][count] scalars for block planes [bz_a[i], bz_b[i]);
+ * n_faces <= 2; n_faces = 0 unregisters.  The pointers must stay valid while the engine runs phases. */
+int plmpm_halo_set_recv(plmpm_handle h, int field, int n_faces, const int* bz_a, const int* bz_b, void* const* recv);
+/* PLMPM_HALO_LOSS_MASS only: add the registered buffers into the loss mass grid (the substep fields are added by
+ * grid_op / grid_op.grad themselves) */
+int plmpm_halo_apply(plmpm_handle h, int field, int frame);
+
+/* ---- particle migration between z-slabs --------------------------------------------------------------
+ * A rank owns the particles whose stencil centre node lies in its slab.  At the first frame of an env step:
+ *   plmpm_migrate_begin  classifies the rows of `frame`, packs the leavers (28 doubles per row: global id, x, v, C,
+ *                        F - I, mu, lam, yield stress) and returns their counts [down, up] and device buffers;
+ *   (the host exchanges counts and rows with the two neighbours)
+ *   plmpm_migrate_finish merges the arrivals, re-sorts everything along the Hilbert curve of the cells and makes the
+ *                        result the frame's content in a NEW storage epoch (so this is also the slab engines' cell
+ *                        re-sort; with no leavers and no arrivals it is exactly that).
+ * The reverse sweep, when it reaches that frame: plmpm_migrate_adjoint_begin packs the adjoint rows (24 doubles) of the
+ * particles that had arrived, to be sent back (send2 = rows to send down / up, recv2 = rows to expect);
+ * plmpm_migrate_adjoint_finish takes the adjoints of the particles that had left and leaves the adjoint frame in the
+ * order of the previous epoch.  State / gradient I/O of frames in epochs > 0 is in storage order; plmpm_get_ids names
+ * the rows. */
+int plmpm_set_ids(plmpm_handle h, const int32_t* ids);                      /* global ids of the epoch-0 rows (caller order) */
+int plmpm_get_ids(plmpm_handle h, int frame, int32_t* ids);
+int plmpm_frame_info(plmpm_handle h, int frame, int32_t* count, int32_t* epoch, int32_t* adjoint_epoch /* -1: not resident */);
+int plmpm_migrate_begin(plmpm_handle h, int frame, int32_t* out2, void** rows_down, void** rows_up);
+int plmpm_migrate_finish(plmpm_handle h, int frame, int n_in_down, const void* rows_down, int n_in_up, const void* rows_up,
+                         int32_t* new_count);
+int plmpm_migrate_adjoint_begin(plmpm_handle h, int frame, int32_t* send2, int32_t* recv2, void** rows_down, void** rows_up);
+int plmpm_migrate_adjoint_finish(plmpm_handle h, int frame, const void* rows_down, const void* rows_up);
+/* the primitive pose adjoints (double) for the cross-rank sum */
 int plmpm_pose_grad_region(plmpm_handle h, int first_frame, int n_frames, void** pos_adj, size_t* pos_count,
                            void** rot_adj, size_t* rot_count, void** gap_adj, size_t* gap_count);
 int plmpm_action_grad_region(plmpm_handle h, void** dev_ptr, size_t* count);
@@ -253,6 +290,9 @@ int plmpm_profile_enable(plmpm_handle h, int on);
 int plmpm_profile_kernel_count(void);
 const char* plmpm_profile_kernel_name(int id);
 int plmpm_profile_read(plmpm_handle h, double* total_ms, int64_t* launches);
+/* Measured HBM roof of the device the buffers live on: a 16-byte-per-lane copy src -> dst and a read-only sweep of
+ * `bytes` bytes, best of `reps` runs, in GB/s of bytes moved (bench.py reports it next to the 8 TB/s spec). */
+int plmpm_measure_hbm(void* src, void* dst, size_t bytes, int reps, void* hip_stream, double* copy_gbs, double* read_gbs);
 /* storage order: perm[i] = original particle index stored at sorted slot i */
 int plmpm_get_order(plmpm_handle h, int32_t* perm);
 

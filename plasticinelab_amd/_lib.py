@@ -26,7 +26,9 @@ class Config(C.Structure):
                 ("dt", C.c_double), ("p_vol", C.c_double), ("p_mass", C.c_double),
                 ("gravity", C.c_double * 3), ("ground_friction", C.c_double),
                 ("svd_grad_clamp", C.c_double), ("slab_z0", C.c_int32), ("slab_z1", C.c_int32),
-                ("store_grid", C.c_int32), ("slab_halo", C.c_int32), ("resort_steps", C.c_int32)]
+                ("store_grid", C.c_int32), ("slab_halo", C.c_int32), ("resort_steps", C.c_int32),
+                ("grid_lo", C.c_int32 * 3), ("grid_hi", C.c_int32 * 3), ("particle_capacity", C.c_int32),
+                ("reserved0", C.c_int32)]
 
 
 class Primitive(C.Structure):
@@ -81,18 +83,26 @@ SYMBOLS = {
     "plmpm_tile_boxes": (_I, [_P, _I, _P, _I, C.POINTER(C.c_int)]),
     "plmpm_get_order": (_I, [_P, _P]),
     "plmpm_fk": (_I, [_P, _I, _I]),
-    "plmpm_p2g": (_I, [_P, _I]),
-    "plmpm_grid_g2p": (_I, [_P, _I]),
+    "plmpm_p2g": (_I, [_P, _I, _I]),
+    "plmpm_grid_g2p": (_I, [_P, _I, _I]),
     "plmpm_grad_scatter": (_I, [_P, _I]),
     "plmpm_grad_gather": (_I, [_P, _I]),
     "plmpm_chain_grad": (_I, [_P, _I, _I, _I]),
-    "plmpm_halo_bytes": (_I, [_P, _I, _I, _I, C.POINTER(C.c_size_t)]),
-    "plmpm_halo_pack": (_I, [_P, _I, _I, _I, _I, _P]),
-    "plmpm_halo_unpack_add": (_I, [_P, _I, _I, _I, _I, _P]),
-    "plmpm_set_halo_window": (_I, [_P, _I, _I, _I, _I]),
-    "plmpm_slab_pre": (_I, [_P, _I, _I, _I, _I, _P, _P, _P]),
-    "plmpm_slab_post": (_I, [_P, _I, _I, _I, _I, _P, _P, _P]),
-    "plmpm_flags_region": (_I, [_P, _I, _I, _I, C.POINTER(_P), C.POINTER(C.c_size_t)]),
+    "plmpm_grid_window": (_I, [_P, _P, _P]),
+    "plmpm_halo_region": (_I, [_P, _I, _I, _I, _I, _I, C.POINTER(_P), C.POINTER(C.c_size_t)]),
+    "plmpm_halo_set_recv": (_I, [_P, _I, _I, _P, _P, _P]),
+    "plmpm_halo_apply": (_I, [_P, _I, _I]),
+    "plmpm_set_ids": (_I, [_P, _P]),
+    "plmpm_get_ids": (_I, [_P, _I, _P]),
+    "plmpm_frame_info": (_I, [_P, _I, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "plmpm_migrate_begin": (_I, [_P, _I, _P, C.POINTER(_P), C.POINTER(_P)]),
+    "plmpm_migrate_finish": (_I, [_P, _I, _I, _P, _I, _P, C.POINTER(C.c_int32)]),
+    "plmpm_migrate_adjoint_begin": (_I, [_P, _I, _P, _P, C.POINTER(_P), C.POINTER(_P)]),
+    "plmpm_migrate_adjoint_finish": (_I, [_P, _I, _P, _P]),
+    "plmpm_primitive_sdf": (_I, [_P, _I, _I, _P, _I, _P]),
+    "plmpm_set_velocity": (_I, [_P, _I, _I, _I]),
+    "plmpm_loss_contact_scalars": (_I, [_P, _P, _P]),
+    "plmpm_measure_hbm": (_I, [_P, _P, C.c_size_t, _I, _P, C.POINTER(_D), C.POINTER(_D)]),
     "plmpm_pose_grad_region": (_I, [_P, _I, _I, C.POINTER(_P), C.POINTER(C.c_size_t), C.POINTER(_P), C.POINTER(C.c_size_t),
                                     C.POINTER(_P), C.POINTER(C.c_size_t)]),
     "plmpm_action_grad_region": (_I, [_P, C.POINTER(_P), C.POINTER(C.c_size_t)]),

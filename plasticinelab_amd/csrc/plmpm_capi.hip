@@ -46,9 +46,11 @@ enum { LS_DENSITY = 0, LS_SDF = 1, LS_MAXGM = 2, LS_DOT = 3, LS_SUMGM = 4, LS_MI
 struct plmpm_sim {
     plmpm_config cfg;
     plmpm_primitive prims[PLMPM_MAX_PRIMITIVES];
-    int N, Npad, n, nb, nblk, P, F, act_total;
+    int N, Npad, n, nblk, P, F, act_total;      // N: rows of storage epoch 0; Npad: padded row capacity of a frame
+    int go[3], nbw[3];                          // grid window: origin node (multiple of 4) and extent in 4^3 blocks
     int act_ofs[PLMPM_MAX_PRIMITIVES + 1];
-    size_t G, tsz, frame_bytes;
+    size_t G, Gfull, tsz, frame_bytes;          // G: nodes of the window (what is allocated), Gfull = n^3
+    std::vector<int> epochN;                    // rows per storage epoch (multi-GPU ranks gain / lose particles by migration)
     hipStream_t stream = nullptr;
     bool bound = false;
     plmpm_workspace ws;
@@ -66,7 +68,19 @@ struct plmpm_sim {
     // multi-GPU: pose adjoints produced by this rank's nodes/particles accumulate in *_l, get summed over
     // ranks by the host and are then merged into the global ppos_a/prot_a the kinematics chain reads
     bool dist = false;
-    int win[4] = {0, 0, 0, 0};        // xy window [x0, x1) x [y0, y1) of the halo planes that travel (default: whole planes)
+    HaloIn halo_in[3];                // per halo field: where the neighbours' copies of the exchanged block planes arrive
+    double target_outside = 0.0;      // sum of the target density over owned nodes outside the grid window (|0 - t| terms)
+    // particle migration between z-slabs (plmpm_migrate_*): per storage epoch the global particle ids, the materials,
+    // the map new slot -> old slot (or -1 - arrival index) and the old slots that left (down list, then up list)
+    int *gid_store = nullptr, *mig_src = nullptr, *mig_leave = nullptr, *mig_dest = nullptr, *mig_cnt = nullptr, *iota = nullptr;
+    char* mats_store = nullptr;
+    double* mig_send[2] = {nullptr, nullptr};
+    int mig_max_rows = 0, sort_cap = 0;
+    std::vector<int32_t> ids0;            // global ids of the epoch-0 rows in caller order (plmpm_set_ids)
+    struct MigInfo { int parent = 0, nout[2] = {0, 0}, nin[2] = {0, 0}; };
+    std::vector<MigInfo> mig;             // per epoch
+    int mig_pending_frame = -1, mig_pending_out[2] = {0, 0};
+    int next_epoch = 1;
     int g2p_deferred = -1;            // slab path: frame whose g2p waits to run fused with the next frame's p2g
     double *ppos_l = nullptr, *prot_l = nullptr, *pgap_l = nullptr;
     // host state
@@ -153,20 +167,23 @@ template <class T> static Dev<T> make_dev(const plmpm_sim* s, int frame = -1) {
     D.P.ground_friction = (T)c.ground_friction;
     D.P.svd_clamp = (T)c.svd_grad_clamp;
     D.P.softness = (T)s->softness;
-    D.N = s->N; D.Npad = s->Npad; D.nb = s->nb; D.nprim = s->P;
+    const int epoch = frame >= 0 ? s->frame_epoch[frame] : 0;
+    D.N = frame >= 0 ? s->epochN[epoch] : s->N; D.Npad = s->Npad; D.nprim = s->P;
+    D.twg = s->Npad / kBlock;
+    for (int d = 0; d < 3; ++d) { D.go[d] = s->go[d]; D.rlo[d] = s->go[d]; D.rhi[d] = s->go[d] + 4 * s->nbw[d]; }
+    D.nbx = s->nbw[0]; D.nby = s->nbw[1]; D.nbz = s->nbw[2];
     D.z0 = c.slab_z0; D.z1 = c.slab_z1;
-    D.zlo = c.slab_z0 - c.slab_halo; D.zhi = c.slab_z1 + c.slab_halo;
-    if (c.slab_z0 <= 0) D.zlo = -(1 << 20);
-    if (c.slab_z1 >= c.n_grid) D.zhi = 1 << 20;
-    for (int d = 0; d < 2; ++d) {
-        D.wlo[d] = s->win[2 * d] <= 0 ? -(1 << 20) : s->win[2 * d];
-        D.whi[d] = s->win[2 * d + 1] >= c.n_grid ? (1 << 20) : s->win[2 * d + 1];
-    }
+    // interior slab faces: the neighbour only exchanges slab_halo node layers beyond the face
+    if (c.slab_z0 > 0) D.rlo[2] = std::max(D.rlo[2], c.slab_z0 - c.slab_halo);
+    if (c.slab_z1 < c.n_grid) D.rhi[2] = std::min(D.rhi[2], c.slab_z1 + c.slab_halo);
     D.err = s->err_d;
     D.frame_bytes = s->frame_bytes;
     D.state = s->state;
     D.adj[0] = (T*)s->adj[0]; D.adj[1] = (T*)s->adj[1];
-    D.mu = (T*)s->mu; D.lam = (T*)s->lam; D.ys = (T*)s->ys;
+    if (s->dist) {      // materials travel with the particles: one set per storage epoch
+        T* m = (T*)(s->mats_store + (size_t)epoch * 3 * s->Npad * s->tsz);
+        D.mu = m; D.lam = m + s->Npad; D.ys = m + 2 * (size_t)s->Npad;
+    } else { D.mu = (T*)s->mu; D.lam = (T*)s->lam; D.ys = (T*)s->ys; }
     const bool framed = s->store && frame >= 0;
     char* gin_base = framed ? s->gstore + (size_t)frame * s->gstride : s->grid_in;
     for (int c = 0; c < 4; ++c) D.gin[c] = (T*)gin_base + (size_t)c * s->G;
@@ -446,12 +463,12 @@ __device__ __forceinline__ double block_max(double v, double* sh) {
     return r;
 }
 // density / sdf losses (loss.py:145-153) + IoU sums (loss.py:239-254)
-template <class T> __global__ void k_loss_reduce(size_t G, int nb, int z0, int z1, const T* gm, const T* td, const T* ts, double* ls) {
+template <class T> __global__ void k_loss_reduce(size_t G, int nbxy, int gz, int z0, int z1, const T* gm, const T* td, const T* ts, double* ls) {
     __shared__ double sh[8];
     double dens = 0, sdf = 0, mx = 0, dot = 0, sum = 0;
-    const unsigned nb2 = (unsigned)nb * (unsigned)nb;         // block index < 2^26 even at 1024^3: 32-bit division
+    const unsigned nb2 = (unsigned)nbxy;                      // blocks per z-plane of the window (32-bit division)
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < G; i += (size_t)gridDim.x * blockDim.x) {
-        int z = (int)((unsigned)(i >> 6) / nb2) * 4 + (int)((i & 63) >> 4);
+        int z = gz + (int)((unsigned)(i >> 6) / nb2) * 4 + (int)((i & 63) >> 4);
         if (z < z0 || z >= z1) continue;                      // nodes owned by another rank
         double g = (double)gm[i], t = (double)td[i];
         dens += fabs(g - t); sdf += (double)ts[i] * g; mx = fmax(mx, g); dot += g * t; sum += g;
@@ -528,11 +545,12 @@ __global__ void k_loss_grad(Dev<T> D, int f, int which, const T* gm, const T* td
         int base[3];
         T fx[3], w[3][3], dw[3][3];
         stencil<T, double>(x, D.P.inv_dx, base, fx, w, dw);
+        clamp_to_reach(D, base);
         double fxa[3] = {0, 0, 0};
         for (int i = 0; i < 3; ++i)
             for (int j = 0; j < 3; ++j)
                 for (int l = 0; l < 3; ++l) {
-                    int idx = node_index(D.nb, base[0] + i, base[1] + j, base[2] + l);
+                    int idx = node_index(D, base[0] + i, base[1] + j, base[2] + l);
                     double diff = (double)gm[idx] - (double)td[idx];
                     double sg = diff > 0 ? 1.0 : (diff < 0 ? -1.0 : 0.0);          // d|x|/dx with sgn(0) = 0
                     double ga = (w_density * sg + w_sdf * (double)ts[idx]) * (double)D.P.p_mass;
@@ -613,21 +631,30 @@ __global__ void k_sdf_sweep(int n, double dx, double inf, const double* dens, co
     if (best != sdf_c[I] || bx != np_c[3 * I] || by != np_c[3 * I + 1] || bz != np_c[3 * I + 2]) *changed = 1;
     sdf[I] = best; npn[3 * I] = bx; npn[3 * I + 1] = by; npn[3 * I + 2] = bz;
 }
-template <class T> __global__ void k_upload_grid(int n, int nb, const double* lin, T* blocked) {
+// host grids are dense (n,n,n) [i][j][k]; the device holds the blocked window.  Upload: the window's part of the dense
+// grid; download: the dense grid is zeroed first, the window's nodes written over it.
+template <class T> __global__ void k_upload_grid(Dev<T> D, int n, const double* lin, T* blocked) {
     size_t I = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (I >= (size_t)n * n * n) return;
-    int k = I % n, j = (I / n) % n, i = I / ((size_t)n * n);
-    blocked[node_index(nb, i, j, k)] = (T)lin[I];
+    if (I >= (size_t)D.nbx * D.nby * D.nbz * 64) return;
+    int nd[3];
+    block_nodes(D, (int)(I >> 6), (int)(I & 63), nd);
+    blocked[I] = (T)lin[((size_t)nd[0] * n + nd[1]) * n + nd[2]];
 }
-template <class T> __global__ void k_download_grid(int n, int nb, const T* blocked, double* lin) {
+template <class T> __global__ void k_download_grid(Dev<T> D, int n, const T* blocked, double* lin) {
     size_t I = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (I >= (size_t)n * n * n) return;
-    int k = I % n, j = (I / n) % n, i = I / ((size_t)n * n);
-    lin[I] = (double)blocked[node_index(nb, i, j, k)];
+    if (I >= (size_t)D.nbx * D.nby * D.nbz * 64) return;
+    int nd[3];
+    block_nodes(D, (int)(I >> 6), (int)(I & 63), nd);
+    lin[((size_t)nd[0] * n + nd[1]) * n + nd[2]] = (double)blocked[I];
+}
+// dst += src (the neighbour's copy of exchanged block planes, fields that no grid kernel adds on first touch)
+template <class T> __global__ void k_add_region(T* dst, const T* src, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] += src[i];
 }
 template <class T> __global__ void k_grid_stats(Dev<T> D, unsigned long long* out) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    size_t G = (size_t)D.nb * D.nb * D.nb * 64;
+    size_t G = (size_t)D.nbx * D.nby * D.nbz * 64;
     if (i < G && D.gin[0][i] > T(0)) atomicAdd(&out[0], 1ULL);
     if (i < G / 64 && D.flags[i]) atomicAdd(&out[1], 1ULL);
 }
@@ -653,7 +680,8 @@ static ChainBufs chain_bufs(const plmpm_sim* s) {
     B.pgv_a = s->pgv_a; B.act_a = s->act_a;
     return B;
 }
-static inline int nblocks_particles(const plmpm_sim* s) { return s->Npad / kBlock; }
+static inline int nblocks_particles(const plmpm_sim* s, int frame) { return (s->epochN[s->frame_epoch[frame]] + kBlock - 1) / kBlock; }
+static const HaloIn kNoHalo = {0, {0, 0}, {0, 0}, {nullptr, nullptr}};
 #ifndef PLB_POSE_WG
 #define PLB_POSE_WG 16
 #endif
@@ -668,14 +696,14 @@ template <class T> static int substep_fwd(plmpm_sim* s, int f) {
     Dev<T> D = make_dev<T>(s, f);
     if (s->store) {
         if (s->dirty[f]) LAUNCH(s, K_CLEAR, (k_clear_active<T>), dim3(nblocks_grid(s)), D);   // frame reused without a backward pass
-        LAUNCH(s, K_P2G, (k_p2g<T, true>), dim3(nblocks_particles(s)), D, f);
-        LAUNCH(s, K_GRID_OP, (k_grid_op<T, false>), dim3(nwg_grid(s)), D, f);                    // keep grid_in for substep_grad
+        LAUNCH(s, K_P2G, (k_p2g<T, true>), dim3(nblocks_particles(s, f)), D, f);
+        LAUNCH(s, K_GRID_OP, (k_grid_op<T, false>), dim3(nwg_grid(s)), D, f, s->halo_in[PLMPM_HALO_GRID_IN]);                    // keep grid_in for substep_grad
         s->dirty[f] = 1;
     } else {
-        LAUNCH(s, K_P2G, (k_p2g<T, true>), dim3(nblocks_particles(s)), D, f);
-        LAUNCH(s, K_GRID_OP, (k_grid_op<T, true>), dim3(nwg_grid(s)), D, f);
+        LAUNCH(s, K_P2G, (k_p2g<T, true>), dim3(nblocks_particles(s, f)), D, f);
+        LAUNCH(s, K_GRID_OP, (k_grid_op<T, true>), dim3(nwg_grid(s)), D, f, kNoHalo);
     }
-    LAUNCH(s, K_G2P, (k_g2p<T>), dim3(nblocks_particles(s)), D, f);
+    LAUNCH(s, K_G2P, (k_g2p<T>), dim3(nblocks_particles(s, f)), D, f);
     return 0;
 }
 template <class T> static int substep_bwd(plmpm_sim* s, int f) {
@@ -684,12 +712,12 @@ template <class T> static int substep_bwd(plmpm_sim* s, int f) {
     // frame f+1 re-sorted by the env step that starts there: its v in THIS frame's order was kept aside
     const T* vnext = s->frame_epoch[f + 1] != s->frame_epoch[f] ? (const T*)(s->vend + (size_t)s->frame_epoch[f + 1] * 3 * s->Npad * s->tsz) : nullptr;
     if (!(s->store && s->dirty[f])) {        // this frame's grid is not resident: recompute it (mpm_simulator.py:265-268)
-        LAUNCH(s, K_P2G_RE, (k_p2g<T, false>), dim3(nblocks_particles(s)), D, f);
-        LAUNCH(s, K_GRID_OP_RE, (k_grid_op<T, false>), dim3(nwg_grid(s)), D, f);
+        LAUNCH(s, K_P2G_RE, (k_p2g<T, false>), dim3(nblocks_particles(s, f)), D, f);
+        LAUNCH(s, K_GRID_OP_RE, (k_grid_op<T, false>), dim3(nwg_grid(s)), D, f, kNoHalo);
     }
-    LAUNCH(s, K_G2P_GRAD, (k_g2p_grad<T>), dim3(nblocks_particles(s)), D, f, src, dst, vnext);
-    LAUNCH(s, K_GRID_OP_GRAD, (k_grid_op_grad<T>), dim3(nwg_grid(s)), D, f);
-    LAUNCH(s, K_P2G_GRAD, (k_p2g_grad<T>), dim3(nblocks_particles(s) + kPoseWG), D, f, src, dst, kPoseWG);
+    LAUNCH(s, K_G2P_GRAD, (k_g2p_grad<T>), dim3(nblocks_particles(s, f)), D, f, src, dst, vnext);
+    LAUNCH(s, K_GRID_OP_GRAD, (k_grid_op_grad<T>), dim3(nwg_grid(s)), D, f, s->halo_in[PLMPM_HALO_GRID_OUT_ADJ]);
+    LAUNCH(s, K_P2G_GRAD, (k_p2g_grad<T>), dim3(nblocks_particles(s, f) + kPoseWG), D, f, src, dst, kPoseWG);
     if (s->store) s->dirty[f] = 0;           // k_grid_op_grad left grid_in / flags of this frame clean
     s->adj_frame[dst] = f;
     return 0;
@@ -701,16 +729,16 @@ template <class T> static int step_fwd_fused(plmpm_sim* s, int first, int n) {
         Dev<T> D = make_dev<T>(s, f);
         if (s->dirty[f]) LAUNCHG_CLEAR(s, D);
         if (f == first) {
-            LAUNCH(s, K_P2G, (k_p2g<T, true>), dim3(nblocks_particles(s)), D, f);
+            LAUNCH(s, K_P2G, (k_p2g<T, true>), dim3(nblocks_particles(s, f)), D, f);
         } else {
             const Vec4<T>* vprev = (const Vec4<T>*)(s->vstore + (size_t)(f - 1) * s->gstride);
-            LAUNCH(s, K_G2P_P2G, (k_g2p_p2g<T>), dim3(nblocks_particles(s)), D, f, vprev);
+            LAUNCH(s, K_G2P_P2G, (k_g2p_p2g<T>), dim3(nblocks_particles(s, f)), D, f, vprev);
         }
-        LAUNCH(s, K_GRID_OP, (k_grid_op<T, false>), dim3(nwg_grid(s)), D, f);
+        LAUNCH(s, K_GRID_OP, (k_grid_op<T, false>), dim3(nwg_grid(s)), D, f, s->halo_in[PLMPM_HALO_GRID_IN]);
         s->dirty[f] = 1;
     }
     Dev<T> D = make_dev<T>(s, first + n - 1);
-    LAUNCH(s, K_G2P, (k_g2p<T>), dim3(nblocks_particles(s)), D, first + n - 1);
+    LAUNCH(s, K_G2P, (k_g2p<T>), dim3(nblocks_particles(s, first + n - 1)), D, first + n - 1);
     return 0;
 }
 
@@ -718,14 +746,15 @@ template <class T> static int step_fwd_fused(plmpm_sim* s, int first, int n) {
 template <class T> static int phase_p2g(plmpm_sim* s, int f) {
     Dev<T> D = make_dev<T>(s, f);
     if (s->dirty[f]) LAUNCH(s, K_CLEAR, (k_clear_active<T>), dim3(nblocks_grid(s)), D);
-    LAUNCH(s, K_P2G, (k_p2g<T, true>), dim3(nblocks_particles(s)), D, f);
+    LAUNCH(s, K_P2G, (k_p2g<T, true>), dim3(nblocks_particles(s, f)), D, f);
     s->dirty[f] = 1;
     return 0;
 }
 template <class T> static int phase_grid_g2p(plmpm_sim* s, int f, bool defer_g2p = false) {
     Dev<T> D = make_dev<T>(s, f);
-    LAUNCH(s, K_GRID_OP, (k_grid_op<T, false>), dim3(nwg_grid(s)), D, f);
-    if (!defer_g2p) LAUNCH(s, K_G2P, (k_g2p<T>), dim3(nblocks_particles(s)), D, f);
+    s->frame_epoch[f + 1] = s->frame_epoch[f];                 // g2p (now or fused into the next p2g) writes frame f + 1 in this order
+    LAUNCH(s, K_GRID_OP, (k_grid_op<T, false>), dim3(nwg_grid(s)), D, f, s->halo_in[PLMPM_HALO_GRID_IN]);
+    if (!defer_g2p) LAUNCH(s, K_G2P, (k_g2p<T>), dim3(nblocks_particles(s, f)), D, f);
     return 0;
 }
 // g2p(f-1), deferred by the previous phase_grid_g2p, fused with p2g(f) exactly as in step_fwd_fused
@@ -733,19 +762,20 @@ template <class T> static int phase_g2p_p2g(plmpm_sim* s, int f) {
     Dev<T> D = make_dev<T>(s, f);
     if (s->dirty[f]) LAUNCHG_CLEAR(s, D);
     const Vec4<T>* vprev = (const Vec4<T>*)(s->vstore + (size_t)(f - 1) * s->gstride);
-    LAUNCH(s, K_G2P_P2G, (k_g2p_p2g<T>), dim3(nblocks_particles(s)), D, f, vprev);
+    LAUNCH(s, K_G2P_P2G, (k_g2p_p2g<T>), dim3(nblocks_particles(s, f)), D, f, vprev);
     s->dirty[f] = 1;
     return 0;
 }
 template <class T> static int phase_grad_scatter(plmpm_sim* s, int f) {
     Dev<T> D = make_dev<T>(s, f);
-    LAUNCH(s, K_G2P_GRAD, (k_g2p_grad<T>), dim3(nblocks_particles(s)), D, f, (f + 1) & 1, f & 1, (const T*)nullptr);
+    const T* vnext = s->frame_epoch[f + 1] != s->frame_epoch[f] ? (const T*)(s->vend + (size_t)s->frame_epoch[f + 1] * 3 * s->Npad * s->tsz) : nullptr;
+    LAUNCH(s, K_G2P_GRAD, (k_g2p_grad<T>), dim3(nblocks_particles(s, f)), D, f, (f + 1) & 1, f & 1, vnext);
     return 0;
 }
 template <class T> static int phase_grad_gather(plmpm_sim* s, int f) {
     Dev<T> D = make_dev<T>(s, f);
-    LAUNCH(s, K_GRID_OP_GRAD, (k_grid_op_grad<T>), dim3(nwg_grid(s)), D, f);
-    LAUNCH(s, K_P2G_GRAD, (k_p2g_grad<T>), dim3(nblocks_particles(s) + kPoseWG), D, f, (f + 1) & 1, f & 1, kPoseWG);
+    LAUNCH(s, K_GRID_OP_GRAD, (k_grid_op_grad<T>), dim3(nwg_grid(s)), D, f, s->halo_in[PLMPM_HALO_GRID_OUT_ADJ]);
+    LAUNCH(s, K_P2G_GRAD, (k_p2g_grad<T>), dim3(nblocks_particles(s, f) + kPoseWG), D, f, (f + 1) & 1, f & 1, kPoseWG);
     s->dirty[f] = 0;
     s->adj_frame[f & 1] = f;
     return 0;
@@ -754,23 +784,30 @@ template <class T> static int phase_grad_gather(plmpm_sim* s, int f) {
 #define DISPATCH(s, fn, ...) ((s)->cfg.dtype == PLMPM_F64 ? fn<double>(__VA_ARGS__) : fn<float>(__VA_ARGS__))
 
 // ---------------------------------------------------------------------------------------------
-static int* perm_of(const plmpm_sim* s, int epoch) { return epoch <= 0 ? s->perm_d : s->perm_store + (size_t)(epoch - 1) * s->Npad; }
+// storage slot -> host row of state / gradient I/O.  Single GPU: the caller's particle index in every epoch.  Slab
+// engines: caller order only in epoch 0; once particles have migrated the rows of a frame are its storage order
+// (plmpm_get_ids names them)
+static int* perm_of(const plmpm_sim* s, int epoch) {
+    if (epoch <= 0) return s->perm_d;
+    return s->dist ? s->iota : s->perm_store + (size_t)(epoch - 1) * s->Npad;
+}
 // material arrays in the storage order of `epoch`, from the caller-order master copy
 template <class T> static int set_materials_t(plmpm_sim* s, int epoch) {
+    s->mats_epoch = epoch;
+    if (s->dist && epoch != 0) return 0;          // slab engines: epochs > 0 got their materials with the migrating rows
     Dev<T> D = make_dev<T>(s);
     hipLaunchKernelGGL((k_set_mats<T>), dim3(s->Npad / 256), dim3(256), 0, s->stream, D, s->mats_master, perm_of(s, epoch));
-    s->mats_epoch = epoch;
     return 0;
 }
 
 template <class T> static int unpack_t(plmpm_sim* s, int f, int hx, int hv, int hF, int hC) {
-    Dev<T> D = make_dev<T>(s);
+    Dev<T> D = make_dev<T>(s, f);
     hipLaunchKernelGGL((k_unpack_frame<T>), dim3(s->Npad / 256), dim3(256), 0, s->stream, D, f, s->staging, perm_of(s, s->frame_epoch[f]), hx, hv, hF, hC);
     return 0;
 }
 
 template <class T> static int pack_t(plmpm_sim* s, int f) {
-    Dev<T> D = make_dev<T>(s);
+    Dev<T> D = make_dev<T>(s, f);
     hipLaunchKernelGGL((k_pack_frame<T>), dim3(s->Npad / 256), dim3(256), 0, s->stream, D, f, s->staging, perm_of(s, s->frame_epoch[f]));
     return 0;
 }
@@ -778,6 +815,7 @@ template <class T> static int pack_t(plmpm_sim* s, int f) {
 template <class T> static int adj_io_t(plmpm_sim* s, int which, int add, int hx, int hv, int hF, int hC, int epoch = -1) {
     Dev<T> D = make_dev<T>(s);
     if (epoch < 0) epoch = s->adj_epoch[which];
+    D.N = s->epochN[epoch];
     hipLaunchKernelGGL((k_adj_io<T>), dim3(s->Npad / 256), dim3(256), 0, s->stream, D, which, s->staging, perm_of(s, epoch), add, hx, hv, hF, hC);
     return 0;
 }
@@ -831,7 +869,8 @@ template <class T> __global__ void k_permute_frame(Dev<T> D, int f, const int* o
     if (i < D.N) perm_new[i] = perm_old[j];
 }
 template <class T> static int resort_frame_t(plmpm_sim* s, int f, int epoch) {
-    Dev<T> D = make_dev<T>(s);
+    Dev<T> D = make_dev<T>(s, f);
+    s->epochN[epoch] = D.N;
     const int nb = s->Npad / 256;
     int bits = 1;
     while ((1 << bits) < s->n) ++bits;
@@ -848,6 +887,8 @@ template <class T> static int resort_frame_t(plmpm_sim* s, int f, int epoch) {
 // adjoint frame `which` from the storage order of epoch `from` to that of epoch `to`, through caller order (staging)
 template <class T> static int convert_adjoint_t(plmpm_sim* s, int which, int from, int to) {
     if (from == to) return 0;
+    if (s->dist) return fail("slab engine: the adjoint frame is in storage epoch %d but epoch %d is needed -- particles migrated in between; "
+                             "run plmpm_migrate_adjoint_begin / _finish on the boundary frame first", from, to);
     adj_io_t<T>(s, which, 0, 1, 1, 1, 1, from);
     HIPCHK(hipMemsetAsync(s->adj[which], 0, (size_t)24 * s->Npad * s->tsz, s->stream));
     adj_io_t<T>(s, which, 1, 1, 1, 1, 1, to);
@@ -856,25 +897,26 @@ template <class T> static int convert_adjoint_t(plmpm_sim* s, int which, int fro
 }
 
 template <class T> static int upload_grid_t(plmpm_sim* s, const double* lin_d, char* dst) {
-    hipLaunchKernelGGL((k_upload_grid<T>), dim3((unsigned)((s->G + 255) / 256)), dim3(256), 0, s->stream, s->n, s->nb, lin_d, (T*)dst);
+    hipLaunchKernelGGL((k_upload_grid<T>), dim3((unsigned)((s->G + 255) / 256)), dim3(256), 0, s->stream, make_dev<T>(s), s->n, lin_d, (T*)dst);
     return 0;
 }
 
 template <class T> static int download_grid_t(plmpm_sim* s, const char* src, double* lin_d) {
-    hipLaunchKernelGGL((k_download_grid<T>), dim3((unsigned)((s->G + 255) / 256)), dim3(256), 0, s->stream, s->n, s->nb, (const T*)src, lin_d);
+    (void)hipMemsetAsync(lin_d, 0, s->Gfull * 8, s->stream);
+    hipLaunchKernelGGL((k_download_grid<T>), dim3((unsigned)((s->G + 255) / 256)), dim3(256), 0, s->stream, make_dev<T>(s), s->n, (const T*)src, lin_d);
     return 0;
 }
 
 template <class T> static int loss_scatter_t(plmpm_sim* s, int f) {
-    Dev<T> D = make_dev<T>(s);
+    Dev<T> D = make_dev<T>(s, f);
     hipMemsetAsync(s->loss_gm, 0, s->G * s->tsz, s->stream);
-    hipLaunchKernelGGL((k_grid_mass<T>), dim3(nblocks_particles(s)), dim3(kBlock), 0, s->stream, D, f, (T*)s->loss_gm);
+    hipLaunchKernelGGL((k_grid_mass<T>), dim3(nblocks_particles(s, f)), dim3(kBlock), 0, s->stream, D, f, (T*)s->loss_gm);
     return 0;
 }
 
 // mode 0: hard min, 1: soft normaliser, 2: soft weighted sum (needs the global normaliser in lscal)
 template <class T> static int loss_contact_pass_t(plmpm_sim* s, int f, int mode) {
-    Dev<T> D = make_dev<T>(s);
+    Dev<T> D = make_dev<T>(s, f);
     bool any = false;
     for (int p = 0; p < s->P; ++p) any |= s->prims[p].action_dim > 0;
     if (any) hipLaunchKernelGGL((k_contact<T>), dim3(std::min(s->Npad / 256, 512)), dim3(256), 0, s->stream, D, f, mode, s->lscal);
@@ -890,13 +932,13 @@ static int loss_reset_scalars(plmpm_sim* s) {
 }
 
 template <class T> static int loss_reduce_t(plmpm_sim* s) {
-    hipLaunchKernelGGL((k_loss_reduce<T>), dim3(256), dim3(256), 0, s->stream, s->G, s->nb, s->cfg.slab_z0, s->cfg.slab_z1,
+    hipLaunchKernelGGL((k_loss_reduce<T>), dim3(256), dim3(256), 0, s->stream, s->G, s->nbw[0] * s->nbw[1], s->go[2], s->cfg.slab_z0, s->cfg.slab_z1,
                        (const T*)s->loss_gm, (const T*)s->loss_td, (const T*)s->loss_ts, s->lscal);
     return 0;
 }
 
 template <class T> static int loss_grad_t(plmpm_sim* s, int f) {
-    Dev<T> D = make_dev<T>(s);
+    Dev<T> D = make_dev<T>(s, f);
     hipLaunchKernelGGL((k_loss_grad<T>), dim3(s->Npad / 256), dim3(256), 0, s->stream, D, f, f & 1, (const T*)s->loss_gm,
                        (const T*)s->loss_td, (const T*)s->loss_ts, s->lscal, s->w_sdf, s->w_density, s->w_contact, s->soft_contact);
     return 0;
@@ -904,8 +946,9 @@ template <class T> static int loss_grad_t(plmpm_sim* s, int f) {
 
 template <class T> static int grid_stats_t(plmpm_sim* s, int f, unsigned long long* d_out) {
     Dev<T> D = make_dev<T>(s);
+    D.N = s->epochN[s->frame_epoch[f]];
     // recompute the scatter of frame f without consuming it, count, then clear
-    hipLaunchKernelGGL((k_p2g<T, false>), dim3(nblocks_particles(s)), dim3(kBlock), 0, s->stream, D, f);
+    hipLaunchKernelGGL((k_p2g<T, false>), dim3(nblocks_particles(s, f)), dim3(kBlock), 0, s->stream, D, f);
     hipLaunchKernelGGL((k_grid_stats<T>), dim3((unsigned)((s->G + 255) / 256)), dim3(256), 0, s->stream, D, d_out);
     hipLaunchKernelGGL((k_clear_active<T>), dim3(nblocks_grid(s)), dim3(kBlock), 0, s->stream, D);
     return 0;
@@ -948,9 +991,19 @@ int plmpm_create(const plmpm_config* cfg, const plmpm_primitive* prims, plmpm_ha
     }
     s->act_total = s->act_ofs[s->P];
     s->N = cfg->n_particles;
-    s->Npad = (int)align_up(s->N, kBlock);
-    s->win[1] = s->win[3] = cfg->n_grid;
-    s->n = cfg->n_grid; s->nb = s->n / 4; s->nblk = s->nb * s->nb * s->nb; s->G = (size_t)s->n * s->n * s->n;
+    const int cap = std::max(cfg->particle_capacity, cfg->n_particles);
+    s->Npad = (int)align_up(cap, kBlock);
+    s->n = cfg->n_grid; s->Gfull = (size_t)s->n * s->n * s->n;
+    // grid window: the box of 4^3 blocks that is allocated and swept (all-zero grid_lo / grid_hi = the whole grid)
+    for (int d = 0; d < 3; ++d) {
+        int lo = cfg->grid_lo[d], hi = cfg->grid_hi[d];
+        if (hi <= lo) { lo = 0; hi = s->n; }
+        lo = std::max(0, lo) / 4 * 4;
+        hi = std::min(s->n, (hi + 3) / 4 * 4);
+        if (hi - lo < 4) { delete s; return fail("grid window axis %d is empty: [%d, %d)", d, cfg->grid_lo[d], cfg->grid_hi[d]); }
+        s->go[d] = lo; s->nbw[d] = (hi - lo) / 4;
+    }
+    s->nblk = s->nbw[0] * s->nbw[1] * s->nbw[2]; s->G = (size_t)s->nblk * 64;
     s->F = cfg->max_frames;
     s->tsz = cfg->dtype == PLMPM_F64 ? 8 : 4;
     s->frame_bytes = (size_t)s->Npad * (24 + 21 * s->tsz);
@@ -960,14 +1013,26 @@ int plmpm_create(const plmpm_config* cfg, const plmpm_primitive* prims, plmpm_ha
     s->ws.grid_bytes = 4 * align_up(s->G * 4 * s->tsz, 256) + align_up((size_t)s->nblk * 4, 256) + 3 * align_up(s->G * s->tsz, 256);
     s->dist = s->cfg.slab_z0 > 0 || s->cfg.slab_z1 < cfg->n_grid || cfg->slab_halo > 0;
     s->resort = cfg->resort_steps > 0 && !s->dist && cfg->substeps > 0;
-    s->n_epochs = s->resort ? s->F / (cfg->substeps * cfg->resort_steps) + 3 : 1;      // +2: the alternating pair of copy-mode episodes
+    // storage epochs: single GPU one per re-sort (+2: the alternating pair of copy-mode episodes); slab engines one per
+    // migration, at most one per env step
+    s->n_epochs = s->resort ? s->F / (cfg->substeps * cfg->resort_steps) + 3 : 1;
+    if (s->dist && cfg->substeps > 0) s->n_epochs = s->F / cfg->substeps + 4;
+    s->epochN.assign(s->n_epochs + 1, s->N);
+    s->mig.assign(s->n_epochs + 1, plmpm_sim::MigInfo());
     s->frame_epoch.assign(s->F + 2, 0);
-    s->sort_tmp_bytes = s->resort ? plmpm_sort_temp_bytes(s->Npad) : 0;
-    s->ws.adjoint_bytes += align_up((size_t)3 * s->N * 8, 256);                      // material master copy
-    if (s->resort)
+    const bool sorts = s->resort || s->dist;
+    s->sort_cap = s->dist ? s->Npad + s->Npad / 2 : s->Npad;          // slab engines sort stayers + arrivals
+    s->mig_max_rows = s->Npad / 4;
+    s->sort_tmp_bytes = sorts ? plmpm_sort_temp_bytes(s->sort_cap) : 0;
+    s->ws.adjoint_bytes += align_up((size_t)3 * s->Npad * 8, 256);                   // material master copy
+    if (sorts)
         s->ws.adjoint_bytes += align_up((size_t)(s->n_epochs - 1) * s->Npad * 4, 256) + align_up((size_t)s->n_epochs * 3 * s->Npad * s->tsz, 256)
-                               + 4 * align_up((size_t)s->Npad * 4, 256) + align_up(s->sort_tmp_bytes, 256) + align_up(s->frame_bytes, 256);
-    if (s->dist) s->ws.misc_bytes += 3 * align_up((size_t)(s->F + 1) * P1 * 4 * 8, 256);
+                               + 4 * align_up((size_t)s->sort_cap * 4, 256) + align_up(s->sort_tmp_bytes, 256) + align_up(s->frame_bytes, 256);
+    if (s->dist)
+        s->ws.adjoint_bytes += 3 * align_up((size_t)s->n_epochs * s->Npad * 4, 256)            // gid_store, mig_src, mig_leave
+                               + align_up((size_t)s->n_epochs * 3 * s->Npad * s->tsz, 256)    // mats_store
+                               + 2 * align_up((size_t)s->Npad * 4, 256) + 256                  // mig_dest, iota, mig_cnt
+                               + 2 * align_up((size_t)s->mig_max_rows * 28 * 8, 256);          // packed rows of the leavers, per direction
     s->store = cfg->store_grid != 0;
     s->gstride = align_up(s->G * 4 * s->tsz, 256);
     if (s->store) s->ws.grid_bytes += 2 * (size_t)s->F * s->gstride + align_up((size_t)s->F * s->nblk * 4, 256);
@@ -977,7 +1042,9 @@ int plmpm_create(const plmpm_config* cfg, const plmpm_primitive* prims, plmpm_ha
                        + 4 * align_up((size_t)(s->F + 1) * P1 * 3 * 8, 256)                       // v,w (+adj)
                        + 4 * align_up((size_t)(s->F + 1) * P1 * 8, 256)                           // gap, gap_vel (+adj)
                        + 2 * align_up((size_t)(s->F + 1) * P1 * PLMPM_MAX_ACTION_DIM * 8, 256)    // action buffers (+adj)
-                       + align_up(LS_COUNT * 8, 256) + align_up((size_t)s->N * 24 * 8, 256) + 512;
+                       + align_up(LS_COUNT * 8, 256) + align_up((size_t)s->Npad * 24 * 8, 256) + 512;
+    if (s->dist) s->ws.misc_bytes += 3 * align_up((size_t)(s->F + 1) * P1 * 4 * 8, 256);
+    memset(s->halo_in, 0, sizeof s->halo_in);
     s->perm.resize(s->N);
     for (int i = 0; i < s->N; ++i) s->perm[i] = i;
     *out = s;
@@ -1007,13 +1074,23 @@ int plmpm_bind_workspace(plmpm_handle s, void* state, void* adjoint, void* grid,
     p = s->adjw + align_up(2 * 24 * s->Npad * s->tsz, 256);
     s->mu = take(s->Npad * s->tsz); s->lam = take(s->Npad * s->tsz); s->ys = take(s->Npad * s->tsz);
     s->perm_d = (int*)take((size_t)s->Npad * 4);
-    s->mats_master = (double*)take((size_t)3 * s->N * 8);
-    if (s->resort) {
+    s->mats_master = (double*)take((size_t)3 * s->Npad * 8);
+    if (s->resort || s->dist) {
         s->perm_store = (int*)take((size_t)(s->n_epochs - 1) * s->Npad * 4);
         s->vend = take((size_t)s->n_epochs * 3 * s->Npad * s->tsz);
-        for (int i = 0; i < 2; ++i) { s->skey[i] = (unsigned*)take((size_t)s->Npad * 4); s->sidx[i] = (int*)take((size_t)s->Npad * 4); }
+        for (int i = 0; i < 2; ++i) { s->skey[i] = (unsigned*)take((size_t)s->sort_cap * 4); s->sidx[i] = (int*)take((size_t)s->sort_cap * 4); }
         s->sort_tmp = take(s->sort_tmp_bytes);
         s->frame_tmp = take(s->frame_bytes);
+    }
+    if (s->dist) {
+        s->gid_store = (int*)take((size_t)s->n_epochs * s->Npad * 4);
+        s->mig_src = (int*)take((size_t)s->n_epochs * s->Npad * 4);
+        s->mig_leave = (int*)take((size_t)s->n_epochs * s->Npad * 4);
+        s->mats_store = take((size_t)s->n_epochs * 3 * s->Npad * s->tsz);
+        s->mig_dest = (int*)take((size_t)s->Npad * 4);
+        s->iota = (int*)take((size_t)s->Npad * 4);
+        s->mig_cnt = (int*)take(256);
+        for (int i = 0; i < 2; ++i) s->mig_send[i] = (double*)take((size_t)s->mig_max_rows * 28 * 8);
     }
     REQUIRE((size_t)(p - s->adjw) <= s->ws.adjoint_bytes, "internal: adjoint workspace overflow");
     p = s->gridw;
@@ -1039,7 +1116,7 @@ int plmpm_bind_workspace(plmpm_handle s, void* state, void* adjoint, void* grid,
     s->pgv = (double*)take(F1 * P1 * 8); s->pgv_a = (double*)take(F1 * P1 * 8);
     s->act = (double*)take(F1 * P1 * PLMPM_MAX_ACTION_DIM * 8); s->act_a = (double*)take(F1 * P1 * PLMPM_MAX_ACTION_DIM * 8);
     s->lscal = (double*)take(LS_COUNT * 8);
-    s->staging = (double*)take((size_t)s->N * 24 * 8);
+    s->staging = (double*)take((size_t)s->Npad * 24 * 8);
     s->err_d = (int*)take(512);
     if (s->dist) { s->ppos_l = (double*)take(F1 * P1 * 3 * 8); s->prot_l = (double*)take(F1 * P1 * 4 * 8); s->pgap_l = (double*)take(F1 * P1 * 8); }
     REQUIRE((size_t)(p - s->miscw) <= s->ws.misc_bytes, "internal: misc workspace overflow");
@@ -1048,11 +1125,19 @@ int plmpm_bind_workspace(plmpm_handle s, void* state, void* adjoint, void* grid,
     HIPCHK(hipMemsetAsync(s->gridw, 0, s->ws.grid_bytes, s->stream));
     HIPCHK(hipMemsetAsync(s->miscw, 0, s->ws.misc_bytes, s->stream));
     HIPCHK(hipMemcpyAsync(s->perm_d, s->perm.data(), (size_t)s->N * 4, hipMemcpyHostToDevice, s->stream));
+    if (s->dist) {
+        std::vector<int> io(s->Npad);
+        for (int i = 0; i < s->Npad; ++i) io[i] = i;
+        HIPCHK(hipMemcpyAsync(s->iota, io.data(), (size_t)s->Npad * 4, hipMemcpyHostToDevice, s->stream));
+        HIPCHK(hipMemcpyAsync(s->gid_store, io.data(), (size_t)s->N * 4, hipMemcpyHostToDevice, s->stream));      // default ids: the row index
+        HIPCHK(hipStreamSynchronize(s->stream));          // `io` goes out of scope
+        s->ids0.assign(io.begin(), io.begin() + s->N);
+    }
     // unit quaternions everywhere so an unset primitive frame is still a valid pose
     std::vector<double> rot(F1 * P1 * 4, 0.0);
     for (size_t i = 0; i < F1 * P1; ++i) rot[4 * i] = 1.0;
     HIPCHK(hipMemcpyAsync(s->prot, rot.data(), rot.size() * 8, hipMemcpyHostToDevice, s->stream));
-    if (s->resort) {
+    if (s->resort || s->dist) {
         // first use of the library sort loads its code object (~20 ms): pay that here, not in the first re-sorted step
         if (plmpm_sort_pairs(s->sort_tmp, s->sort_tmp_bytes, s->skey[0], s->skey[1], s->sidx[0], s->sidx[1], s->Npad, 8, s->stream) != 0)
             return fail("device sort unavailable");
@@ -1071,7 +1156,7 @@ int plmpm_set_stream(plmpm_handle s, void* hip_stream) {
 #define NEED_BOUND(s)                                                                                             \
     do {                                                                                                          \
         REQUIRE((s) && (s)->bound, "workspace not bound");                                                        \
-        REQUIRE((s)->g2p_deferred < 0, "frame %d's g2p is deferred: call plmpm_slab_pre(frame + 1, chain = 1) next", (s)->g2p_deferred); \
+        REQUIRE((s)->g2p_deferred < 0, "frame %d's g2p is deferred: call plmpm_p2g(frame + 1, chain = 1) next", (s)->g2p_deferred); \
     } while (0)
 #define NEED_FRAME(s, f) REQUIRE((f) >= 0 && (f) <= (s)->F, "frame %d out of range [0,%d]", (f), (s)->F)
 
@@ -1136,15 +1221,23 @@ static void compute_order(plmpm_sim* s, const double* x) {
 int plmpm_set_frame(plmpm_handle s, int frame, const double* x, const double* v, const double* F, const double* C, int resort) {
     NEED_BOUND(s);
     NEED_FRAME(s, frame);
-    size_t N = s->N;
     if (resort) {
         REQUIRE(x && v && F && C, "resort needs the full state (all of x, v, F, C)");
         compute_order(s, x);
-        HIPCHK(hipMemcpyAsync(s->perm_d, s->perm.data(), N * 4, hipMemcpyHostToDevice, s->stream));
+        HIPCHK(hipMemcpyAsync(s->perm_d, s->perm.data(), (size_t)s->N * 4, hipMemcpyHostToDevice, s->stream));
         std::fill(s->frame_epoch.begin(), s->frame_epoch.end(), 0);          // a new episode: every frame in the reset order
+        s->epochN[0] = s->N;
+        s->next_epoch = 1;
         s->steps_since_sort = 0;
+        if (s->dist) {       // global ids in the reset order
+            std::vector<int32_t> g(s->N);
+            for (int i = 0; i < s->N; ++i) g[i] = s->ids0[s->perm[i]];
+            HIPCHK(hipMemcpyAsync(s->gid_store, g.data(), (size_t)s->N * 4, hipMemcpyHostToDevice, s->stream));
+            HIPCHK(hipStreamSynchronize(s->stream));
+        }
         if (s->have_mats) DISPATCH(s, set_materials_t, s, 0);
     }
+    const size_t N = s->epochN[s->frame_epoch[frame]];
     if (x) HIPCHK(hipMemcpyAsync(s->staging, x, N * 3 * 8, hipMemcpyHostToDevice, s->stream));
     if (v) HIPCHK(hipMemcpyAsync(s->staging + 3 * N, v, N * 3 * 8, hipMemcpyHostToDevice, s->stream));
     if (F) HIPCHK(hipMemcpyAsync(s->staging + 6 * N, F, N * 9 * 8, hipMemcpyHostToDevice, s->stream));
@@ -1157,7 +1250,7 @@ int plmpm_set_frame(plmpm_handle s, int frame, const double* x, const double* v,
 int plmpm_get_frame(plmpm_handle s, int frame, double* x, double* v, double* F, double* C) {
     NEED_BOUND(s);
     NEED_FRAME(s, frame);
-    size_t N = s->N;
+    const size_t N = s->epochN[s->frame_epoch[frame]];
     DISPATCH(s, pack_t, s, frame);
     if (x) HIPCHK(hipMemcpyAsync(x, s->staging, N * 3 * 8, hipMemcpyDeviceToHost, s->stream));
     if (v) HIPCHK(hipMemcpyAsync(v, s->staging + 3 * N, N * 3 * 8, hipMemcpyDeviceToHost, s->stream));
@@ -1227,6 +1320,76 @@ int plmpm_add_primitive_grad(plmpm_handle s, int prim, int frame, const double* 
     HIPCHK(hipGetLastError());
     return 0;
 }
+}  // extern "C"
+// Primitive.sdf (primive_base.py:57-60; a ti.func in the reference): signed distance of n points to primitive `prim`
+// at its pose of `frame`, evaluated by the same device function the collide / loss kernels use
+template <class T> __global__ void k_prim_sdf(Dev<T> D, int q, int f, const double* pts, int n, double* out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const PrimT<T> pr = prim_at(D, q, f);
+    const double x[3] = {pts[3 * (size_t)i], pts[3 * (size_t)i + 1], pts[3 * (size_t)i + 2]};
+    out[i] = prim_sdf(pr, x);
+}
+extern "C" {
+int plmpm_primitive_sdf(plmpm_handle s, int prim, int frame, const double* points, int n, double* out) {
+    NEED_BOUND(s);
+    NEED_FRAME(s, frame);
+    REQUIRE(prim >= 0 && prim < s->P && points && out && n >= 0, "primitive_sdf: bad arguments");
+    if (n == 0) return 0;
+    double* d_in;
+    HIPCHK(hipMalloc(&d_in, (size_t)n * 4 * 8));
+    double* d_out = d_in + (size_t)n * 3;
+    HIPCHK(hipMemcpyAsync(d_in, points, (size_t)n * 3 * 8, hipMemcpyHostToDevice, s->stream));
+    if (s->cfg.dtype == PLMPM_F64) hipLaunchKernelGGL((k_prim_sdf<double>), dim3((n + 255) / 256), dim3(256), 0, s->stream, make_dev<double>(s), prim, frame, d_in, n, d_out);
+    else hipLaunchKernelGGL((k_prim_sdf<float>), dim3((n + 255) / 256), dim3(256), 0, s->stream, make_dev<float>(s), prim, frame, d_in, n, d_out);
+    HIPCHK(hipMemcpyAsync(out, d_out, (size_t)n * 8, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    (void)hipFree(d_in);
+    return 0;
+}
+// Loss.min_dist / dist_norm of the movable primitives after the last loss evaluation (loss.py:116-135)
+int plmpm_loss_contact_scalars(plmpm_handle s, double* min_dist, double* dist_norm) {
+    NEED_BOUND(s);
+    double ls[LS_COUNT];
+    HIPCHK(hipMemcpyAsync(ls, s->lscal, sizeof ls, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    for (int q = 0; q < s->P; ++q) {
+        if (min_dist) min_dist[q] = ls[LS_MIND + q];
+        if (dist_norm) dist_norm[q] = ls[LS_DNORM + q];
+    }
+    return 0;
+}
+// measured HBM roof of this device: float4 copy of `bytes` (read + write), best of `reps`; GB/s of bytes moved
+__global__ __launch_bounds__(256) void k_copy16(const uint4* __restrict__ in, uint4* __restrict__ out, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) out[i] = in[i];
+}
+__global__ __launch_bounds__(256) void k_read16(const uint4* __restrict__ in, unsigned* __restrict__ out, size_t n) {
+    uint4 a = {0, 0, 0, 0};
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) { uint4 v = in[i]; a.x ^= v.x; a.y ^= v.y; a.z ^= v.z; a.w ^= v.w; }
+    if ((a.x ^ a.y ^ a.z ^ a.w) == 0x9e3779b9u) out[0] = a.x;
+}
+int plmpm_measure_hbm(void* src, void* dst, size_t bytes, int reps, void* hip_stream, double* copy_gbs, double* read_gbs) {
+    REQUIRE(src && dst && bytes >= (1u << 20) && reps > 0 && copy_gbs && read_gbs, "measure_hbm: bad arguments");
+    hipStream_t st = (hipStream_t)hip_stream;
+    hipEvent_t a, b;
+    HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b));
+    const size_t n = bytes / 16;
+    double best[2] = {0, 0};
+    for (int k = 0; k < 2; ++k)
+        for (int r = 0; r < reps + 1; ++r) {
+            HIPCHK(hipEventRecord(a, st));
+            if (k == 0) hipLaunchKernelGGL(k_copy16, dim3(16384), dim3(256), 0, st, (const uint4*)src, (uint4*)dst, n);
+            else hipLaunchKernelGGL(k_read16, dim3(2048), dim3(256), 0, st, (const uint4*)src, (unsigned*)dst, n);
+            HIPCHK(hipEventRecord(b, st));
+            HIPCHK(hipEventSynchronize(b));
+            float ms = 0;
+            HIPCHK(hipEventElapsedTime(&ms, a, b));
+            if (r > 0) best[k] = std::max(best[k], (k == 0 ? 2.0 : 1.0) * (double)bytes / (ms * 1e6));      // first run warms up
+        }
+    (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+    *copy_gbs = best[0]; *read_gbs = best[1];
+    return 0;
+}
 int plmpm_set_softness(plmpm_handle s, double softness) {
     REQUIRE(s, "null handle");
     s->softness = softness;
@@ -1247,6 +1410,28 @@ int plmpm_set_action(plmpm_handle s, int step, int n_substeps, const double* act
             a.a[p * PLMPM_MAX_ACTION_DIM + k] = std::min(1.0, std::max(-1.0, v));      // primitives.py:290
         }
     hipLaunchKernelGGL(k_set_action, dim3(s->P), dim3(kChainThreads), 0, s->stream, chain_args(s), a, step, n_substeps, s->act, s->pv, s->pw, s->pgv);
+    return 0;
+}
+
+// Primitive.set_velocity (primive_base.py:184-192): v, w of the step's frames from action_buffer[step] as stored
+__global__ void k_set_velocity(PrimChainArgs A, int prim, int step, int nsub, const double* actbuf, double* pv, double* pw, double* pgv) {
+    const int p = prim;
+    const double* ab = actbuf + ((size_t)step * A.P + p) * PLMPM_MAX_ACTION_DIM;
+    if (A.action_dim[p] <= 0) return;
+    for (int j = step * nsub + threadIdx.x; j < (step + 1) * nsub; j += blockDim.x) {
+        double* v = pv + ((size_t)j * A.P + p) * 3;
+        double* w = pw + ((size_t)j * A.P + p) * 3;
+        for (int k = 0; k < 3; ++k) v[k] = ab[k] * A.scale[p][k] / nsub;
+        if (A.action_dim[p] > 3) for (int k = 0; k < 3; ++k) w[k] = ab[k + 3] * A.scale[p][k + 3] / nsub;
+        if (A.kin[p] == PLMPM_KIN_CHOPSTICKS) pgv[(size_t)j * A.P + p] = ab[6] * A.scale[p][6] / nsub;
+    }
+}
+int plmpm_set_velocity(plmpm_handle s, int prim, int step, int n_substeps) {
+    NEED_BOUND(s);
+    REQUIRE(prim >= 0 && prim < s->P, "set_velocity: bad primitive index");
+    REQUIRE(n_substeps > 0 && step >= 0 && (step + 1) * n_substeps <= s->F, "set_velocity: frames exceed max_frames");
+    hipLaunchKernelGGL(k_set_velocity, dim3(1), dim3(kChainThreads), 0, s->stream, chain_args(s), prim, step, n_substeps, s->act, s->pv, s->pw, s->pgv);
+    HIPCHK(hipGetLastError());
     return 0;
 }
 
@@ -1283,8 +1468,8 @@ int plmpm_substep(plmpm_handle s, int frame) {
     REQUIRE(frame >= 0 && frame < s->F, "substep: frame %d out of range", frame);
     launch_fk(s, frame, 1);
     if (s->have_mats && s->mats_epoch != s->frame_epoch[frame]) DISPATCH(s, set_materials_t, s, s->frame_epoch[frame]);
-    DISPATCH(s, substep_fwd, s, frame);
     s->frame_epoch[frame + 1] = s->frame_epoch[frame];
+    DISPATCH(s, substep_fwd, s, frame);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -1310,9 +1495,9 @@ int plmpm_step(plmpm_handle s, int first_frame, int n_substeps) {
     ++s->steps_since_sort;
     const int e = s->frame_epoch[first_frame];
     if (s->have_mats && s->mats_epoch != e) DISPATCH(s, set_materials_t, s, e);
+    for (int f = first_frame + 1; f <= first_frame + n_substeps; ++f) s->frame_epoch[f] = e;      // before the launches: they size by epoch
     if (s->store && n_substeps > 1) DISPATCH(s, step_fwd_fused, s, first_frame, n_substeps);
     else for (int f = first_frame; f < first_frame + n_substeps; ++f) DISPATCH(s, substep_fwd, s, f);
-    for (int f = first_frame + 1; f <= first_frame + n_substeps; ++f) s->frame_epoch[f] = e;
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -1420,7 +1605,7 @@ int plmpm_add_frame_grad(plmpm_handle s, int frame, const double* xa, const doub
     NEED_BOUND(s);
     NEED_FRAME(s, frame);
     REQUIRE(s->adj_frame[frame & 1] == frame, "add_frame_grad: adjoint of frame %d is not resident", frame);
-    size_t N = s->N;
+    const size_t N = s->epochN[s->frame_epoch[frame]];
     if (s->adj_epoch[frame & 1] != s->frame_epoch[frame] &&
         DISPATCH(s, convert_adjoint_t, s, frame & 1, s->adj_epoch[frame & 1], s->frame_epoch[frame])) return -1;
     if (xa) HIPCHK(hipMemcpyAsync(s->staging, xa, N * 3 * 8, hipMemcpyHostToDevice, s->stream));
@@ -1435,7 +1620,7 @@ int plmpm_get_frame_grad(plmpm_handle s, int frame, double* xa, double* va, doub
     NEED_BOUND(s);
     NEED_FRAME(s, frame);
     REQUIRE(s->adj_frame[frame & 1] == frame, "get_frame_grad: adjoint of frame %d is not resident", frame);
-    size_t N = s->N;
+    const size_t N = s->epochN[s->adj_epoch[frame & 1]];
     DISPATCH(s, adj_io_t, s, frame & 1, 0, 1, 1, 1, 1);
     if (xa) HIPCHK(hipMemcpyAsync(xa, s->staging, N * 3 * 8, hipMemcpyDeviceToHost, s->stream));
     if (va) HIPCHK(hipMemcpyAsync(va, s->staging + 3 * N, N * 3 * 8, hipMemcpyDeviceToHost, s->stream));
@@ -1450,7 +1635,7 @@ int plmpm_get_frame_grad(plmpm_handle s, int frame, double* xa, double* va, doub
 int plmpm_loss_set_target(plmpm_handle s, const double* density) {
     NEED_BOUND(s);
     REQUIRE(density, "null density");
-    const size_t G = s->G;
+    const size_t G = s->Gfull;                   // the sweeps run on the dense n^3 grid; only the window's part is kept
     double *d_dens, *d_sdf[2], *d_np[2];
     int* d_changed;
     HIPCHK(hipMalloc(&d_dens, G * 8));
@@ -1480,8 +1665,20 @@ int plmpm_loss_set_target(plmpm_handle s, const double* density) {
     HIPCHK(hipStreamSynchronize(s->stream));
     hipFree(d_dens); hipFree(d_changed);
     for (int i = 0; i < 2; ++i) { hipFree(d_sdf[i]); hipFree(d_np[i]); }
-    s->target_max = 0; s->target_sum = 0;
-    for (size_t i = 0; i < G; ++i) { s->target_max = std::max(s->target_max, density[i]); s->target_sum += density[i]; }
+    s->target_max = 0; s->target_sum = 0; s->target_outside = 0;
+    const int n = s->n;
+    for (size_t i = 0; i < G; ++i) {
+        s->target_max = std::max(s->target_max, density[i]);
+        s->target_sum += density[i];
+        if (density[i] != 0.0) {
+            // |grid_m - target| of an owned node outside the grid window is |0 - target|: a constant of the density loss
+            const int k = (int)(i % n), j = (int)((i / n) % n), ii = (int)(i / ((size_t)n * n));
+            const int nd[3] = {ii, j, k};
+            bool inside = true;
+            for (int d = 0; d < 3; ++d) inside &= nd[d] >= s->go[d] && nd[d] < s->go[d] + 4 * s->nbw[d];
+            if (!inside && k >= s->cfg.slab_z0 && k < s->cfg.slab_z1) s->target_outside += std::fabs(density[i]);
+        }
+    }
     s->have_target = true;
     return 0;
 }
@@ -1516,6 +1713,7 @@ int plmpm_loss_partials(plmpm_handle s, int frame, int phase, double* out32) {
     }
     HIPCHK(hipMemcpyAsync(out32, s->lscal, LS_COUNT * 8, hipMemcpyDeviceToHost, s->stream));
     HIPCHK(hipStreamSynchronize(s->stream));
+    if (phase == 0) out32[LS_DENSITY] += s->target_outside;
     return 0;
 }
 
@@ -1583,10 +1781,10 @@ int plmpm_get_grid_mass(plmpm_handle s, int frame, double* out) {
     NEED_FRAME(s, frame);
     REQUIRE(out, "null output");
     double* d_lin;
-    HIPCHK(hipMalloc(&d_lin, s->G * 8));
+    HIPCHK(hipMalloc(&d_lin, s->Gfull * 8));
     DISPATCH(s, loss_scatter_t, s, frame);
     DISPATCH(s, download_grid_t, s, s->loss_gm, d_lin);
-    HIPCHK(hipMemcpyAsync(out, d_lin, s->G * 8, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipMemcpyAsync(out, d_lin, s->Gfull * 8, hipMemcpyDeviceToHost, s->stream));
     HIPCHK(hipStreamSynchronize(s->stream));
     hipFree(d_lin);
     return 0;
@@ -1595,9 +1793,9 @@ int plmpm_loss_get_target_sdf(plmpm_handle s, double* out) {
     NEED_BOUND(s);
     REQUIRE(out && s->have_target, "no target set");
     double* d_lin;
-    HIPCHK(hipMalloc(&d_lin, s->G * 8));
+    HIPCHK(hipMalloc(&d_lin, s->Gfull * 8));
     DISPATCH(s, download_grid_t, s, s->loss_ts, d_lin);
-    HIPCHK(hipMemcpyAsync(out, d_lin, s->G * 8, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipMemcpyAsync(out, d_lin, s->Gfull * 8, hipMemcpyDeviceToHost, s->stream));
     HIPCHK(hipStreamSynchronize(s->stream));
     hipFree(d_lin);
     return 0;
@@ -1622,7 +1820,7 @@ int plmpm_grid_stats(plmpm_handle s, int frame, int64_t* active_nodes, int64_t* 
 int plmpm_tile_boxes(plmpm_handle s, int frame, int32_t* out, int max_workgroups, int* n_workgroups) {
     NEED_BOUND(s);
     NEED_FRAME(s, frame);
-    const int nwg = nblocks_particles(s);
+    const int nwg = nblocks_particles(s, frame);
     if (n_workgroups) *n_workgroups = nwg;
     if (!out) return 0;
     REQUIRE(max_workgroups >= nwg, "tile_boxes: room for %d workgroups, need %d", max_workgroups, nwg);
@@ -1639,19 +1837,28 @@ int plmpm_fk(plmpm_handle s, int first_frame, int n_substeps) {
     REQUIRE(first_frame >= 0 && n_substeps > 0 && first_frame + n_substeps <= s->F, "fk: bad frame range");
     return launch_fk(s, first_frame, n_substeps);
 }
-int plmpm_p2g(plmpm_handle s, int frame) {
-    NEED_BOUND(s);
+int plmpm_p2g(plmpm_handle s, int frame, int chain) {
+    REQUIRE(s && s->bound, "workspace not bound");
     REQUIRE(s->store, "the phase-split substep needs store_grid = 1");
     REQUIRE(frame >= 0 && frame < s->F, "p2g: frame out of range");
-    DISPATCH(s, phase_p2g, s, frame);
+    if (chain) {
+        REQUIRE(frame >= 1 && s->g2p_deferred == frame - 1, "p2g(%d, chain): frame %d's g2p was not deferred (deferred: %d)", frame, frame - 1, s->g2p_deferred);
+        s->g2p_deferred = -1;
+        DISPATCH(s, phase_g2p_p2g, s, frame);
+    } else {
+        REQUIRE(s->g2p_deferred < 0, "frame %d's g2p is deferred: call plmpm_p2g(frame + 1, chain = 1) next", s->g2p_deferred);
+        DISPATCH(s, phase_p2g, s, frame);
+    }
     HIPCHK(hipGetLastError());
     return 0;
 }
-int plmpm_grid_g2p(plmpm_handle s, int frame) {
+int plmpm_grid_g2p(plmpm_handle s, int frame, int chain) {
     NEED_BOUND(s);
     REQUIRE(s->store && frame >= 0 && frame < s->F, "grid_g2p: bad call");
-    DISPATCH(s, phase_grid_g2p, s, frame);
+    REQUIRE(!chain || frame + 1 < s->F, "grid_g2p: only a substep with a successor chains");
+    DISPATCH(s, phase_grid_g2p, s, frame, chain != 0);
     HIPCHK(hipGetLastError());
+    if (chain) s->g2p_deferred = frame;
     return 0;
 }
 int plmpm_grad_scatter(plmpm_handle s, int frame) {
@@ -1688,6 +1895,7 @@ int plmpm_chain_grad(plmpm_handle s, int first_frame, int n_substeps, int step) 
     return 0;
 }
 
+// ---- halos: zero-copy exchange of whole block planes ---------------------------------------------------------------
 static int halo_field(plmpm_sim* s, int field, int frame, char** base, int* ncomp) {
     if (field == PLMPM_HALO_GRID_IN) {
         REQUIRE(s->store && frame >= 0 && frame < s->F, "halo: grid_in needs store_grid and a valid frame");
@@ -1697,87 +1905,310 @@ static int halo_field(plmpm_sim* s, int field, int frame, char** base, int* ncom
     else return fail("unknown halo field %d", field);
     return 0;
 }
-static inline int halo_ncomp(int field) { return field == PLMPM_HALO_GRID_IN ? 4 : (field == PLMPM_HALO_GRID_OUT_ADJ ? 3 : 1); }
-static inline size_t halo_plane_nodes(const plmpm_sim* s) { return (size_t)(s->win[1] - s->win[0]) * (s->win[3] - s->win[2]); }
-int plmpm_set_halo_window(plmpm_handle s, int x0, int x1, int y0, int y1) {
-    REQUIRE(s, "null handle");
-    REQUIRE(0 <= x0 && x0 < x1 && x1 <= s->n && 0 <= y0 && y0 < y1 && y1 <= s->n, "halo window [%d,%d) x [%d,%d) outside the %d^2 plane", x0, x1, y0, y1, s->n);
-    s->win[0] = x0; s->win[1] = x1; s->win[2] = y0; s->win[3] = y1;
+int plmpm_grid_window(plmpm_handle s, int32_t* origin3, int32_t* blocks3) {
+    REQUIRE(s && origin3 && blocks3, "null argument");
+    for (int d = 0; d < 3; ++d) { origin3[d] = s->go[d]; blocks3[d] = s->nbw[d]; }
     return 0;
 }
-int plmpm_halo_bytes(plmpm_handle s, int field, int za, int zb, size_t* bytes) {
-    REQUIRE(s && bytes && za >= 0 && zb <= s->n && za < zb, "halo_bytes: bad plane range [%d,%d)", za, zb);
-    *bytes = (size_t)halo_ncomp(field) * (zb - za) * halo_plane_nodes(s) * s->tsz;
-    return 0;
-}
-// pack (dir 0) or unpack-add (dir 1) every face in one launch
-static int halo_faces(plmpm_sim* s, int dir, int field, int frame, int n_faces, const int* za, const int* zb, void* const* bufs) {
-    REQUIRE(n_faces >= 0 && n_faces <= 2, "a z-slab has at most 2 faces (got %d)", n_faces);
-    if (n_faces == 0) return 0;
+int plmpm_halo_region(plmpm_handle s, int field, int frame, int comp, int bz_a, int bz_b, void** dev_ptr, size_t* count) {
+    NEED_BOUND(s);
+    REQUIRE(dev_ptr && count, "null argument");
     char* base; int nc;
     if (halo_field(s, field, frame, &base, &nc)) return -1;
-    HaloFaces H;
+    REQUIRE(comp >= 0 && comp < nc, "halo_region: field %d has %d components", field, nc);
+    const int ra = bz_a - s->go[2] / 4, rb = bz_b - s->go[2] / 4;       // block planes relative to the window
+    REQUIRE(ra >= 0 && rb <= s->nbw[2] && ra < rb, "halo_region: block planes [%d,%d) outside this rank's grid window (planes [%d,%d))",
+            bz_a, bz_b, s->go[2] / 4, s->go[2] / 4 + s->nbw[2]);
+    const size_t plane = (size_t)s->nbw[0] * s->nbw[1] * 64;
+    *dev_ptr = base + ((size_t)comp * s->G + (size_t)ra * plane) * s->tsz;
+    *count = (size_t)(rb - ra) * plane;
+    return 0;
+}
+int plmpm_halo_set_recv(plmpm_handle s, int field, int n_faces, const int* bz_a, const int* bz_b, void* const* recv) {
+    REQUIRE(s, "null handle");
+    REQUIRE(field >= 0 && field < 3 && n_faces >= 0 && n_faces <= 2, "halo_set_recv: a z-slab has at most 2 faces");
+    HaloIn& H = s->halo_in[field];
     memset(&H, 0, sizeof H);
-    H.n_faces = n_faces;
-    H.x0 = s->win[0]; H.x1 = s->win[1]; H.y0 = s->win[2]; H.y1 = s->win[3];
-    size_t most = 0;
     for (int i = 0; i < n_faces; ++i) {
-        REQUIRE(bufs[i] && za[i] >= 0 && zb[i] <= s->n && za[i] < zb[i], "halo: bad plane range [%d,%d)", za[i], zb[i]);
-        H.za[i] = za[i]; H.zb[i] = zb[i]; H.buf[i] = bufs[i];
-        most = std::max(most, (size_t)nc * (zb[i] - za[i]) * halo_plane_nodes(s));
+        const int ra = bz_a[i] - s->go[2] / 4, rb = bz_b[i] - s->go[2] / 4;
+        REQUIRE(recv[i] && ra >= 0 && rb <= s->nbw[2] && ra < rb, "halo_set_recv: block planes [%d,%d) outside the grid window", bz_a[i], bz_b[i]);
+        H.ba[i] = ra; H.bb[i] = rb; H.buf[i] = recv[i];
     }
-    const dim3 grid((unsigned)((most + 255) / 256), (unsigned)n_faces);
-    int* flags = field == PLMPM_HALO_GRID_IN ? s->fstore + (size_t)frame * s->nblk : nullptr;
-    if (s->cfg.dtype == PLMPM_F64) {
-        if (dir == 0) hipLaunchKernelGGL((k_halo_pack<double>), grid, dim3(256), 0, s->stream, (const double*)base, s->G, nc, s->nb, H);
-        else hipLaunchKernelGGL((k_halo_unpack_add<double>), grid, dim3(256), 0, s->stream, (double*)base, s->G, nc, s->nb, H, flags);
+    H.n = n_faces;
+    return 0;
+}
+int plmpm_halo_apply(plmpm_handle s, int field, int frame) {
+    NEED_BOUND(s);
+    REQUIRE(field == PLMPM_HALO_LOSS_MASS, "halo_apply: the substep fields are added by grid_op / grid_op.grad themselves");
+    char* base; int nc;
+    if (halo_field(s, field, frame, &base, &nc)) return -1;
+    const HaloIn& H = s->halo_in[field];
+    const size_t plane = (size_t)s->nbw[0] * s->nbw[1] * 64;
+    for (int i = 0; i < H.n; ++i) {
+        const size_t cnt = (size_t)(H.bb[i] - H.ba[i]) * plane;
+        for (int c = 0; c < nc; ++c) {
+            char* dst = base + ((size_t)c * s->G + (size_t)H.ba[i] * plane) * s->tsz;
+            const char* src = (const char*)H.buf[i] + (size_t)c * cnt * s->tsz;
+            if (s->cfg.dtype == PLMPM_F64) hipLaunchKernelGGL((k_add_region<double>), dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, s->stream, (double*)dst, (const double*)src, cnt);
+            else hipLaunchKernelGGL((k_add_region<float>), dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, s->stream, (float*)dst, (const float*)src, cnt);
+        }
+    }
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+}  // extern "C"
+// ---- particle migration between z-slabs (env-step boundaries) ----------------------------------------------------------
+// A rank owns the particles whose stencil CENTRE node lies in its slab.  At the first frame of an env step the rows
+// that left are packed and sent to the neighbour, the arrivals are merged in, and the whole set is re-sorted along
+// the Hilbert curve into a new storage epoch (so this is also the slab engines' cell re-sort).  The reverse sweep
+// sends the adjoint rows of the arrivals back where they came from.  Row = 28 doubles: global id, x(3), v(3), C(9),
+// E(9), mu, lam, yield stress; adjoint row = 24 doubles.
+constexpr int kMigRow = 28, kMigAdjRow = 24;
+template <class T> __global__ void k_mig_classify(Dev<T> D, int f, int* dest, int* cnt, int* list0, int* list1, int maxlist) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= D.N) return;
+    const double* X = frame_x(D, f);
+    const int cz = (int)(X[2 * (size_t)D.Npad + i] * (double)D.P.inv_dx - 0.5) + 1;
+    const int d = cz < D.z0 ? 0 : (cz >= D.z1 ? 1 : -1);
+    dest[i] = d;
+    if (d >= 0) {
+        const int k = atomicAdd(&cnt[d], 1);
+        if (k < maxlist) (d == 0 ? list0 : list1)[k] = i;
+    }
+}
+template <class T> __global__ void k_mig_pack(Dev<T> D, int f, const int* list, int n, const int* gid, double* out) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const int i = list[k], Np = D.Npad;
+    const double* X = frame_x(D, f);
+    const T* R = frame_r(D, f);
+    double* r = out + (size_t)k * kMigRow;
+    r[0] = (double)gid[i];
+    for (int d = 0; d < 3; ++d) r[1 + d] = X[(size_t)d * Np + i];
+    for (int d = 0; d < 21; ++d) r[4 + d] = (double)R[(size_t)d * Np + i];
+    r[25] = (double)D.mu[i]; r[26] = (double)D.lam[i]; r[27] = (double)D.ys[i];
+}
+// sort keys of the candidates of the new frame: old slots [0, n_old) (leavers and padding sort last), then the arrivals
+template <class T> __global__ void k_mig_keys(Dev<T> D, int f, int bits, const int* dest, int n_old, const double* in0, int n_in0, const double* in1,
+                                              int n_in1, unsigned* keys, int* idx, int total) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    idx[i] = i;
+    const unsigned last = 1u << (3 * bits);
+    double x[3];
+    if (i < n_old) {
+        if (dest[i] >= 0) { keys[i] = last; return; }
+        const double* X = frame_x(D, f);
+        for (int d = 0; d < 3; ++d) x[d] = X[(size_t)d * D.Npad + i];
+    } else if (i < n_old + n_in0 + n_in1) {
+        const int a = i - n_old;
+        const double* r = a < n_in0 ? in0 + (size_t)a * kMigRow : in1 + (size_t)(a - n_in0) * kMigRow;
+        for (int d = 0; d < 3; ++d) x[d] = r[1 + d];
+    } else { keys[i] = last; return; }
+    int b[3];
+    for (int d = 0; d < 3; ++d) b[d] = min(max((int)(x[d] * (double)D.P.inv_dx - 0.5), 0), D.P.n - 1);
+    keys[i] = hilbert_key_dev((unsigned)b[0], (unsigned)b[1], (unsigned)b[2], bits);
+}
+// the new frame (into `out`), its materials, ids and the slot map; v of the old frame is kept in the old order (vend)
+template <class T> __global__ void k_mig_build(Dev<T> D, int f, int n_new, int n_old, const int* order, const double* in0, int n_in0, const double* in1,
+                                               char* out, T* vend, const int* gid_old, int* gid_new, T* mats_new, int* src) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= D.Npad) return;
+    const int Np = D.Npad;
+    const double* X = frame_x(D, f);
+    const T* R = frame_r(D, f);
+    double* Xo = reinterpret_cast<double*>(out);
+    T* Ro = reinterpret_cast<T*>(out + (size_t)3 * 8 * Np);
+    for (int d = 0; d < 3; ++d) vend[(size_t)d * Np + i] = i < n_old ? R[(size_t)d * Np + i] : T(0);
+    if (i >= n_new) {                               // padding rows: harmless values
+        for (int d = 0; d < 3; ++d) Xo[(size_t)d * Np + i] = 0.5;
+        for (int d = 0; d < 21; ++d) Ro[(size_t)d * Np + i] = T(0);
+        for (int d = 0; d < 3; ++d) mats_new[(size_t)d * Np + i] = T(1);
+        return;
+    }
+    const int j = order[i];
+    if (j < n_old) {
+        for (int d = 0; d < 3; ++d) Xo[(size_t)d * Np + i] = X[(size_t)d * Np + j];
+        for (int d = 0; d < 21; ++d) Ro[(size_t)d * Np + i] = R[(size_t)d * Np + j];
+        mats_new[i] = D.mu[j]; mats_new[(size_t)Np + i] = D.lam[j]; mats_new[2 * (size_t)Np + i] = D.ys[j];
+        gid_new[i] = gid_old[j];
+        src[i] = j;
     } else {
-        if (dir == 0) hipLaunchKernelGGL((k_halo_pack<float>), grid, dim3(256), 0, s->stream, (const float*)base, s->G, nc, s->nb, H);
-        else hipLaunchKernelGGL((k_halo_unpack_add<float>), grid, dim3(256), 0, s->stream, (float*)base, s->G, nc, s->nb, H, flags);
+        const int a = j - n_old;
+        const double* r = a < n_in0 ? in0 + (size_t)a * kMigRow : in1 + (size_t)(a - n_in0) * kMigRow;
+        gid_new[i] = (int)r[0];
+        for (int d = 0; d < 3; ++d) Xo[(size_t)d * Np + i] = r[1 + d];
+        for (int d = 0; d < 21; ++d) Ro[(size_t)d * Np + i] = (T)r[4 + d];
+        for (int d = 0; d < 3; ++d) mats_new[(size_t)d * Np + i] = (T)r[25 + d];
+        src[i] = -1 - a;
     }
-    HIPCHK(hipGetLastError());
+}
+// reverse: adjoint rows of the arrivals -> back buffers; rows of the stayers -> their old slots
+template <class T> __global__ void k_mig_adj_split(const T* adj, T* tmp, int Np, int n_new, const int* src, int n_in0, double* back0, double* back1) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_new) return;
+    const int j = src[i];
+    if (j >= 0) {
+        for (int c = 0; c < kMigAdjRow; ++c) tmp[(size_t)c * Np + j] = adj[(size_t)c * Np + i];
+    } else {
+        const int a = -1 - j;
+        double* r = a < n_in0 ? back0 + (size_t)a * kMigAdjRow : back1 + (size_t)(a - n_in0) * kMigAdjRow;
+        for (int c = 0; c < kMigAdjRow; ++c) r[c] = (double)adj[(size_t)c * Np + i];
+    }
+}
+template <class T> __global__ void k_mig_adj_recv(T* tmp, int Np, const int* list, int n, const double* rows) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const int i = list[k];
+    for (int c = 0; c < kMigAdjRow; ++c) tmp[(size_t)c * Np + i] = (T)rows[(size_t)k * kMigAdjRow + c];
+}
+
+template <class T> static int migrate_begin_t(plmpm_sim* s, int frame, int epoch_new) {
+    Dev<T> D = make_dev<T>(s, frame);
+    int* leave = s->mig_leave + (size_t)epoch_new * s->Npad;
+    HIPCHK(hipMemsetAsync(s->mig_cnt, 0, 8, s->stream));
+    hipLaunchKernelGGL((k_mig_classify<T>), dim3((D.N + 255) / 256), dim3(256), 0, s->stream, D, frame, s->mig_dest, s->mig_cnt, leave,
+                       leave + s->mig_max_rows, s->mig_max_rows);
+    int cnt[2];
+    HIPCHK(hipMemcpyAsync(cnt, s->mig_cnt, 8, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    REQUIRE(cnt[0] <= s->mig_max_rows && cnt[1] <= s->mig_max_rows, "migrate: %d / %d rows leave at once, room for %d per direction", cnt[0], cnt[1], s->mig_max_rows);
+    const int* gid = s->gid_store + (size_t)s->frame_epoch[frame] * s->Npad;
+    for (int d = 0; d < 2; ++d)
+        if (cnt[d] > 0)
+            hipLaunchKernelGGL((k_mig_pack<T>), dim3((cnt[d] + 255) / 256), dim3(256), 0, s->stream, D, frame, leave + (size_t)d * s->mig_max_rows, cnt[d], gid,
+                               s->mig_send[d]);
+    s->mig_pending_out[0] = cnt[0]; s->mig_pending_out[1] = cnt[1];
     return 0;
 }
-int plmpm_halo_pack(plmpm_handle s, int field, int frame, int za, int zb, void* buf) {
-    NEED_BOUND(s);
-    return halo_faces(s, 0, field, frame, 1, &za, &zb, &buf);
-}
-int plmpm_halo_unpack_add(plmpm_handle s, int field, int frame, int za, int zb, const void* buf) {
-    NEED_BOUND(s);
-    void* b = const_cast<void*>(buf);
-    return halo_faces(s, 1, field, frame, 1, &za, &zb, &b);
-}
-int plmpm_slab_pre(plmpm_handle s, int field, int frame, int chain, int n_faces, const int* za, const int* zb, void* const* send) {
-    REQUIRE(field == PLMPM_HALO_GRID_IN || field == PLMPM_HALO_GRID_OUT_ADJ, "slab_pre: field %d has no substep phase", field);
-    REQUIRE(n_faces >= 0 && (n_faces == 0 || (za && zb && send)), "slab_pre: bad face list");
-    if (chain) {
-        REQUIRE(s && s->bound && field == PLMPM_HALO_GRID_IN, "slab_pre: only the forward phase chains");
-        REQUIRE(frame >= 1 && frame < s->F && s->g2p_deferred == frame - 1, "slab_pre(%d, chain): frame %d's g2p was not deferred (deferred: %d)", frame, frame - 1, s->g2p_deferred);
-        s->g2p_deferred = -1;
-        DISPATCH(s, phase_g2p_p2g, s, frame);
-        HIPCHK(hipGetLastError());
-    } else if (field == PLMPM_HALO_GRID_IN ? plmpm_p2g(s, frame) : plmpm_grad_scatter(s, frame)) return -1;
-    return halo_faces(s, 0, field, frame, n_faces, za, zb, send);
-}
-int plmpm_slab_post(plmpm_handle s, int field, int frame, int chain, int n_faces, const int* za, const int* zb, const void* const* recv) {
-    NEED_BOUND(s);
-    REQUIRE(field == PLMPM_HALO_GRID_IN || field == PLMPM_HALO_GRID_OUT_ADJ, "slab_post: field %d has no substep phase", field);
-    REQUIRE(n_faces >= 0 && (n_faces == 0 || (za && zb && recv)), "slab_post: bad face list");
-    REQUIRE(!chain || (field == PLMPM_HALO_GRID_IN && frame + 1 < s->F), "slab_post: only a forward phase with a successor chains");
-    if (halo_faces(s, 1, field, frame, n_faces, za, zb, const_cast<void* const*>(recv))) return -1;
-    if (field == PLMPM_HALO_GRID_OUT_ADJ) return plmpm_grad_gather(s, frame);
-    REQUIRE(s->store && frame >= 0 && frame < s->F, "slab_post: bad call");
-    DISPATCH(s, phase_grid_g2p, s, frame, chain != 0);
-    HIPCHK(hipGetLastError());
-    if (chain) s->g2p_deferred = frame;
+template <class T> static int migrate_finish_t(plmpm_sim* s, int frame, int e_new, int n_in0, const double* in0, int n_in1, const double* in1) {
+    Dev<T> D = make_dev<T>(s, frame);
+    const int e_old = s->frame_epoch[frame], n_old = D.N;
+    const int n_new = n_old - s->mig_pending_out[0] - s->mig_pending_out[1] + n_in0 + n_in1;
+    REQUIRE(n_new > 0 && n_new <= s->Npad, "migrate: %d particles after the exchange, capacity %d (raise particle_capacity)", n_new, s->Npad);
+    const int total = n_old + n_in0 + n_in1;
+    REQUIRE(total <= s->sort_cap, "migrate: %d candidate rows, room for %d", total, s->sort_cap);
+    int bits = 1;
+    while ((1 << bits) < s->n) ++bits;
+    hipLaunchKernelGGL((k_mig_keys<T>), dim3((total + 255) / 256), dim3(256), 0, s->stream, D, frame, bits, s->mig_dest, n_old, in0, n_in0, in1, n_in1,
+                       s->skey[0], s->sidx[0], total);
+    if (plmpm_sort_pairs(s->sort_tmp, s->sort_tmp_bytes, s->skey[0], s->skey[1], s->sidx[0], s->sidx[1], total, 3 * bits + 1, s->stream) != 0)
+        return fail("migrate: device sort failed");
+    T* vend = (T*)(s->vend + (size_t)e_new * 3 * s->Npad * s->tsz);
+    T* mats_new = (T*)(s->mats_store + (size_t)e_new * 3 * s->Npad * s->tsz);
+    hipLaunchKernelGGL((k_mig_build<T>), dim3(s->Npad / 256), dim3(256), 0, s->stream, D, frame, n_new, n_old, s->sidx[1], in0, n_in0, in1, s->frame_tmp, vend,
+                       s->gid_store + (size_t)e_old * s->Npad, s->gid_store + (size_t)e_new * s->Npad, mats_new, s->mig_src + (size_t)e_new * s->Npad);
+    HIPCHK(hipMemcpyAsync(s->state + (size_t)frame * s->frame_bytes, s->frame_tmp, s->frame_bytes, hipMemcpyDeviceToDevice, s->stream));
+    plmpm_sim::MigInfo& m = s->mig[e_new];
+    m.parent = e_old; m.nout[0] = s->mig_pending_out[0]; m.nout[1] = s->mig_pending_out[1]; m.nin[0] = n_in0; m.nin[1] = n_in1;
+    s->epochN[e_new] = n_new;
+    s->frame_epoch[frame] = e_new;
+    s->mats_epoch = e_new;
     return 0;
 }
-int plmpm_flags_region(plmpm_handle s, int frame, int bz_a, int bz_b, void** dev_ptr, size_t* count) {
+template <class T> static int migrate_adjoint_begin_t(plmpm_sim* s, int frame) {
+    const int slot = frame & 1, e = s->adj_epoch[slot];
+    const plmpm_sim::MigInfo& m = s->mig[e];
+    T* tmp = (T*)s->frame_tmp;
+    HIPCHK(hipMemsetAsync(tmp, 0, (size_t)kMigAdjRow * s->Npad * s->tsz, s->stream));
+    hipLaunchKernelGGL((k_mig_adj_split<T>), dim3((s->epochN[e] + 255) / 256), dim3(256), 0, s->stream, (const T*)s->adj[slot], tmp, s->Npad, s->epochN[e],
+                       s->mig_src + (size_t)e * s->Npad, m.nin[0], s->mig_send[0], s->mig_send[1]);
+    return 0;
+}
+template <class T> static int migrate_adjoint_finish_t(plmpm_sim* s, int frame, const double* rows0, const double* rows1) {
+    const int slot = frame & 1, e = s->adj_epoch[slot];
+    const plmpm_sim::MigInfo& m = s->mig[e];
+    T* tmp = (T*)s->frame_tmp;
+    const int* leave = s->mig_leave + (size_t)e * s->Npad;
+    const double* rows[2] = {rows0, rows1};
+    for (int d = 0; d < 2; ++d)
+        if (m.nout[d] > 0) {
+            REQUIRE(rows[d], "migrate_adjoint_finish: %d rows went %s at this boundary, their adjoints are missing", m.nout[d], d ? "up" : "down");
+            hipLaunchKernelGGL((k_mig_adj_recv<T>), dim3((m.nout[d] + 255) / 256), dim3(256), 0, s->stream, tmp, s->Npad, leave + (size_t)d * s->mig_max_rows,
+                               m.nout[d], rows[d]);
+        }
+    HIPCHK(hipMemcpyAsync(s->adj[slot], tmp, (size_t)kMigAdjRow * s->Npad * s->tsz, hipMemcpyDeviceToDevice, s->stream));
+    s->adj_epoch[slot] = m.parent;
+    return 0;
+}
+
+extern "C" {
+int plmpm_set_ids(plmpm_handle s, const int32_t* ids) {
+    REQUIRE(s && ids, "null argument");
+    REQUIRE(s->dist, "set_ids: global particle ids only exist on slab engines");
+    s->ids0.assign(ids, ids + s->N);
+    return 0;
+}
+int plmpm_frame_info(plmpm_handle s, int frame, int32_t* count, int32_t* epoch, int32_t* adjoint_epoch) {
+    REQUIRE(s, "null handle");
+    NEED_FRAME(s, frame);
+    const int e = s->frame_epoch[frame];
+    if (count) *count = s->epochN[e];
+    if (epoch) *epoch = e;
+    if (adjoint_epoch) *adjoint_epoch = s->adj_frame[frame & 1] == frame ? s->adj_epoch[frame & 1] : -1;
+    return 0;
+}
+int plmpm_get_ids(plmpm_handle s, int frame, int32_t* ids) {
     NEED_BOUND(s);
-    REQUIRE(s->store && frame >= 0 && frame < s->F && dev_ptr && count, "flags_region: bad call");
-    REQUIRE(bz_a >= 0 && bz_b <= s->nb && bz_a < bz_b, "flags_region: bad block-plane range");
-    *dev_ptr = s->fstore + (size_t)frame * s->nblk + (size_t)bz_a * s->nb * s->nb;
-    *count = (size_t)(bz_b - bz_a) * s->nb * s->nb;
+    NEED_FRAME(s, frame);
+    REQUIRE(ids && s->dist, "get_ids: slab engines only");
+    const int e = s->frame_epoch[frame];
+    if (e == 0) { memcpy(ids, s->ids0.data(), (size_t)s->N * 4); return 0; }       // epoch 0: rows are in caller order
+    HIPCHK(hipMemcpyAsync(ids, s->gid_store + (size_t)e * s->Npad, (size_t)s->epochN[e] * 4, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    return 0;
+}
+int plmpm_migrate_begin(plmpm_handle s, int frame, int32_t* out2, void** rows_down, void** rows_up) {
+    NEED_BOUND(s);
+    NEED_FRAME(s, frame);
+    REQUIRE(s->dist && out2 && rows_down && rows_up, "migrate_begin: slab engines only; null argument");
+    REQUIRE(s->mig_pending_frame < 0, "migrate_begin: the migration of frame %d is still open", s->mig_pending_frame);
+    // tape mode: a fresh epoch per migration; copy mode (frame 0 over and over): two alternating epochs
+    int e_new = frame == 0 ? (s->frame_epoch[0] == 1 ? 2 : 1) : std::max(s->next_epoch, 3);
+    REQUIRE(e_new < s->n_epochs, "migrate: out of storage epochs (%d)", s->n_epochs);
+    if (DISPATCH(s, migrate_begin_t, s, frame, e_new)) return -1;
+    HIPCHK(hipGetLastError());
+    s->mig_pending_frame = frame;
+    out2[0] = s->mig_pending_out[0]; out2[1] = s->mig_pending_out[1];
+    *rows_down = s->mig_send[0]; *rows_up = s->mig_send[1];
+    return 0;
+}
+int plmpm_migrate_finish(plmpm_handle s, int frame, int n_in_down, const void* rows_down, int n_in_up, const void* rows_up, int32_t* new_count) {
+    NEED_BOUND(s);
+    REQUIRE(s->mig_pending_frame == frame, "migrate_finish(%d): call migrate_begin on that frame first", frame);
+    REQUIRE(n_in_down >= 0 && n_in_up >= 0 && (n_in_down == 0 || rows_down) && (n_in_up == 0 || rows_up), "migrate_finish: bad arrival lists");
+    const int e_new = frame == 0 ? (s->frame_epoch[0] == 1 ? 2 : 1) : std::max(s->next_epoch, 3);
+    if (DISPATCH(s, migrate_finish_t, s, frame, e_new, n_in_down, (const double*)rows_down, n_in_up, (const double*)rows_up)) return -1;
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(s->stream));          // the caller may reuse its receive buffers
+    if (frame != 0) s->next_epoch = e_new + 1;
+    s->mig_pending_frame = -1;
+    if (new_count) *new_count = s->epochN[e_new];
+    return 0;
+}
+int plmpm_migrate_adjoint_begin(plmpm_handle s, int frame, int32_t* send2, int32_t* recv2, void** rows_down, void** rows_up) {
+    NEED_BOUND(s);
+    NEED_FRAME(s, frame);
+    REQUIRE(s->dist && send2 && recv2 && rows_down && rows_up, "migrate_adjoint_begin: slab engines only; null argument");
+    REQUIRE(s->adj_frame[frame & 1] == frame, "migrate_adjoint_begin: adjoint of frame %d is not resident", frame);
+    const int e = s->adj_epoch[frame & 1];
+    REQUIRE(e > 0 && e == s->frame_epoch[frame], "migrate_adjoint_begin: frame %d did not migrate into the epoch its adjoint is in", frame);
+    if (DISPATCH(s, migrate_adjoint_begin_t, s, frame)) return -1;
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(s->stream));
+    send2[0] = s->mig[e].nin[0]; send2[1] = s->mig[e].nin[1];           // adjoints of the arrivals go back where they came from
+    recv2[0] = s->mig[e].nout[0]; recv2[1] = s->mig[e].nout[1];         // ... and those of the rows that left come home
+    *rows_down = s->mig_send[0]; *rows_up = s->mig_send[1];
+    return 0;
+}
+int plmpm_migrate_adjoint_finish(plmpm_handle s, int frame, const void* rows_down, const void* rows_up) {
+    NEED_BOUND(s);
+    NEED_FRAME(s, frame);
+    REQUIRE(s->dist && s->adj_frame[frame & 1] == frame, "migrate_adjoint_finish: bad call");
+    if (DISPATCH(s, migrate_adjoint_finish_t, s, frame, (const double*)rows_down, (const double*)rows_up)) return -1;
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(s->stream));
     return 0;
 }
 int plmpm_pose_grad_region(plmpm_handle s, int first_frame, int n_frames, void** pos_adj, size_t* pos_count, void** rot_adj,

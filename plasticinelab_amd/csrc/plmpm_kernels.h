@@ -76,12 +76,14 @@ struct PrimStatic {
 // everything a kernel needs to find its data
 template <class T> struct Dev {
     SimP<T> P;
-    int N, Npad, nb;                 // particles, padded, blocks per axis
+    int N, Npad;                     // particles of this frame's storage epoch, padded capacity (SoA stride)
+    int go[3];                       // grid window: origin node (multiples of 4) ...
+    int nbx, nby, nbz;               // ... and extent in 4^3 blocks; only this box of the n^3 grid is allocated
+    int twg;                         // stride of the per-frame workgroup tile table (capacity / 256)
     int nprim;
     int z0, z1;                      // owned z-slab (nodes): pose adjoints / loss sums only count these
-    int zlo, zhi;                    // stencil bases of this rank's particles must satisfy zlo <= z, z + 2 < zhi
-    int wlo[2], whi[2];              // ... and, in x and y, stay inside the window of the halo planes that travel
-    int* err;                        // device error word (bit 0: a particle left the slab + halo)
+    int rlo[3], rhi[3];              // reach: stencil bases must satisfy rlo <= base, base + 2 < rhi (window, and slab + halo in z)
+    int* err;                        // device error word (bit 0: a particle left the reach box)
     size_t frame_bytes;
     char* state;                     // particle frames
     T* adj[2];                       // ping-pong adjoint frames
@@ -109,8 +111,14 @@ template <class T> __device__ __forceinline__ T* frame_r(const Dev<T>& D, int f)
     return reinterpret_cast<T*>(D.state + (size_t)f * D.frame_bytes + (size_t)3 * 8 * D.Npad);
 }
 
-__device__ __forceinline__ int node_index(int nb, int i, int j, int k) {
-    return ((((k >> 2) * nb + (j >> 2)) * nb + (i >> 2)) << 6) | ((k & 3) << 4) | ((j & 3) << 2) | (i & 3);
+// node (i, j, k) of the grid -> index inside the allocated window (origin a multiple of 4, so the low bits are the node's)
+template <class T> __device__ __forceinline__ int node_index(const Dev<T>& D, int i, int j, int k) {
+    return (((((k - D.go[2]) >> 2) * D.nby + ((j - D.go[1]) >> 2)) * D.nbx + ((i - D.go[0]) >> 2)) << 6) | ((k & 3) << 4) | ((j & 3) << 2) | (i & 3);
+}
+// block index inside the window -> node coordinates of lane `lane` of the wave that owns the block
+template <class T> __device__ __forceinline__ void block_nodes(const Dev<T>& D, int blk, int lane, int* I) {
+    const int bx = blk % D.nbx, by = (blk / D.nbx) % D.nby, bz = blk / (D.nbx * D.nby);
+    I[0] = D.go[0] + ((bx << 2) | (lane & 3)); I[1] = D.go[1] + ((by << 2) | ((lane >> 2) & 3)); I[2] = D.go[2] + ((bz << 2) | (lane >> 4));
 }
 
 template <class T> __device__ __forceinline__ void load_prims(const Dev<T>& D, int f, PrimT<T>* sp) {
@@ -138,11 +146,33 @@ template <class T> __device__ __forceinline__ void load_prims(const Dev<T>& D, i
 // take the set bits round-robin.  (One wave per block of the whole grid with an early return for the ~95 % empty
 // ones needs ~16 occupancy rounds of flag loads per launch at 128^3; a separate compaction kernel costs a 5 us
 // dispatch on the critical path.)
-template <class T, class Body> __device__ __forceinline__ void for_each_active_block(const Dev<T>& D, Body&& body) {
-    const int nblk = D.nb * D.nb * D.nb, G = gridDim.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+// Multi-GPU: the block planes around a slab face hold partial sums on both neighbours.  Each rank sends its copy of
+// those planes straight out of the grid arrays (the blocked layout keeps a range of block planes contiguous per SoA
+// component: no pack kernel) and the grid kernels add the received copy on first touch (no unpack kernel).
+//   buf[f]: [ncomp][(bb - ba) * nbx * nby * 64] scalars, block planes [ba[f], bb[f]) of the window
+struct HaloIn {
+    int n;                           // faces with a neighbour (0 on a single GPU)
+    int ba[2], bb[2];
+    const void* buf[2];
+};
+template <class T> __device__ __forceinline__ int halo_face_of(const Dev<T>& D, const HaloIn& H, int blk) {
+    const int bz = blk / (D.nbx * D.nby);
+    for (int f = 0; f < H.n; ++f)
+        if (bz >= H.ba[f] && bz < H.bb[f]) return f;
+    return -1;
+}
+// received value of component c at node (blk, lane); blk must lie in face f's planes
+template <class T> __device__ __forceinline__ T halo_value(const Dev<T>& D, const HaloIn& H, int f, int c, int blk, int lane) {
+    const size_t per = (size_t)(H.bb[f] - H.ba[f]) * D.nbx * D.nby * 64;
+    return ((const T*)H.buf[f])[(size_t)c * per + ((size_t)(blk - H.ba[f] * D.nbx * D.nby) << 6) + lane];
+}
+template <class T, class Body> __device__ __forceinline__ void for_each_active_block(const Dev<T>& D, const HaloIn& H, Body&& body) {
+    const int nblk = D.nbx * D.nby * D.nbz, G = gridDim.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int b0 = blockIdx.x; b0 < nblk; b0 += 64 * G) {
         const int b = b0 + lane * G;
-        const unsigned long long m = __ballot(b < nblk && D.flags[b] != 0);
+        // blocks in the exchanged planes are candidates whatever their flag: the neighbour's particles may reach
+        // nodes that none of ours do (the body skips a candidate whose summed mass is zero everywhere)
+        const unsigned long long m = __ballot(b < nblk && (D.flags[b] != 0 || (H.n > 0 && halo_face_of(D, H, b) >= 0)));
         __syncthreads();             // bodies may clear flags: every wave must have taken the same snapshot first
         int rank = 0;
         for (unsigned long long r = m; r; r &= r - 1, ++rank)
@@ -150,10 +180,17 @@ template <class T, class Body> __device__ __forceinline__ void for_each_active_b
     }
 }
 
-// multi-GPU: the 3-wide stencil at `base` must stay inside slab + halo in z and inside the exchanged window in x, y
-template <class T> __device__ __forceinline__ bool outside_halo_reach(const Dev<T>& D, const int* base) {
-    return base[2] < D.zlo || base[2] + 2 >= D.zhi || base[0] < D.wlo[0] || base[0] + 2 >= D.whi[0] ||
-           base[1] < D.wlo[1] || base[1] + 2 >= D.whi[1];
+// The 3-wide stencil at `base` must stay inside the reach box: the allocated grid window, and in z also this rank's
+// slab + halo.  A particle that leaves it raises the error word (the caller fails the step); its base is clamped
+// into the box so that every index computed from it stays inside the allocation.
+template <class T> __device__ __forceinline__ bool clamp_to_reach(const Dev<T>& D, int* base) {
+    bool out = false;
+    for (int d = 0; d < 3; ++d) {
+        const int b = min(max(base[d], D.rlo[d]), D.rhi[d] - 3);
+        out |= b != base[d];
+        base[d] = b;
+    }
+    return out;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -356,12 +393,12 @@ __device__ __forceinline__ Tile block_tile(const int* base, bool valid, int* sre
 // barrier -> fill.
 template <class T> __device__ __forceinline__ void store_tile(const Dev<T>& D, int f, const Tile& t) {
     if (threadIdx.x < 6) {
-        int* q = D.tiles + ((size_t)f * gridDim.x + blockIdx.x) * 8;
+        int* q = D.tiles + ((size_t)f * D.twg + blockIdx.x) * 8;
         q[threadIdx.x] = threadIdx.x < 3 ? t.o[threadIdx.x] : t.e[threadIdx.x - 3];
     }
 }
-template <class T> __device__ __forceinline__ Tile load_tile(const Dev<T>& D, int f, int cap, int wg = blockIdx.x, int nwg = gridDim.x) {
-    const int* q = D.tiles + ((size_t)f * nwg + wg) * 8;
+template <class T> __device__ __forceinline__ Tile load_tile(const Dev<T>& D, int f, int cap, int wg = blockIdx.x) {
+    const int* q = D.tiles + ((size_t)f * D.twg + wg) * 8;
     Tile t;
     int nodes = 1;
     for (int d = 0; d < 3; ++d) { t.o[d] = q[d]; t.e[d] = q[3 + d]; nodes *= t.e[d]; }
@@ -380,7 +417,7 @@ template <class T> __device__ __forceinline__ SortLoad sorted_begin(const Dev<T>
     return s;
 }
 template <class T>
-__device__ __forceinline__ bool sorted_finish(const Dev<T>& D, SortLoad& s, int& p, double* x, int* base) {
+__device__ __forceinline__ bool sorted_finish(const Dev<T>& D, SortLoad& s, int& p, double* x, int* base, bool flag_err = false) {
     const int p0 = blockIdx.x * kBlock + threadIdx.x;
     s.key = (1LL << 40);                                            // padding lanes last
     if (p0 < D.N) {
@@ -393,13 +430,14 @@ __device__ __forceinline__ bool sorted_finish(const Dev<T>& D, SortLoad& s, int&
     p = (p0 & ~63) + src;
     for (int d = 0; d < 3; ++d) x[d] = __shfl(s.x0[d], src);       // the position travels with the sort
     for (int d = 0; d < 3; ++d) base[d] = (int)(x[d] * (double)D.P.inv_dx - 0.5);
+    if (clamp_to_reach(D, base) && p < D.N && flag_err) atomicOr(D.err, 1);
     return p < D.N;
 }
 
 // Load this lane's particle after the wave-local sort by stencil base: p = particle index, x = position,
 // base = stencil base.  Padding lanes (beyond N) sort to the end and return false.
 template <class T>
-__device__ __forceinline__ bool load_sorted_particle(const Dev<T>& D, const double* X, int& p, double* x, int* base) {
+__device__ __forceinline__ bool load_sorted_particle(const Dev<T>& D, const double* X, int& p, double* x, int* base, bool flag_err = false) {
     const int Np = D.Npad;
     const int p0 = blockIdx.x * kBlock + threadIdx.x;
     long long key = (1LL << 40);                                    // padding lanes last
@@ -414,6 +452,7 @@ __device__ __forceinline__ bool load_sorted_particle(const Dev<T>& D, const doub
     // the position travels with the sort (shuffles) instead of a second, dependent trip to memory
     for (int d = 0; d < 3; ++d) x[d] = __shfl(x0[d], src);
     for (int d = 0; d < 3; ++d) base[d] = (int)(x[d] * (double)D.P.inv_dx - 0.5);
+    if (clamp_to_reach(D, base) && p < D.N && flag_err) atomicOr(D.err, 1);
     return p < D.N;
 }
 
@@ -431,8 +470,7 @@ __global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_p2g(Dev<T> D, int f) 
     const int Np = D.Npad;
     int p, base[3];
     double x[3];
-    const bool valid = load_sorted_particle(D, X, p, x, base);
-    if (WRITE_F && valid && outside_halo_reach(D, base)) atomicOr(D.err, 1);
+    const bool valid = load_sorted_particle(D, X, p, x, base, WRITE_F);
     Tile tl = block_tile(base, valid, sred, TileCap<T>::nodes);
     store_tile(D, f, tl);
     const int tn = tl.e[0] * tl.e[1] * tl.e[2];
@@ -471,7 +509,7 @@ __global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_p2g(Dev<T> D, int f) 
                 T a0 = mass, a1 = mom[0], a2 = mom[1], a3 = mom[2];
                 seg_sum4(a0, a1, a2, a3, sg);
                 if (emitter) {
-                    int idx = node_index(D.nb, base[0] + i, base[1] + j, base[2] + l);
+                    int idx = node_index(D, base[0] + i, base[1] + j, base[2] + l);
                     atomicAdd(&D.gin[0][idx], a0); atomicAdd(&D.gin[1][idx], a1);
                     atomicAdd(&D.gin[2][idx], a2); atomicAdd(&D.gin[3][idx], a3);
                     D.flags[idx >> 6] = 1;
@@ -490,7 +528,7 @@ __global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_p2g(Dev<T> D, int f) 
             Vec4<double> a = tile[i];
             if (a.x != 0.0 || a.y != 0.0 || a.z != 0.0 || a.w != 0.0) {
                 int lz = i / exy, r = i - lz * exy, ly = r / ex, lx = r - ly * ex;
-                int idx = node_index(D.nb, tl.o[0] + lx, tl.o[1] + ly, tl.o[2] + lz);
+                int idx = node_index(D, tl.o[0] + lx, tl.o[1] + ly, tl.o[2] + lz);
                 atomicAdd(&D.gin[0][idx], (T)a.x); atomicAdd(&D.gin[1][idx], (T)a.y);
                 atomicAdd(&D.gin[2][idx], (T)a.z); atomicAdd(&D.gin[3][idx], (T)a.w);
                 D.flags[idx >> 6] = 1;
@@ -503,17 +541,30 @@ __global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_p2g(Dev<T> D, int f) 
 // grid_op (mpm_simulator.py:189-221) over active 4^3 blocks; one wave per block.
 // CLEAR: forward pass -- consume grid_in (zero it and the flag for the next substep).
 template <class T, bool CLEAR>
-__global__ __launch_bounds__(kBlock) void k_grid_op(Dev<T> D, int f) {
+__global__ __launch_bounds__(kBlock) void k_grid_op(Dev<T> D, int f, HaloIn H) {
     __shared__ PrimT<T> sp[kMaxPrim];
     load_prims(D, f, sp);
     __syncthreads();
     const int lane = threadIdx.x & 63;
-    for_each_active_block(D, [&](int blk) {
+    for_each_active_block(D, H, [&](int blk) {
         const int idx = (blk << 6) | lane;
-        const int bx = blk % D.nb, by = (blk / D.nb) % D.nb, bz = blk / (D.nb * D.nb);
-        int I[3] = {(bx << 2) | (lane & 3), (by << 2) | ((lane >> 2) & 3), (bz << 2) | (lane >> 4)};
+        int I[3];
+        block_nodes(D, blk, lane, I);
         T m = D.gin[0][idx];
         T mv[3] = {D.gin[1][idx], D.gin[2][idx], D.gin[3][idx]}, vo[3];
+        const int hf = H.n > 0 ? halo_face_of(D, H, blk) : -1;
+        if (hf >= 0) {
+            // symmetric sum exchange: our partial sums + the neighbour's.  The complete sums go back into this
+            // frame's stored grid_in (substep_grad recomputes grid_op from it), and a block that only the neighbour's
+            // particles reach becomes active here too
+            m += halo_value(D, H, hf, 0, blk, lane);
+            for (int c = 0; c < 3; ++c) mv[c] += halo_value(D, H, hf, 1 + c, blk, lane);
+            if (!__any(m != T(0))) return;
+            if (!CLEAR) {
+                D.gin[0][idx] = m; D.gin[1][idx] = mv[0]; D.gin[2][idx] = mv[1]; D.gin[3][idx] = mv[2];
+                if (lane == 0) D.flags[blk] = 1;
+            }
+        }
         grid_node_fwd<T>(D.P, I, m, mv, D.nprim, sp, vo);
         D.grid_out[idx] = Vec4<T>{vo[0], vo[1], vo[2], T(0)};
         if (CLEAR) {
@@ -539,12 +590,13 @@ __global__ __launch_bounds__(kBlock) void k_g2p(Dev<T> D, int f) {
     if (tl.ok) {
         for (int i = threadIdx.x; i < tn; i += kBlock) {
             int lz = i / exy, r = i - lz * exy, ly = r / ex, lx = r - ly * ex;
-            tile[i] = D.grid_out[node_index(D.nb, tl.o[0] + lx, tl.o[1] + ly, tl.o[2] + lz)];
+            tile[i] = D.grid_out[node_index(D, tl.o[0] + lx, tl.o[1] + ly, tl.o[2] + lz)];
         }
         __syncthreads();
     }
     int base[3];
     for (int d = 0; d < 3; ++d) base[d] = (int)(x[d] * (double)D.P.inv_dx - 0.5);
+    clamp_to_reach(D, base);
     if (!valid) return;
     double xn[3];
     T vn[3], Cn[9];
@@ -556,7 +608,7 @@ __global__ __launch_bounds__(kBlock) void k_g2p(Dev<T> D, int f) {
         });
     } else {
         g2p_particle<T, double>(D.P, x, xn, vn, Cn, [&](int i, int j, int l, T* gv) {
-            Vec4<T> a = D.grid_out[node_index(D.nb, base[0] + i, base[1] + j, base[2] + l)];
+            Vec4<T> a = D.grid_out[node_index(D, base[0] + i, base[1] + j, base[2] + l)];
             gv[0] = a.x; gv[1] = a.y; gv[2] = a.z;
         });
     }
@@ -593,7 +645,7 @@ __global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_g2p_p2g(Dev<T> D, int
         if (ta.ok)
             for (int i = threadIdx.x; i < tn; i += kBlock) {
                 int lz = i / exy, r = i - lz * exy, ly = r / ex, lx = r - ly * ex;
-                tile_v[i] = vout_prev[node_index(D.nb, ta.o[0] + lx, ta.o[1] + ly, ta.o[2] + lz)];
+                tile_v[i] = vout_prev[node_index(D, ta.o[0] + lx, ta.o[1] + ly, ta.o[2] + lz)];
             }
     }
     PT_MARK(0);
@@ -622,7 +674,7 @@ __global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_g2p_p2g(Dev<T> D, int
             });
         } else {
             g2p_particle<T, double>(D.P, x0, x, v, C, [&](int i, int j, int l, T* gv) {
-                Vec4<T> a = vout_prev[node_index(D.nb, base0[0] + i, base0[1] + j, base0[2] + l)];
+                Vec4<T> a = vout_prev[node_index(D, base0[0] + i, base0[1] + j, base0[2] + l)];
                 gv[0] = a.x; gv[1] = a.y; gv[2] = a.z;
             });
         }
@@ -635,7 +687,7 @@ __global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_g2p_p2g(Dev<T> D, int
     // ---------------- p2g(f): scatter
     int base[3];
     for (int d = 0; d < 3; ++d) base[d] = (int)(x[d] * (double)D.P.inv_dx - 0.5);
-    if (valid && outside_halo_reach(D, base)) atomicOr(D.err, 1);
+    if (clamp_to_reach(D, base) && valid) atomicOr(D.err, 1);
     __syncthreads();                                                     // everyone is done reading tile_v
     Tile tl = block_tile(base, valid, sred, TileCap<T>::nodes);
     store_tile(D, f, tl);
@@ -671,7 +723,7 @@ __global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_g2p_p2g(Dev<T> D, int
                 T a0 = mass, a1 = mom[0], a2 = mom[1], a3 = mom[2];
                 seg_sum4(a0, a1, a2, a3, sg);
                 if (emitter) {
-                    int idx = node_index(D.nb, base[0] + i, base[1] + j, base[2] + l);
+                    int idx = node_index(D, base[0] + i, base[1] + j, base[2] + l);
                     atomicAdd(&D.gin[0][idx], a0); atomicAdd(&D.gin[1][idx], a1);
                     atomicAdd(&D.gin[2][idx], a2); atomicAdd(&D.gin[3][idx], a3);
                     D.flags[idx >> 6] = 1;
@@ -691,7 +743,7 @@ __global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_g2p_p2g(Dev<T> D, int
             Vec4<double> a = tile[i];
             if (a.x != 0.0 || a.y != 0.0 || a.z != 0.0 || a.w != 0.0) {
                 int lz = i / exy, r = i - lz * exy, ly = r / ex, lx = r - ly * ex;
-                int idx = node_index(D.nb, tl.o[0] + lx, tl.o[1] + ly, tl.o[2] + lz);
+                int idx = node_index(D, tl.o[0] + lx, tl.o[1] + ly, tl.o[2] + lz);
                 atomicAdd(&D.gin[0][idx], (T)a.x); atomicAdd(&D.gin[1][idx], (T)a.y);
                 atomicAdd(&D.gin[2][idx], (T)a.z); atomicAdd(&D.gin[3][idx], (T)a.w);
                 D.flags[idx >> 6] = 1;
@@ -722,7 +774,7 @@ __global__ __launch_bounds__(kBlock) void k_g2p_grad(Dev<T> D, int f, int src, i
     if (tl.ok)
         for (int i = threadIdx.x; i < tn; i += kBlock) {
             int lz = i / exy, r = i - lz * exy, ly = r / ex, lx = r - ly * ex;
-            tile[i] = D.grid_out[node_index(D.nb, tl.o[0] + lx, tl.o[1] + ly, tl.o[2] + lz)];
+            tile[i] = D.grid_out[node_index(D, tl.o[0] + lx, tl.o[1] + ly, tl.o[2] + lz)];
             tile_a[3 * i] = 0.0; tile_a[3 * i + 1] = 0.0; tile_a[3 * i + 2] = 0.0;
         }
     PT_MARK(0);
@@ -762,7 +814,7 @@ __global__ __launch_bounds__(kBlock) void k_g2p_grad(Dev<T> D, int f, int src, i
                 [&](int i, int j, int l, T* gv) {
                     gv[0] = gv[1] = gv[2] = T(0);
                     if (valid) {
-                        Vec4<T> a = D.grid_out[node_index(D.nb, base[0] + i, base[1] + j, base[2] + l)];
+                        Vec4<T> a = D.grid_out[node_index(D, base[0] + i, base[1] + j, base[2] + l)];
                         gv[0] = a.x; gv[1] = a.y; gv[2] = a.z;
                     }
                 },
@@ -770,7 +822,7 @@ __global__ __launch_bounds__(kBlock) void k_g2p_grad(Dev<T> D, int f, int src, i
                     T a0 = ga[0], a1 = ga[1], a2 = ga[2];
                     seg_sum3(a0, a1, a2, sg);
                     if (emitter) {
-                        int idx = node_index(D.nb, base[0] + i, base[1] + j, base[2] + l);
+                        int idx = node_index(D, base[0] + i, base[1] + j, base[2] + l);
                         atomicAdd(&D.goa[0][idx], a0); atomicAdd(&D.goa[1][idx], a1); atomicAdd(&D.goa[2][idx], a2);
                     }
                 });
@@ -787,7 +839,7 @@ __global__ __launch_bounds__(kBlock) void k_g2p_grad(Dev<T> D, int f, int src, i
             const double ax = tile_a[3 * i], ay = tile_a[3 * i + 1], az = tile_a[3 * i + 2];
             if (ax != 0.0 || ay != 0.0 || az != 0.0) {
                 int lz = i / exy, r = i - lz * exy, ly = r / ex, lx = r - ly * ex;
-                int idx = node_index(D.nb, tl.o[0] + lx, tl.o[1] + ly, tl.o[2] + lz);
+                int idx = node_index(D, tl.o[0] + lx, tl.o[1] + ly, tl.o[2] + lz);
                 atomicAdd(&D.goa[0][idx], (T)ax); atomicAdd(&D.goa[1][idx], (T)ay); atomicAdd(&D.goa[2][idx], (T)az);
             }
         }
@@ -802,13 +854,18 @@ __global__ __launch_bounds__(kBlock) void k_g2p_grad(Dev<T> D, int f, int src, i
 // the block touches a movable primitive: its pose adjoints are then still due and the block's inputs are left in
 // place for the POSE = true pass, which clears them.
 template <class T, bool POSE>
-__device__ __forceinline__ bool grid_block_bwd(const Dev<T>& D, int blk, int lane, const PrimT<T>* sp, double* sacc, int* shit) {
+__device__ __forceinline__ bool grid_block_bwd(const Dev<T>& D, const HaloIn& H, int blk, int lane, const PrimT<T>* sp, double* sacc, int* shit) {
     const int idx = (blk << 6) | lane;
-    const int bx = blk % D.nb, by = (blk / D.nb) % D.nb, bz = blk / (D.nb * D.nb);
-    int I[3] = {(bx << 2) | (lane & 3), (by << 2) | ((lane >> 2) & 3), (bz << 2) | (lane >> 4)};
+    int I[3];
+    block_nodes(D, blk, lane, I);
     T gm = D.gin[0][idx];
     T mv[3] = {D.gin[1][idx], D.gin[2][idx], D.gin[3][idx]};
     T va[3] = {D.goa[0][idx], D.goa[1][idx], D.goa[2][idx]}, ma, mva[3];
+    // multi-GPU: add the neighbour's share of grid_v_out.grad on the exchanged planes (POSE = false pass only: a
+    // deferred block gets the sum written back below, so the POSE = true pass reads complete values)
+    const int hf = (!POSE && H.n > 0) ? halo_face_of(D, H, blk) : -1;
+    if (hf >= 0)
+        for (int c = 0; c < 3; ++c) va[c] += halo_value(D, H, hf, c, blk, lane);
     const bool owned = I[2] >= D.z0 && I[2] < D.z1;     // halo nodes are computed on two ranks: count once
     bool due = false;
     grid_node_bwd<T, POSE>(D.P, I, gm, mv, D.nprim, sp, va, &ma, mva, [&](int q, const PoseAdj<T>& pa, bool hit) {
@@ -834,6 +891,7 @@ __device__ __forceinline__ bool grid_block_bwd(const Dev<T>& D, int blk, int lan
     });
     const bool defer = !POSE && __any(due);
     if (!POSE) D.grid_in_adj[idx] = Vec4<T>{ma, mva[0], mva[1], mva[2]};
+    if (defer && hf >= 0) { D.goa[0][idx] = va[0]; D.goa[1][idx] = va[1]; D.goa[2][idx] = va[2]; }
     if (!defer) {
         D.goa[0][idx] = T(0); D.goa[1][idx] = T(0); D.goa[2][idx] = T(0);
         // this frame's grid is consumed: leave grid_in / flags clean for the next scatter into them.  grid_in_adj
@@ -848,13 +906,17 @@ __device__ __forceinline__ bool grid_block_bwd(const Dev<T>& D, int blk, int lan
 // several microseconds each: the whole tail of this kernel when done here) are handed to spare workgroups of the
 // p2g.grad launch that follows, through D.contact.
 template <class T>
-__global__ __launch_bounds__(kBlock) void k_grid_op_grad(Dev<T> D, int f) {
+__global__ __launch_bounds__(kBlock) void k_grid_op_grad(Dev<T> D, int f, HaloIn H) {
     __shared__ PrimT<T> sp[kMaxPrim];
     load_prims(D, f, sp);
     __syncthreads();
     const int lane = threadIdx.x & 63;
-    for_each_active_block(D, [&](int blk) {
-        if (grid_block_bwd<T, false>(D, blk, lane, sp, nullptr, nullptr) && lane == 0)
+    // the forward grid_op marked every block of the exchanged planes that carries mass, so the flags alone are
+    // complete here: no halo candidates
+    HaloIn none;
+    none.n = 0;
+    for_each_active_block(D, none, [&](int blk) {
+        if (grid_block_bwd<T, false>(D, H, blk, lane, sp, nullptr, nullptr) && lane == 0)
             D.contact[1 + atomicAdd(&D.contact[0], 1)] = blk;
     });
 }
@@ -871,7 +933,7 @@ __device__ __forceinline__ void pose_adjoint_blocks(const Dev<T>& D, int f, int 
     __syncthreads();
     const int lane = threadIdx.x & 63, count = D.contact[0];
     for (int i = wg * (kBlock / 64) + (threadIdx.x >> 6); i < count; i += nwg * (kBlock / 64))
-        grid_block_bwd<T, true>(D, D.contact[1 + i], lane, sp, sacc, &shit);
+        grid_block_bwd<T, true>(D, HaloIn{}, D.contact[1 + i], lane, sp, sacc, &shit);
     __syncthreads();
     if (shit && threadIdx.x < D.nprim * 15) {
         int q = threadIdx.x / 15, c = threadIdx.x % 15;
@@ -902,19 +964,20 @@ __global__ __launch_bounds__(kBlock, sizeof(T) == 4 ? PLB_P2G_GRAD_WAVES : 1) vo
     const T* R = frame_r(D, f);
     const int Np = D.Npad;
     PT_BEGIN();
-    const Tile tl = load_tile(D, f, TileCap<T>::nodes, chunk, (int)gridDim.x - npose);   // stored by the scatter of this frame
+    const Tile tl = load_tile(D, f, TileCap<T>::nodes, chunk);   // stored by the scatter of this frame
     double x[3] = {0.5, 0.5, 0.5};
     if (valid) { x[0] = X[p]; x[1] = X[Np + p]; x[2] = X[2 * Np + p]; }
     const int ex = tl.e[0], exy = tl.e[0] * tl.e[1], tn = exy * tl.e[2];
     if (tl.ok) {
         for (int i = threadIdx.x; i < tn; i += kBlock) {
             int lz = i / exy, r = i - lz * exy, ly = r / ex, lx = r - ly * ex;
-            tile[i] = D.grid_in_adj[node_index(D.nb, tl.o[0] + lx, tl.o[1] + ly, tl.o[2] + lz)];
+            tile[i] = D.grid_in_adj[node_index(D, tl.o[0] + lx, tl.o[1] + ly, tl.o[2] + lz)];
         }
         __syncthreads();
     }
     int base[3];
     for (int d = 0; d < 3; ++d) base[d] = (int)(x[d] * (double)D.P.inv_dx - 0.5);
+    clamp_to_reach(D, base);
     PT_MARK(1);
     if (!valid) return;
     // the 27-node gather needs the position only: the other 42 words of particle state are fetched after it, so
@@ -928,7 +991,7 @@ __global__ __launch_bounds__(kBlock, sizeof(T) == 4 ? PLB_P2G_GRAD_WAVES : 1) vo
         });
     } else {
         p2g_gather_grad<T, double>(D.P, x, G, [&](int i, int j, int l, T* g) {
-            Vec4<T> a = D.grid_in_adj[node_index(D.nb, base[0] + i, base[1] + j, base[2] + l)];
+            Vec4<T> a = D.grid_in_adj[node_index(D, base[0] + i, base[1] + j, base[2] + l)];
             g[0] = a.x; g[1] = a.y; g[2] = a.z; g[3] = a.w;
         });
     }
@@ -955,10 +1018,10 @@ __global__ __launch_bounds__(kBlock) void k_grid_mass(Dev<T> D, int f, T* gm) {
     const double* X = frame_x(D, f);
     int p, base[3];
     double x[3];
-    const bool valid = load_sorted_particle(D, X, p, x, base);
+    int base_true[3];
+    const bool valid = load_sorted_particle(D, X, p, x, base, true);
     T fx[3], w[3][3];
-    stencil<T, double>(x, D.P.inv_dx, base, fx, w, nullptr);
-    if (valid && outside_halo_reach(D, base)) atomicOr(D.err, 1);
+    stencil<T, double>(x, D.P.inv_dx, base_true, fx, w, nullptr);
     Tile tl = block_tile(base, valid, sred, TileCap<T>::nodes * 4);
     const int ex = tl.e[0], exy = tl.e[0] * tl.e[1], tn = exy * tl.e[2];
     if (tl.ok) {
@@ -974,7 +1037,7 @@ __global__ __launch_bounds__(kBlock) void k_grid_mass(Dev<T> D, int f, T* gm) {
                 T m = seg_sum(w[i][0] * w[j][1] * w[l][2] * D.P.p_mass, sg);
                 if (emitter) {
                     if (tl.ok) atomicAdd(&tile[(oz + l) * exy + (oy + j) * ex + (ox + i)], (double)m);
-                    else atomicAdd(&gm[node_index(D.nb, base[0] + i, base[1] + j, base[2] + l)], m);
+                    else atomicAdd(&gm[node_index(D, base[0] + i, base[1] + j, base[2] + l)], m);
                 }
             }
     if (tl.ok) {
@@ -983,49 +1046,9 @@ __global__ __launch_bounds__(kBlock) void k_grid_mass(Dev<T> D, int f, T* gm) {
             double a = tile[i];
             if (a != 0.0) {
                 int lz = i / exy, r = i - lz * exy, ly = r / ex, lx = r - ly * ex;
-                atomicAdd(&gm[node_index(D.nb, tl.o[0] + lx, tl.o[1] + ly, tl.o[2] + lz)], (T)a);
+                atomicAdd(&gm[node_index(D, tl.o[0] + lx, tl.o[1] + ly, tl.o[2] + lz)], (T)a);
             }
         }
-    }
-}
-
-// z-slab halo: node planes z in [za, zb), restricted to the xy window [x0, x1) x [y0, y1), of `ncomp` SoA component
-// arrays (stride G) <-> a dense buffer laid out [comp][z - za][y - y0][x - x0].  Unpack adds (symmetric sum
-// exchange).  Both faces of a slab go in one launch (blockIdx.y = face).
-struct HaloFaces {
-    int n_faces;
-    int za[2], zb[2];
-    void* buf[2];
-    int x0, x1, y0, y1;
-};
-template <class T>
-__global__ void k_halo_pack(const T* src, size_t G, int ncomp, int nb, HaloFaces H) {
-    const int fc = blockIdx.y, wx = H.x1 - H.x0, wy = H.y1 - H.y0;
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t per = (size_t)(H.zb[fc] - H.za[fc]) * wy * wx;
-    if (i >= per * ncomp) return;
-    const int c = (int)(i / per);
-    const size_t r = i - (size_t)c * per;
-    const int x = H.x0 + (int)(r % wx), y = H.y0 + (int)((r / wx) % wy), z = H.za[fc] + (int)(r / ((size_t)wx * wy));
-    ((T*)H.buf[fc])[i] = src[(size_t)c * G + node_index(nb, x, y, z)];
-}
-template <class T>
-__global__ void k_halo_unpack_add(T* dst, size_t G, int ncomp, int nb, HaloFaces H, int* flags) {
-    const int fc = blockIdx.y, wx = H.x1 - H.x0, wy = H.y1 - H.y0;
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t per = (size_t)(H.zb[fc] - H.za[fc]) * wy * wx;
-    if (i >= per * ncomp) return;
-    const int c = (int)(i / per);
-    const size_t r = i - (size_t)c * per;
-    const int x = H.x0 + (int)(r % wx), y = H.y0 + (int)((r / wx) % wy), z = H.za[fc] + (int)(r / ((size_t)wx * wy));
-    const T v = ((const T*)H.buf[fc])[i];
-    if (v != T(0)) {
-        const int idx = node_index(nb, x, y, z);
-        // the two faces of a slab are >= 2*halo planes apart, so no two threads of this launch add to the same node
-        dst[(size_t)c * G + idx] += v;
-        // a neighbour's particles reach this node: its block is active here too (this IS the merge of the two ranks'
-        // block flags -- no separate flag exchange)
-        if (flags) flags[idx >> 6] = 1;
     }
 }
 
@@ -1034,7 +1057,7 @@ __global__ void k_halo_unpack_add(T* dst, size_t G, int ncomp, int nb, HaloFaces
 template <class T>
 __global__ __launch_bounds__(kBlock) void k_clear_active(Dev<T> D) {
     const int blk = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
-    const int nblk = D.nb * D.nb * D.nb;
+    const int nblk = D.nbx * D.nby * D.nbz;
     if (blk >= nblk || D.flags[blk] == 0) return;
     const int lane = threadIdx.x & 63;
     const int idx = (blk << 6) | lane;

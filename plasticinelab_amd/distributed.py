@@ -1,32 +1,42 @@
-"""Multi-GPU MPM: z-slab domain decomposition, one process per GPU, halos over RCCL/xGMI.
+"""Multi-GPU MPM: z-slab domain decomposition, one process per GPU, halos and migrating particles over RCCL/xGMI.
 
-What is built (round 1)
-* The grid is cut into z-slabs of node layers; rank r owns nodes ``z in [z_r, z_{r+1})`` and -- for the whole
-  rollout -- the particles whose stencil base lay in that slab at reset (**fixed ownership**).  The reference has
-  no multi-GPU path at all; this is new design.
-* Every rank allocates the full n^3 index space (only touched blocks cost traffic; 288 GB of HBM make the
-  allocation irrelevant) but scatters only its own particles.  After ``p2g`` the ``2*halo`` node planes around each
-  slab face hold partial sums on both neighbours; one **symmetric sum exchange** per face (both sides send their
-  copy, both add what they receive) makes them complete on both, so the pointwise ``grid_op`` and the ``g2p``
-  gather need no further communication.  The reverse pass mirrors it on ``grid_v_out.grad``.
+The reference has no multi-GPU path; this is new design.
+
+* **Slabs.**  The grid is cut into z-slabs whose faces sit on multiples of 4 node layers (the grid is stored in 4^3
+  blocks, z block index slowest).  Rank r owns the nodes ``z in [z_r, z_{r+1})`` and the particles whose stencil
+  CENTRE node lies in that range.
+* **Memory.**  A rank allocates only a *window* of the grid -- the xy bounding box of the body plus a margin, and in z
+  its slab plus the exchanged planes -- and keeps the per-frame grid store on that window (``plmpm_config.grid_lo /
+  grid_hi``): 32 B x window nodes per frame instead of 32 B x n^3.  That is what lets 256^3 and 512^3 rollouts stay
+  in store mode (no forward recompute in ``substep_grad``).
+* **Halos, zero copy.**  After ``p2g`` the block planes next to a face hold partial sums on both neighbours.  One
+  block plane either side of the face (4 node layers: the one-layer stencil reach plus three layers of drift between
+  migrations) is exchanged: each rank sends its copy straight out of the grid arrays -- a range of block planes is
+  contiguous per SoA component, so there is no pack kernel -- and ``grid_op`` adds the received copy on first touch,
+  so there is no unpack kernel either (symmetric sum exchange: both sides end with complete sums, ``g2p`` needs no
+  further communication).  The reverse pass mirrors it on ``grid_v_out.grad``.  A fwd+bwd substep is the same five
+  kernel launches as on one GPU plus two ``batch_isend_irecv`` calls.
+* **Migration.**  Every ``migrate_every`` env steps, before the step starts, the rows whose stencil centre has left the
+  slab are packed on the device and sent to the neighbour; arrivals are merged in and the whole set is re-sorted
+  along the Hilbert curve into a new storage epoch (this is also the slab engines' cell re-sort).  The reverse sweep
+  sends the adjoint rows of the arrivals back where they came from, so gradients are those of the single-GPU run.
+  Particle identity is a global id that travels with the row.
 * Pose adjoints are counted on owned nodes only, summed over ranks once per env step, then the (tiny, serial)
-  kinematics-chain adjoint runs redundantly everywhere, so every rank ends with the full action gradient.
-* The loss sums over owned nodes / local particles and all-reduces a 32-double record.
+  kinematics-chain adjoint runs redundantly everywhere, so every rank ends with the full action gradient.  The loss
+  sums over owned nodes / local particles and all-reduces a 32-double record.
 
-Limits, stated plainly
-* No particle migration yet: a particle whose stencil leaves ``[z_r - halo, z_{r+1} + halo)`` raises
-  (``Engine.check_error``).  Ownership goes by the stencil centre, so ``halo`` node layers (default 4) allow
-  ``halo - 1`` layers of drift either way during a rollout; slabs must be at least ``2*halo`` thick, which caps the rank count for thin bodies (config 3: the cube spans 40 layers).
-* The per-substep exchange is host-driven (two ``plmpm_*`` phase calls + one ``batch_isend_irecv``), so small
-  grids are latency-bound; overlapping the halo with interior blocks is future work.
+Limits, stated plainly: slabs are at least 8 node layers thick (two block planes, so the two faces' exchange planes
+do not overlap), which caps the rank count for thin bodies (config 3's cube spans 40 layers: at most 5 ranks); a
+particle may drift at most 3 layers past its slab between two migrations (it raises otherwise); the exchange is
+issued by the host each substep and is not overlapped with the interior blocks yet.
 
-The communication layer is backend-agnostic (``nccl`` = RCCL on the GPUs; ``gloo`` for the CPU tests and for
-two ranks sharing one GPU, staged through host memory).
+The communication layer is backend-agnostic (``nccl`` = RCCL on the GPUs; ``gloo`` for the CPU tests and for ranks
+sharing one GPU, staged through host memory).
 """
 from __future__ import annotations
 
 from dataclasses import dataclass
-from typing import Callable, List, Optional, Sequence, Tuple
+from typing import Callable, List, Optional, Tuple
 
 import numpy as np
 import torch
@@ -36,12 +46,15 @@ import torch.distributed as dist
 _SUM_SLOTS = (0, 1, 3, 4)
 _MAX_SLOTS = (2,)
 
+HALO_PLANES = 1          # block planes exchanged either side of a face (4 node layers)
+MIN_THICKNESS = 8        # node layers: two block planes, so that the exchange planes of a slab's two faces are disjoint
+
 
 @dataclass
 class SlabLayout:
     n_grid: int
-    bounds: Tuple[int, ...]          # len world+1, node z indices, bounds[0] = 0, bounds[-1] = n_grid
-    halo: int
+    bounds: Tuple[int, ...]          # len world+1, node z indices (multiples of 4), bounds[0] = 0, bounds[-1] = n_grid
+    halo: int = 4 * HALO_PLANES      # node layers a rank's particles may reach beyond its slab
 
     @property
     def world(self):
@@ -52,17 +65,17 @@ class SlabLayout:
 
     def owner_of(self, base_z: np.ndarray) -> np.ndarray:
         """Owner = slab holding the stencil's CENTRE node (base + 1): the 3-wide stencil then reaches exactly one
-        layer beyond either face at reset, leaving ``halo - 1`` layers of drift margin on both sides."""
+        layer beyond either face when ownership is (re)assigned."""
         return np.clip(np.searchsorted(np.asarray(self.bounds[1:-1]), np.asarray(base_z) + 1, side="right"), 0, self.world - 1)
 
     def faces(self, rank) -> List[Tuple[int, int, int]]:
-        """(neighbour rank, za, zb): node planes exchanged with each neighbour."""
+        """(neighbour rank, bz_a, bz_b): block planes exchanged with each neighbour (down first, then up)."""
         out = []
         z0, z1 = self.slab(rank)
         if rank > 0:
-            out.append((rank - 1, max(z0 - self.halo, 0), min(z0 + self.halo, self.n_grid)))
+            out.append((rank - 1, z0 // 4 - HALO_PLANES, z0 // 4 + HALO_PLANES))
         if rank < self.world - 1:
-            out.append((rank + 1, max(z1 - self.halo, 0), min(z1 + self.halo, self.n_grid)))
+            out.append((rank + 1, z1 // 4 - HALO_PLANES, z1 // 4 + HALO_PLANES))
         return out
 
     @staticmethod
@@ -71,104 +84,131 @@ class SlabLayout:
 
     @classmethod
     def balanced(cls, x: np.ndarray, n_grid: int, world: int, halo: int = 4) -> "SlabLayout":
-        """Slab faces at particle-count quantiles of the stencil base z, widened so every slab is >= 2*halo thick."""
+        """Slab faces at particle-count quantiles of the stencil centre z, rounded to multiples of 4 and pushed apart
+        so that every slab is >= MIN_THICKNESS layers thick."""
         if world == 1:
             return cls(n_grid, (0, n_grid), 0)
+        if halo != 4 * HALO_PLANES:
+            raise ValueError(f"slab halos are whole block planes: halo = {4 * HALO_PLANES} node layers (got {halo})")
         bz = np.sort(cls.stencil_base_z(x, n_grid)) + 1        # stencil centres
-        cuts = [int(bz[min(len(bz) - 1, (len(bz) * r) // world)]) for r in range(1, world)]
-        lo, hi = int(bz[0]), int(bz[-1]) + 3
-        min_th = max(2 * halo, 2)
-        # enforce monotone faces with the minimum thickness, sweeping up then down
+        cuts = [int(round(bz[min(len(bz) - 1, (len(bz) * r) // world)] / 4.0)) * 4 for r in range(1, world)]
+        lo, hi = int(bz[0]), int(bz[-1]) + 2
         faces = [0] + cuts + [n_grid]
         for i in range(1, world):
-            faces[i] = max(faces[i], faces[i - 1] + min_th)
+            faces[i] = max(faces[i], faces[i - 1] + MIN_THICKNESS)
         for i in range(world - 1, 0, -1):
-            faces[i] = min(faces[i], faces[i + 1] - min_th)
-        if any(faces[i + 1] - faces[i] < min_th for i in range(world)):
-            raise ValueError(f"cannot cut {n_grid} layers into {world} slabs of >= {min_th} layers (body spans z {lo}..{hi})")
+            faces[i] = min(faces[i], faces[i + 1] - MIN_THICKNESS)
+        if any(faces[i + 1] - faces[i] < MIN_THICKNESS for i in range(world)):
+            raise ValueError(f"cannot cut {n_grid} layers into {world} slabs of >= {MIN_THICKNESS} layers")
+        # a slab without particles is useless: the body (centres lo..hi) must reach into every slab
+        for r in range(world):
+            if faces[r + 1] <= lo or faces[r] > hi:
+                raise ValueError(f"cannot cut the body (stencil centres z {lo}..{hi}) into {world} slabs of >= {MIN_THICKNESS} "
+                                 f"layers with faces on multiples of 4 (got faces {faces})")
         return cls(n_grid, tuple(faces), halo)
 
 
-@dataclass
-class HaloFace:
-    nbr: int
-    za: int
-    zb: int
-    send: torch.Tensor
-    recv: torch.Tensor
-    wire_send: torch.Tensor          # = send / recv unless the backend wants host memory
-    wire_recv: torch.Tensor
-
-
-@dataclass
-class HaloPlan:
-    faces: List[HaloFace]
-    ops: list
-
-
 class HaloComm:
-    """Symmetric sum exchange with the z-neighbours through ``torch.distributed`` point-to-point ops."""
+    """Point-to-point traffic with the two z-neighbours through ``torch.distributed``: the per-substep symmetric sum
+    exchange of block planes (zero-copy send views, persistent receive buffers, op lists cached per frame) and the
+    row exchanges of particle migration."""
 
     def __init__(self, layout: SlabLayout, rank: int, group=None):
         self.layout, self.rank, self.group = layout, rank, group
         self.stage_host = dist.get_backend(group) == "gloo"      # gloo P2P wants host tensors
         # small host records (loss sums) are reduced on the device when the backend is RCCL
         self.scalar_device = torch.device("cpu") if self.stage_host else torch.device("cuda", torch.cuda.current_device())
+        self.backend = dist.get_backend(group)
+        self._recv = {}          # field -> [tensor [ncomp, count] per face]
+        self._ops = {}           # (field, frame) -> cached P2POp list
+        self.down = rank - 1 if rank > 0 else None
+        self.up = rank + 1 if rank < layout.world - 1 else None
 
-    def _wire(self, t: torch.Tensor) -> torch.Tensor:
-        return t.cpu() if (self.stage_host and t.is_cuda) else t
+    # ---- halos
+    def attach(self, engine, field, f=0):
+        """Allocate and register the receive buffers of ``field`` (once)."""
+        faces = self.layout.faces(self.rank)
+        bufs = []
+        for _nbr, a, b in faces:
+            cnt = engine.halo_views(field, f, a, b)[0].numel()
+            bufs.append(torch.zeros(engine.halo_ncomp(field), cnt, dtype=engine.torch_dtype, device=engine.device))
+        engine.halo_set_recv(field, [(a, b) for _n, a, b in faces], bufs)
+        self._recv[field] = bufs
 
-    def exchange(self, *fields):
-        """fields: (pack, unpack_add) pairs, ``pack(za, zb) -> tensor`` and ``unpack_add(za, zb, tensor)``.
-        All fields of all faces travel in ONE batch of point-to-point ops (one latency per substep phase).
-        General-purpose form (fresh buffers every call); the per-substep hot path uses ``plan`` / ``run``."""
+    def exchange(self, engine, field, f):
+        """Send this rank's copy of the exchanged block planes of ``field`` (frame ``f``) to the neighbours and receive
+        theirs into the registered buffers.  The grid kernels (or ``halo_apply``) add them."""
         faces = self.layout.faces(self.rank)
         if not faces:
             return
-        work, ops = [], []
-        for nbr, za, zb in faces:
-            for pack, unpack_add in fields:
-                s = self._wire(pack(za, zb)).contiguous()
-                r = torch.empty_like(s)
-                work.append((za, zb, r, s, unpack_add))
-                ops.append(dist.P2POp(dist.isend, s, nbr, self.group))
-                ops.append(dist.P2POp(dist.irecv, r, nbr, self.group))
+        if field not in self._recv:
+            self.attach(engine, field, f)
+        recv = self._recv[field]
+        if self.stage_host:          # gloo: through host memory (tests; ranks sharing one GPU)
+            ops, hosts = [], []
+            for (nbr, a, b), rb in zip(faces, recv):
+                hs = torch.stack([v for v in engine.halo_views(field, f, a, b)]).cpu()
+                hr = torch.empty_like(hs)
+                hosts.append((hr, rb, hs))
+                ops.append(dist.P2POp(dist.isend, hs, nbr, self.group))
+                ops.append(dist.P2POp(dist.irecv, hr, nbr, self.group))
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+            for hr, rb, _hs in hosts:
+                rb.copy_(hr)                                     # ordered on the engine's stream before the grid kernel
+            return
+        key = (field, f if field == engine.HALO_GRID_IN else -1)
+        ops = self._ops.get(key)
+        if ops is None:
+            ops = []
+            for (nbr, a, b), rb in zip(faces, recv):
+                for c, v in enumerate(engine.halo_views(field, f, a, b)):
+                    ops.append(dist.P2POp(dist.isend, v, nbr, self.group))
+                    ops.append(dist.P2POp(dist.irecv, rb[c], nbr, self.group))
+            self._ops[key] = ops
         for req in dist.batch_isend_irecv(ops):
             req.wait()
-        for za, zb, r, _s, unpack_add in work:
-            unpack_add(za, zb, r)
 
-    def plan(self, pack) -> "HaloPlan":
-        """Persistent buffers and point-to-point op list of one halo field: ``pack(za, zb)`` returns the face's first
-        message, whose storage becomes the face's send buffer for the rest of the run.  Built once per field so that
-        a substep costs two kernel launches per face and one ``batch_isend_irecv`` -- no allocation, no op
-        construction (the host issue rate, not the link, bounds the slab path at 128^3)."""
-        faces, ops = [], []
-        for nbr, za, zb in self.layout.faces(self.rank):
-            send = pack(za, zb).contiguous()
-            recv = torch.empty_like(send)
-            if self.stage_host and send.is_cuda:
-                ws, wr = (torch.empty(send.shape, dtype=send.dtype, pin_memory=True) for _ in range(2))
-            else:
-                ws, wr = send, recv
-            faces.append(HaloFace(nbr, za, zb, send, recv, ws, wr))
-            ops.append(dist.P2POp(dist.isend, ws, nbr, self.group))
-            ops.append(dist.P2POp(dist.irecv, wr, nbr, self.group))
-        return HaloPlan(faces, ops)
+    # ---- rows (migration)
+    def _wire(self, t):
+        return t.cpu() if (self.stage_host and t is not None and t.is_cuda) else t
 
-    def run(self, plan: "HaloPlan"):
-        """Send every face's ``send`` buffer, receive into its ``recv`` buffer."""
-        if not plan.faces:
-            return
-        for fc in plan.faces:
-            if fc.wire_send is not fc.send:
-                fc.wire_send.copy_(fc.send)                      # synchronous device -> pinned host copy
-        for req in dist.batch_isend_irecv(plan.ops):
-            req.wait()
-        for fc in plan.faces:
-            if fc.wire_recv is not fc.recv:
-                fc.recv.copy_(fc.wire_recv, non_blocking=True)   # ordered on the engine's stream before the unpack
+    def exchange_counts(self, n_down: int, n_up: int) -> Tuple[int, int]:
+        """Tell the neighbours how many rows come their way; returns (rows arriving from below, from above)."""
+        ops, got = [], {}
+        for nbr, n, key in ((self.down, n_down, "d"), (self.up, n_up, "u")):
+            if nbr is None:
+                continue
+            s = torch.tensor([n], dtype=torch.int64, device=self.scalar_device)
+            r = torch.zeros(1, dtype=torch.int64, device=self.scalar_device)
+            got[key] = (r, s)
+            ops.append(dist.P2POp(dist.isend, s, nbr, self.group))
+            ops.append(dist.P2POp(dist.irecv, r, nbr, self.group))
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+        return (int(got["d"][0].item()) if "d" in got else 0, int(got["u"][0].item()) if "u" in got else 0)
 
+    def exchange_rows(self, send_down, send_up, n_recv_down: int, n_recv_up: int, width: int, device):
+        """Send whole rows (float64 device tensors or None) down / up; receive ``n_recv_*`` rows of ``width`` doubles."""
+        ops, keep, out = [], [], [None, None]
+        for i, (nbr, snd, nrecv) in enumerate(((self.down, send_down, n_recv_down), (self.up, send_up, n_recv_up))):
+            if nbr is None:
+                continue
+            if snd is not None and snd.numel() > 0:
+                w = self._wire(snd.contiguous())
+                keep.append(w)
+                ops.append(dist.P2POp(dist.isend, w, nbr, self.group))
+            if nrecv > 0:
+                r = torch.empty(nrecv * width, dtype=torch.float64, device="cpu" if self.stage_host else device)
+                out[i] = r
+                ops.append(dist.P2POp(dist.irecv, r, nbr, self.group))
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+        return [None if r is None else r.to(device) for r in out]
+
+    # ---- reductions
     def all_reduce_(self, t: torch.Tensor, op=dist.ReduceOp.SUM):
         if self.layout.world == 1:
             return t
@@ -205,64 +245,86 @@ class HaloComm:
 
 class SlabEngine:
     """Proxy around one rank's ``Engine`` that turns ``step`` / ``step_grad`` / ``loss_*`` into the phase-split,
-    halo-exchanging versions.  ``MPMSimulator``, ``Loss`` and ``Tape`` work on it unchanged."""
+    halo-exchanging, migrating versions.  ``MPMSimulator``, ``Loss`` and ``Tape`` work on it unchanged."""
 
-    def __init__(self, engine, layout: SlabLayout, rank: int, group=None, comm: Optional[HaloComm] = None):
+    def __init__(self, engine, layout: SlabLayout, rank: int, group=None, comm: Optional[HaloComm] = None, migrate_every: int = 1):
         self._e, self.layout, self.rank = engine, layout, rank
         self.comm = comm if comm is not None else HaloComm(layout, rank, group)
         self.soft_contact = False
-        self._plans = {}                           # halo field -> HaloPlan (persistent buffers, built on first use)
+        self.migrate_every = int(migrate_every)        # env steps between two migrations (0: never -- fixed ownership)
+        self._since_migration = 0
+        self.migrations = 0                             # statistics: migrations done, rows sent away
+        self.rows_moved = 0
 
     def __getattr__(self, name):                   # everything not overridden goes straight to the engine
         return getattr(self._e, name)
 
-    # ---- halos
-    def _halo(self, field, f):
-        """Symmetric sum exchange of one halo field.  (The block flags of grid_in need no exchange of their own:
-        plmpm_halo_unpack_add marks the block of every node that receives a non-zero value.)"""
-        e = self._e
-        plan = self._plans.get(field)
-        if plan is None:
-            plan = self._plans[field] = self.comm.plan(lambda za, zb: e.halo_pack(field, f, za, zb))
-        else:
-            for fc in plan.faces:
-                e.halo_pack(field, f, fc.za, fc.zb, out=fc.send)
-        self.comm.run(plan)
-        for fc in plan.faces:
-            e.halo_unpack_add(field, f, fc.za, fc.zb, fc.recv)
+    # ---- state
+    def set_frame(self, f, x=None, v=None, F=None, C_=None, resort=False):
+        self._e.set_frame(f, x=x, v=v, F=F, C_=C_, resort=resort)
+        if resort:
+            self._since_migration = 0              # a new episode: ownership as assigned by the caller
 
-    def _phase(self, field, f, pre, post, chain_in=False, chain_out=False):
-        """One exchange-split phase of a substep: pre(f) | halo sum exchange of ``field`` | post(f).  After the first
-        call the face buffers are persistent and each side of the exchange is ONE library call (two kernel launches
-        before the exchange, two after).  Returns whether g2p(f) was left pending for the next phase (``chain_out``
-        honoured)."""
+    def get_frame_by_id(self, f, want=("x", "v", "F", "C")):
+        """(global ids ascending, rows in that order): the canonical view of a frame whatever its storage epoch."""
+        fr, ids = self._e.get_frame(f, want=want), self._e.get_ids(f)
+        o = np.argsort(ids, kind="stable")
+        return ids[o], {k: (None if a is None else a[o]) for k, a in fr.items()}
+
+    def _check(self):
+        """Combine the device error word over the ranks before anyone raises: a rank that bailed out alone would
+        leave the others waiting in their next exchange."""
+        flags = torch.tensor([float(self._e.error_flags())], dtype=torch.float64, device=self.comm.scalar_device)
+        self.comm.all_reduce_(flags, op=dist.ReduceOp.MAX)
+        self._e.check_error(int(flags.item()))
+
+    # ---- migration
+    def migrate(self, f):
+        """Hand the rows of frame ``f`` whose stencil centre left this slab to the neighbours, take theirs, re-sort."""
         e = self._e
-        plan = self._plans.get(field)
-        if plan is None:
-            pre(f)
-            self._halo(field, f)                # builds the plan
-            post(f)
-            return False
-        e.slab_pre(field, f, plan.faces, chain=chain_in)
-        self.comm.run(plan)
-        e.slab_post(field, f, plan.faces, chain=chain_out)
-        return chain_out
+        self._check()                              # nobody migrates a state that is already wrong
+        (nd, nu), (rows_d, rows_u) = e.migrate_begin(f)
+        in_d, in_u = self.comm.exchange_counts(nd, nu)
+        got_d, got_u = self.comm.exchange_rows(rows_d, rows_u, in_d, in_u, e.MIG_ROW, e.device)
+        e.migrate_finish(f, got_d, got_u)
+        self._since_migration = 0
+        self.migrations += 1
+        self.rows_moved += nd + nu
+
+    def _migrate_adjoint(self, f):
+        e = self._e
+        (_sd, _su), (rd, ru), (rows_d, rows_u) = e.migrate_adjoint_begin(f)
+        got_d, got_u = self.comm.exchange_rows(rows_d, rows_u, rd, ru, e.MIG_ADJ_ROW, e.device)
+        e.migrate_adjoint_finish(f, got_d, got_u)
 
     # ---- hot path
     def step(self, first, n):
         e = self._e
+        if self.layout.world > 1 and self.migrate_every > 0 and self._since_migration >= self.migrate_every:
+            self.migrate(first)
+        self._since_migration += 1
         e.fk(first, n)
         pending = False                         # g2p(f - 1) deferred: it runs fused with p2g(f), as on one GPU
         for f in range(first, first + n):
-            pending = self._phase(e.HALO_GRID_IN, f, e.p2g, e.grid_g2p, chain_in=pending, chain_out=f + 1 < first + n)
+            e.p2g(f, chain=pending)
+            self.comm.exchange(e, e.HALO_GRID_IN, f)
+            pending = f + 1 < first + n
+            e.grid_g2p(f, chain=pending)
 
     def substep(self, f):
         self.step(f, 1)
 
     def step_grad(self, first, n, step):
         e = self._e
-        for f in range(first + n - 1, first - 1, -1):
-            self._phase(e.HALO_GRID_OUT_ADJ, f, e.grad_scatter, e.grad_gather)
+        last = first + n
+        if self.layout.world > 1:
+            adj_epoch = e.frame_info(last)[2]
+            if adj_epoch >= 0 and adj_epoch != e.frame_info(last - 1)[1]:
+                self._migrate_adjoint(last)     # particles migrated at `last`: adjoint rows go back where they came from
+        for f in range(last - 1, first - 1, -1):
+            e.grad_scatter(f)
+            self.comm.exchange(e, e.HALO_GRID_OUT_ADJ, f)
+            e.grad_gather(f)
         for view in e.pose_grad_views(first, n + 1):      # position, rotation, (Chopsticks) gap adjoints
             self.comm.all_reduce_(view)
         e.chain_grad(first, n, step)
@@ -278,7 +340,9 @@ class SlabEngine:
     def _loss_globals(self, f):
         e = self._e
         e.loss_scatter(f)
-        self._halo(e.HALO_LOSS_MASS, f)
+        if self.layout.world > 1:
+            self.comm.exchange(e, e.HALO_LOSS_MASS, f)
+            e.halo_apply(e.HALO_LOSS_MASS, f)
         g = self.comm.reduce_loss_record(e.loss_partials(f, 0), self.soft_contact, 0)
         if self.soft_contact:
             e.loss_set_globals(g)
@@ -287,11 +351,7 @@ class SlabEngine:
 
     def loss_forward(self, f):
         g = self._loss_globals(f)
-        # the error word is combined over the ranks before anyone raises: a rank that bailed out alone would leave
-        # the others waiting in their next exchange
-        flags = torch.tensor([float(self._e.error_flags())], dtype=torch.float64, device=self.comm.scalar_device)
-        self.comm.all_reduce_(flags, op=dist.ReduceOp.MAX)
-        self._e.check_error(int(flags.item()))
+        self._check()
         return self._e.loss_finish(g)
 
     def loss_backward(self, f):
@@ -303,26 +363,46 @@ class SlabEngine:
         raise NotImplementedError("grid_mass on a slab engine returns only this rank's partial grid")
 
 
+def slab_window(x_all: np.ndarray, n_grid: int, layout: SlabLayout, rank: int, xy_margin: int, z_margin: Optional[int] = None):
+    """Grid window (lo3, hi3) in nodes of one rank: the xy bounding box of the whole cloud's stencils plus
+    ``xy_margin`` layers (the same on every rank, so that both sides of a face see the same planes), and in z the slab
+    plus the exchanged block planes, clipped to where the body (plus ``z_margin``) can be."""
+    z_margin = xy_margin if z_margin is None else z_margin
+    b = (np.asarray(x_all) * n_grid - 0.5).astype(np.int64)
+    lo = np.maximum(b.min(0) - [xy_margin, xy_margin, z_margin], 0)
+    hi = np.minimum(b.max(0) + 3 + [xy_margin, xy_margin, z_margin], n_grid)
+    z0, z1 = layout.slab(rank)
+    if rank > 0:                                   # interior face below: the exchanged planes, nothing further down
+        lo[2] = max(0, z0 - 4 * HALO_PLANES)
+    if rank < layout.world - 1:
+        hi[2] = min(n_grid, z1 + 4 * HALO_PLANES)
+    return [int(v) for v in lo], [int(v) for v in hi]
+
+
 def make_slab_env(cfg, rank: int, world: int, *, halo: int = 4, compute_dtype=None, device=None, group=None,
                   target_fn: Optional[Callable] = None, particles: Optional[np.ndarray] = None,
                   layout: Optional[SlabLayout] = None, comm: Optional[HaloComm] = None,
-                  xy_margin: Optional[int] = None):
+                  xy_margin: Optional[int] = 12, migrate_every: int = 1, capacity_factor: float = 1.5,
+                  yield_stress: Optional[np.ndarray] = None):
     """Build this rank's ``TaichiEnv`` over its slab of the scene in ``cfg`` (every rank samples the same seed-0
     particle cloud and keeps its own part).  ``target_fn(all_particles, sim) -> (n,n,n) grid`` may supply the loss
-    target.  ``xy_margin`` (node layers) shrinks the exchanged halo planes to the xy bounding box of the whole
-    particle cloud at reset plus that margin -- a body that moves further than the margin raises, like one that
-    drifts out of its slab; ``None`` sends whole planes.  ``layout`` / ``comm`` override the balanced cut and the torch.distributed communicator (measurement
-    tools: profiles/tools/slab_host_cost.py).  Returns (env, layout, owned_index)."""
+    target.  ``xy_margin`` (node layers): the grid window is the bounding box of the whole cloud at reset plus that
+    margin -- a body that moves further raises, like one that drifts out of its slab between two migrations; ``None``
+    allocates whole planes.  ``migrate_every``: env steps between two migrations.  ``yield_stress``: per-particle
+    values for the WHOLE cloud (each rank keeps its part).  ``layout`` / ``comm`` override the balanced cut and the
+    torch.distributed communicator (measurement tools: profiles/tools/slab_host_cost.py).
+    Returns (env, layout, owned_index)."""
     from .engine import taichi_env as te
     from .engine.losses import Loss
     from .engine.mpm_simulator import MPMSimulator
     from .engine.primitives import Primitives
     from .engine.shapes import Shapes
 
-    x_all, colors = Shapes(cfg.SHAPES).get()
     if particles is not None:                       # caller-chosen cloud (e.g. a subsample), same on every rank
         x_all = np.ascontiguousarray(particles, np.float64)
         colors = np.zeros(len(x_all), np.int32)
+    else:
+        x_all, colors = Shapes(cfg.SHAPES).get()
     quality = cfg.SIMULATOR.quality * 0.5
     n_grid = int(128 * quality)
     if layout is None:
@@ -342,16 +422,21 @@ def make_slab_env(cfg, rank: int, world: int, *, halo: int = 4, compute_dtype=No
     cfg.SIMULATOR["store_grid"] = True
     env.n_particles = len(mine)
     z0, z1 = layout.slab(rank)
-    sim = MPMSimulator(cfg.SIMULATOR, env.primitives, compute_dtype=compute_dtype, device=device,
-                       slab=(z0, z1), slab_halo=layout.halo if world > 1 else 0)
+    window = None
+    if xy_margin is not None:
+        window = slab_window(x_all, n_grid, layout, rank, int(xy_margin))
+    capacity = None
     if world > 1:
-        if xy_margin is not None:
-            b = (x_all[:, :2] * n_grid - 0.5).astype(np.int64)           # stencil bases, same on every rank
-            lo = np.maximum(b.min(0) - int(xy_margin), 0)
-            hi = np.minimum(b.max(0) + 3 + int(xy_margin), n_grid)
-            sim.engine.set_halo_window(lo[0], hi[0], lo[1], hi[1])
-        sim.engine = SlabEngine(sim.engine, layout, rank, group, comm)
+        capacity = int(len(mine) * capacity_factor) + 4096
+    sim = MPMSimulator(cfg.SIMULATOR, env.primitives, compute_dtype=compute_dtype, device=device,
+                       slab=(z0, z1), slab_halo=layout.halo if world > 1 else 0, grid_window=window,
+                       particle_capacity=capacity)
+    if world > 1:
+        sim.engine.set_ids(mine)
+        sim.engine = SlabEngine(sim.engine, layout, rank, group, comm, migrate_every=migrate_every)
         env.primitives._bind(sim.engine)
+    if yield_stress is not None:
+        sim._yield_stress = np.ascontiguousarray(np.asarray(yield_stress, np.float64)[mine])
     env.simulator = sim
     env.renderer = None
     env.loss = Loss(cfg.ENV.loss, sim)

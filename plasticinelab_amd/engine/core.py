@@ -33,7 +33,8 @@ class Engine:
     def __init__(self, *, n_grid: int, n_particles: int, max_frames: int, substeps: int, dt: float, p_vol: float,
                  p_mass: float, gravity: Sequence[float], ground_friction: float, primitives: Sequence[dict] = (),
                  dtype: str = "float32", svd_grad_clamp: float = 1e-6, device: Optional[torch.device] = None,
-                 slab: Optional[Sequence[int]] = None, store_grid="auto", slab_halo: int = 0, resort_steps: int = 4):
+                 slab: Optional[Sequence[int]] = None, store_grid="auto", slab_halo: int = 0, resort_steps: int = 4,
+                 grid_window: Optional[Sequence[Sequence[int]]] = None, particle_capacity: Optional[int] = None):
         self.lib = L.load()
         if not torch.cuda.is_available():
             raise L.EngineError("no ROCm device visible: the MPM engine has no CPU path")
@@ -46,13 +47,21 @@ class Engine:
         cfg.gravity = (C.c_double * 3)(*[float(g) for g in gravity])
         cfg.ground_friction, cfg.svd_grad_clamp = float(ground_friction), float(svd_grad_clamp)
         cfg.slab_z0, cfg.slab_z1 = (0, n_grid) if slab is None else (int(slab[0]), int(slab[1]))
+        # grid window (lo3, hi3) in nodes: only that box of the grid is allocated, stored per frame and swept
+        win_nodes = n_grid ** 3
+        if grid_window is not None:
+            lo, hi = [int(v) for v in grid_window[0]], [int(v) for v in grid_window[1]]
+            cfg.grid_lo, cfg.grid_hi = (C.c_int32 * 3)(*lo), (C.c_int32 * 3)(*hi)
+            win_nodes = int(np.prod([(min(n_grid, (h + 3) // 4 * 4) - max(0, l) // 4 * 4) for l, h in zip(lo, hi)]))
+        cap = int(particle_capacity) if particle_capacity else n_particles
+        cfg.particle_capacity = cap
         if store_grid == "auto":
             # grid_m/grid_v_in + grid_v_out of every frame (8 scalars per node) stay resident -- no forward recompute in
             # substep_grad, fused g2p+p2g forward: 1.45x the substep rate -- while they take at most 40 % of the HBM
             # and, with the particle frames, at most 70 % (288 GB on an MI355X: 128^3 rollouts of up to ~1700 frames)
             tsz = 8 if cfg.dtype == L.F64 else 4
-            grid_b = max_frames * 8 * tsz * n_grid ** 3
-            state_b = (max_frames + 1) * (n_particles + 255) // 256 * 256 * (24 + 21 * tsz)
+            grid_b = max_frames * 8 * tsz * win_nodes
+            state_b = (max_frames + 1) * (cap + 255) // 256 * 256 * (24 + 21 * tsz)
             hbm = torch.cuda.get_device_properties(self.device).total_memory
             store_grid = grid_b <= 0.40 * hbm and grid_b + state_b <= 0.70 * hbm
         cfg.store_grid = int(bool(store_grid))
@@ -74,9 +83,7 @@ class Engine:
             parr[i].lower_bound = (C.c_double * 3)(*p.get("lower_bound", (0.0, 0.0, 0.0)))
             parr[i].upper_bound = (C.c_double * 3)(*p.get("upper_bound", (1.0, 1.0, 1.0)))
             self.action_dims.append(parr[i].action_dim)
-        self._halo_counts = {}
-        self._halo_window = (0, n_grid, 0, n_grid)
-        self._face_cache = {}
+        self._view_cache = {}
         self.cfg, self.n_primitives = cfg, len(primitives)
         self.n_grid, self.n_particles, self.max_frames = n_grid, n_particles, max_frames
         self.dtype = "float64" if cfg.dtype == L.F64 else "float32"
@@ -120,8 +127,14 @@ class Engine:
         x, v, F, C_ = _f64(x, (N, 3)), _f64(v, (N, 3)), _f64(F, (N, 3, 3)), _f64(C_, (N, 3, 3))
         L.check(self.lib.plmpm_set_frame(self.h, f, _ptr(x), _ptr(v), _ptr(F), _ptr(C_), int(resort)))
 
+    def frame_info(self, f):
+        """(rows, storage epoch, epoch of the resident adjoint or -1) of frame f."""
+        n, e, a = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+        L.check(self.lib.plmpm_frame_info(self.h, f, C.byref(n), C.byref(e), C.byref(a)))
+        return n.value, e.value, a.value
+
     def get_frame(self, f, want=("x", "v", "F", "C")):
-        N = self.n_particles
+        N = self.frame_info(f)[0]
         out = {"x": np.empty((N, 3)) if "x" in want else None, "v": np.empty((N, 3)) if "v" in want else None,
                "F": np.empty((N, 3, 3)) if "F" in want else None, "C": np.empty((N, 3, 3)) if "C" in want else None}
         L.check(self.lib.plmpm_get_frame(self.h, f, _ptr(out["x"]), _ptr(out["v"]), _ptr(out["F"]), _ptr(out["C"])))
@@ -192,12 +205,12 @@ class Engine:
         L.check(self.lib.plmpm_segment_carry(self.h, from_frame, to_frame))
 
     def add_frame_grad(self, f, xa=None, va=None, Fa=None, Ca=None):
-        N = self.n_particles
+        N = self.frame_info(f)[0]
         xa, va, Fa, Ca = _f64(xa, (N, 3)), _f64(va, (N, 3)), _f64(Fa, (N, 3, 3)), _f64(Ca, (N, 3, 3))
         L.check(self.lib.plmpm_add_frame_grad(self.h, f, _ptr(xa), _ptr(va), _ptr(Fa), _ptr(Ca)))
 
     def get_frame_grad(self, f):
-        N = self.n_particles
+        N = self.frame_info(f)[0]
         out = {"x": np.empty((N, 3)), "v": np.empty((N, 3)), "F": np.empty((N, 3, 3)), "C": np.empty((N, 3, 3))}
         L.check(self.lib.plmpm_get_frame_grad(self.h, f, _ptr(out["x"]), _ptr(out["v"]), _ptr(out["F"]), _ptr(out["C"])))
         return out
@@ -255,11 +268,13 @@ class Engine:
     def fk(self, first, n):
         L.check(self.lib.plmpm_fk(self.h, first, n))
 
-    def p2g(self, f):
-        L.check(self.lib.plmpm_p2g(self.h, f))
+    def p2g(self, f, chain=False):
+        """p2g(f); ``chain``: fused with the g2p(f - 1) that ``grid_g2p(f - 1, chain=True)`` left pending."""
+        L.check(self.lib.plmpm_p2g(self.h, f, int(chain)))
 
-    def grid_g2p(self, f):
-        L.check(self.lib.plmpm_grid_g2p(self.h, f))
+    def grid_g2p(self, f, chain=False):
+        """grid_op(f) (adds the registered halo planes) + g2p(f); ``chain`` leaves the g2p to the next ``p2g``."""
+        L.check(self.lib.plmpm_grid_g2p(self.h, f, int(chain)))
 
     def grad_scatter(self, f):
         L.check(self.lib.plmpm_grad_scatter(self.h, f))
@@ -274,56 +289,109 @@ class Engine:
     def torch_dtype(self):
         return torch.float64 if self.dtype == "float64" else torch.float32
 
-    def halo_pack(self, field, f, za, zb, out=None):
-        """Planes z in [za, zb) of a halo field as a dense device tensor [comp, zb-za, n, n]; ``out`` (a tensor this
-        method returned earlier for the same field and planes) is refilled in place instead of allocating."""
-        if out is not None:
-            L.check(self.lib.plmpm_halo_pack(self.h, field, f, za, zb, C.c_void_p(out.data_ptr())))
-            return out
-        key = (field, za, zb)
-        count = self._halo_counts.get(key)
-        if count is None:
-            nb = C.c_size_t()
-            L.check(self.lib.plmpm_halo_bytes(self.h, field, za, zb, C.byref(nb)))
-            count = self._halo_counts[key] = nb.value // (8 if self.dtype == "float64" else 4)
-        x0, x1, y0, y1 = self._halo_window
-        buf = torch.empty(count, dtype=self.torch_dtype, device=self.device)
-        L.check(self.lib.plmpm_halo_pack(self.h, field, f, za, zb, C.c_void_p(buf.data_ptr())))
-        return buf.view(-1, zb - za, y1 - y0, x1 - x0)
+    def grid_window(self):
+        """(origin node (3,), extent in 4^3 blocks (3,)) of the allocated grid window."""
+        o, b = np.zeros(3, np.int32), np.zeros(3, np.int32)
+        L.check(self.lib.plmpm_grid_window(self.h, _ptr(o), _ptr(b)))
+        return o, b
 
-    def set_halo_window(self, x0, x1, y0, y1):
-        """Only nodes x in [x0, x1), y in [y0, y1) of the halo planes travel (default: whole planes); the same on
-        every rank.  Particles whose stencil leaves the window raise like those that leave slab + halo."""
-        L.check(self.lib.plmpm_set_halo_window(self.h, int(x0), int(x1), int(y0), int(y1)))
-        self._halo_window = (int(x0), int(x1), int(y0), int(y1))
-        self._halo_counts.clear()
-        self._face_cache.clear()
+    def halo_ncomp(self, field):
+        return {self.HALO_GRID_IN: 4, self.HALO_GRID_OUT_ADJ: 3, self.HALO_LOSS_MASS: 1}[field]
 
-    def halo_unpack_add(self, field, f, za, zb, buf):
-        buf = buf.contiguous()
-        L.check(self.lib.plmpm_halo_unpack_add(self.h, field, f, za, zb, C.c_void_p(buf.data_ptr())))
+    def halo_views(self, field, f, bz_a, bz_b):
+        """One torch view per component of block planes [bz_a, bz_b) of a halo field -- the grid memory itself (zero
+        copy): what a rank sends to the neighbour on that face.  Cached per (field, frame, planes)."""
+        key = (field, f if field == self.HALO_GRID_IN else -1, bz_a, bz_b)
+        v = self._view_cache.get(key)
+        if v is None:
+            v = []
+            for c in range(self.halo_ncomp(field)):
+                p, cnt = C.c_void_p(), C.c_size_t()
+                L.check(self.lib.plmpm_halo_region(self.h, field, f, c, bz_a, bz_b, C.byref(p), C.byref(cnt)))
+                v.append(self._view(p.value, cnt.value, self.torch_dtype))
+            self._view_cache[key] = v
+        return v
 
-    def _face_args(self, field, faces, which):
-        key = (field, which, id(faces))
-        c = self._face_cache.get(key)
-        if c is None:
-            nf = len(faces)
-            c = self._face_cache[key] = ((C.c_int * nf)(*[fc.za for fc in faces]), (C.c_int * nf)(*[fc.zb for fc in faces]),
-                                         (C.c_void_p * nf)(*[getattr(fc, which).data_ptr() for fc in faces]), nf, faces)
-        return c
+    def halo_set_recv(self, field, planes, bufs):
+        """Register where the neighbours' copies of block planes ``planes = [(bz_a, bz_b), ...]`` arrive
+        (``bufs[i]``: contiguous device tensor [ncomp, count]); grid_op / grid_op.grad add them on first touch."""
+        nf = len(planes)
+        za = (C.c_int * max(nf, 1))(*[p[0] for p in planes])
+        zb = (C.c_int * max(nf, 1))(*[p[1] for p in planes])
+        ptr = (C.c_void_p * max(nf, 1))(*[b.data_ptr() for b in bufs])
+        L.check(self.lib.plmpm_halo_set_recv(self.h, field, nf, za, zb, ptr))
+        self._recv_keepalive = getattr(self, "_recv_keepalive", {})
+        self._recv_keepalive[field] = list(bufs)
 
-    def slab_pre(self, field, f, faces, chain=False):
-        """p2g (GRID_IN) or grad_scatter (GRID_OUT_ADJ) of frame f, then pack every face into its ``send`` buffer.
-        ``faces``: the persistent list of a HaloPlan (objects with za, zb, send, recv).  ``chain``: the previous
-        ``slab_post(f - 1, chain=True)`` left g2p(f - 1) pending; it runs fused with this p2g."""
-        za, zb, ptr, nf, _ = self._face_args(field, faces, "send")
-        L.check(self.lib.plmpm_slab_pre(self.h, field, f, int(chain), nf, za, zb, ptr))
+    def halo_apply(self, field, f):
+        L.check(self.lib.plmpm_halo_apply(self.h, field, f))
 
-    def slab_post(self, field, f, faces, chain=False):
-        """unpack-add every face's ``recv`` buffer, then grid_g2p (GRID_IN) or grad_gather (GRID_OUT_ADJ).
-        ``chain``: leave g2p(f) to the next ``slab_pre(f + 1, chain=True)``, which must be the next engine call."""
-        za, zb, ptr, nf, _ = self._face_args(field, faces, "recv")
-        L.check(self.lib.plmpm_slab_post(self.h, field, f, int(chain), nf, za, zb, ptr))
+    # ---- migration (slab engines)
+    def set_ids(self, ids):
+        ids = np.ascontiguousarray(ids, np.int32)
+        assert len(ids) == self.n_particles
+        L.check(self.lib.plmpm_set_ids(self.h, _ptr(ids)))
+
+    def get_ids(self, f):
+        ids = np.empty(self.frame_info(f)[0], np.int32)
+        L.check(self.lib.plmpm_get_ids(self.h, f, _ptr(ids)))
+        return ids
+
+    MIG_ROW, MIG_ADJ_ROW = 28, 24
+
+    def migrate_begin(self, f):
+        """-> ((n_down, n_up), (rows_down, rows_up)): float64 device views of the packed rows that leave frame f."""
+        cnt = np.zeros(2, np.int32)
+        pd, pu = C.c_void_p(), C.c_void_p()
+        L.check(self.lib.plmpm_migrate_begin(self.h, f, _ptr(cnt), C.byref(pd), C.byref(pu)))
+        rows = [self._view(p.value, int(n) * self.MIG_ROW, torch.float64) if n > 0 else None for p, n in ((pd, cnt[0]), (pu, cnt[1]))]
+        return (int(cnt[0]), int(cnt[1])), rows
+
+    def migrate_finish(self, f, rows_down, rows_up):
+        """Merge the arrivals (float64 device tensors of whole rows, or None), re-sort, new storage epoch -> rows."""
+        n = C.c_int32(0)
+        nd = 0 if rows_down is None else rows_down.numel() // self.MIG_ROW
+        nu = 0 if rows_up is None else rows_up.numel() // self.MIG_ROW
+        L.check(self.lib.plmpm_migrate_finish(self.h, f, nd, C.c_void_p(rows_down.data_ptr() if nd else 0),
+                                              nu, C.c_void_p(rows_up.data_ptr() if nu else 0), C.byref(n)))
+        return n.value
+
+    def migrate_adjoint_begin(self, f):
+        """-> ((send_down, send_up), (recv_down, recv_up), (rows_down, rows_up)) for the reverse exchange at frame f."""
+        snd, rcv = np.zeros(2, np.int32), np.zeros(2, np.int32)
+        pd, pu = C.c_void_p(), C.c_void_p()
+        L.check(self.lib.plmpm_migrate_adjoint_begin(self.h, f, _ptr(snd), _ptr(rcv), C.byref(pd), C.byref(pu)))
+        rows = [self._view(p.value, int(n) * self.MIG_ADJ_ROW, torch.float64) if n > 0 else None for p, n in ((pd, snd[0]), (pu, snd[1]))]
+        return (int(snd[0]), int(snd[1])), (int(rcv[0]), int(rcv[1])), rows
+
+    def migrate_adjoint_finish(self, f, rows_down, rows_up):
+        L.check(self.lib.plmpm_migrate_adjoint_finish(self.h, f, C.c_void_p(rows_down.data_ptr() if rows_down is not None else 0),
+                                                      C.c_void_p(rows_up.data_ptr() if rows_up is not None else 0)))
+
+    # ---- per-primitive queries (Primitive.sdf / set_velocity, Loss.min_dist / dist_norm)
+    def primitive_sdf(self, prim, f, points):
+        pts = _f64(points).reshape(-1, 3)
+        out = np.empty(len(pts))
+        L.check(self.lib.plmpm_primitive_sdf(self.h, prim, f, _ptr(pts), len(pts), _ptr(out)))
+        return out
+
+    def set_velocity(self, prim, step, n_substeps):
+        L.check(self.lib.plmpm_set_velocity(self.h, prim, step, n_substeps))
+
+    def loss_contact_scalars(self):
+        md, dn = np.zeros(L.MAX_PRIMITIVES), np.zeros(L.MAX_PRIMITIVES)
+        L.check(self.lib.plmpm_loss_contact_scalars(self.h, _ptr(md), _ptr(dn)))
+        return md[:self.n_primitives], dn[:self.n_primitives]
+
+    def measure_hbm(self, nbytes=1 << 30, reps=5):
+        """(copy GB/s, read GB/s) of this device, measured with the library's own 16-byte-per-lane kernels."""
+        a = torch.zeros(nbytes, dtype=torch.uint8, device=self.device)
+        b = torch.empty_like(a)
+        cg, rg = C.c_double(0), C.c_double(0)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        L.check(self.lib.plmpm_measure_hbm(C.c_void_p(a.data_ptr()), C.c_void_p(b.data_ptr()), nbytes, reps, C.c_void_p(stream),
+                                           C.byref(cg), C.byref(rg)))
+        return cg.value, rg.value
 
     def _view(self, ptr, count, dtype):
         """torch view of engine-owned device memory (inside one of the bound workspaces)."""
@@ -333,11 +401,6 @@ class Engine:
             if 0 <= off and off + count * esz <= b.numel():
                 return b[off:off + count * esz].view(dtype)
         raise L.EngineError("pointer outside the bound workspaces")
-
-    def flags_view(self, f, bz_a, bz_b):
-        p, cnt = C.c_void_p(), C.c_size_t()
-        L.check(self.lib.plmpm_flags_region(self.h, f, bz_a, bz_b, C.byref(p), C.byref(cnt)))
-        return self._view(p.value, cnt.value, torch.int32)
 
     def pose_grad_views(self, first, n_frames):
         pa, pc, ra, rc, ga, gc = C.c_void_p(), C.c_size_t(), C.c_void_p(), C.c_size_t(), C.c_void_p(), C.c_size_t()
@@ -375,8 +438,8 @@ class Engine:
     def check_error(self, flags=None):
         flags = self.error_flags() if flags is None else flags
         if flags & 1:
-            raise L.EngineError("a particle left a rank's z-slab + halo, or the xy window of the exchanged halo planes "
-                                "(fixed ownership, no migration yet): raise slab_halo / xy_margin or use fewer ranks")
+            raise L.EngineError("a particle's stencil left the allocated grid window, or (slab engines) this rank's slab + halo "
+                                "between two migrations: widen grid_window / slab_halo or migrate more often")
 
     def profile_enable(self, on=True):
         L.check(self.lib.plmpm_profile_enable(self.h, int(on)))

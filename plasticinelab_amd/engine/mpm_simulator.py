@@ -21,7 +21,8 @@ from .core import Engine
 
 
 class MPMSimulator:
-    def __init__(self, cfg, primitives=(), compute_dtype=None, device=None, slab=None, slab_halo=0):
+    def __init__(self, cfg, primitives=(), compute_dtype=None, device=None, slab=None, slab_halo=0, grid_window=None,
+                 particle_capacity=None):
         dim = self.dim = cfg.dim
         assert dim == 3, "only the 3-D path exists (the reference's 2-D branches are dead code, SURVEY section 2)"
         assert cfg.dtype == "float64"                         # mpm_simulator.py:8 (host I/O dtype)
@@ -53,7 +54,9 @@ class MPMSimulator:
                              gravity=self.default_gravity, ground_friction=self.ground_friction, primitives=descr,
                              dtype=self.compute_dtype, svd_grad_clamp=float(cfg.get("svd_grad_clamp", 1e-6)),
                              device=device, slab=slab, slab_halo=slab_halo,
-                             store_grid=cfg.get("store_grid", "auto"))
+                             store_grid=cfg.get("store_grid", "auto"),
+                             grid_window=grid_window if grid_window is not None else cfg.get("grid_window", None),
+                             particle_capacity=particle_capacity)
         if hasattr(primitives, "_bind"):
             primitives._bind(self.engine)
         self._mats = None

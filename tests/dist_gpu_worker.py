@@ -1,6 +1,10 @@
 """Worker for tests/test_gpu_distributed.py: one rank of a z-slab run of the Move scene (2000-particle subsample)
-on cuda:0 (all ranks share the single GPU of the test box; halos go through gloo, staged via host memory -- the
-same SlabEngine code path that RCCL drives on a multi-GPU node)."""
+on cuda:0 (all ranks share the single GPU of the test box; halos and migrating rows go through gloo, staged via host
+memory -- the same SlabEngine code path that RCCL drives on a multi-GPU node; PLB_DIST_BACKEND=nccl uses one GPU per
+rank instead).
+
+    dist_gpu_worker.py OUT DTYPE ACTIONS.npy XY_MARGIN|none MIGRATE_EVERY
+"""
 import os
 import sys
 
@@ -13,32 +17,42 @@ sys.path.insert(0, ROOT)
 
 
 def main():
-    out_path, dtype, halo = sys.argv[1], sys.argv[2], int(sys.argv[3])
-    xy_margin = None if len(sys.argv) < 5 or sys.argv[4] == "none" else int(sys.argv[4])
+    out_path, dtype, act_path = sys.argv[1], sys.argv[2], sys.argv[3]
+    xy_margin = None if sys.argv[4] == "none" else int(sys.argv[4])
+    migrate_every = int(sys.argv[5])
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-    torch.cuda.set_device(0)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    from tests.util import GOLDEN, sparse_target
+    backend = os.environ.get("PLB_DIST_BACKEND", "gloo")
+    dev = rank % torch.cuda.device_count() if backend == "nccl" else 0
+    torch.cuda.set_device(dev)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    from tests.util import sparse_target
     from plasticinelab_amd.distributed import make_slab_env
     from plasticinelab_amd.engine.shapes import Shapes
     from plasticinelab_amd.envs.scenes import load_scene
     from plasticinelab_amd.optimizer.solver import Solver
 
-    g = np.load(os.path.join(GOLDEN, "rollout_small.npz"))
+    actions = np.load(act_path)
     cfg = load_scene("Move", 1)
     cfg.ENV.loss.target_path = ""
     x_all, _ = Shapes(cfg.SHAPES).get()
-    n = int(g["n_particles"])
+    n = 2000
     sub = np.ascontiguousarray(x_all[::len(x_all) // n][:n])
-    env, layout, mine = make_slab_env(cfg, rank, world, halo=halo, compute_dtype=dtype, particles=sub, xy_margin=xy_margin,
-                                      target_fn=lambda x, sim: sparse_target("Move3D-v1"))
+    env, layout, mine = make_slab_env(cfg, rank, world, compute_dtype=dtype, particles=sub, xy_margin=xy_margin,
+                                      migrate_every=migrate_every, target_fn=lambda x, sim: sparse_target("Move3D-v1"))
     env.loss.set_weights(10, 10, 1, False)
-    solver = Solver(env, None, None, softness=666.0, horizon=len(g["actions"]))
+    solver = Solver(env, None, None, softness=666.0, horizon=len(actions))
     state0 = env.get_state()["state"]
-    loss, grad = solver.forward(state0, g["actions"])
+    loss, grad = solver.forward(state0, actions)
     sim = env.simulator
-    fr = sim.engine.get_frame(sim.cur)
-    np.savez(f"{out_path}.{rank}.npz", loss=loss, grad=grad, mine=mine, x=fr["x"], v=fr["v"], bounds=np.array(layout.bounds))
+    eng = sim.engine
+    ids, fr = eng.get_frame_by_id(sim.cur, want=("x", "v"))
+    ws = eng.workspace_bytes
+    np.savez(f"{out_path}.{rank}.npz", loss=loss, grad=grad, mine=mine, ids=ids, x=fr["x"], v=fr["v"], bounds=np.array(layout.bounds),
+             migrations=eng.migrations, rows_moved=eng.rows_moved, window=np.concatenate(eng.grid_window()),
+             grid_bytes=ws["grid_bytes"], count=eng.frame_info(sim.cur)[0])
     dist.barrier()
     dist.destroy_process_group()
 

@@ -1,6 +1,8 @@
-"""-m gpu: the real HIP kernels behind the z-slab SlabEngine, 2 ranks vs the oracle-generated golden rollout
-(which the single-rank engine reproduces to 1e-10, test_gpu_rollout).  Both ranks share the box's one GPU and
-exchange halos over gloo; on a multi-GPU node the same code runs over RCCL."""
+"""-m gpu: the real HIP kernels behind the z-slab SlabEngine -- windowed grids, zero-copy block-plane halos added
+inside grid_op / grid_op.grad, particle migration with adjoint rows going back -- N ranks vs the single-rank engine
+and the oracle-generated golden rollout (which the single-rank engine reproduces to 1e-10, test_gpu_rollout).  The
+ranks share the box's one GPU and talk over gloo; on a multi-GPU node the same code runs over RCCL
+(PLB_DIST_BACKEND=nccl, self-skipping below two GPUs)."""
 import os
 import socket
 import subprocess
@@ -21,38 +23,96 @@ def free_port():
         return s.getsockname()[1]
 
 
-# xy_margin: whole halo planes travel (None) or only the body's xy bounding box + that many node layers
-@pytest.mark.parametrize("dtype,world,halo,xy_margin", [("float64", 2, 3, None), ("float32", 2, 3, 8), ("float64", 3, 2, 6)])
-def test_slab_ranks_match_single_rank(tmp_path, dtype, world, halo, xy_margin):
-    g = np.load(os.path.join(GOLDEN, "rollout_small.npz"))
+def launch(tmp_path, world, dtype, actions, xy_margin, migrate_every, backend="gloo"):
     out = str(tmp_path / "r")
+    act = str(tmp_path / "actions.npy")
+    np.save(act, actions)
     port = free_port()
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   HSA_ENABLE_IPC_MODE_LEGACY="0")
-        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_gpu_worker.py"), out, dtype, str(halo),
-                                       "none" if xy_margin is None else str(xy_margin)],
+                   HSA_ENABLE_IPC_MODE_LEGACY="0", PLB_DIST_BACKEND=backend)
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_gpu_worker.py"), out, dtype, act,
+                                       "none" if xy_margin is None else str(xy_margin), str(migrate_every)],
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
-    logs = [p.communicate(timeout=600)[0].decode() for p in procs]
+    logs = [p.communicate(timeout=900)[0].decode() for p in procs]
     for p, lg in zip(procs, logs):
         assert p.returncode == 0, lg[-3000:]
-    res = [np.load(f"{out}.{r}.npz") for r in range(world)]
+    return [np.load(f"{out}.{r}.npz") for r in range(world)]
+
+
+def gather(res, n):
+    x = np.full((n, 3), np.nan); v = np.full((n, 3), np.nan)
+    seen = np.zeros(n, int)
+    for r in res:
+        x[r["ids"]] = r["x"]; v[r["ids"]] = r["v"]
+        seen[r["ids"]] += 1
+    assert (seen == 1).all(), "every particle lives on exactly one rank"
+    return x, v
+
+
+# xy_margin: whole planes allocated (None) or only the body's xy bounding box + that many node layers
+@pytest.mark.parametrize("dtype,world,xy_margin", [("float64", 2, None), ("float32", 2, 8), ("float64", 3, 6)])
+def test_slab_ranks_match_golden_rollout(tmp_path, dtype, world, xy_margin):
+    g = np.load(os.path.join(GOLDEN, "rollout_small.npz"))
+    res = launch(tmp_path, world, dtype, g["actions"], xy_margin, migrate_every=1)
     ltol, gtol, xtol = (1e-10, 1e-7, 1e-10) if dtype == "float64" else (1e-5, 1e-4, 2e-5)
     n = int(g["n_particles"])
-    assert sum(len(r["mine"]) for r in res) == n and min(len(r["mine"]) for r in res) > 0
-    x = np.empty((n, 3)); v = np.empty((n, 3))
+    assert sum(int(r["count"]) for r in res) == n and min(int(r["count"]) for r in res) > 0
     for r in res:
         assert abs(float(r["loss"]) - float(g["loss"])) / abs(float(g["loss"])) < ltol      # every rank has the full loss
         assert relerr(r["grad"], g["grad"]) < gtol                                           # ... and the full gradient
-        x[r["mine"]] = r["x"]; v[r["mine"]] = r["v"]
+        assert int(r["migrations"]) == len(g["actions"]) - 1
+    x, v = gather(res, n)
     assert relerr(x, g["x_final"]) < xtol
     assert relerr(v, g["v_final"]) < (1e-8 if dtype == "float64" else 2e-3)
+    if xy_margin is not None:                       # the window really is a strict part of the 64^3 grid
+        o, b = res[0]["window"][:3], res[0]["window"][3:]
+        assert (b[:2] * 4 < 64).all()
 
 
-def test_leaving_the_slab_or_the_halo_window_raises():
-    """Fixed ownership: a stencil outside slab + halo in z, or outside the exchanged xy window, sets the error word
-    (Engine.check_error raises); inside both it does not."""
+def single_rank(actions, dtype):
+    from tests.test_gpu_rollout import make_env_sub, run_forward
+    env = make_env_sub("Move", 2000, dtype)
+    loss, grad = run_forward(env, actions)
+    fr = env.simulator.engine.get_frame(env.simulator.cur, want=("x", "v"))
+    return loss, grad, fr["x"], fr["v"]
+
+
+@pytest.mark.parametrize("world,migrate_every", [(2, 1), (3, 2)])
+def test_migration_over_a_long_rollout(tmp_path, world, migrate_every):
+    """10 env steps with the manipulators shoving the body along z: rows cross the slab faces, ownership follows them
+    (without migration the run raises, see below), and loss / gradient / trajectory stay those of one rank."""
+    H = 10
+    acts = np.zeros((H, 6))
+    acts[:, 2] = 0.9; acts[:, 5] = 0.9              # both spheres push +z
+    acts[:, 0] = 0.5; acts[:, 3] = -0.5             # ... and squeeze
+    acts += np.random.default_rng(4).uniform(-0.1, 0.1, acts.shape)
+    loss, grad, x1, v1 = single_rank(acts, "float64")
+    res = launch(tmp_path, world, "float64", acts, 10, migrate_every)
+    assert sum(int(r["rows_moved"]) for r in res) > 0, "the rollout was meant to move rows across the faces"
+    for r in res:
+        assert abs(float(r["loss"]) - loss) / abs(loss) < 1e-9
+        assert relerr(r["grad"], grad) < 1e-7
+    x, v = gather(res, 2000)
+    assert relerr(x, x1) < 1e-9 and relerr(v, v1) < 1e-7
+
+
+def test_nccl_backend_two_gpus(tmp_path):
+    """The same run over RCCL, one GPU per rank; needs two devices (skips on the single-GPU test boxes)."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs")
+    g = np.load(os.path.join(GOLDEN, "rollout_small.npz"))
+    res = launch(tmp_path, 2, "float64", g["actions"], 8, 1, backend="nccl")
+    for r in res:
+        assert abs(float(r["loss"]) - float(g["loss"])) / abs(float(g["loss"])) < 1e-10
+        assert relerr(r["grad"], g["grad"]) < 1e-7
+
+
+def test_leaving_the_grid_window_or_the_slab_raises():
+    """A stencil outside the allocated grid window, or outside slab + halo in z, sets the error word
+    (Engine.check_error raises) and is clamped into the window (no out-of-bounds access); inside both it does not."""
     from plasticinelab_amd._lib import EngineError
     from plasticinelab_amd.engine.core import Engine
     from tests import emul
@@ -65,22 +125,26 @@ def test_leaving_the_slab_or_the_halo_window_raises():
     plist = [dict(shape=p.shape, action_dim=p.action_dim, params=emul.prim_par(p), friction=p.friction,
                   action_scale=p.action_scale, lower_bound=p.lower_bound, upper_bound=p.upper_bound) for p in prims]
 
-    def flags(slab, window):
+    def engine(slab, window):
         eng = Engine(n_grid=n, n_particles=sim.n_particles, max_frames=sim.substeps + 1, substeps=sim.substeps, dt=sim.dt,
                      p_vol=sim.p_vol, p_mass=sim.p_mass, gravity=sim.gravity, ground_friction=sim.ground_friction,
-                     primitives=plist, dtype="float32", slab=slab, slab_halo=2, store_grid=True)
-        if window is not None:
-            eng.set_halo_window(*window)
+                     primitives=plist, dtype="float32", slab=slab, slab_halo=4 if slab else 0, store_grid=True, grid_window=window)
         load_state(eng, 0, O.init_state(x0), O.materials(sim), O.init_poses(prims))
         eng.set_action(0, sim.substeps, np.zeros(sum(p.action_dim for p in prims)))
         eng.fk(0, 1)
         eng.p2g(0)
         return eng
 
-    inside = (int(lo[2]), int(hi[2]))
-    assert flags(inside, None).error_flags() == 0
-    assert flags(inside, (max(int(lo[0]) - 2, 0), int(hi[0]) + 2, max(int(lo[1]) - 2, 0), int(hi[1]) + 2)).error_flags() == 0
-    assert flags(inside, (int(lo[0]) + 3, int(hi[0]) + 2, 0, n)).error_flags() & 1         # x window cuts the body
-    assert flags(inside, (0, n, max(int(lo[1]) - 2, 0), int(hi[1]) - 3)).error_flags() & 1         # y window cuts the body
-    with pytest.raises(EngineError, match="z-slab"):
-        flags((int(lo[2]) + 4, int(hi[2])), None).check_error()                            # slab + halo 2 misses 2 layers
+    whole = ([0, 0, 0], [n, n, n])
+    snug = ([int(v) - 2 for v in lo], [int(v) + 2 for v in hi])
+    assert engine(None, None).error_flags() == 0
+    assert engine(None, snug).error_flags() == 0
+    o, blocks = engine(None, snug).grid_window()
+    assert (o % 4 == 0).all() and (o <= np.array(snug[0])).all() and (o + 4 * blocks >= np.array(snug[1])).all()
+    cut_x = ([int(lo[0]) + 8, 0, 0], [n, n, n])
+    assert engine(None, cut_x).error_flags() & 1                         # the window cuts the body in x
+    cut_y = ([0, 0, 0], [n, int(hi[1]) - 8, n])
+    assert engine(None, cut_y).error_flags() & 1
+    assert engine((int(lo[2]) // 4 * 4, n), whole).error_flags() == 0    # slab holds every stencil centre's reach
+    with pytest.raises(EngineError, match="slab"):
+        engine(((int(lo[2]) + 12) // 4 * 4, n), whole).check_error()     # slab + halo 4 misses the body's lower layers
