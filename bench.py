@@ -63,13 +63,12 @@ def pmc_traffic(kernel, workload, dtype):
         return None, None
 
 
-def workload_cfg(n_particles=500_000, quality=2, max_steps=1024):
+def workload_cfg(n_particles=500_000, quality=2, max_steps=1024, yield_stress=200.0, side=0.31):
     from plasticinelab_amd.config import get_cfg_defaults
     cfg = get_cfg_defaults()
-    side = 0.31
     r = 0.05
     cfg.merge({
-        "SIMULATOR": {"quality": quality, "yield_stress": 200.0, "E": 5000.0, "nu": 0.2, "max_steps": max_steps,
+        "SIMULATOR": {"quality": quality, "yield_stress": yield_stress, "E": 5000.0, "nu": 0.2, "max_steps": max_steps,
                       "n_particles": n_particles},
         "SHAPES": [{"shape": "box", "width": (side, side, side), "init_pos": (0.5, 0.2, 0.5), "n_particles": n_particles}],
         "PRIMITIVES": [
@@ -116,7 +115,8 @@ def build_env(args, device, rank=0, world=1, slabs=False):
     from plasticinelab_amd.engine.taichi_env import TaichiEnv
     sub = int(2e-3 // (0.5e-4 / (args.quality * 0.5)))
     frames = max(args.steps, args.warmup, 1) * sub + 1
-    cfg = workload_cfg(args.particles, args.quality, max_steps=frames)
+    cfg = workload_cfg(args.particles, args.quality, max_steps=frames, yield_stress=getattr(args, "yield_stress", 200.0),
+                       side=getattr(args, "side", 0.31))
     if slabs:
         import torch.distributed as dist
         from plasticinelab_amd.distributed import make_slab_env
@@ -145,29 +145,48 @@ def rollout(env, actions):
 
 
 def cpu_baseline(args, env):
-    """Bounded sample of the same workload on the host cores: ONE substep forward + its adjoint through the
-    float64 oracle (oracle/plb_oracle.py, torch CPU) on the workload's initial state.  kind = "port": the
-    reference's own CPU path is Taichi, which cannot be installed here."""
-    from oracle import plb_oracle as O
+    """The reference's CPU path is the Taichi CPU backend, which cannot be installed here; in
+    its place: the C / OpenMP float64 restatement of one substep forward + reverse (oracle/mpm_substep_omp.c, kernel by
+    kernel after mpm_simulator.py:60-278 in the reference's own layout -- AoS particles, dense n^3 grids, atomic
+    scatters; checked against the torch oracle in tests/test_oracle_omp.py), timed on this box's host cores on the
+    workload's particle cloud: median of 5 runs on all cores (the value) and of 3 runs on one core.  kind = "port"."""
+    from oracle.omp_substep import OmpSubstep
     sim_g = env.simulator
-    x0 = env.init_particles
-    sim = O.SimCfg(n_particles=len(x0), quality=args.quality, yield_stress=200.0, E=5000.0, nu=0.2,
-                   ground_friction=sim_g.ground_friction, gravity=tuple(sim_g.default_gravity))
-    prims = [O.PrimCfg(shape="Sphere", radius=p.params()[0], init_pos=tuple(p.cfg.init_pos), friction=p.friction,
-                       action_dim=3, action_scale=tuple(p.cfg.action.scale)) for p in env.primitives]
-    state = tuple(t.requires_grad_(True) for t in O.init_state(x0))
-    mats, poses = O.materials(sim), O.init_poses(prims)
-    a = torch.tensor([0.8, 0, 0, -0.8, 0, 0], dtype=O.DT)
-    vel = [O.set_velocity(p, a[3 * k:3 * k + 3], sim.substeps) for k, p in enumerate(prims)]
-    nxt = [O.forward_kinematics(p, pos, rot, v, w) for p, (pos, rot), (v, w) in zip(prims, poses, vel)]
-    t0 = time.perf_counter()
-    out = O.substep(sim, prims, 666.0, state, mats, poses, nxt)
-    obj = sum((o * o).sum() for o in out)
-    torch.autograd.grad(obj, list(state))
-    dt = time.perf_counter() - t0
-    return {"value": 1.0 / dt, "unit": "substeps/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"1 substep fwd+bwd of the same {len(x0)}-particle / {sim.n_grid}^3 workload through the "
-                      f"float64 torch-CPU oracle ({dt:.1f} s); Taichi (the reference's CPU backend) is not installable here"}
+    x0 = np.ascontiguousarray(getattr(env, "all_particles", None) if getattr(env, "all_particles", None) is not None else env.init_particles)
+    N = len(x0)
+    rng = np.random.default_rng(0)
+    # a state with the features of a running rollout (velocities, velocity gradients, strained F; a third of it yields)
+    v = rng.standard_normal((N, 3)) * 0.2
+    Cm = rng.standard_normal((N, 3, 3)) * 1.0
+    F = np.eye(3) + rng.standard_normal((N, 3, 3)) * 0.02
+    E, nu = 5000.0, 0.2
+    mu, lam = np.full(N, E / (2 * (1 + nu))), np.full(N, E * nu / ((1 + nu) * (1 - 2 * nu)))
+    ys = np.full(N, float(getattr(args, "yield_stress", 200.0)))
+    prims = list(env.primitives)
+    pos = np.array([p.cfg.init_pos for p in prims], float)
+    pos1 = pos + np.array([[0.8, 0, 0], [-0.8, 0, 0]])[:len(prims)] * 0.01 / sim_g.substeps
+    omp = OmpSubstep(sim_g.n_grid, sim_g.dt, sim_g.p_vol, sim_g.p_mass, sim_g.default_gravity, sim_g.ground_friction, 666.0,
+                     [p.params()[0] for p in prims], [p.friction for p in prims], N)
+    cot = [rng.standard_normal((N, 3)), rng.standard_normal((N, 3)), rng.standard_normal((N, 3, 3)), rng.standard_normal((N, 3, 3))]
+
+    def once():
+        t0 = time.perf_counter()
+        omp.forward(pos, pos1, x0, v, Cm, F, mu, lam, ys)
+        omp.backward(pos, pos1, x0, v, Cm, F, mu, lam, ys, *cot)
+        return time.perf_counter() - t0
+
+    cores = os.cpu_count() or 1
+    omp.threads(cores)
+    once()                                                     # first touch of the grids
+    t_all = sorted(once() for _ in range(5))[2]
+    omp.threads(1)
+    t_one = sorted(once() for _ in range(3))[1]
+    omp.threads(cores)
+    return {"value": 1.0 / t_all, "unit": "substeps/s", "cores": cores, "kind": "port",
+            "single_core_value": 1.0 / t_one, "all_core_seconds_per_substep": t_all, "single_core_seconds_per_substep": t_one,
+            "sample": f"one fwd+bwd substep of the {N}-particle / {sim_g.n_grid}^3 workload (seeded perturbed state: v, C, F != 0, I) through "
+                      "oracle/mpm_substep_omp.c (C / OpenMP, float64, dense grids and the reference's recompute schedule): median of 5 runs on "
+                      f"{cores} threads, of 3 runs on 1 thread; Taichi (the reference's own CPU backend) is not installable here"}
 
 
 def main():

@@ -778,6 +778,7 @@ template <class T> static int phase_grad_gather(plmpm_sim* s, int f) {
     LAUNCH(s, K_P2G_GRAD, (k_p2g_grad<T>), dim3(nblocks_particles(s, f) + kPoseWG), D, f, (f + 1) & 1, f & 1, kPoseWG);
     s->dirty[f] = 0;
     s->adj_frame[f & 1] = f;
+    s->adj_epoch[f & 1] = s->frame_epoch[f];
     return 0;
 }
 
@@ -1866,6 +1867,9 @@ int plmpm_grad_scatter(plmpm_handle s, int frame) {
     REQUIRE(s->store && frame >= 0 && frame < s->F, "grad_scatter: bad call");
     REQUIRE(s->dirty[frame], "grad_scatter(%d): the frame's grid is not resident (run the forward substep first)", frame);
     REQUIRE(s->adj_frame[(frame + 1) & 1] == frame + 1, "grad_scatter(%d): adjoint of frame %d is not resident", frame, frame + 1);
+    REQUIRE(s->adj_epoch[(frame + 1) & 1] == s->frame_epoch[frame], "grad_scatter(%d): the adjoint of frame %d is in storage epoch %d, this substep ran in "
+            "epoch %d (particles migrated at that frame: run plmpm_migrate_adjoint_begin / _finish first)", frame, frame + 1,
+            s->adj_epoch[(frame + 1) & 1], s->frame_epoch[frame]);
     DISPATCH(s, phase_grad_scatter, s, frame);
     HIPCHK(hipGetLastError());
     return 0;

@@ -90,21 +90,38 @@ class SlabLayout:
             return cls(n_grid, (0, n_grid), 0)
         if halo != 4 * HALO_PLANES:
             raise ValueError(f"slab halos are whole block planes: halo = {4 * HALO_PLANES} node layers (got {halo})")
-        bz = np.sort(cls.stencil_base_z(x, n_grid)) + 1        # stencil centres
-        cuts = [int(round(bz[min(len(bz) - 1, (len(bz) * r) // world)] / 4.0)) * 4 for r in range(1, world)]
-        lo, hi = int(bz[0]), int(bz[-1]) + 2
-        faces = [0] + cuts + [n_grid]
-        for i in range(1, world):
-            faces[i] = max(faces[i], faces[i - 1] + MIN_THICKNESS)
-        for i in range(world - 1, 0, -1):
-            faces[i] = min(faces[i], faces[i + 1] - MIN_THICKNESS)
-        if any(faces[i + 1] - faces[i] < MIN_THICKNESS for i in range(world)):
-            raise ValueError(f"cannot cut {n_grid} layers into {world} slabs of >= {MIN_THICKNESS} layers")
-        # a slab without particles is useless: the body (centres lo..hi) must reach into every slab
-        for r in range(world):
-            if faces[r + 1] <= lo or faces[r] > hi:
-                raise ValueError(f"cannot cut the body (stencil centres z {lo}..{hi}) into {world} slabs of >= {MIN_THICKNESS} "
-                                 f"layers with faces on multiples of 4 (got faces {faces})")
+        cz = cls.stencil_base_z(x, n_grid) + 1                 # stencil centres
+        # particles per block plane; a face may sit on any multiple of 4.  Choose the world - 1 faces, at least
+        # MIN_THICKNESS apart, that minimise the largest slab's particle count (dynamic programme over the planes)
+        # with no slab left empty.
+        nbp = n_grid // 4
+        cnt = np.bincount(np.clip(cz // 4, 0, nbp - 1), minlength=nbp).astype(np.int64)
+        cum = np.concatenate([[0], np.cumsum(cnt)])           # cum[j] = particles in planes [0, j)
+        gap = MIN_THICKNESS // 4
+        INF = np.iinfo(np.int64).max
+        # best[k][j]: smallest possible maximum load of k slabs covering planes [0, j), the k-th ending at face j
+        best = np.full((world + 1, nbp + 1), INF, dtype=np.int64)
+        prev = np.zeros((world + 1, nbp + 1), dtype=np.int64)
+        best[0][0] = 0
+        for k in range(1, world + 1):
+            for j in range(k * gap, nbp + 1):
+                for i in range((k - 1) * gap, j - gap + 1):
+                    if best[k - 1][i] == INF:
+                        continue
+                    load = cum[j] - cum[i]
+                    if load <= 0:
+                        continue                              # an empty slab is useless
+                    m = max(best[k - 1][i], load)
+                    if m < best[k][j]:
+                        best[k][j], prev[k][j] = m, i
+        if best[world][nbp] == INF:
+            raise ValueError(f"cannot cut the body (stencil centres z {int(cz.min())}..{int(cz.max())}) into {world} non-empty slabs of >= "
+                             f"{MIN_THICKNESS} layers with faces on multiples of 4")
+        faces, j = [n_grid], nbp
+        for k in range(world, 0, -1):
+            j = int(prev[k][j])
+            faces.append(4 * j)
+        faces = faces[::-1]
         return cls(n_grid, tuple(faces), halo)
 
 

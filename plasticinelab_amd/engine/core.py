@@ -34,7 +34,8 @@ class Engine:
                  p_mass: float, gravity: Sequence[float], ground_friction: float, primitives: Sequence[dict] = (),
                  dtype: str = "float32", svd_grad_clamp: float = 1e-6, device: Optional[torch.device] = None,
                  slab: Optional[Sequence[int]] = None, store_grid="auto", slab_halo: int = 0, resort_steps: int = 4,
-                 grid_window: Optional[Sequence[Sequence[int]]] = None, particle_capacity: Optional[int] = None):
+                 grid_window: Optional[Sequence[Sequence[int]]] = None, particle_capacity: Optional[int] = None,
+                 allocate: bool = True):
         self.lib = L.load()
         if not torch.cuda.is_available():
             raise L.EngineError("no ROCm device visible: the MPM engine has no CPU path")
@@ -93,6 +94,9 @@ class Engine:
             ws = L.Workspace()
             L.check(self.lib.plmpm_workspace_bytes(self.h, C.byref(ws)))
             self.workspace_bytes = {k: getattr(ws, k) for k, _ in L.Workspace._fields_}
+            self._bufs = []
+            if not allocate:                  # sizing only (how much HBM would this engine need?): nothing is bound
+                return
             # torch owns the memory; keep the tensors alive as long as the handle
             self._bufs = [torch.empty(max(n, 256), dtype=torch.uint8, device=self.device)
                           for n in (ws.state_bytes, ws.adjoint_bytes, ws.grid_bytes, ws.misc_bytes)]

@@ -43,6 +43,24 @@ def _default_cfg(shape: str) -> CfgNode:
     return cfg
 
 
+class _Field0:
+    """Read-only stand-in for a 0-d Taichi field: ``p.min_dist[None]`` as in the reference (loss.py:123-135)."""
+
+    def __init__(self, read):
+        self._read = read
+
+    def __getitem__(self, key):
+        if key is not None and key != ():
+            raise IndexError("0-d field: index with [None]")
+        return float(self._read())
+
+    def __float__(self):
+        return float(self._read())
+
+    def to_numpy(self):
+        return np.asarray(float(self._read()))
+
+
 class Primitive:
     """One rigid manipulator (reference class Primitive and its shape subclasses)."""
 
@@ -122,6 +140,24 @@ class Primitive:
     @property
     def softness(self):
         return self._softness
+
+    def set_velocity(self, s, n_substeps):      # primive_base.py:184-192: v, w of env step s from action_buffer[s]
+        if self.action_dim > 0:
+            self._eng().set_velocity(self.index, s, n_substeps)
+
+    def sdf(self, f, grid_pos):                 # primive_base.py:57-60 (+ the shape's own sdf, primitives.py)
+        """Signed distance of ``grid_pos`` ((3,) or (n,3)) to the primitive at its pose of frame ``f``."""
+        pts = np.asarray(grid_pos, np.float64)
+        d = self._eng().primitive_sdf(self.index, f, pts.reshape(-1, 3))
+        return float(d[0]) if pts.ndim == 1 else d
+
+    @property
+    def min_dist(self):                         # primive_base.py:37 / loss.py:123-135: after the last compute_loss
+        return _Field0(lambda: self._eng().loss_contact_scalars()[0][self.index])
+
+    @property
+    def dist_norm(self):                        # primive_base.py:39 / loss.py:116-121 (soft contact loss)
+        return _Field0(lambda: self._eng().loss_contact_scalars()[1][self.index])
 
     def get_action_grad(self, s, n):            # primive_base.py:200-206
         if self.action_dim == 0:

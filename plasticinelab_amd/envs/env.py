@@ -33,9 +33,17 @@ class PlasticineEnv(_Base):
     def __init__(self, cfg_path, version, nn=False, compute_dtype=None, target_grid=None):
         self.cfg_path = cfg_path
         cfg = self.load_varaints(cfg_path, version)
-        self.taichi_env = TaichiEnv(cfg, nn, compute_dtype=compute_dtype)
         if target_grid is not None:
             cfg.ENV.loss.target_path = ""
+        else:
+            tp = cfg.ENV.loss.target_path
+            here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+            if tp and not (os.path.exists(tp) or os.path.exists(os.path.join(here, tp))):
+                # the reference ships its targets as plb/envs/assets/*.npy; they are not redistributed here
+                raise FileNotFoundError(
+                    f"target grid {tp!r} of {os.path.basename(cfg_path)} not found: pass make(..., assets_dir=<the reference's "
+                    f"plb/envs/assets>) or make(..., target_grid=<(n,n,n) mass grid>)")
+        self.taichi_env = TaichiEnv(cfg, nn, compute_dtype=compute_dtype)
         self.taichi_env.initialize()
         if target_grid is not None:
             self.taichi_env.loss.load_target_density(grids=target_grid)

@@ -1,4 +1,4 @@
-"""Built-in scene registry: nine of the reference's ten task families (Chopsticks needs its gap DOF, not built).
+"""Built-in scene registry: the reference's ten task families.
 
 The reference keeps one YAML per task under plb/envs/*.yml with five VARIANTS
 each (move.yml:1-80, triplemove.yml:1-89, rope.yml:1-73).  The same parameter

@@ -1,10 +1,13 @@
-"""Worker for tests/test_gpu_distributed.py: one rank of a z-slab run of the Move scene (2000-particle subsample)
-on cuda:0 (all ranks share the single GPU of the test box; halos and migrating rows go through gloo, staged via host
-memory -- the same SlabEngine code path that RCCL drives on a multi-GPU node; PLB_DIST_BACKEND=nccl uses one GPU per
-rank instead).
+"""Worker for tests/test_gpu_distributed.py: one rank of a z-slab run on cuda:0 (all ranks share the single GPU of the
+test box; halos and migrating rows go through gloo, staged via host memory -- the same SlabEngine code path that RCCL
+drives on a multi-GPU node; PLB_DIST_BACKEND=nccl uses one GPU per rank instead).
 
-    dist_gpu_worker.py OUT DTYPE ACTIONS.npy XY_MARGIN|none MIGRATE_EVERY
+    dist_gpu_worker.py OUT DTYPE ACTIONS.npy XY_MARGIN|none MIGRATE_EVERY [SCENE_JSON]
+
+Without SCENE_JSON the scene is Move-v1 with a 2000-particle subsample; with it the synthetic cube of bench.py
+({"particles", "quality", "side", "yield_stress"}: the BASELINE config-3/4/5 workloads at a chosen size).
 """
+import json
 import os
 import sys
 
@@ -20,6 +23,7 @@ def main():
     out_path, dtype, act_path = sys.argv[1], sys.argv[2], sys.argv[3]
     xy_margin = None if sys.argv[4] == "none" else int(sys.argv[4])
     migrate_every = int(sys.argv[5])
+    scene = json.loads(sys.argv[6]) if len(sys.argv) > 6 else None
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     backend = os.environ.get("PLB_DIST_BACKEND", "gloo")
     dev = rank % torch.cuda.device_count() if backend == "nccl" else 0
@@ -35,13 +39,24 @@ def main():
     from plasticinelab_amd.optimizer.solver import Solver
 
     actions = np.load(act_path)
-    cfg = load_scene("Move", 1)
-    cfg.ENV.loss.target_path = ""
-    x_all, _ = Shapes(cfg.SHAPES).get()
-    n = 2000
-    sub = np.ascontiguousarray(x_all[::len(x_all) // n][:n])
-    env, layout, mine = make_slab_env(cfg, rank, world, compute_dtype=dtype, particles=sub, xy_margin=xy_margin,
-                                      migrate_every=migrate_every, target_fn=lambda x, sim: sparse_target("Move3D-v1"))
+    if scene is None:
+        cfg = load_scene("Move", 1)
+        cfg.ENV.loss.target_path = ""
+        x_all, _ = Shapes(cfg.SHAPES).get()
+        n = 2000
+        sub = np.ascontiguousarray(x_all[::len(x_all) // n][:n])
+        env, layout, mine = make_slab_env(cfg, rank, world, compute_dtype=dtype, particles=sub, xy_margin=xy_margin,
+                                          migrate_every=migrate_every, target_fn=lambda x, sim: sparse_target("Move3D-v1"))
+    else:
+        import bench
+        sub_per_step = int(2e-3 // (0.5e-4 / (scene["quality"] * 0.5)))
+        cfg = bench.workload_cfg(scene["particles"], scene["quality"], max_steps=len(actions) * sub_per_step + 1,
+                                 yield_stress=scene.get("yield_stress", 200.0), side=scene.get("side", 0.31))
+        ys = None
+        if scene.get("mixed"):                       # config 5: half the particles yield (50), half do not (1e9)
+            ys = np.where(np.arange(scene["particles"]) % 2 == 0, 50.0, 1e9)
+        env, layout, mine = make_slab_env(cfg, rank, world, compute_dtype=dtype, xy_margin=xy_margin, migrate_every=migrate_every,
+                                          target_fn=bench._target, yield_stress=ys)
     env.loss.set_weights(10, 10, 1, False)
     solver = Solver(env, None, None, softness=666.0, horizon=len(actions))
     state0 = env.get_state()["state"]
@@ -52,7 +67,7 @@ def main():
     ws = eng.workspace_bytes
     np.savez(f"{out_path}.{rank}.npz", loss=loss, grad=grad, mine=mine, ids=ids, x=fr["x"], v=fr["v"], bounds=np.array(layout.bounds),
              migrations=eng.migrations, rows_moved=eng.rows_moved, window=np.concatenate(eng.grid_window()),
-             grid_bytes=ws["grid_bytes"], count=eng.frame_info(sim.cur)[0])
+             grid_bytes=ws["grid_bytes"], total_bytes=sum(ws.values()), count=eng.frame_info(sim.cur)[0])
     dist.barrier()
     dist.destroy_process_group()
 

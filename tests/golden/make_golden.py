@@ -167,7 +167,9 @@ def _target_sdf(tgt, dx):
 def make_gym():
     """The Gym surface (plb/envs/env.py:28-57) on Move-v1 as the ORACLE computes it: 50 copy-mode env steps with
     seeded actions; per step the reward (loss.py:288-298: start_loss - step loss), the loss terms and the IoU, and
-    the 1214-long observation (200 particles x (x, v) + 2 x 7 manipulator state) after steps 1, 25 and 50."""
+    the 1214-long observation (200 particles x (x, v) + 2 x 7 manipulator state) after steps 1, 25 and 50.
+    Softness 0: the reference's Gym path never calls Primitives.set_softness (only the solvers do, solver.py:33), so
+    its manipulators collide with the field's initial value 0 -- hard contact (primive_base.py:93-94: dist <= 0)."""
     import torch
     from tests.util import O, oracle_scene, sparse_target
     cfg, sim, prims, x0 = oracle_scene("Move", 1)
@@ -193,7 +195,7 @@ def make_gym():
         rewards, terms = [], []
         t = time.time()
         for i in range(H):
-            state, poses = O.env_step(sim, prims, 666.0, state, mats, poses, torch.as_tensor(actions[i], dtype=O.DT))
+            state, poses = O.env_step(sim, prims, 0.0, state, mats, poses, torch.as_tensor(actions[i], dtype=O.DT))
             l, parts = O.compute_loss(sim, lcfg, prims, state[0], poses, td, ts)
             rewards.append(float(l0) - float(l))
             terms.append([float(l), float(parts["sdf_loss"]), float(parts["density_loss"]), float(parts["contact_loss"]),

@@ -3,6 +3,7 @@ inside grid_op / grid_op.grad, particle migration with adjoint rows going back -
 and the oracle-generated golden rollout (which the single-rank engine reproduces to 1e-10, test_gpu_rollout).  The
 ranks share the box's one GPU and talk over gloo; on a multi-GPU node the same code runs over RCCL
 (PLB_DIST_BACKEND=nccl, self-skipping below two GPUs)."""
+import json
 import os
 import socket
 import subprocess
@@ -23,7 +24,7 @@ def free_port():
         return s.getsockname()[1]
 
 
-def launch(tmp_path, world, dtype, actions, xy_margin, migrate_every, backend="gloo"):
+def launch(tmp_path, world, dtype, actions, xy_margin, migrate_every, backend="gloo", scene=None):
     out = str(tmp_path / "r")
     act = str(tmp_path / "actions.npy")
     np.save(act, actions)
@@ -33,11 +34,12 @@ def launch(tmp_path, world, dtype, actions, xy_margin, migrate_every, backend="g
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    HSA_ENABLE_IPC_MODE_LEGACY="0", PLB_DIST_BACKEND=backend)
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_gpu_worker.py"), out, dtype, act,
-                                       "none" if xy_margin is None else str(xy_margin), str(migrate_every)],
+                                       "none" if xy_margin is None else str(xy_margin), str(migrate_every)]
+                                      + ([json.dumps(scene)] if scene else []),
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     logs = [p.communicate(timeout=900)[0].decode() for p in procs]
-    for p, lg in zip(procs, logs):
-        assert p.returncode == 0, lg[-3000:]
+    if any(p.returncode != 0 for p in procs):
+        raise AssertionError("\n".join(f"--- rank {r} (rc {p.returncode})\n{lg[-2500:]}" for r, (p, lg) in enumerate(zip(procs, logs))))
     return [np.load(f"{out}.{r}.npz") for r in range(world)]
 
 
@@ -96,6 +98,71 @@ def test_migration_over_a_long_rollout(tmp_path, world, migrate_every):
         assert relerr(r["grad"], grad) < 1e-7
     x, v = gather(res, 2000)
     assert relerr(x, x1) < 1e-9 and relerr(v, v1) < 1e-7
+
+
+def test_config4_grid_in_four_slabs(tmp_path):
+    """BASELINE configs[3] geometry -- the elastic block on a 256^3 grid, 79 substeps per env step -- cut into 4 z-slabs
+    (all four ranks on the box's one GPU, halos over gloo) for 8 env steps with migration: every rank reproduces the
+    single-rank loss and action gradient; the ranks' windowed per-frame grid stores are a fraction of a dense one.
+    200k particles keep four processes + the single-rank run inside the test's time (the 2M-particle workload itself runs
+    on one GPU in test_gpu_fullsize.py)."""
+    import bench
+    import torch
+    from plasticinelab_amd.engine.taichi_env import TaichiEnv
+    from plasticinelab_amd.optimizer.solver import Solver
+    scene = dict(particles=200_000, quality=4, side=0.25, yield_stress=1e9)
+    H, margin = 8, 24
+    acts = bench.seeded_actions(H, 6)
+    # single rank, on the same grid window the slab ranks' windows tile (a dense 256^3 store of 633 frames would not fit)
+    cfg = bench.workload_cfg(scene["particles"], scene["quality"], max_steps=H * 79 + 1, yield_stress=1e9, side=0.25)
+    from plasticinelab_amd.engine.shapes import Shapes
+    x_all, _ = Shapes(cfg.SHAPES).get()
+    b = (x_all * 256 - 0.5).astype(np.int64)
+    cfg.SIMULATOR["grid_window"] = ([int(v) for v in np.maximum(b.min(0) - margin, 0)], [int(v) for v in np.minimum(b.max(0) + 3 + margin, 256)])
+    env = TaichiEnv(cfg, compute_dtype="float64")
+    env.initialize()
+    env.loss.load_target_density(grids=bench._target(env.init_particles, env.simulator))
+    env.loss.set_weights(10, 10, 1, False)
+    loss, grad = Solver(env, None, None, softness=666.0, horizon=H).forward(env.get_state()["state"], acts)
+    single_grid_bytes = env.simulator.engine.workspace_bytes["grid_bytes"]
+    env.simulator.engine.close()
+    del env
+    torch.cuda.empty_cache()
+    res = launch(tmp_path, 4, "float64", acts, margin, 1, scene=scene)
+    assert [int(v) for v in res[0]["bounds"]][1:-1] == sorted(set(int(v) for v in res[0]["bounds"][1:-1]))
+    for r in res:
+        assert abs(float(r["loss"]) - loss) / abs(loss) < 1e-9
+        assert relerr(r["grad"], grad) < 1e-7
+        assert int(r["migrations"]) == H - 1
+        assert int(r["grid_bytes"]) < 0.6 * single_grid_bytes            # a rank stores its slab + halo planes only
+    assert sum(int(r["count"]) for r in res) == scene["particles"]
+    print(f"\n[256^3 in 4 slabs] loss {loss:.9g}, rows moved {[int(r['rows_moved']) for r in res]}, grid store per rank "
+          f"{[round(int(r['grid_bytes']) / 2**30, 2) for r in res]} GiB vs {single_grid_bytes / 2**30:.2f} GiB on one rank")
+
+
+def test_config5_rank_fits_in_hbm():
+    """BASELINE configs[4]: 512^3 grid, 16M particles in a cube of side 0.25, 8 z-slabs.  What one rank has to allocate
+    for a whole env step (159 substeps) in store mode, as plmpm_workspace_bytes reports it -- nothing is allocated
+    here: < 200 GB (a dense per-frame store would need 4.3 GB x 159 per rank)."""
+    from plasticinelab_amd.distributed import SlabLayout, slab_window
+    from plasticinelab_amd.engine.core import Engine
+    n, N, world, margin = 512, 16_000_000, 8, 24
+    x = (np.random.default_rng(0).random((N, 3)) - 0.5) * 0.25 + np.array([0.5, 0.2, 0.5])
+    lay = SlabLayout.balanced(x, n, world)
+    owner = lay.owner_of(SlabLayout.stencil_base_z(x, n))
+    worst = 0
+    for rank in (0, 3, 7):
+        mine = int((owner == rank).sum())
+        lo, hi = slab_window(x, n, lay, rank, margin)
+        eng = Engine(n_grid=n, n_particles=mine, max_frames=160, substeps=159, dt=0.5e-4 / 4, p_vol=(0.5 / n) ** 2, p_mass=(0.5 / n) ** 2,
+                     gravity=(0, -1, 0), ground_friction=1.5, primitives=[], dtype="float32", slab=lay.slab(rank), slab_halo=4,
+                     store_grid=True, grid_window=(lo, hi), particle_capacity=int(1.5 * mine), allocate=False)
+        total = sum(eng.workspace_bytes.values())
+        eng.close()
+        worst = max(worst, total)
+        assert 1.5e6 < mine < 2.6e6
+    print(f"\n[512^3 / 8 slabs] largest rank workspace for a 159-substep env step: {worst / 2**30:.1f} GiB")
+    assert worst < 200e9
 
 
 def test_nccl_backend_two_gpus(tmp_path):

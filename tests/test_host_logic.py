@@ -191,3 +191,34 @@ def test_solver_nn_observation_layout_and_hook_order():
                      ("step_grad", 0, 0), ("frame_grad", 0, []), ("prim_grad", 0, 0), ("prim_grad", 1, 0)]
     # bias gradient = sum over steps of d loss / d action, gated by the clamp (components 0 and 1 are saturated)
     assert np.allclose(grad[-A:], [0.0, 0.0, 3 + 9, 4 + 10, 5 + 11, 6 + 12])
+
+
+def test_make_without_assets_says_what_to_pass():
+    """plb.envs.make(name) needs the reference's target grids (plb/envs/assets/*.npy, not redistributed): the error
+    names the two ways to supply one.  Raised before any GPU object is built, so it is checked on the CPU tier."""
+    import pytest
+    from plasticinelab_amd.envs import make
+    with pytest.raises(FileNotFoundError, match="assets_dir"):
+        make("Move-v1")
+
+
+def test_optimizer_knobs_are_writable():
+    """lr / bounds are plain attributes in the reference (optim.py:12-13): an lr schedule assigns to them."""
+    import numpy as np
+    from plasticinelab_amd.optimizer.optim import Adam, Momentum
+    p = np.zeros(4)
+    o = Adam(p, lr=0.1)
+    o.lr = 0.01
+    o.bounds = (-0.5, 0.5)
+    o.step(np.ones(4))
+    assert abs(p[0] + 0.01) < 1e-9 and o.iter == 1 and o.momentum_buffer.shape == (4,) and o.v_buffer.shape == (4,)
+    m = Momentum(np.zeros(2))
+    m.step(np.ones(2) * 1000)
+    assert m.parameters[0] == -1.0 and abs(m.momentum_buffer[0] - 100.0) < 1e-9      # clipped to bounds
+
+
+def test_scene_strings_cannot_run_code():
+    from plasticinelab_amd.config import as_value
+    assert as_value("(0.5, 0.25*2, 1/4)") == (0.5, 0.5, 0.25) and as_value("127<<16") == 127 << 16
+    assert as_value("__import__('os').system('true')") == "__import__('os').system('true')"
+    assert as_value("box") == "box"
