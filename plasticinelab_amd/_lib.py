@@ -10,7 +10,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libplmpm.so")
+# PLMPM_LIB: another build of the same library (profiling / A-B experiments under profiles/tools); never a fallback
+LIB_PATH = os.environ.get("PLMPM_LIB") or os.path.join(_HERE, "libplmpm.so")
 
 MAX_PRIMITIVES = 8
 MAX_ACTION_DIM = 7

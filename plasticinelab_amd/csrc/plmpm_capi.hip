@@ -149,6 +149,7 @@ static void prof_end(plmpm_sim* s) {
 #define LAUNCHG_CLEAR(s, D) LAUNCH(s, K_CLEAR, (k_clear_active<T>), dim3(nblocks_grid(s)), D)
 #define LAUNCH(s, id, kern, grid, ...)                                                     \
     do {                                                                                   \
+        if (dim3(grid).x == 0) break;            /* a slab rank may hold no particles for a while */ \
         prof_begin(s, id);                                                                 \
         hipLaunchKernelGGL(kern, grid, dim3(kBlock), 0, (s)->stream, __VA_ARGS__);        \
         prof_end(s);                                                                       \
@@ -911,7 +912,8 @@ template <class T> static int download_grid_t(plmpm_sim* s, const char* src, dou
 template <class T> static int loss_scatter_t(plmpm_sim* s, int f) {
     Dev<T> D = make_dev<T>(s, f);
     hipMemsetAsync(s->loss_gm, 0, s->G * s->tsz, s->stream);
-    hipLaunchKernelGGL((k_grid_mass<T>), dim3(nblocks_particles(s, f)), dim3(kBlock), 0, s->stream, D, f, (T*)s->loss_gm);
+    if (nblocks_particles(s, f) > 0)
+        hipLaunchKernelGGL((k_grid_mass<T>), dim3(nblocks_particles(s, f)), dim3(kBlock), 0, s->stream, D, f, (T*)s->loss_gm);
     return 0;
 }
 
@@ -949,7 +951,7 @@ template <class T> static int grid_stats_t(plmpm_sim* s, int f, unsigned long lo
     Dev<T> D = make_dev<T>(s);
     D.N = s->epochN[s->frame_epoch[f]];
     // recompute the scatter of frame f without consuming it, count, then clear
-    hipLaunchKernelGGL((k_p2g<T, false>), dim3(nblocks_particles(s, f)), dim3(kBlock), 0, s->stream, D, f);
+    if (nblocks_particles(s, f) > 0) hipLaunchKernelGGL((k_p2g<T, false>), dim3(nblocks_particles(s, f)), dim3(kBlock), 0, s->stream, D, f);
     hipLaunchKernelGGL((k_grid_stats<T>), dim3((unsigned)((s->G + 255) / 256)), dim3(256), 0, s->stream, D, d_out);
     hipLaunchKernelGGL((k_clear_active<T>), dim3(nblocks_grid(s)), dim3(kBlock), 0, s->stream, D);
     return 0;
@@ -2072,8 +2074,9 @@ template <class T> static int migrate_begin_t(plmpm_sim* s, int frame, int epoch
     Dev<T> D = make_dev<T>(s, frame);
     int* leave = s->mig_leave + (size_t)epoch_new * s->Npad;
     HIPCHK(hipMemsetAsync(s->mig_cnt, 0, 8, s->stream));
-    hipLaunchKernelGGL((k_mig_classify<T>), dim3((D.N + 255) / 256), dim3(256), 0, s->stream, D, frame, s->mig_dest, s->mig_cnt, leave,
-                       leave + s->mig_max_rows, s->mig_max_rows);
+    if (D.N > 0)
+        hipLaunchKernelGGL((k_mig_classify<T>), dim3((D.N + 255) / 256), dim3(256), 0, s->stream, D, frame, s->mig_dest, s->mig_cnt, leave,
+                           leave + s->mig_max_rows, s->mig_max_rows);
     int cnt[2];
     HIPCHK(hipMemcpyAsync(cnt, s->mig_cnt, 8, hipMemcpyDeviceToHost, s->stream));
     HIPCHK(hipStreamSynchronize(s->stream));
@@ -2090,15 +2093,17 @@ template <class T> static int migrate_finish_t(plmpm_sim* s, int frame, int e_ne
     Dev<T> D = make_dev<T>(s, frame);
     const int e_old = s->frame_epoch[frame], n_old = D.N;
     const int n_new = n_old - s->mig_pending_out[0] - s->mig_pending_out[1] + n_in0 + n_in1;
-    REQUIRE(n_new > 0 && n_new <= s->Npad, "migrate: %d particles after the exchange, capacity %d (raise particle_capacity)", n_new, s->Npad);
+    REQUIRE(n_new >= 0 && n_new <= s->Npad, "migrate: %d particles after the exchange, capacity %d (raise particle_capacity)", n_new, s->Npad);
     const int total = n_old + n_in0 + n_in1;
     REQUIRE(total <= s->sort_cap, "migrate: %d candidate rows, room for %d", total, s->sort_cap);
     int bits = 1;
     while ((1 << bits) < s->n) ++bits;
-    hipLaunchKernelGGL((k_mig_keys<T>), dim3((total + 255) / 256), dim3(256), 0, s->stream, D, frame, bits, s->mig_dest, n_old, in0, n_in0, in1, n_in1,
-                       s->skey[0], s->sidx[0], total);
-    if (plmpm_sort_pairs(s->sort_tmp, s->sort_tmp_bytes, s->skey[0], s->skey[1], s->sidx[0], s->sidx[1], total, 3 * bits + 1, s->stream) != 0)
-        return fail("migrate: device sort failed");
+    if (total > 0) {
+        hipLaunchKernelGGL((k_mig_keys<T>), dim3((total + 255) / 256), dim3(256), 0, s->stream, D, frame, bits, s->mig_dest, n_old, in0, n_in0, in1, n_in1,
+                           s->skey[0], s->sidx[0], total);
+        if (plmpm_sort_pairs(s->sort_tmp, s->sort_tmp_bytes, s->skey[0], s->skey[1], s->sidx[0], s->sidx[1], total, 3 * bits + 1, s->stream) != 0)
+            return fail("migrate: device sort failed");
+    }
     T* vend = (T*)(s->vend + (size_t)e_new * 3 * s->Npad * s->tsz);
     T* mats_new = (T*)(s->mats_store + (size_t)e_new * 3 * s->Npad * s->tsz);
     hipLaunchKernelGGL((k_mig_build<T>), dim3(s->Npad / 256), dim3(256), 0, s->stream, D, frame, n_new, n_old, s->sidx[1], in0, n_in0, in1, s->frame_tmp, vend,
@@ -2116,8 +2121,9 @@ template <class T> static int migrate_adjoint_begin_t(plmpm_sim* s, int frame) {
     const plmpm_sim::MigInfo& m = s->mig[e];
     T* tmp = (T*)s->frame_tmp;
     HIPCHK(hipMemsetAsync(tmp, 0, (size_t)kMigAdjRow * s->Npad * s->tsz, s->stream));
-    hipLaunchKernelGGL((k_mig_adj_split<T>), dim3((s->epochN[e] + 255) / 256), dim3(256), 0, s->stream, (const T*)s->adj[slot], tmp, s->Npad, s->epochN[e],
-                       s->mig_src + (size_t)e * s->Npad, m.nin[0], s->mig_send[0], s->mig_send[1]);
+    if (s->epochN[e] > 0)
+        hipLaunchKernelGGL((k_mig_adj_split<T>), dim3((s->epochN[e] + 255) / 256), dim3(256), 0, s->stream, (const T*)s->adj[slot], tmp, s->Npad, s->epochN[e],
+                           s->mig_src + (size_t)e * s->Npad, m.nin[0], s->mig_send[0], s->mig_send[1]);
     return 0;
 }
 template <class T> static int migrate_adjoint_finish_t(plmpm_sim* s, int frame, const double* rows0, const double* rows1) {
