@@ -224,7 +224,11 @@ template <class T> PLB_HD void jacobi_pair(T& app, T& aqq, T& apq, T& arp, T& ar
 // Et = F_tmp - I.  Standard convention: sig >= 0, V a rotation, det U = sign det F.
 // (ti.svd's own convention is third-party and unverified; results downstream are
 // invariant to it whenever det F_tmp > 0.)                 (mpm_simulator.py:87-90)
-template <class T> PLB_HD void svd_eform(const T* Et, Svd3<T>& r) {
+// The decomposition in two halves.  svd_jacobi: the eigen-pairs (lam, V) of F^T F - I (the Jacobi sweeps); svd_finish:
+// singular values and U from them.  (Keeping (lam, V) of the forward pass per particle and frame so that p2g.grad skips
+// the sweeps was measured in round 2: no gain -- that kernel sits as close to its HBM bound as to its VALU bound, and
+// the 24 MB of extra reads cost what the sweeps do; profiles/r02_notes.md.)
+template <class T> PLB_HD void svd_jacobi(const T* Et, T* lam3, T* V) {
     // A = Et + Et^T + Et^T Et = F^T F - I
     T a00 = T(2) * Et[0] + Et[0] * Et[0] + Et[3] * Et[3] + Et[6] * Et[6];
     T a11 = T(2) * Et[4] + Et[1] * Et[1] + Et[4] * Et[4] + Et[7] * Et[7];
@@ -232,7 +236,6 @@ template <class T> PLB_HD void svd_eform(const T* Et, Svd3<T>& r) {
     T a01 = Et[1] + Et[3] + Et[0] * Et[1] + Et[3] * Et[4] + Et[6] * Et[7];
     T a02 = Et[2] + Et[6] + Et[0] * Et[2] + Et[3] * Et[5] + Et[6] * Et[8];
     T a12 = Et[5] + Et[7] + Et[1] * Et[2] + Et[4] * Et[5] + Et[7] * Et[8];
-    T* V = r.V;
     V[0] = V[4] = V[8] = T(1);
     V[1] = V[2] = V[3] = V[5] = V[6] = V[7] = T(0);
 #if defined(__HIPCC__) && !defined(PLB_SVD_UNROLL)
@@ -243,7 +246,10 @@ template <class T> PLB_HD void svd_eform(const T* Et, Svd3<T>& r) {
         jacobi_pair(a00, a22, a02, a01, a12, V, 0, 2);
         jacobi_pair(a11, a22, a12, a01, a02, V, 1, 2);
     }
-    r.lam[0] = a00; r.lam[1] = a11; r.lam[2] = a22;
+    lam3[0] = a00; lam3[1] = a11; lam3[2] = a22;
+}
+template <class T> PLB_HD void svd_finish(const T* Et, Svd3<T>& r) {
+    const T* V = r.V;
     for (int i = 0; i < 3; ++i) {
         T sg = t_fsqrt(t_max(T(1) + r.lam[i], T(0)));
         r.sig[i] = sg;
@@ -277,6 +283,11 @@ template <class T> PLB_HD void svd_eform(const T* Et, Svd3<T>& r) {
             }
         }
     }
+}
+
+template <class T> PLB_HD void svd_eform(const T* Et, Svd3<T>& r) {
+    svd_jacobi(Et, r.lam, r.V);
+    svd_finish(Et, r);
 }
 
 // ---------------------------------------------------------------- constitutive model

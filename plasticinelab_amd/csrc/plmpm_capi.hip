@@ -46,6 +46,7 @@ enum { LS_DENSITY = 0, LS_SDF = 1, LS_MAXGM = 2, LS_DOT = 3, LS_SUMGM = 4, LS_MI
 struct plmpm_sim {
     plmpm_config cfg;
     plmpm_primitive prims[PLMPM_MAX_PRIMITIVES];
+    int gwg = 1, gwg_log2 = 0, fs = 1, nflag = 1;   // grid workgroups (a power of two), flags per workgroup, flag slots = gwg * fs >= nblk
     int N, Npad, n, nblk, P, F, act_total;      // N: rows of storage epoch 0; Npad: padded row capacity of a frame
     int go[3], nbw[3];                          // grid window: origin node (multiple of 4) and extent in 4^3 blocks
     int act_ofs[PLMPM_MAX_PRIMITIVES + 1];
@@ -171,6 +172,7 @@ template <class T> static Dev<T> make_dev(const plmpm_sim* s, int frame = -1) {
     const int epoch = frame >= 0 ? s->frame_epoch[frame] : 0;
     D.N = frame >= 0 ? s->epochN[epoch] : s->N; D.Npad = s->Npad; D.nprim = s->P;
     D.twg = s->Npad / kBlock;
+    D.fgl = s->gwg_log2; D.fs = s->fs;
     for (int d = 0; d < 3; ++d) { D.go[d] = s->go[d]; D.rlo[d] = s->go[d]; D.rhi[d] = s->go[d] + 4 * s->nbw[d]; }
     D.nbx = s->nbw[0]; D.nby = s->nbw[1]; D.nbz = s->nbw[2];
     D.z0 = c.slab_z0; D.z1 = c.slab_z1;
@@ -191,7 +193,7 @@ template <class T> static Dev<T> make_dev(const plmpm_sim* s, int frame = -1) {
     for (int c = 0; c < 3; ++c) D.goa[c] = (T*)s->grid_out_adj + (size_t)c * s->G;
     D.grid_out = (Vec4<T>*)(framed ? s->vstore + (size_t)frame * s->gstride : s->grid_out);
     D.grid_in_adj = (Vec4<T>*)s->grid_in_adj;
-    D.flags = framed ? s->fstore + (size_t)frame * s->nblk : s->flags;
+    D.flags = framed ? s->fstore + (size_t)frame * s->nflag : s->flags;
     D.tiles = s->tiles;
     D.contact = s->contact;
     D.trace = (unsigned long long*)s->staging;      // profiling builds only (needs N * 24 * 8 >= 3 * 16384 * 128 bytes)
@@ -657,7 +659,7 @@ template <class T> __global__ void k_grid_stats(Dev<T> D, unsigned long long* ou
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     size_t G = (size_t)D.nbx * D.nby * D.nbz * 64;
     if (i < G && D.gin[0][i] > T(0)) atomicAdd(&out[0], 1ULL);
-    if (i < G / 64 && D.flags[i]) atomicAdd(&out[1], 1ULL);
+    if (i < G / 64 && D.flags[flag_slot(D, (int)i)]) atomicAdd(&out[1], 1ULL);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -691,7 +693,7 @@ static const HaloIn kNoHalo = {0, {0, 0}, {0, 0}, {nullptr, nullptr}};
 constexpr int kPoseWG = PLB_POSE_WG;
 static inline int nblocks_grid(const plmpm_sim* s) { return (s->nblk + (kBlock / 64) - 1) / (kBlock / 64); }
 // persistent grid kernels: a fixed number of workgroups, each striding over its share of the block flags
-static inline int nwg_grid(const plmpm_sim* s) { return std::min(nblocks_grid(s), kGridWG); }
+static inline int nwg_grid(const plmpm_sim* s) { return s->gwg; }
 
 template <class T> static int substep_fwd(plmpm_sim* s, int f) {
     Dev<T> D = make_dev<T>(s, f);
@@ -1007,13 +1009,19 @@ int plmpm_create(const plmpm_config* cfg, const plmpm_primitive* prims, plmpm_ha
         s->go[d] = lo; s->nbw[d] = (hi - lo) / 4;
     }
     s->nblk = s->nbw[0] * s->nbw[1] * s->nbw[2]; s->G = (size_t)s->nblk * 64;
+    // persistent grid kernels: a power-of-two number of workgroups (<= kGridWG, about one wave per 1-4 blocks), each
+    // with its blocks' flags side by side
+    s->gwg = 1; s->gwg_log2 = 0;
+    while (s->gwg * 2 <= kGridWG && s->gwg * 2 * (kBlock / 64) <= s->nblk) { s->gwg *= 2; ++s->gwg_log2; }
+    s->fs = (s->nblk + s->gwg - 1) / s->gwg;
+    s->nflag = s->gwg * s->fs;
     s->F = cfg->max_frames;
     s->tsz = cfg->dtype == PLMPM_F64 ? 8 : 4;
     s->frame_bytes = (size_t)s->Npad * (24 + 21 * s->tsz);
     size_t P1 = std::max(s->P, 1);
     s->ws.state_bytes = (size_t)(s->F + 1) * s->frame_bytes;
     s->ws.adjoint_bytes = align_up(2 * 24 * s->Npad * s->tsz, 256) + 3 * align_up(s->Npad * s->tsz, 256) + align_up((size_t)s->Npad * 4, 256);
-    s->ws.grid_bytes = 4 * align_up(s->G * 4 * s->tsz, 256) + align_up((size_t)s->nblk * 4, 256) + 3 * align_up(s->G * s->tsz, 256);
+    s->ws.grid_bytes = 4 * align_up(s->G * 4 * s->tsz, 256) + align_up((size_t)s->nflag * 4, 256) + 3 * align_up(s->G * s->tsz, 256);
     s->dist = s->cfg.slab_z0 > 0 || s->cfg.slab_z1 < cfg->n_grid || cfg->slab_halo > 0;
     s->resort = cfg->resort_steps > 0 && !s->dist && cfg->substeps > 0;
     // storage epochs: single GPU one per re-sort (+2: the alternating pair of copy-mode episodes); slab engines one per
@@ -1038,7 +1046,7 @@ int plmpm_create(const plmpm_config* cfg, const plmpm_primitive* prims, plmpm_ha
                                + 2 * align_up((size_t)s->mig_max_rows * 28 * 8, 256);          // packed rows of the leavers, per direction
     s->store = cfg->store_grid != 0;
     s->gstride = align_up(s->G * 4 * s->tsz, 256);
-    if (s->store) s->ws.grid_bytes += 2 * (size_t)s->F * s->gstride + align_up((size_t)s->F * s->nblk * 4, 256);
+    if (s->store) s->ws.grid_bytes += 2 * (size_t)s->F * s->gstride + align_up((size_t)s->F * s->nflag * 4, 256);
     s->ws.grid_bytes += align_up((size_t)(s->F + 1) * (s->Npad / kBlock) * 8 * 4, 256) + align_up((size_t)(s->nblk + 1) * 4, 256);
     s->dirty.assign(s->F + 1, 0);
     s->ws.misc_bytes = 2 * align_up((size_t)(s->F + 1) * P1 * 7 * 8, 256) + 2 * align_up((size_t)(s->F + 1) * P1 * 8 * 8, 256)  // poses(+adj), padded
@@ -1099,12 +1107,12 @@ int plmpm_bind_workspace(plmpm_handle s, void* state, void* adjoint, void* grid,
     p = s->gridw;
     s->grid_in = take(s->G * 4 * s->tsz); s->grid_out = take(s->G * 4 * s->tsz);
     s->grid_out_adj = take(s->G * 4 * s->tsz); s->grid_in_adj = take(s->G * 4 * s->tsz);
-    s->flags = (int*)take((size_t)s->nblk * 4);
+    s->flags = (int*)take((size_t)s->nflag * 4);
     s->loss_gm = take(s->G * s->tsz); s->loss_td = take(s->G * s->tsz); s->loss_ts = take(s->G * s->tsz);
     if (s->store) {
         s->gstore = take((size_t)s->F * s->gstride);
         s->vstore = take((size_t)s->F * s->gstride);
-        s->fstore = (int*)take((size_t)s->F * s->nblk * 4);
+        s->fstore = (int*)take((size_t)s->F * s->nflag * 4);
     }
     s->tiles = (int*)take((size_t)(s->F + 1) * (s->Npad / kBlock) * 8 * 4);
     s->contact = (int*)take((size_t)(s->nblk + 1) * 4);

@@ -80,6 +80,7 @@ template <class T> struct Dev {
     int go[3];                       // grid window: origin node (multiples of 4) ...
     int nbx, nby, nbz;               // ... and extent in 4^3 blocks; only this box of the n^3 grid is allocated
     int twg;                         // stride of the per-frame workgroup tile table (capacity / 256)
+    int fgl, fs;                     // block flags are stored per grid workgroup: flags[(blk & (2^fgl - 1)) * fs + (blk >> fgl)]
     int nprim;
     int z0, z1;                      // owned z-slab (nodes): pose adjoints / loss sums only count these
     int rlo[3], rhi[3];              // reach: stencil bases must satisfy rlo <= base, base + 2 < rhi (window, and slab + halo in z)
@@ -111,9 +112,16 @@ template <class T> __device__ __forceinline__ T* frame_r(const Dev<T>& D, int f)
     return reinterpret_cast<T*>(D.state + (size_t)f * D.frame_bytes + (size_t)3 * 8 * D.Npad);
 }
 
+
 // node (i, j, k) of the grid -> index inside the allocated window (origin a multiple of 4, so the low bits are the node's)
 template <class T> __device__ __forceinline__ int node_index(const Dev<T>& D, int i, int j, int k) {
     return (((((k - D.go[2]) >> 2) * D.nby + ((j - D.go[1]) >> 2)) * D.nbx + ((i - D.go[0]) >> 2)) << 6) | ((k & 3) << 4) | ((j & 3) << 2) | (i & 3);
+}
+// Block flags live where the grid kernels read them: workgroup g of the 2^fgl persistent grid workgroups owns blocks
+// g, g + 2^fgl, g + 2 * 2^fgl, ... (interleaved: the active blocks are spatially clustered) and finds their flags
+// side by side, one coalesced load per 64 blocks (indexed by block they were 64 cache lines per wave load).
+template <class T> __device__ __forceinline__ int flag_slot(const Dev<T>& D, int blk) {
+    return (blk & ((1 << D.fgl) - 1)) * D.fs + (blk >> D.fgl);
 }
 // block index inside the window -> node coordinates of lane `lane` of the wave that owns the block
 template <class T> __device__ __forceinline__ void block_nodes(const Dev<T>& D, int blk, int lane, int* I) {
@@ -166,17 +174,25 @@ template <class T> __device__ __forceinline__ T halo_value(const Dev<T>& D, cons
     const size_t per = (size_t)(H.bb[f] - H.ba[f]) * D.nbx * D.nby * 64;
     return ((const T*)H.buf[f])[(size_t)c * per + ((size_t)(blk - H.ba[f] * D.nbx * D.nby) << 6) + lane];
 }
-template <class T, class Body> __device__ __forceinline__ void for_each_active_block(const Dev<T>& D, const HaloIn& H, Body&& body) {
-    const int nblk = D.nbx * D.nby * D.nbz, G = gridDim.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int b0 = blockIdx.x; b0 < nblk; b0 += 64 * G) {
-        const int b = b0 + lane * G;
+// first 64 flags of this workgroup: issued by the grid kernels before they wait for the primitives' poses, so that the
+// two memory latencies overlap
+template <class T> __device__ __forceinline__ int first_flags(const Dev<T>& D) {
+    const int lane = threadIdx.x & 63;
+    return lane < D.fs ? D.flags[blockIdx.x * D.fs + lane] : 0;
+}
+template <class T, class Body> __device__ __forceinline__ void for_each_active_block(const Dev<T>& D, const HaloIn& H, int flags0, Body&& body) {
+    const int nblk = D.nbx * D.nby * D.nbz, g = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int k0 = 0; k0 < D.fs; k0 += 64) {
+        const int k = k0 + lane, b = g + (k << D.fgl);
+        const bool in = k < D.fs && b < nblk;
+        const int fl = k0 == 0 ? flags0 : (in ? D.flags[g * D.fs + k] : 0);
         // blocks in the exchanged planes are candidates whatever their flag: the neighbour's particles may reach
         // nodes that none of ours do (the body skips a candidate whose summed mass is zero everywhere)
-        const unsigned long long m = __ballot(b < nblk && (D.flags[b] != 0 || (H.n > 0 && halo_face_of(D, H, b) >= 0)));
+        const unsigned long long m = __ballot(in && (fl != 0 || (H.n > 0 && halo_face_of(D, H, b) >= 0)));
         __syncthreads();             // bodies may clear flags: every wave must have taken the same snapshot first
         int rank = 0;
         for (unsigned long long r = m; r; r &= r - 1, ++rank)
-            if ((rank & (kBlock / 64 - 1)) == wave) body(b0 + (__ffsll((long long)r) - 1) * G);
+            if ((rank & (kBlock / 64 - 1)) == wave) body(g + ((k0 + __ffsll((long long)r) - 1) << D.fgl));
     }
 }
 
@@ -302,11 +318,14 @@ template <class T> struct Seg {
     T m1, m2, m4, m8;   // 1 where the lane `d` to the right still belongs to this lane's run
     bool head;          // first lane of a (row-clipped) run
 };
+#ifndef PLB_SEG_STEPS
+#define PLB_SEG_STEPS 4          // 4: runs clipped at the 16-lane DPP rows; 3: at 8 lanes (one reduction step less, a few more LDS atomics)
+#endif
 template <class T> __device__ __forceinline__ Seg<T> wave_segments(int key) {
     const int lane = threadIdx.x & 63;
     int prev = __shfl_up(key, 1);
     Seg<T> s;
-    s.head = ((lane & 15) == 0) || (key != prev);
+    s.head = ((lane & ((1 << PLB_SEG_STEPS) - 1)) == 0) || (key != prev);
     unsigned long long heads = __ballot(s.head);
     unsigned long long higher = lane == 63 ? 0ULL : (heads >> (lane + 1));
     const int end = higher ? lane + __ffsll((long long)higher) - 1 : 63;
@@ -331,7 +350,9 @@ template <class T> __device__ __forceinline__ T seg_sum(T v, const Seg<T>& s) {
     v += row_shl<1>(v) * s.m1;
     v += row_shl<2>(v) * s.m2;
     v += row_shl<4>(v) * s.m4;
+#if PLB_SEG_STEPS >= 4
     v += row_shl<8>(v) * s.m8;
+#endif
     return v;
 }
 // Several values at once.  For float the four steps are single fused v_fmac_f32_dpp instructions (hipcc does
@@ -349,15 +370,20 @@ template <> __device__ __forceinline__ void seg_sum4<float>(float& a, float& b, 
         PLB_DPP_STEP("%0", "%4", "1") PLB_DPP_STEP("%1", "%4", "1") PLB_DPP_STEP("%2", "%4", "1") PLB_DPP_STEP("%3", "%4", "1")
         PLB_DPP_STEP("%0", "%5", "2") PLB_DPP_STEP("%1", "%5", "2") PLB_DPP_STEP("%2", "%5", "2") PLB_DPP_STEP("%3", "%5", "2")
         PLB_DPP_STEP("%0", "%6", "4") PLB_DPP_STEP("%1", "%6", "4") PLB_DPP_STEP("%2", "%6", "4") PLB_DPP_STEP("%3", "%6", "4")
+#if PLB_SEG_STEPS >= 4
         PLB_DPP_STEP("%0", "%7", "8") PLB_DPP_STEP("%1", "%7", "8") PLB_DPP_STEP("%2", "%7", "8") PLB_DPP_STEP("%3", "%7", "8")
+#endif
         : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(s.m1), "v"(s.m2), "v"(s.m4), "v"(s.m8));
 }
 template <> __device__ __forceinline__ void seg_sum3<float>(float& a, float& b, float& c, const Seg<float>& s) {
     asm("s_nop 1\n"
         PLB_DPP_STEP("%0", "%3", "1") PLB_DPP_STEP("%1", "%3", "1") PLB_DPP_STEP("%2", "%3", "1") "s_nop 0\n"
         PLB_DPP_STEP("%0", "%4", "2") PLB_DPP_STEP("%1", "%4", "2") PLB_DPP_STEP("%2", "%4", "2") "s_nop 0\n"
-        PLB_DPP_STEP("%0", "%5", "4") PLB_DPP_STEP("%1", "%5", "4") PLB_DPP_STEP("%2", "%5", "4") "s_nop 0\n"
+        PLB_DPP_STEP("%0", "%5", "4") PLB_DPP_STEP("%1", "%5", "4") PLB_DPP_STEP("%2", "%5", "4")
+#if PLB_SEG_STEPS >= 4
+        "s_nop 0\n"
         PLB_DPP_STEP("%0", "%6", "8") PLB_DPP_STEP("%1", "%6", "8") PLB_DPP_STEP("%2", "%6", "8")
+#endif
         : "+v"(a), "+v"(b), "+v"(c) : "v"(s.m1), "v"(s.m2), "v"(s.m4), "v"(s.m8));
 }
 #undef PLB_DPP_STEP
@@ -512,7 +538,7 @@ __global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_p2g(Dev<T> D, int f) 
                     int idx = node_index(D, base[0] + i, base[1] + j, base[2] + l);
                     atomicAdd(&D.gin[0][idx], a0); atomicAdd(&D.gin[1][idx], a1);
                     atomicAdd(&D.gin[2][idx], a2); atomicAdd(&D.gin[3][idx], a3);
-                    D.flags[idx >> 6] = 1;
+                    D.flags[flag_slot(D, idx >> 6)] = 1;
                 }
             });
         }
@@ -531,7 +557,7 @@ __global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_p2g(Dev<T> D, int f) 
                 int idx = node_index(D, tl.o[0] + lx, tl.o[1] + ly, tl.o[2] + lz);
                 atomicAdd(&D.gin[0][idx], (T)a.x); atomicAdd(&D.gin[1][idx], (T)a.y);
                 atomicAdd(&D.gin[2][idx], (T)a.z); atomicAdd(&D.gin[3][idx], (T)a.w);
-                D.flags[idx >> 6] = 1;
+                D.flags[flag_slot(D, idx >> 6)] = 1;
             }
         }
     }
@@ -543,10 +569,11 @@ __global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_p2g(Dev<T> D, int f) 
 template <class T, bool CLEAR>
 __global__ __launch_bounds__(kBlock) void k_grid_op(Dev<T> D, int f, HaloIn H) {
     __shared__ PrimT<T> sp[kMaxPrim];
+    const int fl0 = first_flags(D);
     load_prims(D, f, sp);
     __syncthreads();
     const int lane = threadIdx.x & 63;
-    for_each_active_block(D, H, [&](int blk) {
+    for_each_active_block(D, H, fl0, [&](int blk) {
         const int idx = (blk << 6) | lane;
         int I[3];
         block_nodes(D, blk, lane, I);
@@ -562,14 +589,14 @@ __global__ __launch_bounds__(kBlock) void k_grid_op(Dev<T> D, int f, HaloIn H) {
             if (!__any(m != T(0))) return;
             if (!CLEAR) {
                 D.gin[0][idx] = m; D.gin[1][idx] = mv[0]; D.gin[2][idx] = mv[1]; D.gin[3][idx] = mv[2];
-                if (lane == 0) D.flags[blk] = 1;
+                if (lane == 0) D.flags[flag_slot(D, blk)] = 1;
             }
         }
         grid_node_fwd<T>(D.P, I, m, mv, D.nprim, sp, vo);
         D.grid_out[idx] = Vec4<T>{vo[0], vo[1], vo[2], T(0)};
         if (CLEAR) {
             D.gin[0][idx] = T(0); D.gin[1][idx] = T(0); D.gin[2][idx] = T(0); D.gin[3][idx] = T(0);
-            if (lane == 0) D.flags[blk] = 0;
+            if (lane == 0) D.flags[flag_slot(D, blk)] = 0;
         }
     });
 }
@@ -726,7 +753,7 @@ __global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_g2p_p2g(Dev<T> D, int
                     int idx = node_index(D, base[0] + i, base[1] + j, base[2] + l);
                     atomicAdd(&D.gin[0][idx], a0); atomicAdd(&D.gin[1][idx], a1);
                     atomicAdd(&D.gin[2][idx], a2); atomicAdd(&D.gin[3][idx], a3);
-                    D.flags[idx >> 6] = 1;
+                    D.flags[flag_slot(D, idx >> 6)] = 1;
                 }
             });
         }
@@ -746,7 +773,7 @@ __global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_g2p_p2g(Dev<T> D, int
                 int idx = node_index(D, tl.o[0] + lx, tl.o[1] + ly, tl.o[2] + lz);
                 atomicAdd(&D.gin[0][idx], (T)a.x); atomicAdd(&D.gin[1][idx], (T)a.y);
                 atomicAdd(&D.gin[2][idx], (T)a.z); atomicAdd(&D.gin[3][idx], (T)a.w);
-                D.flags[idx >> 6] = 1;
+                D.flags[flag_slot(D, idx >> 6)] = 1;
             }
         }
     }
@@ -897,7 +924,7 @@ __device__ __forceinline__ bool grid_block_bwd(const Dev<T>& D, const HaloIn& H,
         // this frame's grid is consumed: leave grid_in / flags clean for the next scatter into them.  grid_in_adj
         // is never cleared -- p2g.grad only reads nodes of active blocks, which are all rewritten every substep.
         D.gin[0][idx] = T(0); D.gin[1][idx] = T(0); D.gin[2][idx] = T(0); D.gin[3][idx] = T(0);
-        if (lane == 0) D.flags[blk] = 0;
+        if (lane == 0) D.flags[flag_slot(D, blk)] = 0;
     }
     return defer;
 }
@@ -908,6 +935,7 @@ __device__ __forceinline__ bool grid_block_bwd(const Dev<T>& D, const HaloIn& H,
 template <class T>
 __global__ __launch_bounds__(kBlock) void k_grid_op_grad(Dev<T> D, int f, HaloIn H) {
     __shared__ PrimT<T> sp[kMaxPrim];
+    const int fl0 = first_flags(D);
     load_prims(D, f, sp);
     __syncthreads();
     const int lane = threadIdx.x & 63;
@@ -915,7 +943,7 @@ __global__ __launch_bounds__(kBlock) void k_grid_op_grad(Dev<T> D, int f, HaloIn
     // complete here: no halo candidates
     HaloIn none;
     none.n = 0;
-    for_each_active_block(D, none, [&](int blk) {
+    for_each_active_block(D, none, fl0, [&](int blk) {
         if (grid_block_bwd<T, false>(D, H, blk, lane, sp, nullptr, nullptr) && lane == 0)
             D.contact[1 + atomicAdd(&D.contact[0], 1)] = blk;
     });
@@ -1058,11 +1086,11 @@ template <class T>
 __global__ __launch_bounds__(kBlock) void k_clear_active(Dev<T> D) {
     const int blk = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
     const int nblk = D.nbx * D.nby * D.nbz;
-    if (blk >= nblk || D.flags[blk] == 0) return;
+    if (blk >= nblk || D.flags[flag_slot(D, blk)] == 0) return;
     const int lane = threadIdx.x & 63;
     const int idx = (blk << 6) | lane;
     D.gin[0][idx] = T(0); D.gin[1][idx] = T(0); D.gin[2][idx] = T(0); D.gin[3][idx] = T(0);
-    if (lane == 0) D.flags[blk] = 0;
+    if (lane == 0) D.flags[flag_slot(D, blk)] = 0;
 }
 
 }  // namespace plb

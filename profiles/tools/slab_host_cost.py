@@ -23,22 +23,31 @@ from plasticinelab_amd import distributed as D  # noqa: E402
 
 
 class LoopbackComm(D.HaloComm):
+    """No neighbours: the registered receive buffers stay zero (one memset per face and exchange stands in for the
+    arrival of a message), so the physics is that of a body with free faces; rows that leave are dropped."""
+
     def __init__(self, layout, rank):
         self.layout, self.rank, self.group = layout, rank, None
         self.stage_host = False
+        self.backend = "loopback"
         self.scalar_device = torch.device("cuda", torch.cuda.current_device())
+        self._recv, self._ops = {}, {}
+        self.down = rank - 1 if rank > 0 else None
+        self.up = rank + 1 if rank < layout.world - 1 else None
 
-    def plan(self, pack):
-        faces = []
-        for nbr, za, zb in self.layout.faces(self.rank):
-            s = pack(za, zb).contiguous()
-            faces.append(D.HaloFace(nbr, za, zb, s, torch.empty_like(s), s, s))
-        return D.HaloPlan(faces, [])
+    def exchange(self, engine, field, f):
+        if not self.layout.faces(self.rank):
+            return
+        if field not in self._recv:
+            self.attach(engine, field, f)
+        for rb in self._recv[field]:
+            rb.zero_()
 
-    def run(self, plan):
-        for fc in plan.faces:
-            fc.recv.copy_(fc.send, non_blocking=True)
-            fc.recv.mul_(0.0)                       # add zeros: the physics stays that of the single-GPU run
+    def exchange_counts(self, n_down, n_up):
+        return 0, 0
+
+    def exchange_rows(self, send_down, send_up, n_recv_down, n_recv_up, width, device):
+        return [None if n == 0 else torch.zeros(n * width, dtype=torch.float64, device=device) for n in (n_recv_down, n_recv_up)]
 
     def all_reduce_(self, t, op=None):
         return t
@@ -55,7 +64,8 @@ def main():
     ap.add_argument("--dtype", default="float32")
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--world", type=int, default=0, help="emulate the middle rank of a balanced N-slab cut (0: one rank owns all)")
-    ap.add_argument("--xy-margin", type=int, default=None)
+    ap.add_argument("--xy-margin", type=int, default=24)
+    ap.add_argument("--migrate-every", type=int, default=1)
     ap.add_argument("--profile", action="store_true", help="cProfile one rollout (top functions by own time)")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
@@ -64,18 +74,17 @@ def main():
     cfg = bench.workload_cfg(args.particles, args.quality, max_steps=max(args.steps, 1) * sub + 1)
     n = int(128 * args.quality * 0.5)
     # interior-rank geometry: rank 1 of 3 owns the whole body and has two faces just outside it
-    layout = D.SlabLayout(n, (0, int(0.31 * n), int(0.70 * n), n), 2)
+    layout = D.SlabLayout(n, (0, int(0.31 * n) // 4 * 4, (int(0.70 * n) + 3) // 4 * 4, n))
     rank, world = 1, 3
     if args.world > 1:                                   # the real cut bench.py would make, seen from a middle rank
         from plasticinelab_amd.engine.shapes import Shapes
         x_all, _ = Shapes(cfg.SHAPES).get()
         world, rank = args.world, args.world // 2
-        halo = max(2, min(4, (int(0.31 * n) + 3) // (2 * world)))
-        layout = D.SlabLayout.balanced(x_all, n, world, halo)
+        layout = D.SlabLayout.balanced(x_all, n, world)
     env, _, mine = D.make_slab_env(cfg, rank, world, compute_dtype=args.dtype, device=dev, target_fn=bench._target,
-                                   layout=layout, comm=LoopbackComm(layout, rank), xy_margin=args.xy_margin)
+                                   layout=layout, comm=LoopbackComm(layout, rank), xy_margin=args.xy_margin, migrate_every=args.migrate_every)
     print(f"rank {rank}/{world}: slab {layout.slab(rank)}, halo {layout.halo}, {len(mine)} particles, "
-          f"window {env.simulator.engine._halo_window}")
+          f"grid window {[list(map(int, a)) for a in env.simulator.engine.grid_window()]}")
     env.loss.set_weights(10, 10, 1, False)
     sim = env.simulator
     state0 = env.get_state()["state"]

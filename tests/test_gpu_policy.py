@@ -72,3 +72,58 @@ def test_policy_gradient_matches_oracle(oracle_c, dtype, ltol, gtol):
     ref = np.concatenate([p.grad.numpy().reshape(-1) for p in ref_policy.parameters()])
     assert abs(loss - float(total)) / abs(float(total)) < ltol
     assert np.abs(ref).max() > 0 and relerr(grad, ref) < gtol
+
+
+def test_per_step_autograd_functions():
+    """plasticinelab_amd.autograd.RolloutSession: one torch.autograd.Function per env step.  (a) A policy between the
+    steps: d loss / d policy-parameters equals SolverNN's (same engine, Tape + hooks); (b) nothing of the adjoint runs
+    before backward(); (c) per-step loss weights -- something the Tape form cannot express -- against the weighted sum of
+    single-step-loss gradients' defining property: linearity in the weights."""
+    from plasticinelab_amd.autograd import RolloutSession
+    from plasticinelab_amd.optimizer.solver_nn import SolverNN
+    from tests.test_gpu_rollout import make_env_sub
+    n_obs, vw, H = 50, 0.5, 3
+    env = make_env_sub("Move", 1500, "float64", soft_contact=True)
+    obs_dim = (1500 // (1500 // n_obs)) * 6 + 7 * len(env.primitives)
+    state0 = env.get_state()["state"]
+    solver = SolverNN(env, make_policy(obs_dim, env.primitives.action_dim), horizon=H, n_observed_particles=n_obs, velocity_weight=vw)
+    loss_ref, grad_ref = solver.forward(state0)
+
+    policy = make_policy(obs_dim, env.primitives.action_dim)
+
+    def rollout(weights):
+        sess = RolloutSession(env, state0, 666.0, n_observed_particles=n_obs, velocity_weight=vw)
+        carry = sess.begin()
+        losses = []
+        for _ in range(H):
+            act = torch.clamp(policy(sess.observe(carry)), -1.0, 1.0)
+            l, carry = sess.step(act, carry)
+            losses.append(l)
+        return sess, sum(w * l for w, l in zip(weights, losses)), losses
+
+    def pgrad():
+        g = np.concatenate([p.grad.numpy().reshape(-1) for p in policy.parameters()])
+        for p in policy.parameters():
+            p.grad = None
+        return g
+
+    sess, total, losses = rollout([1.0] * H)
+    assert abs(float(total) - loss_ref) / abs(loss_ref) < 1e-12
+    assert not sess._grad_started                                   # (b) forward only so far
+    total.backward()
+    g1 = pgrad()
+    assert np.abs(grad_ref).max() > 0 and relerr(g1, grad_ref) < 1e-9      # (a)
+    with pytest.raises(RuntimeError, match="already been differentiated"):
+        sess.step(torch.zeros(env.primitives.action_dim, dtype=torch.float64), torch.zeros((), dtype=torch.float64))
+    # (c) weights (w0, w1, w2): gradient is linear in them
+    basis = []
+    for k in range(H):
+        _, t, _ = rollout([1.0 if j == k else 0.0 for j in range(H)])
+        t.backward()
+        basis.append(pgrad())
+    w = [0.3, -1.7, 2.2]
+    _, t, _ = rollout(w)
+    t.backward()
+    gw = pgrad()
+    assert relerr(gw, sum(wk * b for wk, b in zip(w, basis))) < 1e-9
+    assert relerr(sum(basis), g1) < 1e-9
