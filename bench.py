@@ -283,6 +283,9 @@ def main():
     sub = sim.substeps
     A = env.primitives.action_dim
 
+    # the box's own HBM roofs (reported in `roofline`), measured before anything is timed: 1 GiB copy and read sweeps
+    # with the library's 16 B / lane kernels -- which also brings a fresh box's clocks up before the warm-up steps
+    copy_gbs, read_gbs = sim.engine.measure_hbm() if not args.no_roofline else (None, None)
     if W > 0 and not slabs:
         env.set_state(state0, 666.0, False)
         rollout(env, seeded_actions(W, A))
@@ -343,7 +346,6 @@ def main():
         alg_substep = 4.0 * (150 * N + 57 * nodes)            # this rank's share
         alg_unit = 4.0 * (150 * float(tot[0]) + 57 * float(tot[1]))     # bytes of one substep as counted in `value`
         sum_us = sum(v["avg_us"] * v["launches"] for v in kernels.values()) / (K * sub)     # per fwd+bwd substep
-        copy_gbs, read_gbs = sim.engine.measure_hbm()
         traffic, traffic_src = pmc_traffic(dom, workload, out["dtype"]) if world == 1 else (None, None)
         out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": kernels[dom]["GBps"], "peak": HBM_PEAK_GBS,
                            "unit": "GB/s", "frac": kernels[dom]["GBps"] / HBM_PEAK_GBS,

@@ -1132,6 +1132,7 @@ int plmpm_bind_workspace(plmpm_handle s, void* state, void* adjoint, void* grid,
     if (s->dist) { s->ppos_l = (double*)take(F1 * P1 * 3 * 8); s->prot_l = (double*)take(F1 * P1 * 4 * 8); s->pgap_l = (double*)take(F1 * P1 * 8); }
     REQUIRE((size_t)(p - s->miscw) <= s->ws.misc_bytes, "internal: misc workspace overflow");
     // initial contents: zero grids / adjoints / primitive buffers, identity order
+    HIPCHK(hipMemsetAsync(s->state, 0, s->ws.state_bytes, s->stream));       // frames are first touched here, not inside a caller's timed region
     HIPCHK(hipMemsetAsync(s->adjw, 0, s->ws.adjoint_bytes, s->stream));
     HIPCHK(hipMemsetAsync(s->gridw, 0, s->ws.grid_bytes, s->stream));
     HIPCHK(hipMemsetAsync(s->miscw, 0, s->ws.misc_bytes, s->stream));

@@ -217,6 +217,22 @@ struct Tile {
     int ok;        // fits in the LDS tile
 };
 
+// linear tile index -> (lz, ly, lx).  Tiles hold < 2^11 nodes, so the two divisions are a float multiply by a
+// reciprocal plus one correction each (~8 VALU instructions) instead of the ~30-instruction integer division hipcc
+// expands -- these run once per tile loop in every wave of the particle kernels.
+__device__ __forceinline__ int small_div(int i, int d) {
+    int q = (int)((float)i * __builtin_amdgcn_rcpf((float)d));      // v_rcp_f32: within 1 ulp, the two corrections make it exact
+    q += ((q + 1) * d <= i) ? 1 : 0;
+    q -= (q * d > i) ? 1 : 0;
+    return q;
+}
+__device__ __forceinline__ void tile_coords(int i, int ex, int exy, int& lz, int& ly, int& lx) {
+    lz = small_div(i, exy);
+    const int r = i - lz * exy;
+    ly = small_div(r, ex);
+    lx = r - ly * ex;
+}
+
 // wave-wide min / max of an int: DPP scan inside the rows, row_bcast to chain the rows, result read from lane 63
 // (six VALU steps instead of six dependent trips through the LDS crossbar)
 template <bool MAX> __device__ __forceinline__ int wave_minmax(int v) {
@@ -553,7 +569,8 @@ __global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_p2g(Dev<T> D, int f) 
         for (int i = threadIdx.x; i < tn; i += kBlock) {
             Vec4<double> a = tile[i];
             if (a.x != 0.0 || a.y != 0.0 || a.z != 0.0 || a.w != 0.0) {
-                int lz = i / exy, r = i - lz * exy, ly = r / ex, lx = r - ly * ex;
+                int lz, ly, lx;
+                tile_coords(i, ex, exy, lz, ly, lx);
                 int idx = node_index(D, tl.o[0] + lx, tl.o[1] + ly, tl.o[2] + lz);
                 atomicAdd(&D.gin[0][idx], (T)a.x); atomicAdd(&D.gin[1][idx], (T)a.y);
                 atomicAdd(&D.gin[2][idx], (T)a.z); atomicAdd(&D.gin[3][idx], (T)a.w);
@@ -616,7 +633,8 @@ __global__ __launch_bounds__(kBlock) void k_g2p(Dev<T> D, int f) {
     const int ex = tl.e[0], exy = tl.e[0] * tl.e[1], tn = exy * tl.e[2];
     if (tl.ok) {
         for (int i = threadIdx.x; i < tn; i += kBlock) {
-            int lz = i / exy, r = i - lz * exy, ly = r / ex, lx = r - ly * ex;
+            int lz, ly, lx;
+                tile_coords(i, ex, exy, lz, ly, lx);
             tile[i] = D.grid_out[node_index(D, tl.o[0] + lx, tl.o[1] + ly, tl.o[2] + lz)];
         }
         __syncthreads();
@@ -671,7 +689,8 @@ __global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_g2p_p2g(Dev<T> D, int
         const int ex = ta.e[0], exy = ta.e[0] * ta.e[1], tn = exy * ta.e[2];
         if (ta.ok)
             for (int i = threadIdx.x; i < tn; i += kBlock) {
-                int lz = i / exy, r = i - lz * exy, ly = r / ex, lx = r - ly * ex;
+                int lz, ly, lx;
+                tile_coords(i, ex, exy, lz, ly, lx);
                 tile_v[i] = vout_prev[node_index(D, ta.o[0] + lx, ta.o[1] + ly, ta.o[2] + lz)];
             }
     }
@@ -769,7 +788,8 @@ __global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_g2p_p2g(Dev<T> D, int
         for (int i = threadIdx.x; i < tn; i += kBlock) {
             Vec4<double> a = tile[i];
             if (a.x != 0.0 || a.y != 0.0 || a.z != 0.0 || a.w != 0.0) {
-                int lz = i / exy, r = i - lz * exy, ly = r / ex, lx = r - ly * ex;
+                int lz, ly, lx;
+                tile_coords(i, ex, exy, lz, ly, lx);
                 int idx = node_index(D, tl.o[0] + lx, tl.o[1] + ly, tl.o[2] + lz);
                 atomicAdd(&D.gin[0][idx], (T)a.x); atomicAdd(&D.gin[1][idx], (T)a.y);
                 atomicAdd(&D.gin[2][idx], (T)a.z); atomicAdd(&D.gin[3][idx], (T)a.w);
@@ -800,7 +820,8 @@ __global__ __launch_bounds__(kBlock) void k_g2p_grad(Dev<T> D, int f, int src, i
     const int ex = tl.e[0], exy = tl.e[0] * tl.e[1], tn = exy * tl.e[2];
     if (tl.ok)
         for (int i = threadIdx.x; i < tn; i += kBlock) {
-            int lz = i / exy, r = i - lz * exy, ly = r / ex, lx = r - ly * ex;
+            int lz, ly, lx;
+                tile_coords(i, ex, exy, lz, ly, lx);
             tile[i] = D.grid_out[node_index(D, tl.o[0] + lx, tl.o[1] + ly, tl.o[2] + lz)];
             tile_a[3 * i] = 0.0; tile_a[3 * i + 1] = 0.0; tile_a[3 * i + 2] = 0.0;
         }
@@ -865,7 +886,8 @@ __global__ __launch_bounds__(kBlock) void k_g2p_grad(Dev<T> D, int f, int src, i
         for (int i = threadIdx.x; i < tn; i += kBlock) {
             const double ax = tile_a[3 * i], ay = tile_a[3 * i + 1], az = tile_a[3 * i + 2];
             if (ax != 0.0 || ay != 0.0 || az != 0.0) {
-                int lz = i / exy, r = i - lz * exy, ly = r / ex, lx = r - ly * ex;
+                int lz, ly, lx;
+                tile_coords(i, ex, exy, lz, ly, lx);
                 int idx = node_index(D, tl.o[0] + lx, tl.o[1] + ly, tl.o[2] + lz);
                 atomicAdd(&D.goa[0][idx], (T)ax); atomicAdd(&D.goa[1][idx], (T)ay); atomicAdd(&D.goa[2][idx], (T)az);
             }
@@ -917,7 +939,7 @@ __device__ __forceinline__ bool grid_block_bwd(const Dev<T>& D, const HaloIn& H,
         }
     });
     const bool defer = !POSE && __any(due);
-    if (!POSE) D.grid_in_adj[idx] = Vec4<T>{ma, mva[0], mva[1], mva[2]};
+    if (!POSE) D.grid_in_adj[idx] = Vec4<T>{mva[0], mva[1], mva[2], ma};      // vector part first: (x, y) is an aligned register pair for the packed gather
     if (defer && hf >= 0) { D.goa[0][idx] = va[0]; D.goa[1][idx] = va[1]; D.goa[2][idx] = va[2]; }
     if (!defer) {
         D.goa[0][idx] = T(0); D.goa[1][idx] = T(0); D.goa[2][idx] = T(0);
@@ -977,6 +999,91 @@ __device__ __forceinline__ void pose_adjoint_blocks(const Dev<T>& D, int f, int 
     }
 }
 
+// Packed-fp32 flavour of p2g_gather_grad (mpm_math.h) for the fp32 engine.  On gfx950 a plain v_fma_f32 issues in ~4
+// cycles per wave and v_pk_fma_f32 does two in ~4.9 (profiles/microbench/boundary_valu.hip), so the x and y components
+// of the gathered vector field -- an aligned register pair straight out of the 16-byte tile read {x, y, z, m} -- go
+// through the three axis contractions as one packed multiply-add, z and the mass field as scalar ones.  Same sums in
+// the same order as the scalar version; the SLP vectoriser's own attempt at this costs more in shuffles than it saves.
+#ifndef PLB_P2GG_EARLY_LOADS
+#define PLB_P2GG_EARLY_LOADS 0
+#endif
+#ifndef PLB_PK_GATHER
+#define PLB_PK_GATHER 0          // measured (round 2): p2g_grad 47.3 us with, 46.7 without -- the kernel is as much HBM- as VALU-bound; kept for reference
+#endif
+typedef float plb_f2 __attribute__((ext_vector_type(2)));
+template <class X, class Fetch4>
+__device__ __forceinline__ void p2g_gather_grad_pk(const SimP<float>& P, const X* x, P2GGather<float>& G, Fetch4&& fetch) {
+    int base[3];
+    float fx[3], w[3][3], dw[3][3];
+    stencil<float, X>(x, P.inv_dx, base, fx, w, dw);
+    enum { W = 0, Dd = 1, ZW = 2, ZD = 3 };
+    constexpr int kPairY[9] = {W, Dd, W, ZW, ZD, ZW, W, Dd, W};
+    constexpr int kPairZ[9] = {W, W, Dd, W, W, Dd, ZW, ZW, ZD};
+    constexpr int kCombX[16] = {W, ZW, W, W, ZD, ZW, ZW, Dd, W, W, Dd, W, W, Dd, W, W};
+    constexpr int kCombP[16] = {0, 0, 3, 6, 0, 1, 2, 3, 4, 5, 6, 7, 8, 0, 1, 2};
+    float cz[4][3];
+    for (int n = 0; n < 3; ++n) {
+        const float z = float(n) - fx[2];
+        cz[W][n] = w[n][2]; cz[Dd][n] = dw[n][2]; cz[ZW][n] = z * w[n][2]; cz[ZD][n] = z * dw[n][2];
+    }
+    plb_f2 Fxy[16];                      // final sums, (x, y) components
+    float Fz[16], Fm[3];                 // z component, mass field
+    for (int c = 0; c < 16; ++c) { Fxy[c] = plb_f2{0.f, 0.f}; Fz[c] = 0.f; }
+    Fm[0] = Fm[1] = Fm[2] = 0.f;
+    PLB_ROLL_GATH_I
+    for (int i = 0; i < 3; ++i) {
+        plb_f2 Sxy[9];
+        float Sz[9], Sm[3];
+        for (int q = 0; q < 9; ++q) { Sxy[q] = plb_f2{0.f, 0.f}; Sz[q] = 0.f; }
+        Sm[0] = Sm[1] = Sm[2] = 0.f;
+        PLB_ROLL_GATH_J
+        for (int j = 0; j < 3; ++j) {
+            plb_f2 Rxy[4];
+            float Rz[4], Rm[2];
+            for (int t = 0; t < 4; ++t) { Rxy[t] = plb_f2{0.f, 0.f}; Rz[t] = 0.f; }
+            Rm[0] = Rm[1] = 0.f;
+            for (int l = 0; l < 3; ++l) {
+                const Vec4<float> a = fetch(i, j, l);                    // {mv'_x, mv'_y, mv'_z, m'}
+                const plb_f2 gxy = plb_f2{a.x, a.y};
+                Rm[W] += cz[W][l] * a.w;
+                Rm[Dd] += cz[Dd][l] * a.w;
+                for (int t = 0; t < 4; ++t) {
+                    Rxy[t] += plb_f2{cz[t][l], cz[t][l]} * gxy;
+                    Rz[t] += cz[t][l] * a.z;
+                }
+            }
+            const float yw = sel3(j, w[0][1], w[1][1], w[2][1]), yd = sel3(j, dw[0][1], dw[1][1], dw[2][1]);
+            const float zy = float(j) - fx[1];
+            const float cy[4] = {yw, yd, zy * yw, zy * yd};
+            for (int q = 0; q < 9; ++q) {
+                const float c = cy[kPairY[q]];
+                Sxy[q] += plb_f2{c, c} * Rxy[kPairZ[q]];
+                Sz[q] += c * Rz[kPairZ[q]];
+            }
+            Sm[0] += cy[W] * Rm[W]; Sm[1] += cy[Dd] * Rm[W]; Sm[2] += cy[W] * Rm[Dd];
+        }
+        const float xw = sel3(i, w[0][0], w[1][0], w[2][0]), xd = sel3(i, dw[0][0], dw[1][0], dw[2][0]);
+        const float zx = float(i) - fx[0];
+        const float cx[4] = {xw, xd, zx * xw, zx * xd};
+        for (int c = 0; c < 16; ++c) {
+            const float k = cx[kCombX[c]];
+            Fxy[c] += plb_f2{k, k} * Sxy[kCombP[c]];
+            Fz[c] += k * Sz[kCombP[c]];
+        }
+        Fm[0] += cx[Dd] * Sm[0]; Fm[1] += cx[W] * Sm[1]; Fm[2] += cx[W] * Sm[2];
+    }
+    auto comp = [&](int c, int a) { return a == 0 ? Fxy[c].x : (a == 1 ? Fxy[c].y : Fz[c]); };
+    for (int a = 0; a < 3; ++a) {
+        G.va[a] = P.p_mass * comp(0, a);
+        for (int b = 0; b < 3; ++b) {
+            G.Aa[3 * a + b] = P.dx * comp(1 + b, a);
+            for (int d = 0; d < 3; ++d) G.M[9 * a + 3 * b + d] = P.dx * comp(4 + 3 * b + d, a);
+        }
+        for (int d = 0; d < 3; ++d) G.sv[3 * d + a] = comp(13 + d, a);
+    }
+    for (int d = 0; d < 3; ++d) G.sm[d] = Fm[d];
+}
+
 // ------------------------------------------------------------------------------------------------
 // p2g.grad + svd_grad + compute_F_tmp.grad: gather grid_in_adj, finish adjoint frame `dst`
 template <class T>
@@ -998,7 +1105,8 @@ __global__ __launch_bounds__(kBlock, sizeof(T) == 4 ? PLB_P2G_GRAD_WAVES : 1) vo
     const int ex = tl.e[0], exy = tl.e[0] * tl.e[1], tn = exy * tl.e[2];
     if (tl.ok) {
         for (int i = threadIdx.x; i < tn; i += kBlock) {
-            int lz = i / exy, r = i - lz * exy, ly = r / ex, lx = r - ly * ex;
+            int lz, ly, lx;
+                tile_coords(i, ex, exy, lz, ly, lx);
             tile[i] = D.grid_in_adj[node_index(D, tl.o[0] + lx, tl.o[1] + ly, tl.o[2] + lz)];
         }
         __syncthreads();
@@ -1010,25 +1118,46 @@ __global__ __launch_bounds__(kBlock, sizeof(T) == 4 ? PLB_P2G_GRAD_WAVES : 1) vo
     if (!valid) return;
     // the 27-node gather needs the position only: the other 42 words of particle state are fetched after it, so
     // that they are not live across the loop (the kernel then fits 3 waves per SIMD instead of 2)
-    P2GGather<T> G;
-    if (tl.ok) {
-        const int ox = base[0] - tl.o[0], oy = base[1] - tl.o[1], oz = base[2] - tl.o[2];
-        p2g_gather_grad<T, double>(D.P, x, G, [&](int i, int j, int l, T* g) {
-            Vec4<T> a = tile[(oz + l) * exy + (oy + j) * ex + (ox + i)];
-            g[0] = a.x; g[1] = a.y; g[2] = a.z; g[3] = a.w;
-        });
-    } else {
-        p2g_gather_grad<T, double>(D.P, x, G, [&](int i, int j, int l, T* g) {
-            Vec4<T> a = D.grid_in_adj[node_index(D, base[0] + i, base[1] + j, base[2] + l)];
-            g[0] = a.x; g[1] = a.y; g[2] = a.z; g[3] = a.w;
-        });
-    }
+#if PLB_P2GG_EARLY_LOADS
+    // experiment: issue the particle-state loads before the 27-node gather (they fly during it) and let the register
+    // allocator spill what does not fit, instead of exposing a second memory latency after the loop
     T v[3], C[9], E[9], Ena[9], xa[3], va[3], Ca[9], Ea[9];
     const T* A1 = D.adj[src];
     T* A0 = D.adj[dst];
     for (int d = 0; d < 3; ++d) { v[d] = R[d * Np + p]; xa[d] = A0[d * Np + p]; }
     for (int d = 0; d < 9; ++d) { C[d] = R[(3 + d) * Np + p]; E[d] = R[(12 + d) * Np + p]; Ena[d] = A1[(15 + d) * Np + p]; }
     const T mu = D.mu[p], lam = D.lam[p], ys = D.ys[p];
+#endif
+    P2GGather<T> G;
+#if PLB_PK_GATHER
+    if constexpr (sizeof(T) == 4) {
+        if (tl.ok) {
+            const int ox = base[0] - tl.o[0], oy = base[1] - tl.o[1], oz = base[2] - tl.o[2];
+            p2g_gather_grad_pk(D.P, x, G, [&](int i, int j, int l) { return tile[(oz + l) * exy + (oy + j) * ex + (ox + i)]; });
+        } else
+            p2g_gather_grad_pk(D.P, x, G, [&](int i, int j, int l) { return D.grid_in_adj[node_index(D, base[0] + i, base[1] + j, base[2] + l)]; });
+    } else
+#endif
+    if (tl.ok) {
+        const int ox = base[0] - tl.o[0], oy = base[1] - tl.o[1], oz = base[2] - tl.o[2];
+        p2g_gather_grad<T, double>(D.P, x, G, [&](int i, int j, int l, T* g) {
+            Vec4<T> a = tile[(oz + l) * exy + (oy + j) * ex + (ox + i)];
+            g[0] = a.w; g[1] = a.x; g[2] = a.y; g[3] = a.z;
+        });
+    } else {
+        p2g_gather_grad<T, double>(D.P, x, G, [&](int i, int j, int l, T* g) {
+            Vec4<T> a = D.grid_in_adj[node_index(D, base[0] + i, base[1] + j, base[2] + l)];
+            g[0] = a.w; g[1] = a.x; g[2] = a.y; g[3] = a.z;
+        });
+    }
+#if !PLB_P2GG_EARLY_LOADS
+    T v[3], C[9], E[9], Ena[9], xa[3], va[3], Ca[9], Ea[9];
+    const T* A1 = D.adj[src];
+    T* A0 = D.adj[dst];
+    for (int d = 0; d < 3; ++d) { v[d] = R[d * Np + p]; xa[d] = A0[d * Np + p]; }
+    for (int d = 0; d < 9; ++d) { C[d] = R[(3 + d) * Np + p]; E[d] = R[(12 + d) * Np + p]; Ena[d] = A1[(15 + d) * Np + p]; }
+    const T mu = D.mu[p], lam = D.lam[p], ys = D.ys[p];
+#endif
     p2g_finish_grad<T>(D.P, G, v, C, E, mu, lam, ys, Ena, xa, va, Ca, Ea);
     PT_MARK(2);
     for (int d = 0; d < 3; ++d) { A0[d * Np + p] = xa[d]; A0[(3 + d) * Np + p] = va[d]; }
@@ -1073,7 +1202,8 @@ __global__ __launch_bounds__(kBlock) void k_grid_mass(Dev<T> D, int f, T* gm) {
         for (int i = threadIdx.x; i < tn; i += kBlock) {
             double a = tile[i];
             if (a != 0.0) {
-                int lz = i / exy, r = i - lz * exy, ly = r / ex, lx = r - ly * ex;
+                int lz, ly, lx;
+                tile_coords(i, ex, exy, lz, ly, lx);
                 atomicAdd(&gm[node_index(D, tl.o[0] + lx, tl.o[1] + ly, tl.o[2] + lz)], (T)a);
             }
         }
