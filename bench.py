@@ -117,6 +117,8 @@ def build_env(args, device, rank=0, world=1, slabs=False):
     frames = max(args.steps, args.warmup, 1) * sub + 1
     cfg = workload_cfg(args.particles, args.quality, max_steps=frames, yield_stress=getattr(args, "yield_stress", 200.0),
                        side=getattr(args, "side", 0.31))
+    if getattr(args, "deterministic", False) and not slabs:
+        cfg.SIMULATOR["deterministic"] = True
     if slabs:
         import torch.distributed as dist
         from plasticinelab_amd.distributed import make_slab_env
@@ -138,6 +140,8 @@ def build_env(args, device, rank=0, world=1, slabs=False):
     env.loss.load_target_density(grids=_target(env.init_particles, env.simulator))
     env.loss.set_weights(10, 10, 1, False)
     note = "" if getattr(args, "window", -1) < 0 else f", grid window = body + {args.window} layers"
+    if getattr(args, "deterministic", False):
+        note += ", deterministic accumulation"
     return env, (("single GPU" if world == 1 else f"{world} independent replicas (no collective)") + note)
 
 
@@ -216,6 +220,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--replicas", action="store_true", help="N > 1: independent replicas instead of z-slabs")
+    ap.add_argument("--deterministic", action="store_true", help="single GPU: the bit-reproducible engine (integer-limb accumulation); "
+                    "a cost measurement, not the headline")
     ap.add_argument("--window", type=int, default=-1, help="single GPU: allocate / sweep only the body's bounding box + this many node "
                     "layers of the grid (plmpm_config.grid_lo / grid_hi); -1 = the whole grid, as the reference lays it out")
     args = ap.parse_args()

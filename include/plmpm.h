@@ -82,7 +82,12 @@ typedef struct plmpm_config {
     /* rows every particle frame has room for (>= n_particles; 0 = n_particles).  Slab engines gain and lose
      * particles by migration (plmpm_migrate_*), so their frames are sized with head-room. */
     int32_t particle_capacity;
-    int32_t reserved0;
+    /* 1: bit-reproducible runs.  Every sum that several waves contribute to (grid_m / grid_v_in, grid_v_out.grad, the
+     * loss grid and scalars, pose adjoints) is accumulated in two 64-bit integer limbs instead of floating-point
+     * atomics, so the result does not depend on the arrival order; the same rollout then gives the same bits every
+     * time, on every launch schedule and across re-sorts.  Slower (measured in DESIGN.md); contributions must stay below 2^38 in
+     * magnitude.  Single-GPU engines only (the arrival order of migrating particles is not fixed).  0: fp atomics. */
+    int32_t deterministic;
 } plmpm_config;
 
 /* One rigid manipulator; mirrors Primitive.default_config + per-shape params

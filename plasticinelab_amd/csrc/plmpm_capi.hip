@@ -44,6 +44,9 @@ static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 enum { LS_DENSITY = 0, LS_SDF = 1, LS_MAXGM = 2, LS_DOT = 3, LS_SUMGM = 4, LS_MIND = 8, LS_DNORM = 16, LS_COUNT = 32 };
 
 struct plmpm_sim {
+    bool det = false;                           // cfg.deterministic: integer-limb accumulation (plmpm_kernels.h: det_add)
+    long long* det_grid = nullptr;              //   [8][G] limbs of the grid scatters
+    long long* det_small = nullptr;             //   [LS_COUNT + kMaxPrim * 8][2] limbs of the loss scalars / loss pose adjoints
     plmpm_config cfg;
     plmpm_primitive prims[PLMPM_MAX_PRIMITIVES];
     int gwg = 1, gwg_log2 = 0, fs = 1, nflag = 1;   // grid workgroups (a power of two), flags per workgroup, flag slots = gwg * fs >= nblk
@@ -156,6 +159,41 @@ static void prof_end(plmpm_sim* s) {
         prof_end(s);                                                                       \
     } while (0)
 
+// Scatter launches.  Deterministic engines (cfg.deterministic) run the DET instantiation -- integer-limb accumulation,
+// plmpm_kernels.h -- followed by the sweep that turns the limbs into the T sums the next kernel reads.
+#define DET_RESOLVE(s, d0, d1, d2, d3) \
+    hipLaunchKernelGGL((k_det_resolve<T>), dim3(1024), dim3(256), 0, (s)->stream, (s)->det_grid, (s)->G, d0, d1, d2, d3)
+#define LAUNCH_P2G(s, id, WF, D, f)                                                                              \
+    do {                                                                                                         \
+        if ((s)->det) {                                                                                          \
+            LAUNCH(s, id, (k_p2g<T, WF, true>), dim3(nblocks_particles(s, f)), D, f);                            \
+            DET_RESOLVE(s, D.gin[0], D.gin[1], D.gin[2], D.gin[3]);                                              \
+        } else LAUNCH(s, id, (k_p2g<T, WF>), dim3(nblocks_particles(s, f)), D, f);                               \
+    } while (0)
+#define LAUNCH_G2P_P2G(s, D, f, vprev)                                                                           \
+    do {                                                                                                         \
+        if ((s)->det) {                                                                                          \
+            LAUNCH(s, K_G2P_P2G, (k_g2p_p2g<T, true>), dim3(nblocks_particles(s, f)), D, f, vprev);              \
+            DET_RESOLVE(s, D.gin[0], D.gin[1], D.gin[2], D.gin[3]);                                              \
+        } else LAUNCH(s, K_G2P_P2G, (k_g2p_p2g<T>), dim3(nblocks_particles(s, f)), D, f, vprev);                 \
+    } while (0)
+#define LAUNCH_G2P_GRAD(s, D, f, src, dst, vnext)                                                                \
+    do {                                                                                                         \
+        if ((s)->det) {                                                                                          \
+            LAUNCH(s, K_G2P_GRAD, (k_g2p_grad<T, true>), dim3(nblocks_particles(s, f)), D, f, src, dst, vnext);  \
+            DET_RESOLVE(s, D.goa[0], D.goa[1], D.goa[2], (T*)nullptr);                                           \
+        } else LAUNCH(s, K_G2P_GRAD, (k_g2p_grad<T>), dim3(nblocks_particles(s, f)), D, f, src, dst, vnext);     \
+    } while (0)
+// p2g.grad with the pose adjoints of the blocks in contact: spare workgroups of the same launch, or -- deterministic
+// engines -- one wave walking the contact list in block order first
+#define LAUNCH_P2G_GRAD(s, D, f, src, dst)                                                                       \
+    do {                                                                                                         \
+        if ((s)->det) {                                                                                          \
+            hipLaunchKernelGGL((k_pose_adjoint_det<T>), dim3(1), dim3(64), 0, (s)->stream, D, f);                \
+            LAUNCH(s, K_P2G_GRAD, (k_p2g_grad<T>), dim3(nblocks_particles(s, f)), D, f, src, dst, 0);            \
+        } else LAUNCH(s, K_P2G_GRAD, (k_p2g_grad<T>), dim3(nblocks_particles(s, f) + kPoseWG), D, f, src, dst, kPoseWG); \
+    } while (0)
+
 // ---------------------------------------------------------------------------------------------
 // frame >= 0 with the grid store on: that frame's own grid_in / flags; otherwise the shared scratch grid
 template <class T> static Dev<T> make_dev(const plmpm_sim* s, int frame = -1) {
@@ -196,6 +234,7 @@ template <class T> static Dev<T> make_dev(const plmpm_sim* s, int frame = -1) {
     D.flags = framed ? s->fstore + (size_t)frame * s->nflag : s->flags;
     D.tiles = s->tiles;
     D.contact = s->contact;
+    D.det = s->det_grid; D.det_stride = s->G;
     D.trace = (unsigned long long*)s->staging;      // profiling builds only (needs N * 24 * 8 >= 3 * 16384 * 128 bytes)
     D.ppos = s->ppos; D.prot = s->prot; D.pgap = s->pgap;
     D.ppos_a = s->dist ? s->ppos_l : s->ppos_a;
@@ -466,7 +505,12 @@ __device__ __forceinline__ double block_max(double v, double* sh) {
     return r;
 }
 // density / sdf losses (loss.py:145-153) + IoU sums (loss.py:239-254)
-template <class T> __global__ void k_loss_reduce(size_t G, int nbxy, int gz, int z0, int z1, const T* gm, const T* td, const T* ts, double* ls) {
+// dl: deterministic mode only (else null) -- two integer limbs per loss scalar, see det_add (plmpm_kernels.h)
+__device__ __forceinline__ void ls_add(double* ls, long long* dl, int slot, double v) {
+    if (dl) det_add(dl + 2 * slot, dl + 2 * slot + 1, v);
+    else atomicAdd(&ls[slot], v);
+}
+template <class T> __global__ void k_loss_reduce(size_t G, int nbxy, int gz, int z0, int z1, const T* gm, const T* td, const T* ts, double* ls, long long* dl) {
     __shared__ double sh[8];
     double dens = 0, sdf = 0, mx = 0, dot = 0, sum = 0;
     const unsigned nb2 = (unsigned)nbxy;                      // blocks per z-plane of the window (32-bit division)
@@ -479,7 +523,7 @@ template <class T> __global__ void k_loss_reduce(size_t G, int nbxy, int gz, int
     dens = block_sum(dens, sh); sdf = block_sum(sdf, sh); dot = block_sum(dot, sh); sum = block_sum(sum, sh);
     mx = block_max(mx, sh);
     if (threadIdx.x == 0) {
-        atomicAdd(&ls[LS_DENSITY], dens); atomicAdd(&ls[LS_SDF], sdf); atomicAdd(&ls[LS_DOT], dot); atomicAdd(&ls[LS_SUMGM], sum);
+        ls_add(ls, dl, LS_DENSITY, dens); ls_add(ls, dl, LS_SDF, sdf); ls_add(ls, dl, LS_DOT, dot); ls_add(ls, dl, LS_SUMGM, sum);
         atomicMax(reinterpret_cast<unsigned long long*>(&ls[LS_MAXGM]), (unsigned long long)__double_as_longlong(mx));
     }
 }
@@ -506,7 +550,7 @@ __device__ __forceinline__ double block_min(double v, double* sh) {
     __syncthreads();
     return r;
 }
-template <class T> __global__ void k_contact(Dev<T> D, int f, int mode, double* ls) {
+template <class T> __global__ void k_contact(Dev<T> D, int f, int mode, double* ls, long long* dl) {
     __shared__ double sh[8];
     const double* X = frame_x(D, f);
     for (int q = 0; q < D.nprim; ++q) {
@@ -530,16 +574,17 @@ template <class T> __global__ void k_contact(Dev<T> D, int f, int mode, double* 
                 atomicMin(reinterpret_cast<unsigned long long*>(&ls[LS_MIND + q]), (unsigned long long)__double_as_longlong(m));
         } else {
             const double v = block_sum(acc, sh);
-            if (threadIdx.x == 0) atomicAdd(&ls[(mode == 1 ? LS_DNORM : LS_MIND) + q], v);
+            if (threadIdx.x == 0) ls_add(ls, dl, (mode == 1 ? LS_DNORM : LS_MIND) + q, v);
         }
     }
 }
 // compute_loss_kernel_grad (loss.py:210-237) per particle: density + sdf through grid_m, contact through sdf.
 template <class T>
 __global__ void k_loss_grad(Dev<T> D, int f, int which, const T* gm, const T* td, const T* ts, const double* ls,
-                            double w_sdf, double w_density, double w_contact, int soft) {
+                            double w_sdf, double w_density, double w_contact, int soft, long long* dl) {
     __shared__ double sacc[kMaxPrim * 8];
-    if (threadIdx.x < kMaxPrim * 8) sacc[threadIdx.x] = 0.0;
+    __shared__ long long sdet[kMaxPrim * 8 * 2];          // deterministic mode: integer limbs instead of sacc
+    if (threadIdx.x < kMaxPrim * 8) { sacc[threadIdx.x] = 0.0; sdet[2 * threadIdx.x] = 0; sdet[2 * threadIdx.x + 1] = 0; }
     __syncthreads();
     int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p < D.N) {
@@ -588,15 +633,26 @@ __global__ void k_loss_grad(Dev<T> D, int f, int which, const T* gm, const T* td
                 inv_trans_adj(x, pr.pos, pr.rot, iq, loca, pa, ra);
                 for (int d = 0; d < 3; ++d) xa[d] -= pa[d];  // d/dx = -d/dpos
             }
-            for (int d = 0; d < 3; ++d) if (pa[d] != 0.0) atomicAdd(&sacc[q * 8 + d], pa[d]);
-            for (int d = 0; d < 4; ++d) if (ra[d] != 0.0) atomicAdd(&sacc[q * 8 + 3 + d], ra[d]);
-            if (ga != 0.0) atomicAdd(&sacc[q * 8 + 7], ga);
+            if (dl) {
+                for (int d = 0; d < 3; ++d) det_add(&sdet[2 * (q * 8 + d)], &sdet[2 * (q * 8 + d) + 1], pa[d]);
+                for (int d = 0; d < 4; ++d) det_add(&sdet[2 * (q * 8 + 3 + d)], &sdet[2 * (q * 8 + 3 + d) + 1], ra[d]);
+                det_add(&sdet[2 * (q * 8 + 7)], &sdet[2 * (q * 8 + 7) + 1], ga);
+            } else {
+                for (int d = 0; d < 3; ++d) if (pa[d] != 0.0) atomicAdd(&sacc[q * 8 + d], pa[d]);
+                for (int d = 0; d < 4; ++d) if (ra[d] != 0.0) atomicAdd(&sacc[q * 8 + 3 + d], ra[d]);
+                if (ga != 0.0) atomicAdd(&sacc[q * 8 + 7], ga);
+            }
         }
         T* A = D.adj[which];
         for (int d = 0; d < 3; ++d) A[d * D.Npad + p] += (T)xa[d];
     }
     __syncthreads();
-    if (threadIdx.x < D.nprim * 8) {
+    if (dl) {
+        // the workgroup's integer sums go on into the global limbs (slot LS_COUNT + q * 8 + c); k_det_small_resolve adds
+        // the totals into the pose adjoints
+        if (threadIdx.x < D.nprim * 8 * 2 && sdet[threadIdx.x] != 0)
+            atomicAdd(reinterpret_cast<unsigned long long*>(dl + 2 * LS_COUNT + threadIdx.x), (unsigned long long)sdet[threadIdx.x]);
+    } else if (threadIdx.x < D.nprim * 8) {
         double v = sacc[threadIdx.x];
         int q = threadIdx.x / 8, c = threadIdx.x % 8;
         if (v != 0.0) {
@@ -605,6 +661,20 @@ __global__ void k_loss_grad(Dev<T> D, int f, int which, const T* gm, const T* td
             else atomicAdd(&D.pgap_a[(size_t)f * D.nprim + q], v);
         }
     }
+}
+// deterministic mode: the integer limbs of the loss scalars and of k_loss_grad's pose adjoints -> their double targets
+template <class T> __global__ void k_det_small_resolve(Dev<T> D, int f, long long* dl, double* ls) {
+    const int t = threadIdx.x;
+    if (t >= LS_COUNT + D.nprim * 8) return;
+    const long long hi = dl[2 * t], lo = dl[2 * t + 1];
+    if (!(hi | lo)) return;
+    dl[2 * t] = 0; dl[2 * t + 1] = 0;
+    const double v = det_value(hi, lo);
+    if (t < LS_COUNT) { ls[t] += v; return; }
+    const int q = (t - LS_COUNT) / 8, c = (t - LS_COUNT) % 8;
+    if (c < 3) D.ppos_a[((size_t)f * D.nprim + q) * 3 + c] += v;
+    else if (c < 7) D.prot_a[((size_t)f * D.nprim + q) * 4 + (c - 3)] += v;
+    else D.pgap_a[(size_t)f * D.nprim + q] += v;
 }
 // target SDF sweep (loss.py:81-101), double, linear [i][j][k] layout
 __global__ void k_sdf_sweep(int n, double dx, double inf, const double* dens, const double* sdf_c, const double* np_c,
@@ -699,11 +769,11 @@ template <class T> static int substep_fwd(plmpm_sim* s, int f) {
     Dev<T> D = make_dev<T>(s, f);
     if (s->store) {
         if (s->dirty[f]) LAUNCH(s, K_CLEAR, (k_clear_active<T>), dim3(nblocks_grid(s)), D);   // frame reused without a backward pass
-        LAUNCH(s, K_P2G, (k_p2g<T, true>), dim3(nblocks_particles(s, f)), D, f);
+        LAUNCH_P2G(s, K_P2G, true, D, f);
         LAUNCH(s, K_GRID_OP, (k_grid_op<T, false>), dim3(nwg_grid(s)), D, f, s->halo_in[PLMPM_HALO_GRID_IN]);                    // keep grid_in for substep_grad
         s->dirty[f] = 1;
     } else {
-        LAUNCH(s, K_P2G, (k_p2g<T, true>), dim3(nblocks_particles(s, f)), D, f);
+        LAUNCH_P2G(s, K_P2G, true, D, f);
         LAUNCH(s, K_GRID_OP, (k_grid_op<T, true>), dim3(nwg_grid(s)), D, f, kNoHalo);
     }
     LAUNCH(s, K_G2P, (k_g2p<T>), dim3(nblocks_particles(s, f)), D, f);
@@ -715,12 +785,12 @@ template <class T> static int substep_bwd(plmpm_sim* s, int f) {
     // frame f+1 re-sorted by the env step that starts there: its v in THIS frame's order was kept aside
     const T* vnext = s->frame_epoch[f + 1] != s->frame_epoch[f] ? (const T*)(s->vend + (size_t)s->frame_epoch[f + 1] * 3 * s->Npad * s->tsz) : nullptr;
     if (!(s->store && s->dirty[f])) {        // this frame's grid is not resident: recompute it (mpm_simulator.py:265-268)
-        LAUNCH(s, K_P2G_RE, (k_p2g<T, false>), dim3(nblocks_particles(s, f)), D, f);
+        LAUNCH_P2G(s, K_P2G_RE, false, D, f);
         LAUNCH(s, K_GRID_OP_RE, (k_grid_op<T, false>), dim3(nwg_grid(s)), D, f, kNoHalo);
     }
-    LAUNCH(s, K_G2P_GRAD, (k_g2p_grad<T>), dim3(nblocks_particles(s, f)), D, f, src, dst, vnext);
+    LAUNCH_G2P_GRAD(s, D, f, src, dst, vnext);
     LAUNCH(s, K_GRID_OP_GRAD, (k_grid_op_grad<T>), dim3(nwg_grid(s)), D, f, s->halo_in[PLMPM_HALO_GRID_OUT_ADJ]);
-    LAUNCH(s, K_P2G_GRAD, (k_p2g_grad<T>), dim3(nblocks_particles(s, f) + kPoseWG), D, f, src, dst, kPoseWG);
+    LAUNCH_P2G_GRAD(s, D, f, src, dst);
     if (s->store) s->dirty[f] = 0;           // k_grid_op_grad left grid_in / flags of this frame clean
     s->adj_frame[dst] = f;
     return 0;
@@ -732,10 +802,10 @@ template <class T> static int step_fwd_fused(plmpm_sim* s, int first, int n) {
         Dev<T> D = make_dev<T>(s, f);
         if (s->dirty[f]) LAUNCHG_CLEAR(s, D);
         if (f == first) {
-            LAUNCH(s, K_P2G, (k_p2g<T, true>), dim3(nblocks_particles(s, f)), D, f);
+            LAUNCH_P2G(s, K_P2G, true, D, f);
         } else {
             const Vec4<T>* vprev = (const Vec4<T>*)(s->vstore + (size_t)(f - 1) * s->gstride);
-            LAUNCH(s, K_G2P_P2G, (k_g2p_p2g<T>), dim3(nblocks_particles(s, f)), D, f, vprev);
+            LAUNCH_G2P_P2G(s, D, f, vprev);
         }
         LAUNCH(s, K_GRID_OP, (k_grid_op<T, false>), dim3(nwg_grid(s)), D, f, s->halo_in[PLMPM_HALO_GRID_IN]);
         s->dirty[f] = 1;
@@ -749,7 +819,7 @@ template <class T> static int step_fwd_fused(plmpm_sim* s, int first, int n) {
 template <class T> static int phase_p2g(plmpm_sim* s, int f) {
     Dev<T> D = make_dev<T>(s, f);
     if (s->dirty[f]) LAUNCH(s, K_CLEAR, (k_clear_active<T>), dim3(nblocks_grid(s)), D);
-    LAUNCH(s, K_P2G, (k_p2g<T, true>), dim3(nblocks_particles(s, f)), D, f);
+    LAUNCH_P2G(s, K_P2G, true, D, f);
     s->dirty[f] = 1;
     return 0;
 }
@@ -765,20 +835,20 @@ template <class T> static int phase_g2p_p2g(plmpm_sim* s, int f) {
     Dev<T> D = make_dev<T>(s, f);
     if (s->dirty[f]) LAUNCHG_CLEAR(s, D);
     const Vec4<T>* vprev = (const Vec4<T>*)(s->vstore + (size_t)(f - 1) * s->gstride);
-    LAUNCH(s, K_G2P_P2G, (k_g2p_p2g<T>), dim3(nblocks_particles(s, f)), D, f, vprev);
+    LAUNCH_G2P_P2G(s, D, f, vprev);
     s->dirty[f] = 1;
     return 0;
 }
 template <class T> static int phase_grad_scatter(plmpm_sim* s, int f) {
     Dev<T> D = make_dev<T>(s, f);
     const T* vnext = s->frame_epoch[f + 1] != s->frame_epoch[f] ? (const T*)(s->vend + (size_t)s->frame_epoch[f + 1] * 3 * s->Npad * s->tsz) : nullptr;
-    LAUNCH(s, K_G2P_GRAD, (k_g2p_grad<T>), dim3(nblocks_particles(s, f)), D, f, (f + 1) & 1, f & 1, vnext);
+    LAUNCH_G2P_GRAD(s, D, f, (f + 1) & 1, f & 1, vnext);
     return 0;
 }
 template <class T> static int phase_grad_gather(plmpm_sim* s, int f) {
     Dev<T> D = make_dev<T>(s, f);
     LAUNCH(s, K_GRID_OP_GRAD, (k_grid_op_grad<T>), dim3(nwg_grid(s)), D, f, s->halo_in[PLMPM_HALO_GRID_OUT_ADJ]);
-    LAUNCH(s, K_P2G_GRAD, (k_p2g_grad<T>), dim3(nblocks_particles(s, f) + kPoseWG), D, f, (f + 1) & 1, f & 1, kPoseWG);
+    LAUNCH_P2G_GRAD(s, D, f, (f + 1) & 1, f & 1);
     s->dirty[f] = 0;
     s->adj_frame[f & 1] = f;
     s->adj_epoch[f & 1] = s->frame_epoch[f];
@@ -914,8 +984,13 @@ template <class T> static int download_grid_t(plmpm_sim* s, const char* src, dou
 template <class T> static int loss_scatter_t(plmpm_sim* s, int f) {
     Dev<T> D = make_dev<T>(s, f);
     hipMemsetAsync(s->loss_gm, 0, s->G * s->tsz, s->stream);
-    if (nblocks_particles(s, f) > 0)
-        hipLaunchKernelGGL((k_grid_mass<T>), dim3(nblocks_particles(s, f)), dim3(kBlock), 0, s->stream, D, f, (T*)s->loss_gm);
+    if (nblocks_particles(s, f) > 0) {
+        if (s->det) {
+            hipLaunchKernelGGL((k_grid_mass<T, true>), dim3(nblocks_particles(s, f)), dim3(kBlock), 0, s->stream, D, f, (T*)s->loss_gm);
+            DET_RESOLVE(s, (T*)s->loss_gm, (T*)nullptr, (T*)nullptr, (T*)nullptr);
+        } else
+            hipLaunchKernelGGL((k_grid_mass<T>), dim3(nblocks_particles(s, f)), dim3(kBlock), 0, s->stream, D, f, (T*)s->loss_gm);
+    }
     return 0;
 }
 
@@ -924,7 +999,10 @@ template <class T> static int loss_contact_pass_t(plmpm_sim* s, int f, int mode)
     Dev<T> D = make_dev<T>(s, f);
     bool any = false;
     for (int p = 0; p < s->P; ++p) any |= s->prims[p].action_dim > 0;
-    if (any) hipLaunchKernelGGL((k_contact<T>), dim3(std::min(s->Npad / 256, 512)), dim3(256), 0, s->stream, D, f, mode, s->lscal);
+    if (any) {
+        hipLaunchKernelGGL((k_contact<T>), dim3(std::min(s->Npad / 256, 512)), dim3(256), 0, s->stream, D, f, mode, s->lscal, s->det_small);
+        if (s->det) hipLaunchKernelGGL((k_det_small_resolve<T>), dim3(1), dim3(128), 0, s->stream, D, f, s->det_small, s->lscal);
+    }
     return 0;
 }
 static int loss_reset_scalars(plmpm_sim* s) {
@@ -938,14 +1016,16 @@ static int loss_reset_scalars(plmpm_sim* s) {
 
 template <class T> static int loss_reduce_t(plmpm_sim* s) {
     hipLaunchKernelGGL((k_loss_reduce<T>), dim3(256), dim3(256), 0, s->stream, s->G, s->nbw[0] * s->nbw[1], s->go[2], s->cfg.slab_z0, s->cfg.slab_z1,
-                       (const T*)s->loss_gm, (const T*)s->loss_td, (const T*)s->loss_ts, s->lscal);
+                       (const T*)s->loss_gm, (const T*)s->loss_td, (const T*)s->loss_ts, s->lscal, s->det_small);
+    if (s->det) hipLaunchKernelGGL((k_det_small_resolve<T>), dim3(1), dim3(128), 0, s->stream, make_dev<T>(s), 0, s->det_small, s->lscal);
     return 0;
 }
 
 template <class T> static int loss_grad_t(plmpm_sim* s, int f) {
     Dev<T> D = make_dev<T>(s, f);
     hipLaunchKernelGGL((k_loss_grad<T>), dim3(s->Npad / 256), dim3(256), 0, s->stream, D, f, f & 1, (const T*)s->loss_gm,
-                       (const T*)s->loss_td, (const T*)s->loss_ts, s->lscal, s->w_sdf, s->w_density, s->w_contact, s->soft_contact);
+                       (const T*)s->loss_td, (const T*)s->loss_ts, s->lscal, s->w_sdf, s->w_density, s->w_contact, s->soft_contact, s->det_small);
+    if (s->det) hipLaunchKernelGGL((k_det_small_resolve<T>), dim3(1), dim3(128), 0, s->stream, D, f, s->det_small, s->lscal);
     return 0;
 }
 
@@ -953,7 +1033,7 @@ template <class T> static int grid_stats_t(plmpm_sim* s, int f, unsigned long lo
     Dev<T> D = make_dev<T>(s);
     D.N = s->epochN[s->frame_epoch[f]];
     // recompute the scatter of frame f without consuming it, count, then clear
-    if (nblocks_particles(s, f) > 0) hipLaunchKernelGGL((k_p2g<T, false>), dim3(nblocks_particles(s, f)), dim3(kBlock), 0, s->stream, D, f);
+    LAUNCH_P2G(s, K_P2G_RE, false, D, f);
     hipLaunchKernelGGL((k_grid_stats<T>), dim3((unsigned)((s->G + 255) / 256)), dim3(256), 0, s->stream, D, d_out);
     hipLaunchKernelGGL((k_clear_active<T>), dim3(nblocks_grid(s)), dim3(kBlock), 0, s->stream, D);
     return 0;
@@ -1055,6 +1135,12 @@ int plmpm_create(const plmpm_config* cfg, const plmpm_primitive* prims, plmpm_ha
                        + 2 * align_up((size_t)(s->F + 1) * P1 * PLMPM_MAX_ACTION_DIM * 8, 256)    // action buffers (+adj)
                        + align_up(LS_COUNT * 8, 256) + align_up((size_t)s->Npad * 24 * 8, 256) + 512;
     if (s->dist) s->ws.misc_bytes += 3 * align_up((size_t)(s->F + 1) * P1 * 4 * 8, 256);
+    s->det = cfg->deterministic != 0;
+    if (s->det && s->dist) { delete s; return fail("deterministic = 1 is a single-GPU mode: the order in which migrating particles arrive at a slab is not fixed"); }
+    if (s->det) {
+        s->ws.grid_bytes += align_up(s->G * 8 * 8, 256);                                  // [8][G] integer limbs
+        s->ws.misc_bytes += align_up((size_t)(LS_COUNT + kMaxPrim * 8) * 2 * 8, 256);
+    }
     memset(s->halo_in, 0, sizeof s->halo_in);
     s->perm.resize(s->N);
     for (int i = 0; i < s->N; ++i) s->perm[i] = i;
@@ -1116,6 +1202,7 @@ int plmpm_bind_workspace(plmpm_handle s, void* state, void* adjoint, void* grid,
     }
     s->tiles = (int*)take((size_t)(s->F + 1) * (s->Npad / kBlock) * 8 * 4);
     s->contact = (int*)take((size_t)(s->nblk + 1) * 4);
+    s->det_grid = s->det ? (long long*)take(s->G * 8 * 8) : nullptr;
     REQUIRE((size_t)(p - s->gridw) <= s->ws.grid_bytes, "internal: grid workspace overflow");
     p = s->miscw;
     size_t P1 = std::max(s->P, 1), F1 = s->F + 1;
@@ -1130,6 +1217,7 @@ int plmpm_bind_workspace(plmpm_handle s, void* state, void* adjoint, void* grid,
     s->staging = (double*)take((size_t)s->Npad * 24 * 8);
     s->err_d = (int*)take(512);
     if (s->dist) { s->ppos_l = (double*)take(F1 * P1 * 3 * 8); s->prot_l = (double*)take(F1 * P1 * 4 * 8); s->pgap_l = (double*)take(F1 * P1 * 8); }
+    s->det_small = s->det ? (long long*)take((size_t)(LS_COUNT + kMaxPrim * 8) * 2 * 8) : nullptr;
     REQUIRE((size_t)(p - s->miscw) <= s->ws.misc_bytes, "internal: misc workspace overflow");
     // initial contents: zero grids / adjoints / primitive buffers, identity order
     HIPCHK(hipMemsetAsync(s->state, 0, s->ws.state_bytes, s->stream));       // frames are first touched here, not inside a caller's timed region

@@ -96,6 +96,8 @@ template <class T> struct Dev {
     int* tiles;                      // [(F+1)][workgroups][8]: stencil box of each 256-particle workgroup, per frame
     int* contact;                    // [0] = n, [1..n] = blocks whose pose adjoints are still due (grid_op.grad -> p2g.grad)
     unsigned long long* trace;       // profiling builds only
+    long long* det;                  // deterministic mode only (else null): two-limb fixed-point accumulators, [8][det_stride]
+    size_t det_stride;               //   component c of a node: hi limb det[c * stride + idx], lo limb det[(4 + c) * stride + idx]
     // primitives (double): pos[(F+1)][P][3], rot[(F+1)][P][4], gap[(F+1)][P] (Chopsticks) and adjoints
     const double *ppos, *prot, *pgap;
     double *ppos_a, *prot_a, *pgap_a;
@@ -112,6 +114,46 @@ template <class T> __device__ __forceinline__ T* frame_r(const Dev<T>& D, int f)
     return reinterpret_cast<T*>(D.state + (size_t)f * D.frame_bytes + (size_t)3 * 8 * D.Npad);
 }
 
+
+// ---- deterministic accumulation (plmpm_config.deterministic) ---------------------------------------------------------
+// Floating-point atomics add in whatever order the waves arrive, so two runs of the same rollout differ in the last
+// bits.  The deterministic engine accumulates every sum that more than one wave contributes to in two 64-bit integer
+// limbs instead -- hi counts units of 2^-24, lo the remainder in units of 2^-76 -- and integer adds commute exactly:
+// the result is the same for every arrival order, every re-sort and every workgroup schedule.  A contribution a is
+// split without error (|a| < 2^38; anything finer than 2^-76 is rounded once, per contribution, the same way in every
+// run), so the sums are also more accurate than the fp32 / fp64 atomics they replace.  Up to 2^12 contributions per
+// accumulator before the lo limb could wrap.
+__device__ __forceinline__ void det_split(double a, long long& hi, long long& lo) {
+    const double h = rint(a * 0x1p24);
+    hi = (long long)h;
+    lo = (long long)rint((a - h * 0x1p-24) * 0x1p76);
+}
+__device__ __forceinline__ void det_add(long long* hi, long long* lo, double a) {
+    if (a == 0.0) return;
+    long long h, l;
+    det_split(a, h, l);
+    if (h) atomicAdd(reinterpret_cast<unsigned long long*>(hi), (unsigned long long)h);
+    if (l) atomicAdd(reinterpret_cast<unsigned long long*>(lo), (unsigned long long)l);
+}
+__device__ __forceinline__ double det_value(long long hi, long long lo) { return (double)hi * 0x1p-24 + (double)lo * 0x1p-76; }
+// component c (< 4) of grid node idx
+template <class T> __device__ __forceinline__ void det_add_node(const Dev<T>& D, int c, int idx, double a) {
+    det_add(D.det + (size_t)c * D.det_stride + idx, D.det + (size_t)(4 + c) * D.det_stride + idx, a);
+}
+// one component of an LDS limb tile on to the global limbs
+template <class T> __device__ __forceinline__ void det_flush_node(const Dev<T>& D, int c, int idx, long long hi, long long lo) {
+    if (hi) atomicAdd(reinterpret_cast<unsigned long long*>(D.det + (size_t)c * D.det_stride + idx), (unsigned long long)hi);
+    if (lo) atomicAdd(reinterpret_cast<unsigned long long*>(D.det + (size_t)(4 + c) * D.det_stride + idx), (unsigned long long)lo);
+}
+// limbs -> the T arrays the scatter would have added into (dst[c] += sum, limbs cleared); dense sweep of the window
+template <class T> __global__ void k_det_resolve(long long* det, size_t G, T* d0, T* d1, T* d2, T* d3) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < G; i += (size_t)gridDim.x * blockDim.x) {
+#define PLB_DET_RESOLVE(c, dst) if (dst) { long long* h = det + (size_t)(c) * G + i; long long* l = det + (size_t)(4 + (c)) * G + i; \
+            const long long hv = *h, lv = *l; if (hv | lv) { dst[i] += (T)det_value(hv, lv); *h = 0; *l = 0; } }
+        PLB_DET_RESOLVE(0, d0) PLB_DET_RESOLVE(1, d1) PLB_DET_RESOLVE(2, d2) PLB_DET_RESOLVE(3, d3)
+#undef PLB_DET_RESOLVE
+    }
+}
 
 // node (i, j, k) of the grid -> index inside the allocated window (origin a multiple of 4, so the low bits are the node's)
 template <class T> __device__ __forceinline__ int node_index(const Dev<T>& D, int i, int j, int k) {
@@ -501,7 +543,9 @@ __device__ __forceinline__ bool load_sorted_particle(const Dev<T>& D, const doub
 // ------------------------------------------------------------------------------------------------
 // p2g: compute_F_tmp + svd + von Mises + stress + APIC scatter      (mpm_simulator.py:82-90,157-184)
 // WRITE_F: store F[f+1] (forward) or not (recompute in substep_grad).
-template <class T, bool WRITE_F>
+// DET: deterministic mode -- the LDS tile and the global flush accumulate integer limbs (8 per node instead of 4
+// doubles: half the tile capacity), see det_add.
+template <class T, bool WRITE_F, bool DET = false>
 __global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_p2g(Dev<T> D, int f) {
     __shared__ int sred[32];
     // accumulate in double: on gfx950 ds_add_f64 is ~5x cheaper per instruction than ds_add_f32
@@ -513,11 +557,11 @@ __global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_p2g(Dev<T> D, int f) 
     int p, base[3];
     double x[3];
     const bool valid = load_sorted_particle(D, X, p, x, base, WRITE_F);
-    Tile tl = block_tile(base, valid, sred, TileCap<T>::nodes);
+    Tile tl = block_tile(base, valid, sred, DET ? TileCap<T>::nodes / 2 : TileCap<T>::nodes);
     store_tile(D, f, tl);
     const int tn = tl.e[0] * tl.e[1] * tl.e[2];
     if (tl.ok) {
-        for (int i = threadIdx.x; i < tn; i += kBlock) tile[i] = Vec4<double>{0.0, 0.0, 0.0, 0.0};
+        for (int i = threadIdx.x; i < (DET ? 2 * tn : tn); i += kBlock) tile[i] = Vec4<double>{0.0, 0.0, 0.0, 0.0};
         __syncthreads();
     }
     {
@@ -542,8 +586,13 @@ __global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_p2g(Dev<T> D, int f) 
                 seg_sum4(a0, a1, a2, a3, sg);
                 if (PLB_ABLATE & 1) { if (a0 + a1 + a2 + a3 == T(-1e30)) tile[0].x = 1.0; return; }
                 if (emitter) {
-                    double* q = reinterpret_cast<double*>(&tile[(oz + l) * exy + (oy + j) * ex + (ox + i)]);
-                    atomicAdd(q, (double)a0); atomicAdd(q + 1, (double)a1); atomicAdd(q + 2, (double)a2); atomicAdd(q + 3, (double)a3);
+                    if constexpr (DET) {          // node: 4 hi limbs, then 4 lo limbs
+                        long long* q = reinterpret_cast<long long*>(tile) + 8 * ((oz + l) * exy + (oy + j) * ex + (ox + i));
+                        det_add(q, q + 4, (double)a0); det_add(q + 1, q + 5, (double)a1); det_add(q + 2, q + 6, (double)a2); det_add(q + 3, q + 7, (double)a3);
+                    } else {
+                        double* q = reinterpret_cast<double*>(&tile[(oz + l) * exy + (oy + j) * ex + (ox + i)]);
+                        atomicAdd(q, (double)a0); atomicAdd(q + 1, (double)a1); atomicAdd(q + 2, (double)a2); atomicAdd(q + 3, (double)a3);
+                    }
                 }
             });
         } else {
@@ -552,8 +601,13 @@ __global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_p2g(Dev<T> D, int f) 
                 seg_sum4(a0, a1, a2, a3, sg);
                 if (emitter) {
                     int idx = node_index(D, base[0] + i, base[1] + j, base[2] + l);
-                    atomicAdd(&D.gin[0][idx], a0); atomicAdd(&D.gin[1][idx], a1);
-                    atomicAdd(&D.gin[2][idx], a2); atomicAdd(&D.gin[3][idx], a3);
+                    if constexpr (DET) {
+                        det_add_node(D, 0, idx, (double)a0); det_add_node(D, 1, idx, (double)a1);
+                        det_add_node(D, 2, idx, (double)a2); det_add_node(D, 3, idx, (double)a3);
+                    } else {
+                        atomicAdd(&D.gin[0][idx], a0); atomicAdd(&D.gin[1][idx], a1);
+                        atomicAdd(&D.gin[2][idx], a2); atomicAdd(&D.gin[3][idx], a3);
+                    }
                     D.flags[flag_slot(D, idx >> 6)] = 1;
                 }
             });
@@ -567,6 +621,19 @@ __global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_p2g(Dev<T> D, int f) 
         __syncthreads();
         const int ex = tl.e[0], exy = tl.e[0] * tl.e[1];
         for (int i = threadIdx.x; i < tn; i += kBlock) {
+            if constexpr (DET) {
+                const long long* q = reinterpret_cast<const long long*>(tile) + 8 * i;
+                long long any = 0;
+                for (int c = 0; c < 8; ++c) any |= q[c];
+                if (any) {
+                    int lz, ly, lx;
+                    tile_coords(i, ex, exy, lz, ly, lx);
+                    int idx = node_index(D, tl.o[0] + lx, tl.o[1] + ly, tl.o[2] + lz);
+                    for (int c = 0; c < 4; ++c) det_flush_node(D, c, idx, q[c], q[4 + c]);
+                    D.flags[flag_slot(D, idx >> 6)] = 1;
+                }
+                continue;
+            }
             Vec4<double> a = tile[i];
             if (a.x != 0.0 || a.y != 0.0 || a.z != 0.0 || a.w != 0.0) {
                 int lz, ly, lx;
@@ -668,7 +735,7 @@ __global__ __launch_bounds__(kBlock) void k_g2p(Dev<T> D, int f) {
 // are written once and go straight on (in registers) into the scatter; the LDS region first holds the
 // grid_v_out(f-1) tile, then -- after the gather -- is reused for the f64 accumulation tile of grid_in(f).
 // D is built for frame f (grid_in / flags of f); vout_prev is grid_v_out of substep f-1.
-template <class T>
+template <class T, bool DET = false>
 __global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_g2p_p2g(Dev<T> D, int f, const Vec4<T>* vout_prev) {
     __shared__ int sred[32];
     __shared__ Vec4<double> tile[TileCap<T>::nodes];
@@ -735,14 +802,14 @@ __global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_g2p_p2g(Dev<T> D, int
     for (int d = 0; d < 3; ++d) base[d] = (int)(x[d] * (double)D.P.inv_dx - 0.5);
     if (clamp_to_reach(D, base) && valid) atomicOr(D.err, 1);
     __syncthreads();                                                     // everyone is done reading tile_v
-    Tile tl = block_tile(base, valid, sred, TileCap<T>::nodes);
+    Tile tl = block_tile(base, valid, sred, DET ? TileCap<T>::nodes / 2 : TileCap<T>::nodes);
     store_tile(D, f, tl);
     const int tn = tl.e[0] * tl.e[1] * tl.e[2];
 #ifdef PLB_DEBUG_COUNTERS      // tile statistics for plmpm_debug_counters (same-address atomics: keep out of production builds)
     if (threadIdx.x == 0) { atomicAdd(D.err + (tl.ok ? 2 : 1), 1); if (tl.ok) atomicAdd(D.err + 3, tn); }
 #endif
     if (tl.ok) {
-        for (int i = threadIdx.x; i < tn; i += kBlock) tile[i] = Vec4<double>{0.0, 0.0, 0.0, 0.0};
+        for (int i = threadIdx.x; i < (DET ? 2 * tn : tn); i += kBlock) tile[i] = Vec4<double>{0.0, 0.0, 0.0, 0.0};
         __syncthreads();
     }
     PT_MARK(3);
@@ -760,8 +827,13 @@ __global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_g2p_p2g(Dev<T> D, int
                 seg_sum4(a0, a1, a2, a3, sg);
                 if (PLB_ABLATE & 1) { if (a0 + a1 + a2 + a3 == T(-1e30)) tile[0].x = 1.0; return; }
                 if (emitter) {
-                    double* q = reinterpret_cast<double*>(&tile[(oz + l) * exy + (oy + j) * ex + (ox + i)]);
-                    atomicAdd(q, (double)a0); atomicAdd(q + 1, (double)a1); atomicAdd(q + 2, (double)a2); atomicAdd(q + 3, (double)a3);
+                    if constexpr (DET) {          // node: 4 hi limbs, then 4 lo limbs
+                        long long* q = reinterpret_cast<long long*>(tile) + 8 * ((oz + l) * exy + (oy + j) * ex + (ox + i));
+                        det_add(q, q + 4, (double)a0); det_add(q + 1, q + 5, (double)a1); det_add(q + 2, q + 6, (double)a2); det_add(q + 3, q + 7, (double)a3);
+                    } else {
+                        double* q = reinterpret_cast<double*>(&tile[(oz + l) * exy + (oy + j) * ex + (ox + i)]);
+                        atomicAdd(q, (double)a0); atomicAdd(q + 1, (double)a1); atomicAdd(q + 2, (double)a2); atomicAdd(q + 3, (double)a3);
+                    }
                 }
             });
         } else {
@@ -770,8 +842,13 @@ __global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_g2p_p2g(Dev<T> D, int
                 seg_sum4(a0, a1, a2, a3, sg);
                 if (emitter) {
                     int idx = node_index(D, base[0] + i, base[1] + j, base[2] + l);
-                    atomicAdd(&D.gin[0][idx], a0); atomicAdd(&D.gin[1][idx], a1);
-                    atomicAdd(&D.gin[2][idx], a2); atomicAdd(&D.gin[3][idx], a3);
+                    if constexpr (DET) {
+                        det_add_node(D, 0, idx, (double)a0); det_add_node(D, 1, idx, (double)a1);
+                        det_add_node(D, 2, idx, (double)a2); det_add_node(D, 3, idx, (double)a3);
+                    } else {
+                        atomicAdd(&D.gin[0][idx], a0); atomicAdd(&D.gin[1][idx], a1);
+                        atomicAdd(&D.gin[2][idx], a2); atomicAdd(&D.gin[3][idx], a3);
+                    }
                     D.flags[flag_slot(D, idx >> 6)] = 1;
                 }
             });
@@ -786,6 +863,19 @@ __global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_g2p_p2g(Dev<T> D, int
         __syncthreads();
         const int ex = tl.e[0], exy = tl.e[0] * tl.e[1];
         for (int i = threadIdx.x; i < tn; i += kBlock) {
+            if constexpr (DET) {
+                const long long* q = reinterpret_cast<const long long*>(tile) + 8 * i;
+                long long any = 0;
+                for (int c = 0; c < 8; ++c) any |= q[c];
+                if (any) {
+                    int lz, ly, lx;
+                    tile_coords(i, ex, exy, lz, ly, lx);
+                    int idx = node_index(D, tl.o[0] + lx, tl.o[1] + ly, tl.o[2] + lz);
+                    for (int c = 0; c < 4; ++c) det_flush_node(D, c, idx, q[c], q[4 + c]);
+                    D.flags[flag_slot(D, idx >> 6)] = 1;
+                }
+                continue;
+            }
             Vec4<double> a = tile[i];
             if (a.x != 0.0 || a.y != 0.0 || a.z != 0.0 || a.w != 0.0) {
                 int lz, ly, lx;
@@ -803,7 +893,7 @@ __global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_g2p_p2g(Dev<T> D, int
 
 // ------------------------------------------------------------------------------------------------
 // g2p.grad: scatter grid_v_out.grad, x[f].grad partial -> adjoint frame `dst`.  vnext: see below (nullptr = frame f+1)
-template <class T>
+template <class T, bool DET = false>
 __global__ __launch_bounds__(kBlock) void k_g2p_grad(Dev<T> D, int f, int src, int dst, const T* vnext) {
     // 960 nodes x (16 + 24) bytes = 37.5 KiB: four workgroups per CU (the kernel needs 126 VGPRs = 4 waves per SIMD)
     constexpr int CAP = sizeof(T) == 4 ? 960 : 480;
@@ -815,7 +905,7 @@ __global__ __launch_bounds__(kBlock) void k_g2p_grad(Dev<T> D, int f, int src, i
     double x[3];
     PT_BEGIN();
     if (blockIdx.x == 0 && threadIdx.x == 0) D.contact[0] = 0;     // the list k_grid_op_grad(f) is about to fill
-    const Tile tl = load_tile(D, f, CAP);                           // stored by the scatter of this frame
+    const Tile tl = load_tile(D, f, DET ? CAP / 2 : CAP);           // stored by the scatter of this frame (DET: 6 limbs per node in tile_a)
     SortLoad sl = sorted_begin(D, X);
     const int ex = tl.e[0], exy = tl.e[0] * tl.e[1], tn = exy * tl.e[2];
     if (tl.ok)
@@ -824,6 +914,7 @@ __global__ __launch_bounds__(kBlock) void k_g2p_grad(Dev<T> D, int f, int src, i
                 tile_coords(i, ex, exy, lz, ly, lx);
             tile[i] = D.grid_out[node_index(D, tl.o[0] + lx, tl.o[1] + ly, tl.o[2] + lz)];
             tile_a[3 * i] = 0.0; tile_a[3 * i + 1] = 0.0; tile_a[3 * i + 2] = 0.0;
+            if (DET) { tile_a[3 * (tn + i)] = 0.0; tile_a[3 * (tn + i) + 1] = 0.0; tile_a[3 * (tn + i) + 2] = 0.0; }   // lo limbs
         }
     PT_MARK(0);
     const bool valid = sorted_finish(D, sl, p, x, base);
@@ -842,7 +933,36 @@ __global__ __launch_bounds__(kBlock) void k_g2p_grad(Dev<T> D, int f, int src, i
         PT_MARK(2);
         const Seg<T> sg = wave_segments<T>(valid ? (base[2] * D.P.n + base[1]) * D.P.n + base[0] : -1);
         const bool emitter = sg.head && valid;
-        if (tl.ok) {
+        if constexpr (DET) {
+            // deterministic mode: integer limbs in tile_a (hi at [3 i + c], lo at [3 (tn + i) + c]) or, without a tile,
+            // in the global limb grid
+            const int ox = base[0] - tl.o[0], oy = base[1] - tl.o[1], oz = base[2] - tl.o[2];
+            long long* la = reinterpret_cast<long long*>(tile_a);
+            g2p_particle_grad<T, double>(D.P, x, vn, xna, vna, Cna, xa,
+                [&](int i, int j, int l, T* gv) {
+                    gv[0] = gv[1] = gv[2] = T(0);
+                    if (tl.ok) {
+                        Vec4<T> a = tile[(oz + l) * exy + (oy + j) * ex + (ox + i)];
+                        gv[0] = a.x; gv[1] = a.y; gv[2] = a.z;
+                    } else if (valid) {
+                        Vec4<T> a = D.grid_out[node_index(D, base[0] + i, base[1] + j, base[2] + l)];
+                        gv[0] = a.x; gv[1] = a.y; gv[2] = a.z;
+                    }
+                },
+                [&](int i, int j, int l, const T* ga) {
+                    T a0 = ga[0], a1 = ga[1], a2 = ga[2];
+                    seg_sum3(a0, a1, a2, sg);
+                    if (!emitter) return;
+                    if (tl.ok) {
+                        const int node = (oz + l) * exy + (oy + j) * ex + (ox + i);
+                        long long *h = la + 3 * node, *lo = la + 3 * (tn + node);
+                        det_add(h, lo, (double)a0); det_add(h + 1, lo + 1, (double)a1); det_add(h + 2, lo + 2, (double)a2);
+                    } else {
+                        int idx = node_index(D, base[0] + i, base[1] + j, base[2] + l);
+                        det_add_node(D, 0, idx, (double)a0); det_add_node(D, 1, idx, (double)a1); det_add_node(D, 2, idx, (double)a2);
+                    }
+                });
+        } else if (tl.ok) {
             const int ox = base[0] - tl.o[0], oy = base[1] - tl.o[1], oz = base[2] - tl.o[2];
             g2p_particle_grad<T, double>(D.P, x, vn, xna, vna, Cna, xa,
                 [&](int i, int j, int l, T* gv) {
@@ -884,6 +1004,17 @@ __global__ __launch_bounds__(kBlock) void k_g2p_grad(Dev<T> D, int f, int src, i
     if (tl.ok) {
         __syncthreads();
         for (int i = threadIdx.x; i < tn; i += kBlock) {
+            if constexpr (DET) {
+                const long long* h = reinterpret_cast<const long long*>(tile_a) + 3 * i;
+                const long long* lo = reinterpret_cast<const long long*>(tile_a) + 3 * (tn + i);
+                if (h[0] | h[1] | h[2] | lo[0] | lo[1] | lo[2]) {
+                    int lz, ly, lx;
+                    tile_coords(i, ex, exy, lz, ly, lx);
+                    int idx = node_index(D, tl.o[0] + lx, tl.o[1] + ly, tl.o[2] + lz);
+                    for (int c = 0; c < 3; ++c) det_flush_node(D, c, idx, h[c], lo[c]);
+                }
+                continue;
+            }
             const double ax = tile_a[3 * i], ay = tile_a[3 * i + 1], az = tile_a[3 * i + 2];
             if (ax != 0.0 || ay != 0.0 || az != 0.0) {
                 int lz, ly, lx;
@@ -996,6 +1127,41 @@ __device__ __forceinline__ void pose_adjoint_blocks(const Dev<T>& D, int f, int 
             else if (c < 14) atomicAdd(&D.prot_a[((size_t)(f + 1) * D.nprim + q) * 4 + (c - 10)], v);
             else atomicAdd(&D.pgap_a[(size_t)f * D.nprim + q], v);
         }
+    }
+}
+
+// Deterministic mode: the list of blocks in contact is filled through an atomic counter, so its order -- and with it
+// the order of the floating-point pose sums -- varies from run to run.  Here ONE wave walks the list in increasing
+// block order (k_p2g_grad is then launched without pose workgroups).
+template <class T>
+__global__ __launch_bounds__(64) void k_pose_adjoint_det(Dev<T> D, int f) {
+    __shared__ PrimT<T> sp[kMaxPrim];
+    __shared__ double sacc[kMaxPrim * 15];
+    __shared__ int shit;
+    load_prims(D, f, sp);
+    for (int i = threadIdx.x; i < kMaxPrim * 15; i += 64) sacc[i] = 0.0;
+    if (threadIdx.x == 0) shit = 0;
+    __syncthreads();
+    const int lane = threadIdx.x, count = D.contact[0];
+    int last = -1;
+    for (int it = 0; it < count; ++it) {
+        int best = 0x7fffffff;
+        for (int i = lane; i < count; i += 64) { const int b = D.contact[1 + i]; if (b > last && b < best) best = b; }
+        best = wave_min(best);
+        grid_block_bwd<T, true>(D, HaloIn{}, best, lane, sp, sacc, &shit);
+        last = best;
+    }
+    __syncthreads();
+    if (!shit) return;
+    for (int t = threadIdx.x; t < D.nprim * 15; t += 64) {
+        const int q = t / 15, c = t % 15;
+        const double v = sacc[t];
+        if (v == 0.0) continue;
+        if (c < 3) D.ppos_a[((size_t)f * D.nprim + q) * 3 + c] += v;
+        else if (c < 7) D.prot_a[((size_t)f * D.nprim + q) * 4 + (c - 3)] += v;
+        else if (c < 10) D.ppos_a[((size_t)(f + 1) * D.nprim + q) * 3 + (c - 7)] += v;
+        else if (c < 14) D.prot_a[((size_t)(f + 1) * D.nprim + q) * 4 + (c - 10)] += v;
+        else D.pgap_a[(size_t)f * D.nprim + q] += v;
     }
 }
 
@@ -1168,7 +1334,7 @@ __global__ __launch_bounds__(kBlock, sizeof(T) == 4 ? PLB_P2G_GRAD_WAVES : 1) vo
 
 // compute_grid_m_kernel (mpm_simulator.py:382-392): mass-only scatter for the loss, same LDS-tile +
 // wave pre-reduction scheme as k_p2g.  gm is a dense blocked T grid (zeroed by the caller).
-template <class T>
+template <class T, bool DET = false>
 __global__ __launch_bounds__(kBlock) void k_grid_mass(Dev<T> D, int f, T* gm) {
     __shared__ int sred[32];
     __shared__ double tile[TileCap<T>::nodes * 4];
@@ -1179,10 +1345,10 @@ __global__ __launch_bounds__(kBlock) void k_grid_mass(Dev<T> D, int f, T* gm) {
     const bool valid = load_sorted_particle(D, X, p, x, base, true);
     T fx[3], w[3][3];
     stencil<T, double>(x, D.P.inv_dx, base_true, fx, w, nullptr);
-    Tile tl = block_tile(base, valid, sred, TileCap<T>::nodes * 4);
+    Tile tl = block_tile(base, valid, sred, DET ? TileCap<T>::nodes * 2 : TileCap<T>::nodes * 4);     // DET: hi limb at [i], lo at [tn + i]
     const int ex = tl.e[0], exy = tl.e[0] * tl.e[1], tn = exy * tl.e[2];
     if (tl.ok) {
-        for (int i = threadIdx.x; i < tn; i += kBlock) tile[i] = 0.0;
+        for (int i = threadIdx.x; i < (DET ? 2 * tn : tn); i += kBlock) tile[i] = 0.0;
         __syncthreads();
     }
     const Seg<T> sg = wave_segments<T>(valid ? (base[2] * D.P.n + base[1]) * D.P.n + base[0] : -1);
@@ -1193,13 +1359,26 @@ __global__ __launch_bounds__(kBlock) void k_grid_mass(Dev<T> D, int f, T* gm) {
             for (int l = 0; l < 3; ++l) {
                 T m = seg_sum(w[i][0] * w[j][1] * w[l][2] * D.P.p_mass, sg);
                 if (emitter) {
-                    if (tl.ok) atomicAdd(&tile[(oz + l) * exy + (oy + j) * ex + (ox + i)], (double)m);
+                    if (tl.ok && DET) {
+                        long long* q = reinterpret_cast<long long*>(tile) + (oz + l) * exy + (oy + j) * ex + (ox + i);
+                        det_add(q, q + tn, (double)m);
+                    } else if (tl.ok) atomicAdd(&tile[(oz + l) * exy + (oy + j) * ex + (ox + i)], (double)m);
+                    else if constexpr (DET) det_add_node(D, 0, node_index(D, base[0] + i, base[1] + j, base[2] + l), (double)m);
                     else atomicAdd(&gm[node_index(D, base[0] + i, base[1] + j, base[2] + l)], m);
                 }
             }
     if (tl.ok) {
         __syncthreads();
         for (int i = threadIdx.x; i < tn; i += kBlock) {
+            if constexpr (DET) {
+                const long long* q = reinterpret_cast<const long long*>(tile) + i;
+                if (q[0] | q[tn]) {
+                    int lz, ly, lx;
+                    tile_coords(i, ex, exy, lz, ly, lx);
+                    det_flush_node(D, 0, node_index(D, tl.o[0] + lx, tl.o[1] + ly, tl.o[2] + lz), q[0], q[tn]);
+                }
+                continue;
+            }
             double a = tile[i];
             if (a != 0.0) {
                 int lz, ly, lx;

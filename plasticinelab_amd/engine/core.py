@@ -35,7 +35,7 @@ class Engine:
                  dtype: str = "float32", svd_grad_clamp: float = 1e-6, device: Optional[torch.device] = None,
                  slab: Optional[Sequence[int]] = None, store_grid="auto", slab_halo: int = 0, resort_steps: int = 4,
                  grid_window: Optional[Sequence[Sequence[int]]] = None, particle_capacity: Optional[int] = None,
-                 allocate: bool = True):
+                 allocate: bool = True, deterministic: bool = False):
         self.lib = L.load()
         if not torch.cuda.is_available():
             raise L.EngineError("no ROCm device visible: the MPM engine has no CPU path")
@@ -70,6 +70,9 @@ class Engine:
         # re-sort the particles every so many env steps (single GPU); PLMPM_RESORT_STEPS overrides for experiments
         cfg.resort_steps = int(os.environ.get("PLMPM_RESORT_STEPS", resort_steps))
         self.store_grid = bool(store_grid)
+        # bit-reproducible runs: integer-limb accumulation instead of floating-point atomics (include/plmpm.h)
+        cfg.deterministic = int(bool(deterministic))
+        self.deterministic = bool(deterministic)
         parr = (L.Primitive * max(len(primitives), 1))()
         self.action_dims = []
         for i, p in enumerate(primitives):

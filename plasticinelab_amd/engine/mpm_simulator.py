@@ -56,7 +56,7 @@ class MPMSimulator:
                              device=device, slab=slab, slab_halo=slab_halo,
                              store_grid=cfg.get("store_grid", "auto"),
                              grid_window=grid_window if grid_window is not None else cfg.get("grid_window", None),
-                             particle_capacity=particle_capacity)
+                             particle_capacity=particle_capacity, deterministic=bool(cfg.get("deterministic", False)))
         if hasattr(primitives, "_bind"):
             primitives._bind(self.engine)
         self._mats = None
