@@ -39,6 +39,13 @@ template <class T> struct TileCap;
 #ifndef PLB_TILECAP
 #define PLB_TILECAP 1024
 #endif
+// Scatter tiles of k_p2g / k_g2p_p2g component-major ([4][cap] doubles) instead of node-major ([cap][4]): a
+// ds_add_f64 of one component then hits bank 2 n mod 64 for node n (the emitting lanes of one instruction hold
+// different nodes: conflicts only between n and n + 32) instead of (8 n + 2 c) mod 64 (conflicts between n and n + 8).
+// Measured (round 2): no gain (g2p_p2g 54.8 -> 55.3 us) -- the kernel does not wait on those conflicts.  Kept off.
+#ifndef PLB_TILE_SOA
+#define PLB_TILE_SOA 0
+#endif
 template <> struct TileCap<float> { static constexpr int nodes = PLB_TILECAP; };
 template <> struct TileCap<double> { static constexpr int nodes = 512; };
 
@@ -490,6 +497,28 @@ template <class T> __device__ __forceinline__ Tile load_tile(const Dev<T>& D, in
     return t;
 }
 
+// The in-wave sort only has to make lanes that share a stencil base adjacent, and the storage order already is the
+// Hilbert order of the cells at the last re-sort: while few particles have changed cell since, the lanes come in as
+// ~8-10 runs of equal keys and the ~250 VALU instructions of the bitonic network buy nothing.  So count the runs first
+// (one shuffle, one ballot) and skip the sort below PLB_SORT_SKIP_RUNS of them -- wave-uniform branch; the segmented
+// reduction is correct for any lane order, fewer lanes per run only means a few more LDS atomics.  0: always sort.
+// Measured (round 2, profiles/r02_notes.md): thresholds 12 / 18 / 28 all LOSE (6 064 -> 6 005 / 5 960 / 5 766
+// substeps/s): the extra LDS atomics of the shorter runs cost more than the sort.  Kept off, as a record.
+#ifndef PLB_SORT_SKIP_RUNS
+#define PLB_SORT_SKIP_RUNS 0
+#endif
+__device__ __forceinline__ bool wave_runs_few(long long key) {
+#if PLB_SORT_SKIP_RUNS > 0
+    const int lane = threadIdx.x & 63;
+    const unsigned lo = (unsigned)key, hi = (unsigned)(key >> 32);
+    const unsigned plo = (unsigned)__shfl_up((int)lo, 1), phi = (unsigned)__shfl_up((int)hi, 1);
+    const bool head = lane == 0 || lo != plo || hi != phi;
+    return __popcll(__ballot(head)) <= PLB_SORT_SKIP_RUNS;
+#else
+    return false;
+#endif
+}
+
 // Sorted particle load in two halves so that independent memory traffic can be issued in between.
 struct SortLoad { double x0[3]; long long key; };
 template <class T> __device__ __forceinline__ SortLoad sorted_begin(const Dev<T>& D, const double* X) {
@@ -510,9 +539,14 @@ __device__ __forceinline__ bool sorted_finish(const Dev<T>& D, SortLoad& s, int&
         s.key = ((long long)b[2] * D.P.n + b[1]) * D.P.n + b[0];
     }
     // padding lanes carry the largest key either way; the 32-bit network needs (cells << 6) to fit
-    const int src = D.P.n <= 256 ? wave_sort_lanes32(p0 < D.N ? (unsigned)s.key : 0x3ffffffu) : wave_sort_lanes(s.key);
-    p = (p0 & ~63) + src;
-    for (int d = 0; d < 3; ++d) x[d] = __shfl(s.x0[d], src);       // the position travels with the sort
+    if (wave_runs_few(s.key)) {
+        p = p0;
+        for (int d = 0; d < 3; ++d) x[d] = s.x0[d];
+    } else {
+        const int src = D.P.n <= 256 ? wave_sort_lanes32(p0 < D.N ? (unsigned)s.key : 0x3ffffffu) : wave_sort_lanes(s.key);
+        p = (p0 & ~63) + src;
+        for (int d = 0; d < 3; ++d) x[d] = __shfl(s.x0[d], src);   // the position travels with the sort
+    }
     for (int d = 0; d < 3; ++d) base[d] = (int)(x[d] * (double)D.P.inv_dx - 0.5);
     if (clamp_to_reach(D, base) && p < D.N && flag_err) atomicOr(D.err, 1);
     return p < D.N;
@@ -531,10 +565,15 @@ __device__ __forceinline__ bool load_sorted_particle(const Dev<T>& D, const doub
         for (int d = 0; d < 3; ++d) { x0[d] = X[d * Np + p0]; b[d] = (int)(x0[d] * (double)D.P.inv_dx - 0.5); }
         key = ((long long)b[2] * D.P.n + b[1]) * D.P.n + b[0];
     }
-    const int src = D.P.n <= 256 ? wave_sort_lanes32(p0 < D.N ? (unsigned)key : 0x3ffffffu) : wave_sort_lanes(key);
-    p = (p0 & ~63) + src;
-    // the position travels with the sort (shuffles) instead of a second, dependent trip to memory
-    for (int d = 0; d < 3; ++d) x[d] = __shfl(x0[d], src);
+    if (wave_runs_few(key)) {
+        p = p0;
+        for (int d = 0; d < 3; ++d) x[d] = x0[d];
+    } else {
+        const int src = D.P.n <= 256 ? wave_sort_lanes32(p0 < D.N ? (unsigned)key : 0x3ffffffu) : wave_sort_lanes(key);
+        p = (p0 & ~63) + src;
+        // the position travels with the sort (shuffles) instead of a second, dependent trip to memory
+        for (int d = 0; d < 3; ++d) x[d] = __shfl(x0[d], src);
+    }
     for (int d = 0; d < 3; ++d) base[d] = (int)(x[d] * (double)D.P.inv_dx - 0.5);
     if (clamp_to_reach(D, base) && p < D.N && flag_err) atomicOr(D.err, 1);
     return p < D.N;
@@ -551,6 +590,7 @@ __global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_p2g(Dev<T> D, int f) 
     // accumulate in double: on gfx950 ds_add_f64 is ~5x cheaper per instruction than ds_add_f32
     // (profiles/microbench/lds_atomics.hip), and the node sums lose no precision
     __shared__ Vec4<double> tile[TileCap<T>::nodes];
+    constexpr int kPS = DET ? TileCap<T>::nodes / 2 : TileCap<T>::nodes;      // plane stride of the component-major layout
     const double* X = frame_x(D, f);
     const T* R = frame_r(D, f);
     const int Np = D.Npad;
@@ -561,7 +601,12 @@ __global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_p2g(Dev<T> D, int f) 
     store_tile(D, f, tl);
     const int tn = tl.e[0] * tl.e[1] * tl.e[2];
     if (tl.ok) {
+#if PLB_TILE_SOA
+        for (int i = threadIdx.x; i < tn; i += kBlock)
+            for (int k = 0; k < (DET ? 8 : 4); ++k) reinterpret_cast<double*>(tile)[k * kPS + i] = 0.0;
+#else
         for (int i = threadIdx.x; i < (DET ? 2 * tn : tn); i += kBlock) tile[i] = Vec4<double>{0.0, 0.0, 0.0, 0.0};
+#endif
         __syncthreads();
     }
     {
@@ -586,6 +631,16 @@ __global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_p2g(Dev<T> D, int f) 
                 seg_sum4(a0, a1, a2, a3, sg);
                 if (PLB_ABLATE & 1) { if (a0 + a1 + a2 + a3 == T(-1e30)) tile[0].x = 1.0; return; }
                 if (emitter) {
+#if PLB_TILE_SOA
+                    if constexpr (DET) {          // planes 0-3: hi limbs, 4-7: lo limbs
+                        long long* q = reinterpret_cast<long long*>(tile) + ((oz + l) * exy + (oy + j) * ex + (ox + i));
+                        det_add(q, q + 4 * kPS, (double)a0); det_add(q + kPS, q + 5 * kPS, (double)a1);
+                        det_add(q + 2 * kPS, q + 6 * kPS, (double)a2); det_add(q + 3 * kPS, q + 7 * kPS, (double)a3);
+                    } else {
+                        double* q = reinterpret_cast<double*>(tile) + ((oz + l) * exy + (oy + j) * ex + (ox + i));
+                        atomicAdd(q, (double)a0); atomicAdd(q + kPS, (double)a1); atomicAdd(q + 2 * kPS, (double)a2); atomicAdd(q + 3 * kPS, (double)a3);
+                    }
+#else
                     if constexpr (DET) {          // node: 4 hi limbs, then 4 lo limbs
                         long long* q = reinterpret_cast<long long*>(tile) + 8 * ((oz + l) * exy + (oy + j) * ex + (ox + i));
                         det_add(q, q + 4, (double)a0); det_add(q + 1, q + 5, (double)a1); det_add(q + 2, q + 6, (double)a2); det_add(q + 3, q + 7, (double)a3);
@@ -593,6 +648,7 @@ __global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_p2g(Dev<T> D, int f) 
                         double* q = reinterpret_cast<double*>(&tile[(oz + l) * exy + (oy + j) * ex + (ox + i)]);
                         atomicAdd(q, (double)a0); atomicAdd(q + 1, (double)a1); atomicAdd(q + 2, (double)a2); atomicAdd(q + 3, (double)a3);
                     }
+#endif
                 }
             });
         } else {
@@ -622,9 +678,12 @@ __global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_p2g(Dev<T> D, int f) 
         const int ex = tl.e[0], exy = tl.e[0] * tl.e[1];
         for (int i = threadIdx.x; i < tn; i += kBlock) {
             if constexpr (DET) {
-                const long long* q = reinterpret_cast<const long long*>(tile) + 8 * i;
+                long long q[8];
                 long long any = 0;
-                for (int c = 0; c < 8; ++c) any |= q[c];
+                for (int c = 0; c < 8; ++c) {
+                    q[c] = reinterpret_cast<const long long*>(tile)[PLB_TILE_SOA ? c * kPS + i : 8 * i + c];
+                    any |= q[c];
+                }
                 if (any) {
                     int lz, ly, lx;
                     tile_coords(i, ex, exy, lz, ly, lx);
@@ -634,7 +693,12 @@ __global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_p2g(Dev<T> D, int f) 
                 }
                 continue;
             }
+#if PLB_TILE_SOA
+            const double* tq = reinterpret_cast<const double*>(tile);
+            Vec4<double> a{tq[i], tq[kPS + i], tq[2 * kPS + i], tq[3 * kPS + i]};
+#else
             Vec4<double> a = tile[i];
+#endif
             if (a.x != 0.0 || a.y != 0.0 || a.z != 0.0 || a.w != 0.0) {
                 int lz, ly, lx;
                 tile_coords(i, ex, exy, lz, ly, lx);
@@ -739,6 +803,7 @@ template <class T, bool DET = false>
 __global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_g2p_p2g(Dev<T> D, int f, const Vec4<T>* vout_prev) {
     __shared__ int sred[32];
     __shared__ Vec4<double> tile[TileCap<T>::nodes];
+    constexpr int kPS = DET ? TileCap<T>::nodes / 2 : TileCap<T>::nodes;      // plane stride of the component-major layout
     Vec4<T>* tile_v = reinterpret_cast<Vec4<T>*>(tile);          // first use of the same LDS
     const int Np = D.Npad;
     // ---------------- g2p(f-1): gather
@@ -809,7 +874,12 @@ __global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_g2p_p2g(Dev<T> D, int
     if (threadIdx.x == 0) { atomicAdd(D.err + (tl.ok ? 2 : 1), 1); if (tl.ok) atomicAdd(D.err + 3, tn); }
 #endif
     if (tl.ok) {
+#if PLB_TILE_SOA
+        for (int i = threadIdx.x; i < tn; i += kBlock)
+            for (int k = 0; k < (DET ? 8 : 4); ++k) reinterpret_cast<double*>(tile)[k * kPS + i] = 0.0;
+#else
         for (int i = threadIdx.x; i < (DET ? 2 * tn : tn); i += kBlock) tile[i] = Vec4<double>{0.0, 0.0, 0.0, 0.0};
+#endif
         __syncthreads();
     }
     PT_MARK(3);
@@ -827,6 +897,16 @@ __global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_g2p_p2g(Dev<T> D, int
                 seg_sum4(a0, a1, a2, a3, sg);
                 if (PLB_ABLATE & 1) { if (a0 + a1 + a2 + a3 == T(-1e30)) tile[0].x = 1.0; return; }
                 if (emitter) {
+#if PLB_TILE_SOA
+                    if constexpr (DET) {          // planes 0-3: hi limbs, 4-7: lo limbs
+                        long long* q = reinterpret_cast<long long*>(tile) + ((oz + l) * exy + (oy + j) * ex + (ox + i));
+                        det_add(q, q + 4 * kPS, (double)a0); det_add(q + kPS, q + 5 * kPS, (double)a1);
+                        det_add(q + 2 * kPS, q + 6 * kPS, (double)a2); det_add(q + 3 * kPS, q + 7 * kPS, (double)a3);
+                    } else {
+                        double* q = reinterpret_cast<double*>(tile) + ((oz + l) * exy + (oy + j) * ex + (ox + i));
+                        atomicAdd(q, (double)a0); atomicAdd(q + kPS, (double)a1); atomicAdd(q + 2 * kPS, (double)a2); atomicAdd(q + 3 * kPS, (double)a3);
+                    }
+#else
                     if constexpr (DET) {          // node: 4 hi limbs, then 4 lo limbs
                         long long* q = reinterpret_cast<long long*>(tile) + 8 * ((oz + l) * exy + (oy + j) * ex + (ox + i));
                         det_add(q, q + 4, (double)a0); det_add(q + 1, q + 5, (double)a1); det_add(q + 2, q + 6, (double)a2); det_add(q + 3, q + 7, (double)a3);
@@ -834,6 +914,7 @@ __global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_g2p_p2g(Dev<T> D, int
                         double* q = reinterpret_cast<double*>(&tile[(oz + l) * exy + (oy + j) * ex + (ox + i)]);
                         atomicAdd(q, (double)a0); atomicAdd(q + 1, (double)a1); atomicAdd(q + 2, (double)a2); atomicAdd(q + 3, (double)a3);
                     }
+#endif
                 }
             });
         } else {
@@ -864,9 +945,12 @@ __global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_g2p_p2g(Dev<T> D, int
         const int ex = tl.e[0], exy = tl.e[0] * tl.e[1];
         for (int i = threadIdx.x; i < tn; i += kBlock) {
             if constexpr (DET) {
-                const long long* q = reinterpret_cast<const long long*>(tile) + 8 * i;
+                long long q[8];
                 long long any = 0;
-                for (int c = 0; c < 8; ++c) any |= q[c];
+                for (int c = 0; c < 8; ++c) {
+                    q[c] = reinterpret_cast<const long long*>(tile)[PLB_TILE_SOA ? c * kPS + i : 8 * i + c];
+                    any |= q[c];
+                }
                 if (any) {
                     int lz, ly, lx;
                     tile_coords(i, ex, exy, lz, ly, lx);
@@ -876,7 +960,12 @@ __global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_g2p_p2g(Dev<T> D, int
                 }
                 continue;
             }
+#if PLB_TILE_SOA
+            const double* tq = reinterpret_cast<const double*>(tile);
+            Vec4<double> a{tq[i], tq[kPS + i], tq[2 * kPS + i], tq[3 * kPS + i]};
+#else
             Vec4<double> a = tile[i];
+#endif
             if (a.x != 0.0 || a.y != 0.0 || a.z != 0.0 || a.w != 0.0) {
                 int lz, ly, lx;
                 tile_coords(i, ex, exy, lz, ly, lx);
