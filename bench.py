@@ -231,36 +231,74 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", 0)) % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
-    dist = None
+    dist, ctl = None, None
     if world > 1:
+        import datetime
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = os.environ.get("PLB_DIST_BACKEND", "nccl")     # "gloo" lets two ranks share one GPU (testing only)
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=device)
+            # control plane (agreement, barriers, the max over ranks) on its own gloo group: it keeps working when the
+            # data plane -- RCCL point-to-point between slabs -- does not
+            ctl = dist.new_group(backend="gloo", timeout=datetime.timedelta(seconds=1800))
         else:
             dist.init_process_group(backend)
-    red_dev = device if (dist is None or dist.get_backend() == "nccl") else torch.device("cpu")
 
     def barrier():
+        torch.cuda.synchronize()
         if dist is not None:
-            dist.barrier()
+            dist.barrier(group=ctl)
         torch.cuda.synchronize()
 
     def agree(ok):
         """True only if every rank succeeded."""
         if dist is None:
             return ok
-        t = torch.tensor([1.0 if ok else 0.0], device=red_dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        t = torch.tensor([1.0 if ok else 0.0])
+        if ctl is None and dist.get_backend() == "nccl":
+            t = t.to(device)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=ctl)
         return bool(t.item() > 0.5)
+
+    def max_over_ranks(x):
+        if dist is None:
+            return x
+        t = torch.tensor([x], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=ctl)
+        return float(t.item())
+
+    # A slab run that HANGS (a rank stuck in an RCCL call has no exception to catch) must not take the whole job with
+    # it: if the slab build + warm-up has not been agreed on within PLB_SLAB_TIMEOUT seconds, every rank replaces its
+    # own process image by the replica run of the same command (fresh GPU context, fresh rendezvous one port up).
+    def arm_watchdog():
+        import threading
+        limit = float(os.environ.get("PLB_SLAB_TIMEOUT", 300))
+
+        def fire():
+            sys.stderr.write(f"[bench] rank {rank}: slab warm-up not finished after {limit:.0f} s -- re-running as replicas\n")
+            sys.stderr.flush()
+            env2 = dict(os.environ)
+            env2["MASTER_PORT"] = str(int(env2.get("MASTER_PORT", "29500")) + 1)
+            env2["TORCHELASTIC_USE_AGENT_STORE"] = "False"       # rank 0 hosts the new store itself
+            env2["PLB_BENCH_NOTE"] = f"slab warm-up timed out after {limit:.0f} s"
+            argv = [sys.executable, os.path.abspath(__file__)] + [a for a in sys.argv[1:] if a != "--replicas"] + ["--replicas"]
+            os.execve(sys.executable, argv, env2)
+
+        t = threading.Timer(limit, fire)
+        t.daemon = True
+        t.start()
+        return t
 
     K, W = args.steps, args.warmup
     slabs = world > 1 and not args.replicas
     env, state0 = None, None
     if slabs:
         note = ""
+        watchdog = arm_watchdog()
         try:
+            if os.environ.get("PLB_BENCH_FAKE_HANG") == str(rank):      # test hook for the watchdog
+                time.sleep(1e6)
             env, parallelism = build_env(args, device, rank, world, slabs=True)
             ok = True
         except Exception as e:                                    # noqa: BLE001
@@ -276,14 +314,17 @@ def main():
             ok = agree(ok)
         else:
             ok = False
+        watchdog.cancel()
         if not ok:
             if rank == 0:
                 print(f"[bench] slab path unavailable ({note or 'another rank failed'}); falling back to replicas", file=sys.stderr)
             env, slabs, state0 = None, False, None
-            if 'torch' in sys.modules:
-                torch.cuda.empty_cache()
+            os.environ["PLB_BENCH_NOTE"] = "slab path unavailable" + (f": {note[:120]}" if note else "")
+            torch.cuda.empty_cache()
     if env is None:
         env, parallelism = build_env(args, device, rank, world, slabs=False)
+        if os.environ.get("PLB_BENCH_NOTE"):
+            parallelism += f" ({os.environ['PLB_BENCH_NOTE']})"
         state0 = env.get_state()["state"]
     sim = env.simulator
     sub = sim.substeps
@@ -302,10 +343,7 @@ def main():
     loss = rollout(env, acts)
     barrier()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = max_over_ranks(elapsed)
     total_substeps = K * sub * (1 if slabs else world)         # slabs: one shared workload; replicas: one each
     value = total_substeps / elapsed
 
@@ -334,9 +372,12 @@ def main():
         prof = sim.engine.profile_read()
         sim.engine.profile_enable(False)
         N = sim.n_particles                                   # this rank's particles (at reset)
-        tot = torch.tensor([float(N), float(nodes)], dtype=torch.float64, device=red_dev)
+        tot = torch.tensor([float(N), float(nodes)], dtype=torch.float64)
         if dist is not None:
-            dist.all_reduce(tot)                              # halo nodes are active on both neighbours: counted twice, as they are swept twice
+            if ctl is None and dist.get_backend() == "nccl":
+                tot = tot.to(device)
+            dist.all_reduce(tot, group=ctl)                   # halo nodes are active on both neighbours: counted twice, as they are swept twice
+            tot = tot.cpu()
         if slabs is False and world > 1:
             tot /= world                                      # replicas: every rank holds the whole workload
     if rank == 0 and not args.no_roofline:
