@@ -28,13 +28,19 @@
 #define PLB_ROLL_G2PG_I PLB_ROLL
 #endif
 #ifndef PLB_ROLL_G2PG_J
-#define PLB_ROLL_G2PG_J                 // measured: unrolling j (9 nodes per iteration) helps the reverse loops a little,
-#endif                                  // unrolling i as well costs registers and is slower
+#define PLB_ROLL_G2PG_J PLB_ROLL        // rolled: 128 instead of 168 VGPRs, which buys g2p.grad its 4th wave per SIMD (round 2:
+#endif                                  // 37.0 -> 35.0 us); unrolled at 3 waves was the round-1 choice.  Unrolling i as well is slower
 #ifndef PLB_ROLL_P2G_I
 #define PLB_ROLL_P2G_I PLB_ROLL
 #endif
 #ifndef PLB_ROLL_G2P_I
 #define PLB_ROLL_G2P_I PLB_ROLL
+#endif
+#ifndef PLB_ROLL_P2G_J
+#define PLB_ROLL_P2G_J PLB_ROLL         // rolled: 8 B less scratch in the fused forward kernel, 55.1 -> 53.9 us (round 2)
+#endif
+#ifndef PLB_ROLL_G2P_J
+#define PLB_ROLL_G2P_J
 #endif
 #ifndef PLB_ROLL_GATH_I
 #define PLB_ROLL_GATH_I PLB_ROLL
@@ -52,6 +58,8 @@
 #define PLB_ROLL_GATH_J
 #define PLB_ROLL_P2G_I
 #define PLB_ROLL_G2P_I
+#define PLB_ROLL_P2G_J
+#define PLB_ROLL_G2P_J
 #define PLB_UNROLL
 #endif
 
@@ -482,6 +490,7 @@ PLB_HD void p2g_particle(const SimP<T>& P, const X* x, const T* v, const T* C, c
         const T wi = sel3(i, w[0][0], w[1][0], w[2][0]);
         const T fi = T(i);
         T qi[3] = {q0[0] + fi * ax[0], q0[1] + fi * ax[1], q0[2] + fi * ax[2]};
+        PLB_ROLL_P2G_J
         for (int j = 0; j < 3; ++j) {
             T qj[3] = {qi[0] + T(j) * ay[0], qi[1] + T(j) * ay[1], qi[2] + T(j) * ay[2]};
             const T wij = wi * w[j][1];
@@ -512,6 +521,7 @@ PLB_HD void g2p_particle(const SimP<T>& P, const X* x, X* xn, T* vn, T* Cn, Fetc
     PLB_ROLL_G2P_I
     for (int i = 0; i < 3; ++i) {
         T Sww[3] = {T(0), T(0), T(0)}, Szw[3] = {T(0), T(0), T(0)}, Swz[3] = {T(0), T(0), T(0)};
+        PLB_ROLL_G2P_J
         for (int j = 0; j < 3; ++j) {
             T Rw[3] = {T(0), T(0), T(0)}, Rz[3] = {T(0), T(0), T(0)};
             for (int l = 0; l < 3; ++l) {

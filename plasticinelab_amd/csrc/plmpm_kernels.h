@@ -33,7 +33,10 @@ constexpr int kBlock = 256;          // threads per workgroup in particle kernel
 #define PLB_P2G_GRAD_WAVES 2
 #endif
 constexpr int kMaxPrim = 8;
-constexpr int kGridWG = 512;         // workgroups of the persistent grid kernels (4 waves each, one wave per block)
+#ifndef PLB_GRID_WG
+#define PLB_GRID_WG 512
+#endif
+constexpr int kGridWG = PLB_GRID_WG;         // workgroups of the persistent grid kernels (4 waves each, one wave per block)
 // LDS tile capacity (nodes) of the scatter/gather kernels: 16 KiB per tile for either scalar type
 template <class T> struct TileCap;
 #ifndef PLB_TILECAP
@@ -982,10 +985,19 @@ __global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_g2p_p2g(Dev<T> D, int
 
 // ------------------------------------------------------------------------------------------------
 // g2p.grad: scatter grid_v_out.grad, x[f].grad partial -> adjoint frame `dst`.  vnext: see below (nullptr = frame f+1)
+// g2p.grad at 4 waves per SIMD: with the j loop of g2p_particle_grad rolled (PLB_ROLL_G2PG_J, mpm_math.h) the fp32 kernel
+// needs 128 VGPRs without scratch instead of 168, and four 37.5 KiB workgroups fit a CU's LDS: 37.0 -> 35.0 us
+// (round 2; 5 waves = 96 VGPRs + 100 B scratch and a smaller tile was not faster)
+#ifndef PLB_G2PG_WAVES
+#define PLB_G2PG_WAVES 4
+#endif
+#ifndef PLB_G2PG_CAP
+#define PLB_G2PG_CAP 960
+#endif
 template <class T, bool DET = false>
-__global__ __launch_bounds__(kBlock) void k_g2p_grad(Dev<T> D, int f, int src, int dst, const T* vnext) {
-    // 960 nodes x (16 + 24) bytes = 37.5 KiB: four workgroups per CU (the kernel needs 126 VGPRs = 4 waves per SIMD)
-    constexpr int CAP = sizeof(T) == 4 ? 960 : 480;
+__global__ __launch_bounds__(kBlock, sizeof(T) == 4 ? PLB_G2PG_WAVES : 1) void k_g2p_grad(Dev<T> D, int f, int src, int dst, const T* vnext) {
+    // 960 nodes x (16 + 24) bytes = 37.5 KiB: four workgroups per CU (128 VGPRs = 4 waves per SIMD, see PLB_G2PG_WAVES)
+    constexpr int CAP = sizeof(T) == 4 ? PLB_G2PG_CAP : 480;
     __shared__ Vec4<T> tile[CAP];                    // v_out values
     __shared__ double tile_a[CAP * 3];               // v_out adjoint accumulation (f64, see k_p2g)
     const double* X = frame_x(D, f);
@@ -1174,8 +1186,11 @@ __device__ __forceinline__ bool grid_block_bwd(const Dev<T>& D, const HaloIn& H,
 // Persistent over the active blocks.  The double-precision pose adjoints of the blocks in contact (a few dozen waves,
 // several microseconds each: the whole tail of this kernel when done here) are handed to spare workgroups of the
 // p2g.grad launch that follows, through D.contact.
+#ifndef PLB_GOG_WAVES
+#define PLB_GOG_WAVES 1          // 4 (128 VGPRs + 60 B scratch) measured: 14.1 -> 17.8 us
+#endif
 template <class T>
-__global__ __launch_bounds__(kBlock) void k_grid_op_grad(Dev<T> D, int f, HaloIn H) {
+__global__ __launch_bounds__(kBlock, sizeof(T) == 4 ? PLB_GOG_WAVES : 1) void k_grid_op_grad(Dev<T> D, int f, HaloIn H) {
     __shared__ PrimT<T> sp[kMaxPrim];
     const int fl0 = first_flags(D);
     load_prims(D, f, sp);

@@ -64,14 +64,22 @@ def main():
     for k, v in merged.items():
         if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
             v["hbm_bytes_per_launch"] = (2.0 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024.0
-        m = re.match(r"k_([a-z0-9_]+)<(float|double)(?:, (true|false))?>", k)
+        m = re.match(r"k_([a-z0-9_]+)<(float|double)((?:, (?:true|false))*)>", k)
         key = k
         if m:
             key = m.group(1)
-            if key == "p2g" and m.group(3) == "false":
-                key = "p2g_recompute"
-            if key == "grid_op" and m.group(3) == "true":
-                key = "grid_op_clear"
+            flags = [t == "true" for t in re.findall(r"true|false", m.group(3))]
+            # template flags: k_p2g<T, WRITE_F, DET>, k_grid_op<T, CLEAR>, k_g2p_p2g / k_g2p_grad / k_grid_mass<T, DET>
+            if key == "p2g":
+                if flags and not flags[0]:
+                    key = "p2g_recompute"
+                if len(flags) > 1 and flags[1]:
+                    key += "_det"
+            elif key == "grid_op":
+                if flags and flags[0]:
+                    key = "grid_op_clear"
+            elif flags and flags[0]:
+                key += "_det"
             if (m.group(2) == "float") != (a.dtype == "f32"):
                 continue
         kernels[key] = v
