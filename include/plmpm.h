@@ -227,6 +227,12 @@ int plmpm_p2g(plmpm_handle h, int frame, int chain);
  * g2p to the next plmpm_p2g(frame + 1, chain = 1), which must be the next call.  The last substep of an env step
  * passes chain = 0. */
 int plmpm_grid_g2p(plmpm_handle h, int frame, int chain);
+/* Overlap of the exchange with grid work (optional).  Blocks outside the exchanged planes do not need the neighbours'
+ * values: plmpm_grid_interior runs grid_op on them while the halos are still in flight; the plmpm_grid_g2p(frame) that
+ * follows -- after the halos have arrived -- then only does the blocks of the exchanged planes and g2p.
+ * plmpm_grad_gather_interior / plmpm_grad_gather are the same split of grid_op.grad. */
+int plmpm_grid_interior(plmpm_handle h, int frame);
+int plmpm_grad_gather_interior(plmpm_handle h, int frame);
 int plmpm_grad_scatter(plmpm_handle h, int frame);                          /* g2p.grad */
 int plmpm_grad_gather(plmpm_handle h, int frame);                           /* grid_op.grad (+ halo planes) + p2g.grad + clear */
 int plmpm_chain_grad(plmpm_handle h, int first_frame, int n_substeps, int step);   /* fk.grad + set_velocity.grad */

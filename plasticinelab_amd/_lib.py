@@ -88,6 +88,8 @@ SYMBOLS = {
     "plmpm_grid_g2p": (_I, [_P, _I, _I]),
     "plmpm_grad_scatter": (_I, [_P, _I]),
     "plmpm_grad_gather": (_I, [_P, _I]),
+    "plmpm_grid_interior": (_I, [_P, _I]),
+    "plmpm_grad_gather_interior": (_I, [_P, _I]),
     "plmpm_chain_grad": (_I, [_P, _I, _I, _I]),
     "plmpm_grid_window": (_I, [_P, _P, _P]),
     "plmpm_halo_region": (_I, [_P, _I, _I, _I, _I, _I, C.POINTER(_P), C.POINTER(C.c_size_t)]),

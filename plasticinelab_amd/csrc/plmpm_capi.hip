@@ -72,6 +72,7 @@ struct plmpm_sim {
     // multi-GPU: pose adjoints produced by this rank's nodes/particles accumulate in *_l, get summed over
     // ranks by the host and are then merged into the global ppos_a/prot_a the kinematics chain reads
     bool dist = false;
+    int interior_fwd = -1, interior_bwd = -1;      // frame whose interior grid blocks plmpm_grid_interior / _grad_gather_interior already did
     HaloIn halo_in[3];                // per halo field: where the neighbours' copies of the exchanged block planes arrive
     double target_outside = 0.0;      // sum of the target density over owned nodes outside the grid window (|0 - t| terms)
     // particle migration between z-slabs (plmpm_migrate_*): per storage epoch the global particle ids, the materials,
@@ -754,7 +755,7 @@ static ChainBufs chain_bufs(const plmpm_sim* s) {
     return B;
 }
 static inline int nblocks_particles(const plmpm_sim* s, int frame) { return (s->epochN[s->frame_epoch[frame]] + kBlock - 1) / kBlock; }
-static const HaloIn kNoHalo = {0, {0, 0}, {0, 0}, {nullptr, nullptr}};
+static const HaloIn kNoHalo = {0, {0, 0}, {0, 0}, {nullptr, nullptr}, 0};
 #ifndef PLB_POSE_WG
 #define PLB_POSE_WG 16
 #endif
@@ -823,10 +824,15 @@ template <class T> static int phase_p2g(plmpm_sim* s, int f) {
     s->dirty[f] = 1;
     return 0;
 }
-template <class T> static int phase_grid_g2p(plmpm_sim* s, int f, bool defer_g2p = false) {
+// part: 0 every active block | 1 only the blocks outside the exchanged planes (nothing else: the halos may still be in
+// flight) | 2 the blocks of the exchanged planes, then g2p
+template <class T> static int phase_grid_g2p(plmpm_sim* s, int f, bool defer_g2p = false, int part = 0) {
     Dev<T> D = make_dev<T>(s, f);
     s->frame_epoch[f + 1] = s->frame_epoch[f];                 // g2p (now or fused into the next p2g) writes frame f + 1 in this order
-    LAUNCH(s, K_GRID_OP, (k_grid_op<T, false>), dim3(nwg_grid(s)), D, f, s->halo_in[PLMPM_HALO_GRID_IN]);
+    HaloIn H = s->halo_in[PLMPM_HALO_GRID_IN];
+    H.part = part;
+    LAUNCH(s, K_GRID_OP, (k_grid_op<T, false>), dim3(nwg_grid(s)), D, f, H);
+    if (part == 1) return 0;
     if (!defer_g2p) LAUNCH(s, K_G2P, (k_g2p<T>), dim3(nblocks_particles(s, f)), D, f);
     return 0;
 }
@@ -845,9 +851,12 @@ template <class T> static int phase_grad_scatter(plmpm_sim* s, int f) {
     LAUNCH_G2P_GRAD(s, D, f, (f + 1) & 1, f & 1, vnext);
     return 0;
 }
-template <class T> static int phase_grad_gather(plmpm_sim* s, int f) {
+template <class T> static int phase_grad_gather(plmpm_sim* s, int f, int part = 0) {
     Dev<T> D = make_dev<T>(s, f);
-    LAUNCH(s, K_GRID_OP_GRAD, (k_grid_op_grad<T>), dim3(nwg_grid(s)), D, f, s->halo_in[PLMPM_HALO_GRID_OUT_ADJ]);
+    HaloIn H = s->halo_in[PLMPM_HALO_GRID_OUT_ADJ];
+    H.part = part;
+    LAUNCH(s, K_GRID_OP_GRAD, (k_grid_op_grad<T>), dim3(nwg_grid(s)), D, f, H);
+    if (part == 1) return 0;
     LAUNCH_P2G_GRAD(s, D, f, (f + 1) & 1, f & 1);
     s->dirty[f] = 0;
     s->adj_frame[f & 1] = f;
@@ -1952,11 +1961,22 @@ int plmpm_p2g(plmpm_handle s, int frame, int chain) {
     HIPCHK(hipGetLastError());
     return 0;
 }
+int plmpm_grid_interior(plmpm_handle s, int frame) {
+    NEED_BOUND(s);
+    REQUIRE(s->store && frame >= 0 && frame < s->F, "grid_interior: bad call");
+    REQUIRE(s->halo_in[PLMPM_HALO_GRID_IN].n > 0, "grid_interior: no halo planes are registered for PLMPM_HALO_GRID_IN (nothing to overlap with)");
+    DISPATCH(s, phase_grid_g2p, s, frame, false, 1);
+    HIPCHK(hipGetLastError());
+    s->interior_fwd = frame;
+    return 0;
+}
 int plmpm_grid_g2p(plmpm_handle s, int frame, int chain) {
     NEED_BOUND(s);
     REQUIRE(s->store && frame >= 0 && frame < s->F, "grid_g2p: bad call");
     REQUIRE(!chain || frame + 1 < s->F, "grid_g2p: only a substep with a successor chains");
-    DISPATCH(s, phase_grid_g2p, s, frame, chain != 0);
+    const int part = s->interior_fwd == frame ? 2 : 0;         // the interior blocks were done by plmpm_grid_interior
+    s->interior_fwd = -1;
+    DISPATCH(s, phase_grid_g2p, s, frame, chain != 0, part);
     HIPCHK(hipGetLastError());
     if (chain) s->g2p_deferred = frame;
     return 0;
@@ -1973,10 +1993,21 @@ int plmpm_grad_scatter(plmpm_handle s, int frame) {
     HIPCHK(hipGetLastError());
     return 0;
 }
+int plmpm_grad_gather_interior(plmpm_handle s, int frame) {
+    NEED_BOUND(s);
+    REQUIRE(s->store && frame >= 0 && frame < s->F, "grad_gather_interior: bad call");
+    REQUIRE(s->halo_in[PLMPM_HALO_GRID_OUT_ADJ].n > 0, "grad_gather_interior: no halo planes are registered for PLMPM_HALO_GRID_OUT_ADJ");
+    DISPATCH(s, phase_grad_gather, s, frame, 1);
+    HIPCHK(hipGetLastError());
+    s->interior_bwd = frame;
+    return 0;
+}
 int plmpm_grad_gather(plmpm_handle s, int frame) {
     NEED_BOUND(s);
     REQUIRE(s->store && frame >= 0 && frame < s->F, "grad_gather: bad call");
-    DISPATCH(s, phase_grad_gather, s, frame);
+    const int part = s->interior_bwd == frame ? 2 : 0;
+    s->interior_bwd = -1;
+    DISPATCH(s, phase_grad_gather, s, frame, part);
     HIPCHK(hipGetLastError());
     return 0;
 }

@@ -214,6 +214,9 @@ struct HaloIn {
     int n;                           // faces with a neighbour (0 on a single GPU)
     int ba[2], bb[2];
     const void* buf[2];
+    int part;                        // 0: every active block | 1: only blocks outside the exchanged planes (they do not
+                                     // need the neighbours' values: this pass can run while the halos are in flight) | 2: only
+                                     // the blocks of the exchanged planes
 };
 template <class T> __device__ __forceinline__ int halo_face_of(const Dev<T>& D, const HaloIn& H, int blk) {
     const int bz = blk / (D.nbx * D.nby);
@@ -232,7 +235,8 @@ template <class T> __device__ __forceinline__ int first_flags(const Dev<T>& D) {
     const int lane = threadIdx.x & 63;
     return lane < D.fs ? D.flags[blockIdx.x * D.fs + lane] : 0;
 }
-template <class T, class Body> __device__ __forceinline__ void for_each_active_block(const Dev<T>& D, const HaloIn& H, int flags0, Body&& body) {
+// CAND: blocks of the exchanged planes are candidates whatever their flag
+template <bool CAND, class T, class Body> __device__ __forceinline__ void for_each_active_block(const Dev<T>& D, const HaloIn& H, int flags0, Body&& body) {
     const int nblk = D.nbx * D.nby * D.nbz, g = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int k0 = 0; k0 < D.fs; k0 += 64) {
         const int k = k0 + lane, b = g + (k << D.fgl);
@@ -240,7 +244,8 @@ template <class T, class Body> __device__ __forceinline__ void for_each_active_b
         const int fl = k0 == 0 ? flags0 : (in ? D.flags[g * D.fs + k] : 0);
         // blocks in the exchanged planes are candidates whatever their flag: the neighbour's particles may reach
         // nodes that none of ours do (the body skips a candidate whose summed mass is zero everywhere)
-        const unsigned long long m = __ballot(in && (fl != 0 || (H.n > 0 && halo_face_of(D, H, b) >= 0)));
+        const bool face = H.n > 0 && halo_face_of(D, H, b) >= 0;
+        const unsigned long long m = __ballot(in && (fl != 0 || (CAND && face)) && (H.part == 0 || (H.part == 2) == face));
         __syncthreads();             // bodies may clear flags: every wave must have taken the same snapshot first
         int rank = 0;
         for (unsigned long long r = m; r; r &= r - 1, ++rank)
@@ -724,7 +729,7 @@ __global__ __launch_bounds__(kBlock) void k_grid_op(Dev<T> D, int f, HaloIn H) {
     load_prims(D, f, sp);
     __syncthreads();
     const int lane = threadIdx.x & 63;
-    for_each_active_block(D, H, fl0, [&](int blk) {
+    for_each_active_block<true>(D, H, fl0, [&](int blk) {
         const int idx = (blk << 6) | lane;
         int I[3];
         block_nodes(D, blk, lane, I);
@@ -1198,9 +1203,7 @@ __global__ __launch_bounds__(kBlock, sizeof(T) == 4 ? PLB_GOG_WAVES : 1) void k_
     const int lane = threadIdx.x & 63;
     // the forward grid_op marked every block of the exchanged planes that carries mass, so the flags alone are
     // complete here: no halo candidates
-    HaloIn none;
-    none.n = 0;
-    for_each_active_block(D, none, fl0, [&](int blk) {
+    for_each_active_block<false>(D, H, fl0, [&](int blk) {
         if (grid_block_bwd<T, false>(D, H, blk, lane, sp, nullptr, nullptr) && lane == 0)
             D.contact[1 + atomicAdd(&D.contact[0], 1)] = blk;
     });

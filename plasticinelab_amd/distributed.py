@@ -155,9 +155,21 @@ class HaloComm:
     def exchange(self, engine, field, f):
         """Send this rank's copy of the exchanged block planes of ``field`` (frame ``f``) to the neighbours and receive
         theirs into the registered buffers.  The grid kernels (or ``halo_apply``) add them."""
+        self.exchange_finish(self.exchange_start(engine, field, f))
+
+    def exchange_finish(self, reqs):
+        """Make the engine's stream wait for an exchange begun with ``exchange_start``."""
+        for req in reqs or ():
+            req.wait()
+
+    def exchange_start(self, engine, field, f):
+        """Begin the exchange and return its requests without waiting: over RCCL the transfers run on the communicator's
+        own stream, ordered behind what the engine's stream has enqueued so far, and the engine may go on enqueueing
+        work that does not touch the exchanged planes (``Engine.grid_interior``) until ``exchange_finish``.  (gloo, the
+        test transport, goes through host memory and is complete on return.)"""
         faces = self.layout.faces(self.rank)
         if not faces:
-            return
+            return []
         if field not in self._recv:
             self.attach(engine, field, f)
         recv = self._recv[field]
@@ -173,7 +185,7 @@ class HaloComm:
                 req.wait()
             for hr, rb, _hs in hosts:
                 rb.copy_(hr)                                     # ordered on the engine's stream before the grid kernel
-            return
+            return []
         key = (field, f if field == engine.HALO_GRID_IN else -1)
         ops = self._ops.get(key)
         if ops is None:
@@ -183,8 +195,7 @@ class HaloComm:
                     ops.append(dist.P2POp(dist.isend, v, nbr, self.group))
                     ops.append(dist.P2POp(dist.irecv, rb[c], nbr, self.group))
             self._ops[key] = ops
-        for req in dist.batch_isend_irecv(ops):
-            req.wait()
+        return dist.batch_isend_irecv(ops)
 
     # ---- rows (migration)
     def _wire(self, t):
@@ -264,8 +275,13 @@ class SlabEngine:
     """Proxy around one rank's ``Engine`` that turns ``step`` / ``step_grad`` / ``loss_*`` into the phase-split,
     halo-exchanging, migrating versions.  ``MPMSimulator``, ``Loss`` and ``Tape`` work on it unchanged."""
 
-    def __init__(self, engine, layout: SlabLayout, rank: int, group=None, comm: Optional[HaloComm] = None, migrate_every: int = 1):
+    def __init__(self, engine, layout: SlabLayout, rank: int, group=None, comm: Optional[HaloComm] = None, migrate_every: int = 1,
+                 overlap: bool = False):
         self._e, self.layout, self.rank = engine, layout, rank
+        # overlap: grid_op / grid_op.grad of the blocks outside the exchanged planes run while the halos are in flight
+        # (one more launch per phase: worth it when a rank's kernels are long against the exchange -- configs 4 and 5 --
+        # not when the host is what bounds the substep, as at 128^3 cut four ways)
+        self.overlap = bool(overlap) and bool(layout.faces(rank))
         self.comm = comm if comm is not None else HaloComm(layout, rank, group)
         self.soft_contact = False
         self.migrate_every = int(migrate_every)        # env steps between two migrations (0: never -- fixed ownership)
@@ -324,7 +340,12 @@ class SlabEngine:
         pending = False                         # g2p(f - 1) deferred: it runs fused with p2g(f), as on one GPU
         for f in range(first, first + n):
             e.p2g(f, chain=pending)
-            self.comm.exchange(e, e.HALO_GRID_IN, f)
+            if self.overlap:
+                reqs = self.comm.exchange_start(e, e.HALO_GRID_IN, f)
+                e.grid_interior(f)
+                self.comm.exchange_finish(reqs)
+            else:
+                self.comm.exchange(e, e.HALO_GRID_IN, f)
             pending = f + 1 < first + n
             e.grid_g2p(f, chain=pending)
 
@@ -340,7 +361,12 @@ class SlabEngine:
                 self._migrate_adjoint(last)     # particles migrated at `last`: adjoint rows go back where they came from
         for f in range(last - 1, first - 1, -1):
             e.grad_scatter(f)
-            self.comm.exchange(e, e.HALO_GRID_OUT_ADJ, f)
+            if self.overlap:
+                reqs = self.comm.exchange_start(e, e.HALO_GRID_OUT_ADJ, f)
+                e.grad_gather_interior(f)
+                self.comm.exchange_finish(reqs)
+            else:
+                self.comm.exchange(e, e.HALO_GRID_OUT_ADJ, f)
             e.grad_gather(f)
         for view in e.pose_grad_views(first, n + 1):      # position, rotation, (Chopsticks) gap adjoints
             self.comm.all_reduce_(view)
@@ -400,14 +426,15 @@ def make_slab_env(cfg, rank: int, world: int, *, halo: int = 4, compute_dtype=No
                   target_fn: Optional[Callable] = None, particles: Optional[np.ndarray] = None,
                   layout: Optional[SlabLayout] = None, comm: Optional[HaloComm] = None,
                   xy_margin: Optional[int] = 12, migrate_every: int = 1, capacity_factor: float = 1.5,
-                  yield_stress: Optional[np.ndarray] = None):
+                  yield_stress: Optional[np.ndarray] = None, overlap: bool = False):
     """Build this rank's ``TaichiEnv`` over its slab of the scene in ``cfg`` (every rank samples the same seed-0
     particle cloud and keeps its own part).  ``target_fn(all_particles, sim) -> (n,n,n) grid`` may supply the loss
     target.  ``xy_margin`` (node layers): the grid window is the bounding box of the whole cloud at reset plus that
     margin -- a body that moves further raises, like one that drifts out of its slab between two migrations; ``None``
     allocates whole planes.  ``migrate_every``: env steps between two migrations.  ``yield_stress``: per-particle
     values for the WHOLE cloud (each rank keeps its part).  ``layout`` / ``comm`` override the balanced cut and the
-    torch.distributed communicator (measurement tools: profiles/tools/slab_host_cost.py).
+    torch.distributed communicator (measurement tools: profiles/tools/slab_host_cost.py).  ``overlap``: run grid_op /
+    grid_op.grad of the blocks outside the exchanged planes while the halos are in flight (``SlabEngine.overlap``).
     Returns (env, layout, owned_index)."""
     from .engine import taichi_env as te
     from .engine.losses import Loss
@@ -450,7 +477,7 @@ def make_slab_env(cfg, rank: int, world: int, *, halo: int = 4, compute_dtype=No
                        particle_capacity=capacity)
     if world > 1:
         sim.engine.set_ids(mine)
-        sim.engine = SlabEngine(sim.engine, layout, rank, group, comm, migrate_every=migrate_every)
+        sim.engine = SlabEngine(sim.engine, layout, rank, group, comm, migrate_every=migrate_every, overlap=overlap)
         env.primitives._bind(sim.engine)
     if yield_stress is not None:
         sim._yield_stress = np.ascontiguousarray(np.asarray(yield_stress, np.float64)[mine])

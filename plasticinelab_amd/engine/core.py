@@ -283,6 +283,15 @@ class Engine:
         """grid_op(f) (adds the registered halo planes) + g2p(f); ``chain`` leaves the g2p to the next ``p2g``."""
         L.check(self.lib.plmpm_grid_g2p(self.h, f, int(chain)))
 
+    def grid_interior(self, f):
+        """grid_op(f) on the blocks outside the exchanged planes only (they need nothing from the neighbours): runs
+        while the halos are in flight; the ``grid_g2p(f)`` that follows then does the exchanged planes and g2p."""
+        L.check(self.lib.plmpm_grid_interior(self.h, f))
+
+    def grad_gather_interior(self, f):
+        """The same split of grid_op.grad: interior blocks now, the exchanged planes + p2g.grad in ``grad_gather(f)``."""
+        L.check(self.lib.plmpm_grad_gather_interior(self.h, f))
+
     def grad_scatter(self, f):
         L.check(self.lib.plmpm_grad_scatter(self.h, f))
 

@@ -35,13 +35,14 @@ class LoopbackComm(D.HaloComm):
         self.down = rank - 1 if rank > 0 else None
         self.up = rank + 1 if rank < layout.world - 1 else None
 
-    def exchange(self, engine, field, f):
+    def exchange_start(self, engine, field, f):
         if not self.layout.faces(self.rank):
-            return
+            return []
         if field not in self._recv:
             self.attach(engine, field, f)
         for rb in self._recv[field]:
             rb.zero_()
+        return []
 
     def exchange_counts(self, n_down, n_up):
         return 0, 0
@@ -66,6 +67,7 @@ def main():
     ap.add_argument("--world", type=int, default=0, help="emulate the middle rank of a balanced N-slab cut (0: one rank owns all)")
     ap.add_argument("--xy-margin", type=int, default=24)
     ap.add_argument("--migrate-every", type=int, default=1)
+    ap.add_argument("--overlap", action="store_true", help="interior grid blocks launched before the exchange is waited for")
     ap.add_argument("--profile", action="store_true", help="cProfile one rollout (top functions by own time)")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
@@ -82,7 +84,8 @@ def main():
         world, rank = args.world, args.world // 2
         layout = D.SlabLayout.balanced(x_all, n, world)
     env, _, mine = D.make_slab_env(cfg, rank, world, compute_dtype=args.dtype, device=dev, target_fn=bench._target,
-                                   layout=layout, comm=LoopbackComm(layout, rank), xy_margin=args.xy_margin, migrate_every=args.migrate_every)
+                                   layout=layout, comm=LoopbackComm(layout, rank), xy_margin=args.xy_margin, migrate_every=args.migrate_every,
+                                   overlap=args.overlap)
     print(f"rank {rank}/{world}: slab {layout.slab(rank)}, halo {layout.halo}, {len(mine)} particles, "
           f"grid window {[list(map(int, a)) for a in env.simulator.engine.grid_window()]}")
     env.loss.set_weights(10, 10, 1, False)

@@ -26,6 +26,7 @@ def main():
     scene = json.loads(sys.argv[6]) if len(sys.argv) > 6 else None
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     backend = os.environ.get("PLB_DIST_BACKEND", "gloo")
+    overlap = os.environ.get("PLB_TEST_OVERLAP") == "1"      # interior grid blocks while the halos are in flight
     dev = rank % torch.cuda.device_count() if backend == "nccl" else 0
     torch.cuda.set_device(dev)
     if backend == "nccl":
@@ -46,7 +47,7 @@ def main():
         n = 2000
         sub = np.ascontiguousarray(x_all[::len(x_all) // n][:n])
         env, layout, mine = make_slab_env(cfg, rank, world, compute_dtype=dtype, particles=sub, xy_margin=xy_margin,
-                                          migrate_every=migrate_every, target_fn=lambda x, sim: sparse_target("Move3D-v1"))
+                                          migrate_every=migrate_every, target_fn=lambda x, sim: sparse_target("Move3D-v1"), overlap=overlap)
     else:
         import bench
         sub_per_step = int(2e-3 // (0.5e-4 / (scene["quality"] * 0.5)))
@@ -56,7 +57,7 @@ def main():
         if scene.get("mixed"):                       # config 5: half the particles yield (50), half do not (1e9)
             ys = np.where(np.arange(scene["particles"]) % 2 == 0, 50.0, 1e9)
         env, layout, mine = make_slab_env(cfg, rank, world, compute_dtype=dtype, xy_margin=xy_margin, migrate_every=migrate_every,
-                                          target_fn=bench._target, yield_stress=ys)
+                                          target_fn=bench._target, yield_stress=ys, overlap=overlap)
     env.loss.set_weights(10, 10, 1, False)
     solver = Solver(env, None, None, softness=666.0, horizon=len(actions))
     state0 = env.get_state()["state"]

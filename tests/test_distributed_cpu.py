@@ -115,6 +115,15 @@ class ToyEngine:
             self._g2p(f)
         self.calls.append(("grid_g2p", f, bool(chain)))
 
+    def grid_interior(self, f):
+        # the blocks outside the exchanged planes: nothing of the neighbours' may have been added yet
+        assert ("grid_g2p", f, True) not in self.calls and ("grid_g2p", f, False) not in self.calls
+        self.calls.append(("grid_interior", f))
+
+    def grad_gather_interior(self, f):
+        assert self.adj_frame == f + 1
+        self.calls.append(("grad_gather_interior", f))
+
     def _g2p(self, f):
         fr = self.frames[f]
         self.read[f] = {int(i): float(self.gin[f][0, b:b + 3, 1, 2].sum()) for i, b in zip(fr["ids"], fr["bz"])}
@@ -242,7 +251,7 @@ class ToyEngine:
         self.calls.append(("loss_backward_local", f))
 
 
-def _world(rank, world, port, ids, bz_all, w_all, drift, out):
+def _world(rank, world, port, ids, bz_all, w_all, drift, out, overlap=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -251,7 +260,7 @@ def _world(rank, world, port, ids, bz_all, w_all, drift, out):
         assert all(b - a >= 8 and a % 4 == 0 for a, b in zip(layout.bounds, layout.bounds[1:]))
         mine = np.nonzero(layout.owner_of(SlabLayout.stencil_base_z(x, N)) == rank)[0]
         toy = ToyEngine([ids[i] for i in mine], [bz_all[i] for i in mine], [w_all[i] for i in mine], drift, layout, rank)
-        eng = SlabEngine(toy, layout, rank, migrate_every=1)
+        eng = SlabEngine(toy, layout, rank, migrate_every=1, overlap=overlap)
         last = STEPS * SUB
         for k in range(STEPS):
             eng.step(k * SUB, SUB)
@@ -269,10 +278,10 @@ def _world(rank, world, port, ids, bz_all, w_all, drift, out):
         dist.destroy_process_group()
 
 
-def run(world, ids, bz, w, drift):
+def run(world, ids, bz, w, drift, overlap=False):
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_world, args=(world, free_port(), ids, bz, w, drift, out), nprocs=world, join=True)
+    mp.spawn(_world, args=(world, free_port(), ids, bz, w, drift, out, overlap), nprocs=world, join=True)
     return dict(out)
 
 
@@ -306,8 +315,8 @@ def test_layout_balanced_and_faces():
     assert hi0[2] == lay.bounds[1] + 4 and lo0[2] < lay.bounds[1] - 8 and lo0[:2] == lo[:2]   # same xy window on every rank
 
 
-@pytest.mark.parametrize("WORLD", [2, 3])
-def test_ranks_equal_one_rank(WORLD):
+@pytest.mark.parametrize("WORLD,OVERLAP", [(2, False), (3, False), (3, True)])
+def test_ranks_equal_one_rank(WORLD, OVERLAP):
     rng = np.random.default_rng(1)
     n = 48
     ids = list(range(100, 100 + n))
@@ -315,8 +324,13 @@ def test_ranks_equal_one_rank(WORLD):
     w = [float(v) for v in rng.random(n) + 0.5]
     drift = {i: int(d) for i, d in zip(ids, rng.integers(-1, 2, n))}        # -1 / 0 / +1 layers per env step
     one = run(1, ids, bz, w, drift)[0]
-    many = run(WORLD, ids, bz, w, drift)
+    many = run(WORLD, ids, bz, w, drift, OVERLAP)
     assert many[0]["bounds"] == many[1]["bounds"]
+    if OVERLAP:       # every substep ran its interior pass between the scatter and the face pass, forward and reverse
+        for r in range(WORLD):
+            o = many[r]["order"]
+            assert o.count("grid_interior") == STEPS * SUB and o.count("grad_gather_interior") == STEPS * SUB
+            assert all(o[i + 1] == "grid_g2p" for i, c in enumerate(o) if c == "grid_interior")
     assert sum(many[r]["moved"] for r in range(WORLD)) > 0, "the toy rollout was meant to migrate rows"
     assert all(many[r]["migrations"] == STEPS - 1 for r in range(WORLD))    # before every env step but the first
     for k in range(STEPS + 1):
