@@ -18,9 +18,6 @@
 //     backward_svd (mpm_simulator.py:143-151) is reproduced as a pairwise
 //     attenuation min(1, |s_j^2 - s_i^2| / clamp) so results match it.
 #pragma once
-#ifndef PLB_SVD_EARLY_EXIT
-#define PLB_SVD_EARLY_EXIT 0
-#endif
 #include <math.h>
 #include <stdint.h>
 
@@ -136,15 +133,11 @@ template <class T> PLB_HD T sel3(int i, T a, T b, T c) { return i == 0 ? a : (i 
 template <class T> struct Tol;
 template <> struct Tol<float> {
     static constexpr int sweeps = 4;
-    static constexpr int optional_sweeps = 1;      // sweeps the early exit may skip (PLB_SVD_EARLY_EXIT)
-    static PLB_HD float eps() { return 6e-8f; }
     static PLB_HD float dd() { return 2e-2f; }
     static PLB_HD float small_angle() { return 1e-6f; }
 };
 template <> struct Tol<double> {
     static constexpr int sweeps = 8;
-    static constexpr int optional_sweeps = 4;
-    static PLB_HD double eps() { return 1.2e-16; }
     static PLB_HD double dd() { return 1e-4; }
     static PLB_HD double small_angle() { return 1e-12; }
 };
@@ -257,16 +250,6 @@ template <class T> PLB_HD void svd_jacobi(const T* Et, T* lam3, T* V) {
 #pragma unroll 1
 #endif
     for (int sw = 0; sw < Tol<T>::sweeps; ++sw) {
-#if defined(__HIP_DEVICE_COMPILE__) && PLB_SVD_EARLY_EXIT
-        // the last sweep(s) only matter for a fraction of a percent of the matrices (host study, profiles/r02_notes.md:
-        // 99.3 % have their off-diagonal below 1e-7 of the spectrum after three sweeps): leave the loop -- the whole
-        // wave together -- once every lane is converged to the scalar type's round-off
-        if (sw >= Tol<T>::sweeps - Tol<T>::optional_sweeps) {
-            const T off = t_max(t_abs(a01), t_max(t_abs(a02), t_abs(a12)));
-            const T nrm = t_abs(a00) + t_abs(a11) + t_abs(a22);
-            if (!__any(off > Tol<T>::eps() * nrm)) break;
-        }
-#endif
         jacobi_pair(a00, a11, a01, a02, a12, V, 0, 1);
         jacobi_pair(a00, a22, a02, a01, a12, V, 0, 2);
         jacobi_pair(a11, a22, a12, a01, a02, V, 1, 2);

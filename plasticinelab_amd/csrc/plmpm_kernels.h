@@ -42,13 +42,6 @@ template <class T> struct TileCap;
 #ifndef PLB_TILECAP
 #define PLB_TILECAP 1024
 #endif
-// Scatter tiles of k_p2g / k_g2p_p2g component-major ([4][cap] doubles) instead of node-major ([cap][4]): a
-// ds_add_f64 of one component then hits bank 2 n mod 64 for node n (the emitting lanes of one instruction hold
-// different nodes: conflicts only between n and n + 32) instead of (8 n + 2 c) mod 64 (conflicts between n and n + 8).
-// Measured (round 2): no gain (g2p_p2g 54.8 -> 55.3 us) -- the kernel does not wait on those conflicts.  Kept off.
-#ifndef PLB_TILE_SOA
-#define PLB_TILE_SOA 0
-#endif
 template <> struct TileCap<float> { static constexpr int nodes = PLB_TILECAP; };
 template <> struct TileCap<double> { static constexpr int nodes = 512; };
 
@@ -505,28 +498,6 @@ template <class T> __device__ __forceinline__ Tile load_tile(const Dev<T>& D, in
     return t;
 }
 
-// The in-wave sort only has to make lanes that share a stencil base adjacent, and the storage order already is the
-// Hilbert order of the cells at the last re-sort: while few particles have changed cell since, the lanes come in as
-// ~8-10 runs of equal keys and the ~250 VALU instructions of the bitonic network buy nothing.  So count the runs first
-// (one shuffle, one ballot) and skip the sort below PLB_SORT_SKIP_RUNS of them -- wave-uniform branch; the segmented
-// reduction is correct for any lane order, fewer lanes per run only means a few more LDS atomics.  0: always sort.
-// Measured (round 2, profiles/r02_notes.md): thresholds 12 / 18 / 28 all LOSE (6 064 -> 6 005 / 5 960 / 5 766
-// substeps/s): the extra LDS atomics of the shorter runs cost more than the sort.  Kept off, as a record.
-#ifndef PLB_SORT_SKIP_RUNS
-#define PLB_SORT_SKIP_RUNS 0
-#endif
-__device__ __forceinline__ bool wave_runs_few(long long key) {
-#if PLB_SORT_SKIP_RUNS > 0
-    const int lane = threadIdx.x & 63;
-    const unsigned lo = (unsigned)key, hi = (unsigned)(key >> 32);
-    const unsigned plo = (unsigned)__shfl_up((int)lo, 1), phi = (unsigned)__shfl_up((int)hi, 1);
-    const bool head = lane == 0 || lo != plo || hi != phi;
-    return __popcll(__ballot(head)) <= PLB_SORT_SKIP_RUNS;
-#else
-    return false;
-#endif
-}
-
 // Sorted particle load in two halves so that independent memory traffic can be issued in between.
 struct SortLoad { double x0[3]; long long key; };
 template <class T> __device__ __forceinline__ SortLoad sorted_begin(const Dev<T>& D, const double* X) {
@@ -547,14 +518,11 @@ __device__ __forceinline__ bool sorted_finish(const Dev<T>& D, SortLoad& s, int&
         s.key = ((long long)b[2] * D.P.n + b[1]) * D.P.n + b[0];
     }
     // padding lanes carry the largest key either way; the 32-bit network needs (cells << 6) to fit
-    if (wave_runs_few(s.key)) {
-        p = p0;
-        for (int d = 0; d < 3; ++d) x[d] = s.x0[d];
-    } else {
-        const int src = D.P.n <= 256 ? wave_sort_lanes32(p0 < D.N ? (unsigned)s.key : 0x3ffffffu) : wave_sort_lanes(s.key);
-        p = (p0 & ~63) + src;
-        for (int d = 0; d < 3; ++d) x[d] = __shfl(s.x0[d], src);   // the position travels with the sort
-    }
+    // (skipping the sort when the lanes already come in few runs of equal keys was measured in round 2: the extra LDS
+    // atomics of the shorter runs cost more than the sort, profiles/r02_notes.md)
+    const int src = D.P.n <= 256 ? wave_sort_lanes32(p0 < D.N ? (unsigned)s.key : 0x3ffffffu) : wave_sort_lanes(s.key);
+    p = (p0 & ~63) + src;
+    for (int d = 0; d < 3; ++d) x[d] = __shfl(s.x0[d], src);       // the position travels with the sort
     for (int d = 0; d < 3; ++d) base[d] = (int)(x[d] * (double)D.P.inv_dx - 0.5);
     if (clamp_to_reach(D, base) && p < D.N && flag_err) atomicOr(D.err, 1);
     return p < D.N;
@@ -573,15 +541,10 @@ __device__ __forceinline__ bool load_sorted_particle(const Dev<T>& D, const doub
         for (int d = 0; d < 3; ++d) { x0[d] = X[d * Np + p0]; b[d] = (int)(x0[d] * (double)D.P.inv_dx - 0.5); }
         key = ((long long)b[2] * D.P.n + b[1]) * D.P.n + b[0];
     }
-    if (wave_runs_few(key)) {
-        p = p0;
-        for (int d = 0; d < 3; ++d) x[d] = x0[d];
-    } else {
-        const int src = D.P.n <= 256 ? wave_sort_lanes32(p0 < D.N ? (unsigned)key : 0x3ffffffu) : wave_sort_lanes(key);
-        p = (p0 & ~63) + src;
-        // the position travels with the sort (shuffles) instead of a second, dependent trip to memory
-        for (int d = 0; d < 3; ++d) x[d] = __shfl(x0[d], src);
-    }
+    const int src = D.P.n <= 256 ? wave_sort_lanes32(p0 < D.N ? (unsigned)key : 0x3ffffffu) : wave_sort_lanes(key);
+    p = (p0 & ~63) + src;
+    // the position travels with the sort (shuffles) instead of a second, dependent trip to memory
+    for (int d = 0; d < 3; ++d) x[d] = __shfl(x0[d], src);
     for (int d = 0; d < 3; ++d) base[d] = (int)(x[d] * (double)D.P.inv_dx - 0.5);
     if (clamp_to_reach(D, base) && p < D.N && flag_err) atomicOr(D.err, 1);
     return p < D.N;
@@ -598,7 +561,6 @@ __global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_p2g(Dev<T> D, int f) 
     // accumulate in double: on gfx950 ds_add_f64 is ~5x cheaper per instruction than ds_add_f32
     // (profiles/microbench/lds_atomics.hip), and the node sums lose no precision
     __shared__ Vec4<double> tile[TileCap<T>::nodes];
-    constexpr int kPS = DET ? TileCap<T>::nodes / 2 : TileCap<T>::nodes;      // plane stride of the component-major layout
     const double* X = frame_x(D, f);
     const T* R = frame_r(D, f);
     const int Np = D.Npad;
@@ -609,12 +571,7 @@ __global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_p2g(Dev<T> D, int f) 
     store_tile(D, f, tl);
     const int tn = tl.e[0] * tl.e[1] * tl.e[2];
     if (tl.ok) {
-#if PLB_TILE_SOA
-        for (int i = threadIdx.x; i < tn; i += kBlock)
-            for (int k = 0; k < (DET ? 8 : 4); ++k) reinterpret_cast<double*>(tile)[k * kPS + i] = 0.0;
-#else
         for (int i = threadIdx.x; i < (DET ? 2 * tn : tn); i += kBlock) tile[i] = Vec4<double>{0.0, 0.0, 0.0, 0.0};
-#endif
         __syncthreads();
     }
     {
@@ -639,16 +596,6 @@ __global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_p2g(Dev<T> D, int f) 
                 seg_sum4(a0, a1, a2, a3, sg);
                 if (PLB_ABLATE & 1) { if (a0 + a1 + a2 + a3 == T(-1e30)) tile[0].x = 1.0; return; }
                 if (emitter) {
-#if PLB_TILE_SOA
-                    if constexpr (DET) {          // planes 0-3: hi limbs, 4-7: lo limbs
-                        long long* q = reinterpret_cast<long long*>(tile) + ((oz + l) * exy + (oy + j) * ex + (ox + i));
-                        det_add(q, q + 4 * kPS, (double)a0); det_add(q + kPS, q + 5 * kPS, (double)a1);
-                        det_add(q + 2 * kPS, q + 6 * kPS, (double)a2); det_add(q + 3 * kPS, q + 7 * kPS, (double)a3);
-                    } else {
-                        double* q = reinterpret_cast<double*>(tile) + ((oz + l) * exy + (oy + j) * ex + (ox + i));
-                        atomicAdd(q, (double)a0); atomicAdd(q + kPS, (double)a1); atomicAdd(q + 2 * kPS, (double)a2); atomicAdd(q + 3 * kPS, (double)a3);
-                    }
-#else
                     if constexpr (DET) {          // node: 4 hi limbs, then 4 lo limbs
                         long long* q = reinterpret_cast<long long*>(tile) + 8 * ((oz + l) * exy + (oy + j) * ex + (ox + i));
                         det_add(q, q + 4, (double)a0); det_add(q + 1, q + 5, (double)a1); det_add(q + 2, q + 6, (double)a2); det_add(q + 3, q + 7, (double)a3);
@@ -656,7 +603,6 @@ __global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_p2g(Dev<T> D, int f) 
                         double* q = reinterpret_cast<double*>(&tile[(oz + l) * exy + (oy + j) * ex + (ox + i)]);
                         atomicAdd(q, (double)a0); atomicAdd(q + 1, (double)a1); atomicAdd(q + 2, (double)a2); atomicAdd(q + 3, (double)a3);
                     }
-#endif
                 }
             });
         } else {
@@ -689,7 +635,7 @@ __global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_p2g(Dev<T> D, int f) 
                 long long q[8];
                 long long any = 0;
                 for (int c = 0; c < 8; ++c) {
-                    q[c] = reinterpret_cast<const long long*>(tile)[PLB_TILE_SOA ? c * kPS + i : 8 * i + c];
+                    q[c] = reinterpret_cast<const long long*>(tile)[8 * i + c];
                     any |= q[c];
                 }
                 if (any) {
@@ -701,12 +647,7 @@ __global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_p2g(Dev<T> D, int f) 
                 }
                 continue;
             }
-#if PLB_TILE_SOA
-            const double* tq = reinterpret_cast<const double*>(tile);
-            Vec4<double> a{tq[i], tq[kPS + i], tq[2 * kPS + i], tq[3 * kPS + i]};
-#else
             Vec4<double> a = tile[i];
-#endif
             if (a.x != 0.0 || a.y != 0.0 || a.z != 0.0 || a.w != 0.0) {
                 int lz, ly, lx;
                 tile_coords(i, ex, exy, lz, ly, lx);
@@ -811,7 +752,6 @@ template <class T, bool DET = false>
 __global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_g2p_p2g(Dev<T> D, int f, const Vec4<T>* vout_prev) {
     __shared__ int sred[32];
     __shared__ Vec4<double> tile[TileCap<T>::nodes];
-    constexpr int kPS = DET ? TileCap<T>::nodes / 2 : TileCap<T>::nodes;      // plane stride of the component-major layout
     Vec4<T>* tile_v = reinterpret_cast<Vec4<T>*>(tile);          // first use of the same LDS
     const int Np = D.Npad;
     // ---------------- g2p(f-1): gather
@@ -882,12 +822,7 @@ __global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_g2p_p2g(Dev<T> D, int
     if (threadIdx.x == 0) { atomicAdd(D.err + (tl.ok ? 2 : 1), 1); if (tl.ok) atomicAdd(D.err + 3, tn); }
 #endif
     if (tl.ok) {
-#if PLB_TILE_SOA
-        for (int i = threadIdx.x; i < tn; i += kBlock)
-            for (int k = 0; k < (DET ? 8 : 4); ++k) reinterpret_cast<double*>(tile)[k * kPS + i] = 0.0;
-#else
         for (int i = threadIdx.x; i < (DET ? 2 * tn : tn); i += kBlock) tile[i] = Vec4<double>{0.0, 0.0, 0.0, 0.0};
-#endif
         __syncthreads();
     }
     PT_MARK(3);
@@ -905,16 +840,6 @@ __global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_g2p_p2g(Dev<T> D, int
                 seg_sum4(a0, a1, a2, a3, sg);
                 if (PLB_ABLATE & 1) { if (a0 + a1 + a2 + a3 == T(-1e30)) tile[0].x = 1.0; return; }
                 if (emitter) {
-#if PLB_TILE_SOA
-                    if constexpr (DET) {          // planes 0-3: hi limbs, 4-7: lo limbs
-                        long long* q = reinterpret_cast<long long*>(tile) + ((oz + l) * exy + (oy + j) * ex + (ox + i));
-                        det_add(q, q + 4 * kPS, (double)a0); det_add(q + kPS, q + 5 * kPS, (double)a1);
-                        det_add(q + 2 * kPS, q + 6 * kPS, (double)a2); det_add(q + 3 * kPS, q + 7 * kPS, (double)a3);
-                    } else {
-                        double* q = reinterpret_cast<double*>(tile) + ((oz + l) * exy + (oy + j) * ex + (ox + i));
-                        atomicAdd(q, (double)a0); atomicAdd(q + kPS, (double)a1); atomicAdd(q + 2 * kPS, (double)a2); atomicAdd(q + 3 * kPS, (double)a3);
-                    }
-#else
                     if constexpr (DET) {          // node: 4 hi limbs, then 4 lo limbs
                         long long* q = reinterpret_cast<long long*>(tile) + 8 * ((oz + l) * exy + (oy + j) * ex + (ox + i));
                         det_add(q, q + 4, (double)a0); det_add(q + 1, q + 5, (double)a1); det_add(q + 2, q + 6, (double)a2); det_add(q + 3, q + 7, (double)a3);
@@ -922,7 +847,6 @@ __global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_g2p_p2g(Dev<T> D, int
                         double* q = reinterpret_cast<double*>(&tile[(oz + l) * exy + (oy + j) * ex + (ox + i)]);
                         atomicAdd(q, (double)a0); atomicAdd(q + 1, (double)a1); atomicAdd(q + 2, (double)a2); atomicAdd(q + 3, (double)a3);
                     }
-#endif
                 }
             });
         } else {
@@ -956,7 +880,7 @@ __global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_g2p_p2g(Dev<T> D, int
                 long long q[8];
                 long long any = 0;
                 for (int c = 0; c < 8; ++c) {
-                    q[c] = reinterpret_cast<const long long*>(tile)[PLB_TILE_SOA ? c * kPS + i : 8 * i + c];
+                    q[c] = reinterpret_cast<const long long*>(tile)[8 * i + c];
                     any |= q[c];
                 }
                 if (any) {
@@ -968,12 +892,7 @@ __global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_g2p_p2g(Dev<T> D, int
                 }
                 continue;
             }
-#if PLB_TILE_SOA
-            const double* tq = reinterpret_cast<const double*>(tile);
-            Vec4<double> a{tq[i], tq[kPS + i], tq[2 * kPS + i], tq[3 * kPS + i]};
-#else
             Vec4<double> a = tile[i];
-#endif
             if (a.x != 0.0 || a.y != 0.0 || a.z != 0.0 || a.w != 0.0) {
                 int lz, ly, lx;
                 tile_coords(i, ex, exy, lz, ly, lx);
@@ -1272,91 +1191,6 @@ __global__ __launch_bounds__(64) void k_pose_adjoint_det(Dev<T> D, int f) {
     }
 }
 
-// Packed-fp32 flavour of p2g_gather_grad (mpm_math.h) for the fp32 engine.  On gfx950 a plain v_fma_f32 issues in ~4
-// cycles per wave and v_pk_fma_f32 does two in ~4.9 (profiles/microbench/boundary_valu.hip), so the x and y components
-// of the gathered vector field -- an aligned register pair straight out of the 16-byte tile read {x, y, z, m} -- go
-// through the three axis contractions as one packed multiply-add, z and the mass field as scalar ones.  Same sums in
-// the same order as the scalar version; the SLP vectoriser's own attempt at this costs more in shuffles than it saves.
-#ifndef PLB_P2GG_EARLY_LOADS
-#define PLB_P2GG_EARLY_LOADS 0
-#endif
-#ifndef PLB_PK_GATHER
-#define PLB_PK_GATHER 0          // measured (round 2): p2g_grad 47.3 us with, 46.7 without -- the kernel is as much HBM- as VALU-bound; kept for reference
-#endif
-typedef float plb_f2 __attribute__((ext_vector_type(2)));
-template <class X, class Fetch4>
-__device__ __forceinline__ void p2g_gather_grad_pk(const SimP<float>& P, const X* x, P2GGather<float>& G, Fetch4&& fetch) {
-    int base[3];
-    float fx[3], w[3][3], dw[3][3];
-    stencil<float, X>(x, P.inv_dx, base, fx, w, dw);
-    enum { W = 0, Dd = 1, ZW = 2, ZD = 3 };
-    constexpr int kPairY[9] = {W, Dd, W, ZW, ZD, ZW, W, Dd, W};
-    constexpr int kPairZ[9] = {W, W, Dd, W, W, Dd, ZW, ZW, ZD};
-    constexpr int kCombX[16] = {W, ZW, W, W, ZD, ZW, ZW, Dd, W, W, Dd, W, W, Dd, W, W};
-    constexpr int kCombP[16] = {0, 0, 3, 6, 0, 1, 2, 3, 4, 5, 6, 7, 8, 0, 1, 2};
-    float cz[4][3];
-    for (int n = 0; n < 3; ++n) {
-        const float z = float(n) - fx[2];
-        cz[W][n] = w[n][2]; cz[Dd][n] = dw[n][2]; cz[ZW][n] = z * w[n][2]; cz[ZD][n] = z * dw[n][2];
-    }
-    plb_f2 Fxy[16];                      // final sums, (x, y) components
-    float Fz[16], Fm[3];                 // z component, mass field
-    for (int c = 0; c < 16; ++c) { Fxy[c] = plb_f2{0.f, 0.f}; Fz[c] = 0.f; }
-    Fm[0] = Fm[1] = Fm[2] = 0.f;
-    PLB_ROLL_GATH_I
-    for (int i = 0; i < 3; ++i) {
-        plb_f2 Sxy[9];
-        float Sz[9], Sm[3];
-        for (int q = 0; q < 9; ++q) { Sxy[q] = plb_f2{0.f, 0.f}; Sz[q] = 0.f; }
-        Sm[0] = Sm[1] = Sm[2] = 0.f;
-        PLB_ROLL_GATH_J
-        for (int j = 0; j < 3; ++j) {
-            plb_f2 Rxy[4];
-            float Rz[4], Rm[2];
-            for (int t = 0; t < 4; ++t) { Rxy[t] = plb_f2{0.f, 0.f}; Rz[t] = 0.f; }
-            Rm[0] = Rm[1] = 0.f;
-            for (int l = 0; l < 3; ++l) {
-                const Vec4<float> a = fetch(i, j, l);                    // {mv'_x, mv'_y, mv'_z, m'}
-                const plb_f2 gxy = plb_f2{a.x, a.y};
-                Rm[W] += cz[W][l] * a.w;
-                Rm[Dd] += cz[Dd][l] * a.w;
-                for (int t = 0; t < 4; ++t) {
-                    Rxy[t] += plb_f2{cz[t][l], cz[t][l]} * gxy;
-                    Rz[t] += cz[t][l] * a.z;
-                }
-            }
-            const float yw = sel3(j, w[0][1], w[1][1], w[2][1]), yd = sel3(j, dw[0][1], dw[1][1], dw[2][1]);
-            const float zy = float(j) - fx[1];
-            const float cy[4] = {yw, yd, zy * yw, zy * yd};
-            for (int q = 0; q < 9; ++q) {
-                const float c = cy[kPairY[q]];
-                Sxy[q] += plb_f2{c, c} * Rxy[kPairZ[q]];
-                Sz[q] += c * Rz[kPairZ[q]];
-            }
-            Sm[0] += cy[W] * Rm[W]; Sm[1] += cy[Dd] * Rm[W]; Sm[2] += cy[W] * Rm[Dd];
-        }
-        const float xw = sel3(i, w[0][0], w[1][0], w[2][0]), xd = sel3(i, dw[0][0], dw[1][0], dw[2][0]);
-        const float zx = float(i) - fx[0];
-        const float cx[4] = {xw, xd, zx * xw, zx * xd};
-        for (int c = 0; c < 16; ++c) {
-            const float k = cx[kCombX[c]];
-            Fxy[c] += plb_f2{k, k} * Sxy[kCombP[c]];
-            Fz[c] += k * Sz[kCombP[c]];
-        }
-        Fm[0] += cx[Dd] * Sm[0]; Fm[1] += cx[W] * Sm[1]; Fm[2] += cx[W] * Sm[2];
-    }
-    auto comp = [&](int c, int a) { return a == 0 ? Fxy[c].x : (a == 1 ? Fxy[c].y : Fz[c]); };
-    for (int a = 0; a < 3; ++a) {
-        G.va[a] = P.p_mass * comp(0, a);
-        for (int b = 0; b < 3; ++b) {
-            G.Aa[3 * a + b] = P.dx * comp(1 + b, a);
-            for (int d = 0; d < 3; ++d) G.M[9 * a + 3 * b + d] = P.dx * comp(4 + 3 * b + d, a);
-        }
-        for (int d = 0; d < 3; ++d) G.sv[3 * d + a] = comp(13 + d, a);
-    }
-    for (int d = 0; d < 3; ++d) G.sm[d] = Fm[d];
-}
-
 // ------------------------------------------------------------------------------------------------
 // p2g.grad + svd_grad + compute_F_tmp.grad: gather grid_in_adj, finish adjoint frame `dst`
 template <class T>
@@ -1391,26 +1225,7 @@ __global__ __launch_bounds__(kBlock, sizeof(T) == 4 ? PLB_P2G_GRAD_WAVES : 1) vo
     if (!valid) return;
     // the 27-node gather needs the position only: the other 42 words of particle state are fetched after it, so
     // that they are not live across the loop (the kernel then fits 3 waves per SIMD instead of 2)
-#if PLB_P2GG_EARLY_LOADS
-    // experiment: issue the particle-state loads before the 27-node gather (they fly during it) and let the register
-    // allocator spill what does not fit, instead of exposing a second memory latency after the loop
-    T v[3], C[9], E[9], Ena[9], xa[3], va[3], Ca[9], Ea[9];
-    const T* A1 = D.adj[src];
-    T* A0 = D.adj[dst];
-    for (int d = 0; d < 3; ++d) { v[d] = R[d * Np + p]; xa[d] = A0[d * Np + p]; }
-    for (int d = 0; d < 9; ++d) { C[d] = R[(3 + d) * Np + p]; E[d] = R[(12 + d) * Np + p]; Ena[d] = A1[(15 + d) * Np + p]; }
-    const T mu = D.mu[p], lam = D.lam[p], ys = D.ys[p];
-#endif
     P2GGather<T> G;
-#if PLB_PK_GATHER
-    if constexpr (sizeof(T) == 4) {
-        if (tl.ok) {
-            const int ox = base[0] - tl.o[0], oy = base[1] - tl.o[1], oz = base[2] - tl.o[2];
-            p2g_gather_grad_pk(D.P, x, G, [&](int i, int j, int l) { return tile[(oz + l) * exy + (oy + j) * ex + (ox + i)]; });
-        } else
-            p2g_gather_grad_pk(D.P, x, G, [&](int i, int j, int l) { return D.grid_in_adj[node_index(D, base[0] + i, base[1] + j, base[2] + l)]; });
-    } else
-#endif
     if (tl.ok) {
         const int ox = base[0] - tl.o[0], oy = base[1] - tl.o[1], oz = base[2] - tl.o[2];
         p2g_gather_grad<T, double>(D.P, x, G, [&](int i, int j, int l, T* g) {
@@ -1423,14 +1238,12 @@ __global__ __launch_bounds__(kBlock, sizeof(T) == 4 ? PLB_P2G_GRAD_WAVES : 1) vo
             g[0] = a.w; g[1] = a.x; g[2] = a.y; g[3] = a.z;
         });
     }
-#if !PLB_P2GG_EARLY_LOADS
     T v[3], C[9], E[9], Ena[9], xa[3], va[3], Ca[9], Ea[9];
     const T* A1 = D.adj[src];
     T* A0 = D.adj[dst];
     for (int d = 0; d < 3; ++d) { v[d] = R[d * Np + p]; xa[d] = A0[d * Np + p]; }
     for (int d = 0; d < 9; ++d) { C[d] = R[(3 + d) * Np + p]; E[d] = R[(12 + d) * Np + p]; Ena[d] = A1[(15 + d) * Np + p]; }
     const T mu = D.mu[p], lam = D.lam[p], ys = D.ys[p];
-#endif
     p2g_finish_grad<T>(D.P, G, v, C, E, mu, lam, ys, Ena, xa, va, Ca, Ea);
     PT_MARK(2);
     for (int d = 0; d < 3; ++d) { A0[d * Np + p] = xa[d]; A0[(3 + d) * Np + p] = va[d]; }
