@@ -96,6 +96,32 @@ def test_fp32_engine_tracks_fp64_engine_full_size():
     assert relerr(g32, g64) < 1e-4
 
 
+def test_fp32_engine_tracks_fp64_engine_over_the_benchmark_horizon():
+    """The rollout `bench.py --steps 20` times -- 20 env steps = 780 substeps forward + reverse, 5 re-sorts, the cube
+    squeezed between the two manipulators until part of it yields -- in the fp32 engine against the fp64 engine: loss
+    and action gradient within the north-star 1e-4 (measured: 4e-7 and 3e-5; horizons 2 / 5 / 10: 6e-6 / 5e-6 / 2e-5)."""
+    import torch
+    import bench
+
+    class A:
+        particles, quality, steps, warmup = 500_000, 2, 20, 0
+    out = {}
+    for dtype in ("float64", "float32"):
+        A.dtype = dtype
+        env, _ = bench.build_env(A, torch.device("cuda", 0))
+        acts = bench.seeded_actions(A.steps, env.primitives.action_dim)
+        env.set_state(env.get_state()["state"], 666.0, False)
+        loss = bench.rollout(env, acts)
+        out[dtype] = (float(loss), env.primitives.get_grad(A.steps).copy())
+        env.simulator.engine.close()
+        del env
+        torch.cuda.empty_cache()
+    (l64, g64), (l32, g32) = out["float64"], out["float32"]
+    print(f"\n[config 3, 20 env steps] loss rel {abs(l32 - l64) / abs(l64):.2e}; action-gradient max-rel {relerr(g32, g64):.2e}")
+    assert abs(l32 - l64) / abs(l64) < 1e-5
+    assert relerr(g32, g64) < 1e-4
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # BASELINE configs[3]: synthetic elastic block, 256^3 grid, 2M particles (here on one GPU; the z-slab cut of the same
 # workload is checked against the single-rank engine in test_gpu_distributed.py at a size the box can run N ranks of)
