@@ -918,6 +918,9 @@ __global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_g2p_p2g(Dev<T> D, int
 #ifndef PLB_G2PG_CAP
 #define PLB_G2PG_CAP 960
 #endif
+#ifndef PLB_G2PG_FIX8
+#define PLB_G2PG_FIX8 1
+#endif
 template <class T, bool DET = false>
 __global__ __launch_bounds__(kBlock, sizeof(T) == 4 ? PLB_G2PG_WAVES : 1) void k_g2p_grad(Dev<T> D, int f, int src, int dst, const T* vnext) {
     // 960 nodes x (16 + 24) bytes = 37.5 KiB: four workgroups per CU (128 VGPRs = 4 waves per SIMD, see PLB_G2PG_WAVES)
@@ -933,7 +936,22 @@ __global__ __launch_bounds__(kBlock, sizeof(T) == 4 ? PLB_G2PG_WAVES : 1) void k
     const Tile tl = load_tile(D, f, DET ? CAP / 2 : CAP);           // stored by the scatter of this frame (DET: 6 limbs per node in tile_a)
     SortLoad sl = sorted_begin(D, X);
     const int ex = tl.e[0], exy = tl.e[0] * tl.e[1], tn = exy * tl.e[2];
-    if (tl.ok)
+    // Fixed-shape tile: a box of at most 8 nodes per axis (most are: the mean box is ~6^3 nodes) is laid out in LDS with
+    // the CONSTANT strides 8 / 64 instead of its own extents -- the 27 + 27 tile addresses of a particle's stencil become
+    // immediates off one base register, the fill / flush loops get their node coordinates from shifts instead of
+    // divisions.  fp32 engine (the f64 tiles hold fewer than 512 nodes); workgroup-uniform choice.  Measured (round 2):
+    // 35.0 -> 34.3 us here; the same in k_g2p_p2g's gather and in k_p2g_grad changed nothing and in k_g2p_p2g's scatter
+    // cost 2 us (512 instead of ~230 tile slots to zero and flush), so only this kernel has it.
+    const bool fix8 = PLB_G2PG_FIX8 && !DET && sizeof(T) == 4 && CAP >= 512 && tl.ok && tl.e[0] <= 8 && tl.e[1] <= 8 && tl.e[2] <= 8;
+    const int n8 = tl.e[2] << 6;                                    // slots of the z planes in use
+    if (fix8) {
+        for (int i = threadIdx.x; i < n8; i += kBlock) {
+            const int lx = i & 7, ly = (i >> 3) & 7, lz = i >> 6;
+            if (lx < tl.e[0] && ly < tl.e[1] && lz < tl.e[2])
+                tile[i] = D.grid_out[node_index(D, tl.o[0] + lx, tl.o[1] + ly, tl.o[2] + lz)];
+            tile_a[3 * i] = 0.0; tile_a[3 * i + 1] = 0.0; tile_a[3 * i + 2] = 0.0;
+        }
+    } else if (tl.ok)
         for (int i = threadIdx.x; i < tn; i += kBlock) {
             int lz, ly, lx;
                 tile_coords(i, ex, exy, lz, ly, lx);
@@ -987,6 +1005,23 @@ __global__ __launch_bounds__(kBlock, sizeof(T) == 4 ? PLB_G2PG_WAVES : 1) void k
                         det_add_node(D, 0, idx, (double)a0); det_add_node(D, 1, idx, (double)a1); det_add_node(D, 2, idx, (double)a2);
                     }
                 });
+        } else if (fix8) {
+            const int b0 = ((base[2] - tl.o[2]) << 6) + ((base[1] - tl.o[1]) << 3) + (base[0] - tl.o[0]);
+            const Vec4<T>* tb = tile + b0;
+            double* ab = tile_a + 3 * b0;
+            g2p_particle_grad<T, double>(D.P, x, vn, xna, vna, Cna, xa,
+                [&](int i, int j, int l, T* gv) {
+                    Vec4<T> a = tb[(l << 6) + (j << 3) + i];
+                    gv[0] = a.x; gv[1] = a.y; gv[2] = a.z;
+                },
+                [&](int i, int j, int l, const T* ga) {
+                    T a0 = ga[0], a1 = ga[1], a2 = ga[2];
+                    seg_sum3(a0, a1, a2, sg);
+                    if (emitter) {
+                        double* q = ab + 3 * ((l << 6) + (j << 3) + i);
+                        atomicAdd(q, (double)a0); atomicAdd(q + 1, (double)a1); atomicAdd(q + 2, (double)a2);
+                    }
+                });
         } else if (tl.ok) {
             const int ox = base[0] - tl.o[0], oy = base[1] - tl.o[1], oz = base[2] - tl.o[2];
             g2p_particle_grad<T, double>(D.P, x, vn, xna, vna, Cna, xa,
@@ -1026,7 +1061,16 @@ __global__ __launch_bounds__(kBlock, sizeof(T) == 4 ? PLB_G2PG_WAVES : 1) void k
         }
     }
     PT_MARK(3);
-    if (tl.ok) {
+    if (fix8) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < n8; i += kBlock) {
+            const double ax = tile_a[3 * i], ay = tile_a[3 * i + 1], az = tile_a[3 * i + 2];
+            if (ax != 0.0 || ay != 0.0 || az != 0.0) {
+                int idx = node_index(D, tl.o[0] + (i & 7), tl.o[1] + ((i >> 3) & 7), tl.o[2] + (i >> 6));
+                atomicAdd(&D.goa[0][idx], (T)ax); atomicAdd(&D.goa[1][idx], (T)ay); atomicAdd(&D.goa[2][idx], (T)az);
+            }
+        }
+    } else if (tl.ok) {
         __syncthreads();
         for (int i = threadIdx.x; i < tn; i += kBlock) {
             if constexpr (DET) {
