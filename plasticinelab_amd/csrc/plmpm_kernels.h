@@ -454,8 +454,9 @@ template <> __device__ __forceinline__ void seg_sum3<float>(float& a, float& b, 
 }
 #undef PLB_DPP_STEP
 
-// all threads call; valid == false for padding lanes.  sred: LDS int[6*4+8]
-__device__ __forceinline__ Tile block_tile(const int* base, bool valid, int* sred, int cap) {
+// all threads call; valid == false for padding lanes.  sred: LDS int[6*4+8], written once per kernel.
+// In two halves so that a kernel can put its own barrier between them: every wave publishes its box ...
+__device__ __forceinline__ void block_tile_publish(const int* base, bool valid, int* sred) {
     int lo[3], hi[3];
     for (int d = 0; d < 3; ++d) {
         lo[d] = wave_min(valid ? base[d] : 0x7fffffff);
@@ -464,7 +465,9 @@ __device__ __forceinline__ Tile block_tile(const int* base, bool valid, int* sre
     int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (lane == 0)
         for (int d = 0; d < 3; ++d) { sred[wave * 6 + d] = lo[d]; sred[wave * 6 + 3 + d] = hi[d]; }
-    __syncthreads();
+}
+// ... and, after a __syncthreads(), every thread combines them
+__device__ __forceinline__ Tile block_tile_collect(const int* sred, int cap) {
     Tile t;
     int nodes = 1;
     for (int d = 0; d < 3; ++d) {
@@ -475,8 +478,12 @@ __device__ __forceinline__ Tile block_tile(const int* base, bool valid, int* sre
         nodes *= t.e[d];
     }
     t.ok = (nodes > 0 && nodes <= cap) ? 1 : 0;
-    __syncthreads();
     return t;
+}
+__device__ __forceinline__ Tile block_tile(const int* base, bool valid, int* sred, int cap) {
+    block_tile_publish(base, valid, sred);
+    __syncthreads();
+    return block_tile_collect(sred, cap);
 }
 
 // The box of frame f is computed once, by the kernel that scatters frame f (it has to reduce over the workgroup
@@ -814,8 +821,9 @@ __global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_g2p_p2g(Dev<T> D, int
     int base[3];
     for (int d = 0; d < 3; ++d) base[d] = (int)(x[d] * (double)D.P.inv_dx - 0.5);
     if (clamp_to_reach(D, base) && valid) atomicOr(D.err, 1);
-    __syncthreads();                                                     // everyone is done reading tile_v
-    Tile tl = block_tile(base, valid, sred, DET ? TileCap<T>::nodes / 2 : TileCap<T>::nodes);
+    block_tile_publish(base, valid, sred);
+    __syncthreads();                                                     // everyone is done reading tile_v, and has published its box
+    Tile tl = block_tile_collect(sred, DET ? TileCap<T>::nodes / 2 : TileCap<T>::nodes);
     store_tile(D, f, tl);
     const int tn = tl.e[0] * tl.e[1] * tl.e[2];
 #ifdef PLB_DEBUG_COUNTERS      // tile statistics for plmpm_debug_counters (same-address atomics: keep out of production builds)
