@@ -86,7 +86,8 @@ typedef struct plmpm_config {
      * loss grid and scalars, pose adjoints) is accumulated in two 64-bit integer limbs instead of floating-point
      * atomics, so the result does not depend on the arrival order; the same rollout then gives the same bits every
      * time, on every launch schedule and across re-sorts.  Slower (measured in DESIGN.md); contributions must stay below 2^38 in
-     * magnitude.  Single-GPU engines only (the arrival order of migrating particles is not fixed).  0: fp atomics. */
+     * magnitude.  Slab engines: the rows that migrate leave in slot order, so a fixed rank layout reproduces too (the
+     * host's reductions across ranks must be order-fixed as well: gloo and RCCL rings are).  0: fp atomics. */
     int32_t deterministic;
 } plmpm_config;
 

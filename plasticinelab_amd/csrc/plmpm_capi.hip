@@ -1145,7 +1145,6 @@ int plmpm_create(const plmpm_config* cfg, const plmpm_primitive* prims, plmpm_ha
                        + align_up(LS_COUNT * 8, 256) + align_up((size_t)s->Npad * 24 * 8, 256) + 512;
     if (s->dist) s->ws.misc_bytes += 3 * align_up((size_t)(s->F + 1) * P1 * 4 * 8, 256);
     s->det = cfg->deterministic != 0;
-    if (s->det && s->dist) { delete s; return fail("deterministic = 1 is a single-GPU mode: the order in which migrating particles arrive at a slab is not fixed"); }
     if (s->det) {
         s->ws.grid_bytes += align_up(s->G * 8 * 8, 256);                                  // [8][G] integer limbs
         s->ws.misc_bytes += align_up((size_t)(LS_COUNT + kMaxPrim * 8) * 2 * 8, 256);
@@ -2209,6 +2208,17 @@ template <class T> static int migrate_begin_t(plmpm_sim* s, int frame, int epoch
     HIPCHK(hipMemcpyAsync(cnt, s->mig_cnt, 8, hipMemcpyDeviceToHost, s->stream));
     HIPCHK(hipStreamSynchronize(s->stream));
     REQUIRE(cnt[0] <= s->mig_max_rows && cnt[1] <= s->mig_max_rows, "migrate: %d / %d rows leave at once, room for %d per direction", cnt[0], cnt[1], s->mig_max_rows);
+    if (s->det)
+        // the lists were filled through an atomic cursor: put them in slot order, so that the rows leave -- and arrive,
+        // and tie-break the neighbour's stable re-sort -- in the same order in every run
+        for (int d = 0; d < 2; ++d)
+            if (cnt[d] > 1) {
+                int* list = leave + (size_t)d * s->mig_max_rows;
+                HIPCHK(hipMemcpyAsync(s->skey[0], list, (size_t)cnt[d] * 4, hipMemcpyDeviceToDevice, s->stream));
+                if (plmpm_sort_pairs(s->sort_tmp, s->sort_tmp_bytes, s->skey[0], s->skey[1], s->sidx[0], s->sidx[1], cnt[d], 32, s->stream) != 0)
+                    return fail("migrate: device sort failed");
+                HIPCHK(hipMemcpyAsync(list, s->skey[1], (size_t)cnt[d] * 4, hipMemcpyDeviceToDevice, s->stream));
+            }
     const int* gid = s->gid_store + (size_t)s->frame_epoch[frame] * s->Npad;
     for (int d = 0; d < 2; ++d)
         if (cnt[d] > 0)

@@ -40,9 +40,11 @@ def main():
     from plasticinelab_amd.optimizer.solver import Solver
 
     actions = np.load(act_path)
+    deterministic = os.environ.get("PLB_TEST_DETERMINISTIC") == "1"
     if scene is None:
         cfg = load_scene("Move", 1)
         cfg.ENV.loss.target_path = ""
+        cfg.SIMULATOR["deterministic"] = deterministic
         x_all, _ = Shapes(cfg.SHAPES).get()
         n = 2000
         sub = np.ascontiguousarray(x_all[::len(x_all) // n][:n])
@@ -53,6 +55,7 @@ def main():
         sub_per_step = int(2e-3 // (0.5e-4 / (scene["quality"] * 0.5)))
         cfg = bench.workload_cfg(scene["particles"], scene["quality"], max_steps=len(actions) * sub_per_step + 1,
                                  yield_stress=scene.get("yield_stress", 200.0), side=scene.get("side", 0.31))
+        cfg.SIMULATOR["deterministic"] = deterministic
         ys = None
         if scene.get("mixed"):                       # config 5: half the particles yield (50), half do not (1e9)
             ys = np.where(np.arange(scene["particles"]) % 2 == 0, 50.0, 1e9)

@@ -96,9 +96,23 @@ def test_large_cloud_is_bit_reproducible():
     assert np.isfinite(out[0][0]) and np.abs(out[0][1]).max() > 0
 
 
-def test_deterministic_slab_engine_is_refused():
-    from plasticinelab_amd.engine.core import Engine
-    from plasticinelab_amd._lib import EngineError
-    with pytest.raises(EngineError, match="single-GPU"):
-        Engine(n_grid=64, n_particles=1000, max_frames=20, substeps=19, dt=1e-4, p_vol=1.5e-5, p_mass=1.5e-5,
-               gravity=(0, -1, 0), ground_friction=1.5, slab=(0, 32), slab_halo=4, deterministic=True)
+def test_deterministic_slab_ranks_are_bit_reproducible(tmp_path):
+    """Two and three z-slab ranks (gloo on the one GPU) with migration every env step, the rollout run twice: every
+    rank's loss, action gradient and final particles are the same bits both times -- the leaving rows are packed in
+    slot order, so the arrival order (which tie-breaks the neighbour's stable re-sort) is fixed too."""
+    from tests.test_gpu_distributed import launch
+    H = 6
+    acts = np.zeros((H, 6))
+    acts[:, 2] = 0.9; acts[:, 5] = 0.9              # both spheres push +z: rows cross the faces
+    acts[:, 0] = 0.5; acts[:, 3] = -0.5
+    acts += np.random.default_rng(4).uniform(-0.1, 0.1, acts.shape)
+    for world in (2, 3):
+        runs = []
+        for k in range(2):
+            d = tmp_path / f"w{world}_{k}"
+            d.mkdir()
+            runs.append(launch(d, world, "float32", acts, 10, 1, deterministic=True))
+        assert sum(int(r["rows_moved"]) for r in runs[0]) > 0
+        for a, b in zip(*runs):
+            for key in ("loss", "grad", "ids", "x", "v"):
+                assert np.ascontiguousarray(a[key]).tobytes() == np.ascontiguousarray(b[key]).tobytes(), (world, key)

@@ -24,7 +24,7 @@ def free_port():
         return s.getsockname()[1]
 
 
-def launch(tmp_path, world, dtype, actions, xy_margin, migrate_every, backend="gloo", scene=None, overlap=False):
+def launch(tmp_path, world, dtype, actions, xy_margin, migrate_every, backend="gloo", scene=None, overlap=False, deterministic=False):
     out = str(tmp_path / "r")
     act = str(tmp_path / "actions.npy")
     np.save(act, actions)
@@ -32,7 +32,7 @@ def launch(tmp_path, world, dtype, actions, xy_margin, migrate_every, backend="g
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   HSA_ENABLE_IPC_MODE_LEGACY="0", PLB_DIST_BACKEND=backend, PLB_TEST_OVERLAP="1" if overlap else "0")
+                   HSA_ENABLE_IPC_MODE_LEGACY="0", PLB_DIST_BACKEND=backend, PLB_TEST_OVERLAP="1" if overlap else "0", PLB_TEST_DETERMINISTIC="1" if deterministic else "0")
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_gpu_worker.py"), out, dtype, act,
                                        "none" if xy_margin is None else str(xy_margin), str(migrate_every)]
                                       + ([json.dumps(scene)] if scene else []),
