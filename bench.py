@@ -220,6 +220,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--replicas", action="store_true", help="N > 1: independent replicas instead of z-slabs")
+    ap.add_argument("--yield-stress", type=float, default=200.0, help="von Mises yield stress of the cube (200 = the workload; 1e9 = elastic: an "
+                    "experiment knob, not the headline)")
     ap.add_argument("--deterministic", action="store_true", help="single GPU: the bit-reproducible engine (integer-limb accumulation); "
                     "a cost measurement, not the headline")
     ap.add_argument("--window", type=int, default=-1, help="single GPU: allocate / sweep only the body's bounding box + this many node "
