@@ -16,6 +16,8 @@
 
 // plmpm_sort.hip
 extern "C" size_t plmpm_sort_temp_bytes(int n);
+extern "C" size_t plmpm_scan_temp_bytes(size_t n);
+extern "C" int plmpm_exclusive_scan(void* tmp, size_t bytes, const unsigned* in, unsigned* out, size_t n, void* stream);
 extern "C" int plmpm_sort_pairs(void* tmp, size_t bytes, const unsigned* kin, unsigned* kout, const int* vin, int* vout, int n, int key_bits,
                                 void* stream);
 
@@ -44,6 +46,7 @@ static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 enum { LS_DENSITY = 0, LS_SDF = 1, LS_MAXGM = 2, LS_DOT = 3, LS_SUMGM = 4, LS_MIND = 8, LS_DNORM = 16, LS_COUNT = 32 };
 
 struct plmpm_sim {
+    bool mats_uniform = false, mats_filled = false;   // set_materials: all particles alike / device arrays written at least once
     bool det = false;                           // cfg.deterministic: integer-limb accumulation (plmpm_kernels.h: det_add)
     long long* det_grid = nullptr;              //   [8][G] limbs of the grid scatters
     long long* det_small = nullptr;             //   [LS_COUNT + kMaxPrim * 8][2] limbs of the loss scalars / loss pose adjoints
@@ -118,6 +121,8 @@ struct plmpm_sim {
     int* sidx[2] = {nullptr, nullptr};
     void* sort_tmp = nullptr;
     size_t sort_tmp_bytes = 0;
+    unsigned* cell_hist = nullptr;              // counting-sort flavour of the single-GPU re-sort: particles per cell (curve order)
+    size_t cell_bins = 0;                       //   0: grid too fine for it, the radix sort is used
     char* frame_tmp = nullptr;
     std::vector<int> frame_epoch;
     int mats_epoch = 0;
@@ -876,8 +881,11 @@ static int* perm_of(const plmpm_sim* s, int epoch) {
 }
 // material arrays in the storage order of `epoch`, from the caller-order master copy
 template <class T> static int set_materials_t(plmpm_sim* s, int epoch) {
+    const bool filled = s->mats_filled;
     s->mats_epoch = epoch;
     if (s->dist && epoch != 0) return 0;          // slab engines: epochs > 0 got their materials with the migrating rows
+    if (s->mats_uniform && filled && !s->dist) return 0;      // every particle the same: a permutation changes nothing
+    s->mats_filled = true;
     Dev<T> D = make_dev<T>(s);
     hipLaunchKernelGGL((k_set_mats<T>), dim3(s->Npad / 256), dim3(256), 0, s->stream, D, s->mats_master, perm_of(s, epoch));
     return 0;
@@ -951,12 +959,46 @@ template <class T> __global__ void k_permute_frame(Dev<T> D, int f, const int* o
     for (int d = 0; d < 3; ++d) vend[d * Np + i] = R[d * Np + i];          // old order, same slot
     if (i < D.N) perm_new[i] = perm_old[j];
 }
+// Counting sort by cell along the curve: a particle's key IS its bin, so the order is histogram -> exclusive scan ->
+// scatter through a per-bin cursor -- 4 launches instead of the ~20 of the library radix sort (0.13 ms for 500k pairs,
+// launch-bound).  The order inside a cell is whatever the cursor hands out (the in-wave sort does not care); the
+// deterministic engine and grids with more than 2^25 cells take the radix sort.
+template <class T> __global__ void k_cell_hist(Dev<T> D, int f, int bits, unsigned* keys, unsigned* hist) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= D.N) return;
+    const double* X = frame_x(D, f);
+    int b[3];
+    for (int d = 0; d < 3; ++d) b[d] = min(max((int)(X[d * D.Npad + i] * (double)D.P.inv_dx - 0.5), 0), D.P.n - 1);
+    const unsigned k = hilbert_key_dev((unsigned)b[0], (unsigned)b[1], (unsigned)b[2], bits);
+    keys[i] = k;
+    atomicAdd(&hist[k], 1u);
+}
+__global__ void k_cell_scatter(int n, int npad, const unsigned* keys, unsigned* cursor, int* order) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npad) return;
+    if (i >= n) { order[i] = i; return; }                   // padding slots stay where they are
+    order[atomicAdd(&cursor[keys[i]], 1u)] = i;
+}
 template <class T> static int resort_frame_t(plmpm_sim* s, int f, int epoch) {
     Dev<T> D = make_dev<T>(s, f);
     s->epochN[epoch] = D.N;
     const int nb = s->Npad / 256;
     int bits = 1;
     while ((1 << bits) < s->n) ++bits;
+    if (s->cell_bins && !s->det) {
+        HIPCHK(hipMemsetAsync(s->cell_hist, 0, s->cell_bins * 4, s->stream));
+        hipLaunchKernelGGL((k_cell_hist<T>), dim3(nb), dim3(256), 0, s->stream, D, f, bits, s->skey[0], s->cell_hist);
+        if (plmpm_exclusive_scan(s->sort_tmp, s->sort_tmp_bytes, s->cell_hist, s->cell_hist, s->cell_bins, s->stream) != 0) return fail("resort: device scan failed");
+        hipLaunchKernelGGL(k_cell_scatter, dim3(nb), dim3(256), 0, s->stream, D.N, s->Npad, s->skey[0], s->cell_hist, s->sidx[1]);
+        T* vend = (T*)(s->vend + (size_t)epoch * 3 * s->Npad * s->tsz);
+        hipLaunchKernelGGL((k_permute_frame<T>), dim3(nb), dim3(256), 0, s->stream, D, f, s->sidx[1], s->frame_tmp, vend,
+                           perm_of(s, s->frame_epoch[f]), perm_of(s, epoch));
+        HIPCHK(hipMemcpyAsync(s->state + (size_t)f * s->frame_bytes, s->frame_tmp, s->frame_bytes, hipMemcpyDeviceToDevice, s->stream));
+        s->frame_epoch[f] = epoch;
+        return 0;
+    }
+    // (keys without the lowest 1 / 2 curve levels -- fewer radix passes -- were measured: the kernels lose more to the
+    // coarser order than the sort saves, profiles/r02_notes.md)
     hipLaunchKernelGGL((k_hilbert_keys<T>), dim3(nb), dim3(256), 0, s->stream, D, f, bits, s->skey[0], s->sidx[0]);
     if (plmpm_sort_pairs(s->sort_tmp, s->sort_tmp_bytes, s->skey[0], s->skey[1], s->sidx[0], s->sidx[1], s->Npad, 3 * bits + 1, s->stream) != 0)
         return fail("resort: device sort failed");
@@ -967,14 +1009,29 @@ template <class T> static int resort_frame_t(plmpm_sim* s, int f, int epoch) {
     s->frame_epoch[f] = epoch;
     return 0;
 }
-// adjoint frame `which` from the storage order of epoch `from` to that of epoch `to`, through caller order (staging)
+// adjoint frame `which` from the storage order of epoch `from` to that of epoch `to`: slot j of `to` holds the particle
+// (caller index perm_to[j]) that sat in slot inv_from[perm_to[j]] of `from` -- one gather pass over the 24 rows.  (Through
+// the float64 caller-order staging buffer, as state I/O goes, this was two passes and 0.18 ms per re-sort boundary.)
+__global__ void k_inv_perm(const int* perm, int n, int* inv) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) inv[perm[i]] = i;
+}
+template <class T> __global__ void k_adj_regather(const T* in, T* out, const int* inv_from, const int* perm_to, int n, int Np) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= Np) return;
+    if (j >= n) { for (int d = 0; d < 24; ++d) out[(size_t)d * Np + j] = T(0); return; }
+    const int i = inv_from[perm_to[j]];
+    for (int d = 0; d < 24; ++d) out[(size_t)d * Np + j] = in[(size_t)d * Np + i];
+}
 template <class T> static int convert_adjoint_t(plmpm_sim* s, int which, int from, int to) {
     if (from == to) return 0;
     if (s->dist) return fail("slab engine: the adjoint frame is in storage epoch %d but epoch %d is needed -- particles migrated in between; "
                              "run plmpm_migrate_adjoint_begin / _finish on the boundary frame first", from, to);
-    adj_io_t<T>(s, which, 0, 1, 1, 1, 1, from);
-    HIPCHK(hipMemsetAsync(s->adj[which], 0, (size_t)24 * s->Npad * s->tsz, s->stream));
-    adj_io_t<T>(s, which, 1, 1, 1, 1, 1, to);
+    const int nb = s->Npad / 256;
+    int* inv = s->sidx[0];                               // sort scratch: idle during the reverse sweep
+    hipLaunchKernelGGL(k_inv_perm, dim3(nb), dim3(256), 0, s->stream, perm_of(s, from), s->N, inv);
+    hipLaunchKernelGGL((k_adj_regather<T>), dim3(nb), dim3(256), 0, s->stream, (const T*)s->adj[which], (T*)s->frame_tmp, inv, perm_of(s, to), s->N, s->Npad);
+    HIPCHK(hipMemcpyAsync(s->adj[which], s->frame_tmp, (size_t)24 * s->Npad * s->tsz, hipMemcpyDeviceToDevice, s->stream));
     s->adj_epoch[which] = to;
     return 0;
 }
@@ -1014,12 +1071,13 @@ template <class T> static int loss_contact_pass_t(plmpm_sim* s, int f, int mode)
     }
     return 0;
 }
+// loss scalars to their start values, on the device (no host buffer to keep alive, no synchronisation)
+__global__ void k_ls_init(double* ls, int soft) {
+    const int i = threadIdx.x;
+    if (i < LS_COUNT) ls[i] = (!soft && i >= LS_MIND && i < LS_MIND + kMaxPrim) ? 100000.0 : 0.0;      // loss.py:189-191
+}
 static int loss_reset_scalars(plmpm_sim* s) {
-    double init[LS_COUNT];
-    for (int i = 0; i < LS_COUNT; ++i) init[i] = 0.0;
-    if (!s->soft_contact) for (int q = 0; q < kMaxPrim; ++q) init[LS_MIND + q] = 100000.0;      // loss.py:189-191
-    HIPCHK(hipMemcpyAsync(s->lscal, init, sizeof init, hipMemcpyHostToDevice, s->stream));
-    HIPCHK(hipStreamSynchronize(s->stream));
+    hipLaunchKernelGGL(k_ls_init, dim3(1), dim3(64), 0, s->stream, s->lscal, s->soft_contact ? 1 : 0);
     return 0;
 }
 
@@ -1124,6 +1182,16 @@ int plmpm_create(const plmpm_config* cfg, const plmpm_primitive* prims, plmpm_ha
     s->sort_cap = s->dist ? s->Npad + s->Npad / 2 : s->Npad;          // slab engines sort stayers + arrivals
     s->mig_max_rows = s->Npad / 4;
     s->sort_tmp_bytes = sorts ? plmpm_sort_temp_bytes(s->sort_cap) : 0;
+    s->cell_bins = 0;
+    if (s->resort) {                                       // counting-sort re-sort: one bin per cell of the 2^bits cube
+        int cb = 1;
+        while ((1 << cb) < s->n) ++cb;
+        if (3 * cb <= 25) {
+            s->cell_bins = (size_t)1 << (3 * cb);
+            s->sort_tmp_bytes = std::max(s->sort_tmp_bytes, plmpm_scan_temp_bytes(s->cell_bins));
+            s->ws.adjoint_bytes += align_up(s->cell_bins * 4, 256);
+        }
+    }
     s->ws.adjoint_bytes += align_up((size_t)3 * s->Npad * 8, 256);                   // material master copy
     if (sorts)
         s->ws.adjoint_bytes += align_up((size_t)(s->n_epochs - 1) * s->Npad * 4, 256) + align_up((size_t)s->n_epochs * 3 * s->Npad * s->tsz, 256)
@@ -1185,6 +1253,7 @@ int plmpm_bind_workspace(plmpm_handle s, void* state, void* adjoint, void* grid,
         s->vend = take((size_t)s->n_epochs * 3 * s->Npad * s->tsz);
         for (int i = 0; i < 2; ++i) { s->skey[i] = (unsigned*)take((size_t)s->sort_cap * 4); s->sidx[i] = (int*)take((size_t)s->sort_cap * 4); }
         s->sort_tmp = take(s->sort_tmp_bytes);
+        if (s->cell_bins) s->cell_hist = (unsigned*)take(s->cell_bins * 4);
         s->frame_tmp = take(s->frame_bytes);
     }
     if (s->dist) {
@@ -1272,6 +1341,11 @@ int plmpm_set_materials(plmpm_handle s, const double* mu, const double* lam, con
     NEED_BOUND(s);
     REQUIRE(mu && lam && ys, "null argument");
     size_t nb = (size_t)s->N * 8;
+    // the common case -- one material for the whole body -- needs no re-gather when the storage order changes
+    bool uni = true;
+    for (int i = 1; i < s->N && uni; ++i) uni = mu[i] == mu[0] && lam[i] == lam[0] && ys[i] == ys[0];
+    s->mats_uniform = uni;
+    s->mats_filled = false;
     HIPCHK(hipMemcpyAsync(s->mats_master, mu, nb, hipMemcpyHostToDevice, s->stream));
     HIPCHK(hipMemcpyAsync(s->mats_master + s->N, lam, nb, hipMemcpyHostToDevice, s->stream));
     HIPCHK(hipMemcpyAsync(s->mats_master + 2 * (size_t)s->N, ys, nb, hipMemcpyHostToDevice, s->stream));
@@ -1878,9 +1952,14 @@ int plmpm_loss_forward(plmpm_handle s, int frame, double* out6) {
 
 int plmpm_loss_backward(plmpm_handle s, int frame) {
     NEED_BOUND(s);
-    double ls[LS_COUNT];
-    if (loss_globals_single(s, frame, ls)) return -1;       // recompute grid_m and the contact scalars (loss.py:210-237)
-    if (plmpm_loss_set_globals(s, ls)) return -1;
+    NEED_FRAME(s, frame);
+    REQUIRE(s->have_target, "loss: no target density set");
+    // recompute grid_m and the contact scalars (loss.py:210-237) -- all of it stays on the device: the adjoint needs the
+    // mass grid and the per-primitive contact scalars, not the density / sdf sums, and nothing of it on the host
+    if (plmpm_loss_scatter(s, frame)) return -1;
+    if (loss_reset_scalars(s)) return -1;
+    DISPATCH(s, loss_contact_pass_t, s, frame, s->soft_contact ? 1 : 0);
+    if (s->soft_contact) DISPATCH(s, loss_contact_pass_t, s, frame, 2);
     return plmpm_loss_backward_local(s, frame);
 }
 

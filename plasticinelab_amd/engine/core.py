@@ -33,7 +33,7 @@ class Engine:
     def __init__(self, *, n_grid: int, n_particles: int, max_frames: int, substeps: int, dt: float, p_vol: float,
                  p_mass: float, gravity: Sequence[float], ground_friction: float, primitives: Sequence[dict] = (),
                  dtype: str = "float32", svd_grad_clamp: float = 1e-6, device: Optional[torch.device] = None,
-                 slab: Optional[Sequence[int]] = None, store_grid="auto", slab_halo: int = 0, resort_steps: int = 4,
+                 slab: Optional[Sequence[int]] = None, store_grid="auto", slab_halo: int = 0, resort_steps: int = 2,
                  grid_window: Optional[Sequence[Sequence[int]]] = None, particle_capacity: Optional[int] = None,
                  allocate: bool = True, deterministic: bool = False):
         self.lib = L.load()

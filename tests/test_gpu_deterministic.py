@@ -41,7 +41,7 @@ def same_bits(a, b):
 @pytest.mark.parametrize("soft", [False, True])
 @pytest.mark.parametrize("dtype", ["float64", "float32"])
 def test_move_v1_rollout_is_bit_reproducible(dtype, soft):
-    """Move-v1 (64^3, 10k particles, 2 manipulators), 12 env steps x 19 substeps forward + reverse: 3 re-sorts inside."""
+    """Move-v1 (64^3, 10k particles, 2 manipulators), 12 env steps x 19 substeps forward + reverse, re-sorts inside."""
     g = np.load(os.path.join(GOLDEN, "rollout_move_v1.npz"))
     actions = g["actions"][:12]
     env = make_env(dtype, soft)

@@ -97,7 +97,7 @@ def test_fp32_engine_tracks_fp64_engine_full_size():
 
 
 def test_fp32_engine_tracks_fp64_engine_over_the_benchmark_horizon():
-    """The rollout `bench.py --steps 20` times -- 20 env steps = 780 substeps forward + reverse, 5 re-sorts, the cube
+    """The rollout `bench.py --steps 20` times -- 20 env steps = 780 substeps forward + reverse, a re-sort every other step, the cube
     squeezed between the two manipulators until part of it yields -- in the fp32 engine against the fp64 engine: loss
     and action gradient within the north-star 1e-4 (measured: 4e-7 and 3e-5; horizons 2 / 5 / 10: 6e-6 / 5e-6 / 2e-5)."""
     import torch
