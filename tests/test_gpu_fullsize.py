@@ -125,6 +125,31 @@ def test_fp32_engine_tracks_fp64_engine_over_the_benchmark_horizon():
 # ---------------------------------------------------------------------------------------------------------------------
 # BASELINE configs[3]: synthetic elastic block, 256^3 grid, 2M particles (here on one GPU; the z-slab cut of the same
 # workload is checked against the single-rank engine in test_gpu_distributed.py at a size the box can run N ranks of)
+def test_resort_on_a_256_grid_does_not_change_the_physics(monkeypatch):
+    """The counting-sort re-sort at 256^3 (2^24 cells along the curve: its largest single-GPU case; finer grids take the
+    radix sort): 200k particles, 3 env steps of 79 substeps with a re-sort before the 2nd and 3rd, float64 engine,
+    against the same rollout without re-sorts."""
+    import torch
+    import bench
+
+    class A:
+        particles, quality, steps, warmup, yield_stress, side, dtype = 200_000, 4, 3, 0, 200.0, 0.2, "float64"
+    out = {}
+    for R in ("0", "1"):
+        monkeypatch.setenv("PLMPM_RESORT_STEPS", R)
+        env, _ = bench.build_env(A, torch.device("cuda", 0))
+        acts = bench.seeded_actions(A.steps, env.primitives.action_dim)
+        env.set_state(env.get_state()["state"], 666.0, False)
+        loss = bench.rollout(env, acts)
+        fr = env.simulator.engine.get_frame(env.simulator.cur, want=("x", "v"))
+        out[R] = (np.array([float(loss)]), env.primitives.get_grad(A.steps).copy(), fr["x"], fr["v"])
+        env.simulator.engine.close()
+        del env
+        torch.cuda.empty_cache()
+    for a, b in zip(out["0"], out["1"]):
+        assert relerr(a, b) < 1e-9
+
+
 def build4(dtype):
     import torch
     import bench
