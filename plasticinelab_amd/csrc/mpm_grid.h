@@ -655,11 +655,13 @@ PLB_HD void fk_fwd_d(const double* pos, const double* rot, const double* v, cons
 PLB_HD void qmul_adj_d(const double* q, const double* r, const double* o_a, double* q_a, double* r_a) {
     double o[4];
     qmul_raw_d(q, r, o);
-    double nrm = sqrt(o[0] * o[0] + o[1] * o[1] + o[2] * o[2] + o[3] * o[3]);
+    // one reciprocal instead of eight divisions: this runs in the serial double-precision chain of k_fk_chain_grad, where
+    // every division is ~40 dependent instructions on a single lane
+    const double inv = 1.0 / sqrt(o[0] * o[0] + o[1] * o[1] + o[2] * o[2] + o[3] * o[3]);
     double on[4], dotv = 0;
-    for (int i = 0; i < 4; ++i) { on[i] = o[i] / nrm; dotv += on[i] * o_a[i]; }
+    for (int i = 0; i < 4; ++i) { on[i] = o[i] * inv; dotv += on[i] * o_a[i]; }
     double oa[4];
-    for (int i = 0; i < 4; ++i) oa[i] = (o_a[i] - on[i] * dotv) / nrm;
+    for (int i = 0; i < 4; ++i) oa[i] = (o_a[i] - on[i] * dotv) * inv;
     r_a[0] += oa[0] * q[0] + oa[1] * q[1] + oa[2] * q[2] + oa[3] * q[3];
     r_a[1] += -oa[0] * q[1] + oa[1] * q[0] + oa[2] * q[3] - oa[3] * q[2];
     r_a[2] += -oa[0] * q[2] - oa[1] * q[3] + oa[2] * q[0] + oa[3] * q[1];
