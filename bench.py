@@ -42,6 +42,10 @@ ALG = {
     "p2g_recompute": (27, 8), "grid_op_recompute": (0, 7), "g2p_grad": (18, 9),
     "grid_op_grad": (0, 11), "p2g_grad": (54, 4), "clear_active": (0, 0),
     "g2p_p2g": (51, 7),        # g2p(f-1) + p2g(f) fused
+    # fused-grid engine (the default on one GPU): grid_op / grid_op.grad evaluated inside the particle kernels' tile
+    # fills, so their rows are added to the kernel that absorbs them (grid_op: 0 N + 11 A, its recompute in the reverse
+    # pass 0 N + 7 A, grid_op.grad 0 N + 11 A)
+    "gridop+g2p": (15, 14), "gridop+g2p_p2g": (51, 18), "gridop+g2p_grad": (18, 16), "gridop_grad+p2g_grad": (54, 15),
 }
 HBM_PEAK_GBS = 8000.0          # MI355X spec (MI355X_MICROARCH.md); the copy / read rates this box reaches are measured live
 PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc.json")

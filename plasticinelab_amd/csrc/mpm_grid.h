@@ -535,8 +535,10 @@ template <class T> PLB_HD void boundary_axis_grad(const SimP<T>& P, const int* I
 
 // ------------------------------------------------------------------ grid_op for one node
 // m, mv: grid_m / grid_v_in.  Returns false (and vout = 0) when the node is empty (m <= 1e-12).
+// touch (optional): set when the node is in contact with a movable primitive (its pose adjoints are due in the reverse pass).
 template <class T>
-PLB_HD bool grid_node_fwd(const SimP<T>& P, const int* I, T m, const T* mv, int nprim, const PrimT<T>* prims, T* vout) {
+PLB_HD bool grid_node_fwd(const SimP<T>& P, const int* I, T m, const T* mv, int nprim, const PrimT<T>* prims, T* vout,
+                          bool* touch = nullptr) {
     if (!(m > T(1e-12))) { vout[0] = vout[1] = vout[2] = T(0); return false; }
     T inv = T(1) / m;
     T v[3] = {inv * mv[0] + P.grav[0], inv * mv[1] + P.grav[1], inv * mv[2] + P.grav[2]};
@@ -544,7 +546,10 @@ PLB_HD bool grid_node_fwd(const SimP<T>& P, const int* I, T m, const T* mv, int 
     for (int p = 0; p < nprim; ++p) {
         CollideTmp<T> c;
         T vn[3];
-        if (collide_eval(prims[p], P.softness, P.dt, gp, v, c, vn)) { v[0] = vn[0]; v[1] = vn[1]; v[2] = vn[2]; }
+        if (collide_eval(prims[p], P.softness, P.dt, gp, v, c, vn)) {
+            v[0] = vn[0]; v[1] = vn[1]; v[2] = vn[2];
+            if (touch && prims[p].movable) *touch = true;
+        }
     }
     for (int d = 0; d < 3; ++d) boundary_axis(P, I, d, v);
     vout[0] = v[0]; vout[1] = v[1]; vout[2] = v[2];

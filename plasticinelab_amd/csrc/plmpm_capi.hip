@@ -105,6 +105,14 @@ struct plmpm_sim {
     char* vstore = nullptr;      // grid_v_out per frame (AoS T4)
     int* fstore = nullptr;
     int* contact = nullptr;      // [0] = n, [1..n]: blocks whose pose adjoints k_grid_op_grad left to the k_p2g_grad launch
+                                 // (two lists of nblk + 1: fused-grid engines alternate between them, frame by frame)
+    // Fused-grid engines (one GPU, grid store, not deterministic): grid_op / grid_op.grad are evaluated inside the tile
+    // fills of the particle kernels (plmpm_kernels.h: fg_node_vout / fg_node_gadj) -- 1 launch per forward substep and 2
+    // per reverse substep instead of 2 and 3.  The grids of the frame the last reverse substep finished with
+    // (fg_pending) are cleared by the next g2p.grad, or by k_clear_boxes when something else comes first.
+    bool fg = false;
+    int fg_pending = -1;
+    char* grid_out_adj2 = nullptr;   // second grid_v_out.grad buffer (frames alternate)
     int* tiles = nullptr;        // per-frame stencil boxes of the particle workgroups: [(F+1)][Npad/256][8]
     // Per-env-step storage order ("epochs").  Epoch 0 is the order chosen at reset (perm_d).  With cfg.resort_steps,
     // plmpm_step re-sorts the step's first frame along the Hilbert curve before it starts (epoch = step index); the
@@ -137,9 +145,12 @@ struct plmpm_sim {
     size_t ev_next = 0;
 };
 
-enum KernelId { K_P2G = 0, K_GRID_OP, K_G2P, K_P2G_RE, K_GRID_OP_RE, K_G2P_GRAD, K_GRID_OP_GRAD, K_P2G_GRAD, K_CLEAR, K_G2P_P2G, K_COUNT };
+enum KernelId { K_P2G = 0, K_GRID_OP, K_G2P, K_P2G_RE, K_GRID_OP_RE, K_G2P_GRAD, K_GRID_OP_GRAD, K_P2G_GRAD, K_CLEAR, K_G2P_P2G,
+                // fused-grid engines: the same particle kernels with grid_op / grid_op.grad evaluated in their tile fills
+                K_FG_G2P, K_FG_G2P_P2G, K_FG_G2P_GRAD, K_FG_P2G_GRAD, K_COUNT };
 static const char* kKernelNames[K_COUNT] = {"p2g", "grid_op", "g2p", "p2g_recompute", "grid_op_recompute",
-                                            "g2p_grad", "grid_op_grad", "p2g_grad", "clear_active", "g2p_p2g"};
+                                            "g2p_grad", "grid_op_grad", "p2g_grad", "clear_active", "g2p_p2g",
+                                            "gridop+g2p", "gridop+g2p_p2g", "gridop+g2p_grad", "gridop_grad+p2g_grad"};
 
 static void prof_begin(plmpm_sim* s, int id) {
     if (!s->prof) return;
@@ -178,17 +189,23 @@ static void prof_end(plmpm_sim* s) {
     } while (0)
 #define LAUNCH_G2P_P2G(s, D, f, vprev)                                                                           \
     do {                                                                                                         \
+        PrevGrid<T> pg_;                                                                                         \
+        memset(&pg_, 0, sizeof pg_);                                                                             \
+        pg_.vout = vprev;                                                                                        \
         if ((s)->det) {                                                                                          \
-            LAUNCH(s, K_G2P_P2G, (k_g2p_p2g<T, true>), dim3(nblocks_particles(s, f)), D, f, vprev);              \
+            LAUNCH(s, K_G2P_P2G, (k_g2p_p2g<T, true>), dim3(nblocks_particles(s, f)), D, f, pg_);                \
             DET_RESOLVE(s, D.gin[0], D.gin[1], D.gin[2], D.gin[3]);                                              \
-        } else LAUNCH(s, K_G2P_P2G, (k_g2p_p2g<T>), dim3(nblocks_particles(s, f)), D, f, vprev);                 \
+        } else LAUNCH(s, K_G2P_P2G, (k_g2p_p2g<T>), dim3(nblocks_particles(s, f)), D, f, pg_);                   \
     } while (0)
 #define LAUNCH_G2P_GRAD(s, D, f, src, dst, vnext)                                                                \
     do {                                                                                                         \
+        ClearArgs<T> ca_;                                                                                        \
+        memset(&ca_, 0, sizeof ca_);                                                                             \
+        ca_.frame = -1;                                                                                          \
         if ((s)->det) {                                                                                          \
-            LAUNCH(s, K_G2P_GRAD, (k_g2p_grad<T, true>), dim3(nblocks_particles(s, f)), D, f, src, dst, vnext);  \
+            LAUNCH(s, K_G2P_GRAD, (k_g2p_grad<T, true>), dim3(nblocks_particles(s, f)), D, f, src, dst, vnext, ca_);  \
             DET_RESOLVE(s, D.goa[0], D.goa[1], D.goa[2], (T*)nullptr);                                           \
-        } else LAUNCH(s, K_G2P_GRAD, (k_g2p_grad<T>), dim3(nblocks_particles(s, f)), D, f, src, dst, vnext);     \
+        } else LAUNCH(s, K_G2P_GRAD, (k_g2p_grad<T>), dim3(nblocks_particles(s, f)), D, f, src, dst, vnext, ca_);     \
     } while (0)
 // p2g.grad with the pose adjoints of the blocks in contact: spare workgroups of the same launch, or -- deterministic
 // engines -- one wave walking the contact list in block order first
@@ -202,7 +219,8 @@ static void prof_end(plmpm_sim* s) {
 
 // ---------------------------------------------------------------------------------------------
 // frame >= 0 with the grid store on: that frame's own grid_in / flags; otherwise the shared scratch grid
-template <class T> static Dev<T> make_dev(const plmpm_sim* s, int frame = -1) {
+// fg: a launch of the fused-grid path -- the frame's parity picks the grid_v_out.grad buffer and the contact list
+template <class T> static Dev<T> make_dev(const plmpm_sim* s, int frame = -1, bool fg = false) {
     Dev<T> D;
     const plmpm_config& c = s->cfg;
     double dx = 1.0 / c.n_grid;
@@ -234,12 +252,18 @@ template <class T> static Dev<T> make_dev(const plmpm_sim* s, int frame = -1) {
     const bool framed = s->store && frame >= 0;
     char* gin_base = framed ? s->gstore + (size_t)frame * s->gstride : s->grid_in;
     for (int c = 0; c < 4; ++c) D.gin[c] = (T*)gin_base + (size_t)c * s->G;
-    for (int c = 0; c < 3; ++c) D.goa[c] = (T*)s->grid_out_adj + (size_t)c * s->G;
+    {
+        char* ga = s->grid_out_adj;
+        char* gb = s->grid_out_adj2 ? s->grid_out_adj2 : s->grid_out_adj;
+        if (fg && (frame & 1)) std::swap(ga, gb);
+        for (int c = 0; c < 3; ++c) { D.goa[c] = (T*)ga + (size_t)c * s->G; D.goa_prev[c] = (T*)gb + (size_t)c * s->G; }
+    }
     D.grid_out = (Vec4<T>*)(framed ? s->vstore + (size_t)frame * s->gstride : s->grid_out);
     D.grid_in_adj = (Vec4<T>*)s->grid_in_adj;
     D.flags = framed ? s->fstore + (size_t)frame * s->nflag : s->flags;
     D.tiles = s->tiles;
-    D.contact = s->contact;
+    D.contact = s->contact + ((fg && (frame & 1)) ? s->nblk + 1 : 0);
+    D.contact_next = s->contact + ((fg && (frame & 1)) ? 0 : s->nblk + 1);
     D.det = s->det_grid; D.det_stride = s->G;
     D.trace = (unsigned long long*)s->staging;      // profiling builds only (needs N * 24 * 8 >= 3 * 16384 * 128 bytes)
     D.ppos = s->ppos; D.prot = s->prot; D.pgap = s->pgap;
@@ -771,8 +795,44 @@ static inline int nblocks_grid(const plmpm_sim* s) { return (s->nblk + (kBlock /
 // persistent grid kernels: a fixed number of workgroups, each striding over its share of the block flags
 static inline int nwg_grid(const plmpm_sim* s) { return s->gwg; }
 
+// clear arguments for the grids of frame `frame` (fused-grid engines)
+#ifndef PLB_FUSE_GRID_DEFAULT
+#define PLB_FUSE_GRID_DEFAULT 0      // measured (round 3, profiles/r03_notes.md): not yet faster than the grid kernels at config 3
+#endif
+template <class T> static ClearArgs<T> clear_args(const plmpm_sim* s, int frame) {
+    ClearArgs<T> A;
+    memset(&A, 0, sizeof A);
+    A.frame = frame;
+    if (frame < 0) return A;
+    const Dev<T> Df = make_dev<T>(s, frame, true);
+    A.nwg = nblocks_particles(s, frame);
+    for (int c = 0; c < 4; ++c) A.gin[c] = Df.gin[c];
+    for (int c = 0; c < 3; ++c) A.goa[c] = Df.goa[c];
+    A.flags = Df.flags;
+    return A;
+}
+// the frame a fused-grid reverse substep left behind, when no g2p.grad of the frame before it follows
+template <class T> static int fg_flush_t(plmpm_sim* s) {
+    if (s->fg_pending < 0) return 0;
+    const int f = s->fg_pending;
+    Dev<T> D = make_dev<T>(s, f, true);
+    hipLaunchKernelGGL((k_clear_boxes<T>), dim3(nblocks_particles(s, f)), dim3(kBlock), 0, s->stream, D, clear_args<T>(s, f));
+    s->dirty[f] = 0;
+    s->fg_pending = -1;
+    return 0;
+}
+#define FG_FLUSH(s) do { if ((s)->fg_pending >= 0) fg_flush_t<T>(s); } while (0)
+
 template <class T> static int substep_fwd(plmpm_sim* s, int f) {
+    FG_FLUSH(s);
     Dev<T> D = make_dev<T>(s, f);
+    if (s->fg) {                 // p2g | g2p with grid_op in its tile fill
+        if (s->dirty[f]) LAUNCH(s, K_CLEAR, (k_clear_active<T>), dim3(nblocks_grid(s)), D);
+        LAUNCH_P2G(s, K_P2G, true, D, f);
+        s->dirty[f] = 1;
+        LAUNCH(s, K_FG_G2P, (k_g2p<T, true>), dim3(nblocks_particles(s, f)), D, f);
+        return 0;
+    }
     if (s->store) {
         if (s->dirty[f]) LAUNCH(s, K_CLEAR, (k_clear_active<T>), dim3(nblocks_grid(s)), D);   // frame reused without a backward pass
         LAUNCH_P2G(s, K_P2G, true, D, f);
@@ -790,6 +850,23 @@ template <class T> static int substep_bwd(plmpm_sim* s, int f) {
     const int src = (f + 1) & 1, dst = f & 1;
     // frame f+1 re-sorted by the env step that starts there: its v in THIS frame's order was kept aside
     const T* vnext = s->frame_epoch[f + 1] != s->frame_epoch[f] ? (const T*)(s->vend + (size_t)s->frame_epoch[f + 1] * 3 * s->Npad * s->tsz) : nullptr;
+    if (s->fg && s->dirty[f]) {
+        // g2p.grad (+ grid_op in its tile fill, + the clear of frame f+1's grids) | p2g.grad (+ grid_op.grad in its tile fill)
+        const bool chained = s->fg_pending == f + 1;
+        if (!chained) {
+            FG_FLUSH(s);
+            hipMemsetAsync(s->contact, 0, 4, s->stream);                          // both contact counters: no g2p.grad reset them
+            hipMemsetAsync(s->contact + s->nblk + 1, 0, 4, s->stream);
+        }
+        Dev<T> Dg = make_dev<T>(s, f, true);
+        LAUNCH(s, K_FG_G2P_GRAD, (k_g2p_grad<T, false, true>), dim3(nblocks_particles(s, f)), Dg, f, src, dst, vnext, clear_args<T>(s, chained ? f + 1 : -1));
+        if (chained) s->dirty[f + 1] = 0;
+        LAUNCH(s, K_FG_P2G_GRAD, (k_p2g_grad<T, true>), dim3(nblocks_particles(s, f) + kPoseWG), Dg, f, src, dst, kPoseWG);
+        s->fg_pending = f;                   // dirty[f] stays set until the frame's grids are cleared
+        s->adj_frame[dst] = f;
+        return 0;
+    }
+    FG_FLUSH(s);
     if (!(s->store && s->dirty[f])) {        // this frame's grid is not resident: recompute it (mpm_simulator.py:265-268)
         LAUNCH_P2G(s, K_P2G_RE, false, D, f);
         LAUNCH(s, K_GRID_OP_RE, (k_grid_op<T, false>), dim3(nwg_grid(s)), D, f, kNoHalo);
@@ -804,6 +881,25 @@ template <class T> static int substep_bwd(plmpm_sim* s, int f) {
 
 // Whole env step forward in store mode: p2g(f0) | grid_op(f0) | [g2p(f-1)+p2g(f) fused | grid_op(f)] ... | g2p(last)
 template <class T> static int step_fwd_fused(plmpm_sim* s, int first, int n) {
+    FG_FLUSH(s);
+    if (s->fg) {                 // p2g(f0) | [g2p(f-1) + p2g(f) with grid_op(f-1) in the tile fill] ... | g2p(last) with grid_op(last)
+        for (int f = first; f < first + n; ++f) {
+            Dev<T> D = make_dev<T>(s, f);
+            if (s->dirty[f]) LAUNCHG_CLEAR(s, D);
+            if (f == first) LAUNCH_P2G(s, K_P2G, true, D, f);
+            else {
+                PrevGrid<T> pg;
+                memset(&pg, 0, sizeof pg);
+                for (int c = 0; c < 4; ++c) pg.gin[c] = (const T*)(s->gstore + (size_t)(f - 1) * s->gstride) + (size_t)c * s->G;
+                pg.vout = (const Vec4<T>*)(s->vstore + (size_t)(f - 1) * s->gstride);      // only written / read by workgroups whose box exceeds the LDS tile
+                LAUNCH(s, K_FG_G2P_P2G, (k_g2p_p2g<T, false, true>), dim3(nblocks_particles(s, f)), D, f, pg);
+            }
+            s->dirty[f] = 1;
+        }
+        Dev<T> D = make_dev<T>(s, first + n - 1);
+        LAUNCH(s, K_FG_G2P, (k_g2p<T, true>), dim3(nblocks_particles(s, first + n - 1)), D, first + n - 1);
+        return 0;
+    }
     for (int f = first; f < first + n; ++f) {
         Dev<T> D = make_dev<T>(s, f);
         if (s->dirty[f]) LAUNCHG_CLEAR(s, D);
@@ -823,6 +919,7 @@ template <class T> static int step_fwd_fused(plmpm_sim* s, int first, int n) {
 
 // phase-split variants used by the multi-GPU driver (store_grid mode only)
 template <class T> static int phase_p2g(plmpm_sim* s, int f) {
+    FG_FLUSH(s);
     Dev<T> D = make_dev<T>(s, f);
     if (s->dirty[f]) LAUNCH(s, K_CLEAR, (k_clear_active<T>), dim3(nblocks_grid(s)), D);
     LAUNCH_P2G(s, K_P2G, true, D, f);
@@ -843,6 +940,7 @@ template <class T> static int phase_grid_g2p(plmpm_sim* s, int f, bool defer_g2p
 }
 // g2p(f-1), deferred by the previous phase_grid_g2p, fused with p2g(f) exactly as in step_fwd_fused
 template <class T> static int phase_g2p_p2g(plmpm_sim* s, int f) {
+    FG_FLUSH(s);
     Dev<T> D = make_dev<T>(s, f);
     if (s->dirty[f]) LAUNCHG_CLEAR(s, D);
     const Vec4<T>* vprev = (const Vec4<T>*)(s->vstore + (size_t)(f - 1) * s->gstride);
@@ -851,6 +949,7 @@ template <class T> static int phase_g2p_p2g(plmpm_sim* s, int f) {
     return 0;
 }
 template <class T> static int phase_grad_scatter(plmpm_sim* s, int f) {
+    FG_FLUSH(s);
     Dev<T> D = make_dev<T>(s, f);
     const T* vnext = s->frame_epoch[f + 1] != s->frame_epoch[f] ? (const T*)(s->vend + (size_t)s->frame_epoch[f + 1] * 3 * s->Npad * s->tsz) : nullptr;
     LAUNCH_G2P_GRAD(s, D, f, (f + 1) & 1, f & 1, vnext);
@@ -1204,7 +1303,15 @@ int plmpm_create(const plmpm_config* cfg, const plmpm_primitive* prims, plmpm_ha
     s->store = cfg->store_grid != 0;
     s->gstride = align_up(s->G * 4 * s->tsz, 256);
     if (s->store) s->ws.grid_bytes += 2 * (size_t)s->F * s->gstride + align_up((size_t)s->F * s->nflag * 4, 256);
-    s->ws.grid_bytes += align_up((size_t)(s->F + 1) * (s->Npad / kBlock) * 8 * 4, 256) + align_up((size_t)(s->nblk + 1) * 4, 256);
+    s->ws.grid_bytes += align_up((size_t)(s->F + 1) * (s->Npad / kBlock) * 8 * 4, 256) + align_up((size_t)2 * (s->nblk + 1) * 4, 256);
+    // fused-grid path (grid_op inside the particle kernels' tile fills): one GPU, grid store, floating-point atomics.
+    // PLMPM_FUSE_GRID=0 keeps the grid kernels (A/B measurements, and the reference for the parity test of the fused path)
+    {
+        const char* e = getenv("PLMPM_FUSE_GRID");
+        const bool want = e ? e[0] != '0' : (PLB_FUSE_GRID_DEFAULT != 0);
+        s->fg = s->store && !s->dist && cfg->deterministic == 0 && want;
+    }
+    if (s->fg) s->ws.grid_bytes += align_up(s->G * 4 * s->tsz, 256);
     s->dirty.assign(s->F + 1, 0);
     s->ws.misc_bytes = 2 * align_up((size_t)(s->F + 1) * P1 * 7 * 8, 256) + 2 * align_up((size_t)(s->F + 1) * P1 * 8 * 8, 256)  // poses(+adj), padded
                        + 4 * align_up((size_t)(s->F + 1) * P1 * 3 * 8, 256)                       // v,w (+adj)
@@ -1278,7 +1385,8 @@ int plmpm_bind_workspace(plmpm_handle s, void* state, void* adjoint, void* grid,
         s->fstore = (int*)take((size_t)s->F * s->nflag * 4);
     }
     s->tiles = (int*)take((size_t)(s->F + 1) * (s->Npad / kBlock) * 8 * 4);
-    s->contact = (int*)take((size_t)(s->nblk + 1) * 4);
+    s->contact = (int*)take((size_t)2 * (s->nblk + 1) * 4);
+    if (s->fg) s->grid_out_adj2 = take(s->G * 4 * s->tsz);
     s->det_grid = s->det ? (long long*)take(s->G * 8 * 8) : nullptr;
     REQUIRE((size_t)(p - s->gridw) <= s->ws.grid_bytes, "internal: grid workspace overflow");
     p = s->miscw;

@@ -94,10 +94,12 @@ template <class T> struct Dev {
     T *mu, *lam, *ys;
     T* gin[4];                       // grid_m, grid_v_in x/y/z (SoA, accumulated)
     T* goa[3];                       // grid_v_out.grad x/y/z (SoA, accumulated)
+    T* goa_prev[3];                  // fused-grid engines: the other of the two grid_v_out.grad buffers (frames alternate)
     Vec4<T>*grid_out, *grid_in_adj;  // AoS
     int* flags;
     int* tiles;                      // [(F+1)][workgroups][8]: stencil box of each 256-particle workgroup, per frame
     int* contact;                    // [0] = n, [1..n] = blocks whose pose adjoints are still due (grid_op.grad -> p2g.grad)
+    int* contact_next;               // fused-grid engines: the list of the frame before this one (its counter is reset here)
     unsigned long long* trace;       // profiling builds only
     long long* det;                  // deterministic mode only (else null): two-limb fixed-point accumulators, [8][det_stride]
     size_t det_stride;               //   component c of a node: hi limb det[c * stride + idx], lo limb det[(4 + c) * stride + idx]
@@ -505,6 +507,82 @@ template <class T> __device__ __forceinline__ Tile load_tile(const Dev<T>& D, in
     return t;
 }
 
+// Workgroup barrier that only orders LDS traffic: __syncthreads() also waits for every global load the wave has in
+// flight (vmcnt(0)), which would serialise the particle loads issued before it with the tile fill behind it.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// ---- grid_op folded into the particle kernels (fused-grid engines: one GPU, per-frame grid store) ----------------------
+// grid_op (mpm_simulator.py:189-221) is pointwise per node: v_out = f(grid_m, grid_v_in, poses).  Instead of a kernel
+// of its own between the scatter and the gather (a launch boundary + one latency-bound pass for 2 % of the bytes),
+// the kernels that gather v_out evaluate it while they fill their LDS tile from grid_m / grid_v_in -- redundantly for
+// nodes that lie in several workgroups' boxes (a node is in ~4.5 boxes at config 3), which costs ~1-2 % of their
+// vector work.  Likewise grid_op.grad: the tile fill of p2g.grad evaluates the pointwise adjoint from grid_v_out.grad
+// and the frame's own grid_m / grid_v_in.  Nothing is written back, so nothing can be cleared by the kernel that
+// reads it (other workgroups read the same nodes): frame f's grids are cleared by g2p.grad of frame f - 1, over the
+// stencil boxes of frame f's workgroups (clear_boxes), and the two grid_v_out.grad buffers alternate between frames.
+#ifndef PLB_FG_ABL
+#define PLB_FG_ABL 0          // profiling only: 1 tile fills ignore the primitives, 2 no clear of the previous frame's grids
+#endif
+template <class T> struct PrevGrid {
+    const Vec4<T>* vout;             // grid_v_out of the previous substep (engines with grid kernels)
+    const T* gin[4];                 // grid_m / grid_v_in of the previous substep (fused-grid engines)
+};
+// v_out of node (ix, iy, iz) from grid_m / grid_v_in; touch: the node is in contact with a movable primitive
+template <class T> __device__ __forceinline__ Vec4<T> fg_node_vout(const Dev<T>& D, const T* const* gin, const PrimT<T>* sp, int ix, int iy, int iz,
+                                                                    bool* touch = nullptr, int* index = nullptr) {
+    const int idx = node_index(D, ix, iy, iz);
+    if (index) *index = idx;
+    const T m = gin[0][idx];
+    const T mv[3] = {gin[1][idx], gin[2][idx], gin[3][idx]};
+    T vo[3];
+    const int I[3] = {ix, iy, iz};
+    grid_node_fwd<T>(D.P, I, m, mv, (PLB_FG_ABL & 1) ? 0 : D.nprim, sp, vo, touch);
+    return Vec4<T>{vo[0], vo[1], vo[2], T(0)};
+}
+// {grid_v_in.grad, grid_m.grad} of node (ix, iy, iz) from grid_v_out.grad and the frame's grid_m / grid_v_in (the
+// pose adjoints of the nodes in contact are computed once per node elsewhere: pose_adjoint_blocks)
+template <class T> __device__ __forceinline__ Vec4<T> fg_node_gadj(const Dev<T>& D, const PrimT<T>* sp, int ix, int iy, int iz, int* index = nullptr) {
+    const int idx = node_index(D, ix, iy, iz);
+    if (index) *index = idx;
+    const T gm = D.gin[0][idx];
+    const T mv[3] = {D.gin[1][idx], D.gin[2][idx], D.gin[3][idx]};
+    const T va[3] = {D.goa[0][idx], D.goa[1][idx], D.goa[2][idx]};
+    T ma, mva[3];
+    const int I[3] = {ix, iy, iz};
+    grid_node_bwd<T, false>(D.P, I, gm, mv, (PLB_FG_ABL & 1) ? 0 : D.nprim, sp, va, &ma, mva, [](int, const PoseAdj<T>&, bool) {});
+    return Vec4<T>{mva[0], mva[1], mva[2], ma};
+}
+// a node in contact with a movable primitive: its block goes on the frame's contact list, once (bit 1 of the block flag)
+template <class T> __device__ __forceinline__ void fg_mark_contact(const Dev<T>& D, int idx) {
+    const int blk = idx >> 6;
+    if (!(atomicOr(&D.flags[flag_slot(D, blk)], 2) & 2)) D.contact[1 + atomicAdd(&D.contact[0], 1)] = blk;
+}
+// The grids of a frame whose reverse substep is complete, cleared over the stencil boxes of its particle workgroups
+// (every scatter of the frame -- through a tile or direct -- stays inside its workgroup's box): grid_m / grid_v_in,
+// the block flags and the grid_v_out.grad buffer the frame used.
+template <class T> struct ClearArgs {
+    int frame;                       // < 0: nothing to clear
+    int nwg;                         // particle workgroups of that frame
+    T* gin[4];
+    T* goa[3];
+    int* flags;
+};
+template <class T> __device__ __forceinline__ void clear_boxes(const Dev<T>& D, const ClearArgs<T>& A) {
+    for (int wg = blockIdx.x; wg < A.nwg; wg += gridDim.x) {
+        const int* q = D.tiles + ((size_t)A.frame * D.twg + wg) * 8;
+        const int o0 = q[0], o1 = q[1], o2 = q[2], ex = q[3], exy = q[3] * q[4], tn = exy * q[5];
+        for (int i = threadIdx.x; i < tn; i += kBlock) {
+            int lz, ly, lx;
+            tile_coords(i, ex, exy, lz, ly, lx);
+            const int idx = node_index(D, o0 + lx, o1 + ly, o2 + lz);
+            A.gin[0][idx] = T(0); A.gin[1][idx] = T(0); A.gin[2][idx] = T(0); A.gin[3][idx] = T(0);
+            A.goa[0][idx] = T(0); A.goa[1][idx] = T(0); A.goa[2][idx] = T(0);
+            A.flags[flag_slot(D, idx >> 6)] = 0;
+        }
+    }
+}
+template <class T> __global__ __launch_bounds__(kBlock) void k_clear_boxes(Dev<T> D, ClearArgs<T> A) { clear_boxes(D, A); }
+
 // Sorted particle load in two halves so that independent memory traffic can be issued in between.
 struct SortLoad { double x0[3]; long long key; };
 template <class T> __device__ __forceinline__ SortLoad sorted_begin(const Dev<T>& D, const double* X) {
@@ -707,9 +785,11 @@ __global__ __launch_bounds__(kBlock) void k_grid_op(Dev<T> D, int f, HaloIn H) {
 
 // ------------------------------------------------------------------------------------------------
 // g2p (mpm_simulator.py:223-242): gather v_out through an LDS tile, write x,v,C of frame f+1
-template <class T>
+// FG: fused-grid engines -- v_out is evaluated from grid_m / grid_v_in while the tile is filled (fg_node_vout)
+template <class T, bool FG = false>
 __global__ __launch_bounds__(kBlock) void k_g2p(Dev<T> D, int f) {
     __shared__ Vec4<T> tile[TileCap<T>::nodes];
+    __shared__ PrimT<T> sp[FG ? kMaxPrim : 1];
     const int p = blockIdx.x * kBlock + threadIdx.x;
     const bool valid = p < D.N;
     const double* X = frame_x(D, f);
@@ -718,7 +798,19 @@ __global__ __launch_bounds__(kBlock) void k_g2p(Dev<T> D, int f) {
     double x[3] = {0.5, 0.5, 0.5};
     if (valid) { x[0] = X[p]; x[1] = X[Np + p]; x[2] = X[2 * Np + p]; }
     const int ex = tl.e[0], exy = tl.e[0] * tl.e[1], tn = exy * tl.e[2];
-    if (tl.ok) {
+    if constexpr (FG) {
+        // v_out of every node of the box: into the LDS tile, or -- a box too large for it -- into the frame's grid_v_out
+        // in HBM, which the gather below then reads (workgroups with overlapping boxes write the same values)
+        load_prims(D, f, sp);
+        lds_barrier();
+        for (int i = threadIdx.x; i < tn; i += kBlock) {
+            int lz, ly, lx, idx;
+            tile_coords(i, ex, exy, lz, ly, lx);
+            const Vec4<T> a = fg_node_vout(D, D.gin, sp, tl.o[0] + lx, tl.o[1] + ly, tl.o[2] + lz, nullptr, &idx);
+            if (tl.ok) tile[i] = a; else D.grid_out[idx] = a;
+        }
+        __syncthreads();
+    } else if (tl.ok) {
         for (int i = threadIdx.x; i < tn; i += kBlock) {
             int lz, ly, lx;
                 tile_coords(i, ex, exy, lz, ly, lx);
@@ -755,10 +847,13 @@ __global__ __launch_bounds__(kBlock) void k_g2p(Dev<T> D, int f) {
 // are written once and go straight on (in registers) into the scatter; the LDS region first holds the
 // grid_v_out(f-1) tile, then -- after the gather -- is reused for the f64 accumulation tile of grid_in(f).
 // D is built for frame f (grid_in / flags of f); vout_prev is grid_v_out of substep f-1.
-template <class T, bool DET = false>
-__global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_g2p_p2g(Dev<T> D, int f, const Vec4<T>* vout_prev) {
+// FG (fused-grid engines): grid_op of substep f-1 is evaluated in the tile fill, from grid_m / grid_v_in of frame f-1.
+template <class T, bool DET = false, bool FG = false>
+__global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_g2p_p2g(Dev<T> D, int f, PrevGrid<T> G0) {
     __shared__ int sred[32];
     __shared__ Vec4<double> tile[TileCap<T>::nodes];
+    __shared__ PrimT<T> sp[FG ? kMaxPrim : 1];
+    const Vec4<T>* vout_prev = G0.vout;          // FG: the previous frame's grid_v_out store, written here for boxes too large for the tile
     Vec4<T>* tile_v = reinterpret_cast<Vec4<T>*>(tile);          // first use of the same LDS
     const int Np = D.Npad;
     // ---------------- g2p(f-1): gather
@@ -772,9 +867,17 @@ __global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_g2p_p2g(Dev<T> D, int
     // the tile fill is issued right behind the position loads and overlaps with them and with the sort
     const Tile ta = load_tile(D, f - 1, (int)(TileCap<T>::nodes * sizeof(Vec4<double>) / sizeof(Vec4<T>)));
     SortLoad sl = sorted_begin(D, X0);
+    if constexpr (FG) { load_prims(D, f - 1, sp); lds_barrier(); }       // poses of substep f-1 (issued behind the position loads)
     {
         const int ex = ta.e[0], exy = ta.e[0] * ta.e[1], tn = exy * ta.e[2];
-        if (ta.ok)
+        if constexpr (FG) {
+            for (int i = threadIdx.x; i < tn; i += kBlock) {
+                int lz, ly, lx, idx;
+                tile_coords(i, ex, exy, lz, ly, lx);
+                const Vec4<T> a = fg_node_vout(D, G0.gin, sp, ta.o[0] + lx, ta.o[1] + ly, ta.o[2] + lz, nullptr, &idx);
+                if (ta.ok) tile_v[i] = a; else const_cast<Vec4<T>*>(vout_prev)[idx] = a;
+            }
+        } else if (ta.ok)
             for (int i = threadIdx.x; i < tn; i += kBlock) {
                 int lz, ly, lx;
                 tile_coords(i, ex, exy, lz, ly, lx);
@@ -929,8 +1032,12 @@ __global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_g2p_p2g(Dev<T> D, int
 #ifndef PLB_G2PG_FIX8
 #define PLB_G2PG_FIX8 1
 #endif
-template <class T, bool DET = false>
-__global__ __launch_bounds__(kBlock, sizeof(T) == 4 ? PLB_G2PG_WAVES : 1) void k_g2p_grad(Dev<T> D, int f, int src, int dst, const T* vnext) {
+// FG (fused-grid engines; never DET): v_out comes from grid_m / grid_v_in in the tile fill, which also finds the blocks
+// in contact with a movable primitive (D.contact, consumed by the pose workgroups of the k_p2g_grad launch behind this
+// one); the grids of the frame the previous reverse substep finished with are cleared at the end (CA).
+template <class T, bool DET = false, bool FG = false>
+__global__ __launch_bounds__(kBlock, sizeof(T) == 4 ? PLB_G2PG_WAVES : 1) void k_g2p_grad(Dev<T> D, int f, int src, int dst, const T* vnext, ClearArgs<T> CA) {
+    __shared__ PrimT<T> sp[FG ? kMaxPrim : 1];
     // 960 nodes x (16 + 24) bytes = 37.5 KiB: four workgroups per CU (128 VGPRs = 4 waves per SIMD, see PLB_G2PG_WAVES)
     constexpr int CAP = sizeof(T) == 4 ? PLB_G2PG_CAP : 480;
     __shared__ Vec4<T> tile[CAP];                    // v_out values
@@ -940,9 +1047,12 @@ __global__ __launch_bounds__(kBlock, sizeof(T) == 4 ? PLB_G2PG_WAVES : 1) void k
     int p, base[3];
     double x[3];
     PT_BEGIN();
-    if (blockIdx.x == 0 && threadIdx.x == 0) D.contact[0] = 0;     // the list k_grid_op_grad(f) is about to fill
+    if (blockIdx.x == 0 && threadIdx.x == 0) (FG ? D.contact_next : D.contact)[0] = 0;     // the list k_grid_op_grad(f) (FG: this kernel for frame f-1) is about to fill
     const Tile tl = load_tile(D, f, DET ? CAP / 2 : CAP);           // stored by the scatter of this frame (DET: 6 limbs per node in tile_a)
     SortLoad sl = sorted_begin(D, X);
+    if constexpr (FG) { load_prims(D, f, sp); lds_barrier(); }
+    // FG: v_out of a tile node, and the node's block on to the contact list if it touches a movable primitive
+
     const int ex = tl.e[0], exy = tl.e[0] * tl.e[1], tn = exy * tl.e[2];
     // Fixed-shape tile: a box of at most 8 nodes per axis (most are: the mean box is ~6^3 nodes) is laid out in LDS with
     // the CONSTANT strides 8 / 64 instead of its own extents -- the 27 + 27 tile addresses of a particle's stencil become
@@ -952,7 +1062,22 @@ __global__ __launch_bounds__(kBlock, sizeof(T) == 4 ? PLB_G2PG_WAVES : 1) void k
     // cost 2 us (512 instead of ~230 tile slots to zero and flush), so only this kernel has it.
     const bool fix8 = PLB_G2PG_FIX8 && !DET && sizeof(T) == 4 && CAP >= 512 && tl.ok && tl.e[0] <= 8 && tl.e[1] <= 8 && tl.e[2] <= 8;
     const int n8 = tl.e[2] << 6;                                    // slots of the z planes in use
-    if (fix8) {
+    if constexpr (FG) {
+        // one loop over the box whatever the tile layout (fixed 8-strides, the box's own extents, or no tile at all: then
+        // v_out goes to the frame's grid_v_out in HBM and the gather reads it from there)
+        for (int i = threadIdx.x; i < tn; i += kBlock) {
+            int lz, ly, lx, idx;
+            tile_coords(i, ex, exy, lz, ly, lx);
+            bool touch = false;
+            const Vec4<T> a = fg_node_vout(D, D.gin, sp, tl.o[0] + lx, tl.o[1] + ly, tl.o[2] + lz, &touch, &idx);
+            if (touch) fg_mark_contact(D, idx);
+            if (fix8) tile[(lz << 6) + (ly << 3) + lx] = a;
+            else if (tl.ok) tile[i] = a;
+            else D.grid_out[idx] = a;
+        }
+        if (tl.ok)
+            for (int i = threadIdx.x; i < (fix8 ? n8 : tn); i += kBlock) { tile_a[3 * i] = 0.0; tile_a[3 * i + 1] = 0.0; tile_a[3 * i + 2] = 0.0; }
+    } else if (fix8) {
         for (int i = threadIdx.x; i < n8; i += kBlock) {
             const int lx = i & 7, ly = (i >> 3) & 7, lz = i >> 6;
             if (lx < tl.e[0] && ly < tl.e[1] && lz < tl.e[2])
@@ -1103,6 +1228,7 @@ __global__ __launch_bounds__(kBlock, sizeof(T) == 4 ? PLB_G2PG_WAVES : 1) void k
     }
     PT_MARK(4);
     PT_END(D, 10);
+    if constexpr (FG) { if (CA.frame >= 0 && !(PLB_FG_ABL & 2)) clear_boxes(D, CA); }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1110,7 +1236,8 @@ __global__ __launch_bounds__(kBlock, sizeof(T) == 4 ? PLB_G2PG_WAVES : 1) void k
 // One wave, one 4^3 block.  POSE = false computes the velocity adjoint only and returns true when an owned node of
 // the block touches a movable primitive: its pose adjoints are then still due and the block's inputs are left in
 // place for the POSE = true pass, which clears them.
-template <class T, bool POSE>
+// KEEP (fused-grid engines, POSE pass): leave the block's inputs alone -- particle workgroups of the same launch read them.
+template <class T, bool POSE, bool KEEP = false>
 __device__ __forceinline__ bool grid_block_bwd(const Dev<T>& D, const HaloIn& H, int blk, int lane, const PrimT<T>* sp, double* sacc, int* shit) {
     const int idx = (blk << 6) | lane;
     int I[3];
@@ -1149,7 +1276,7 @@ __device__ __forceinline__ bool grid_block_bwd(const Dev<T>& D, const HaloIn& H,
     const bool defer = !POSE && __any(due);
     if (!POSE) D.grid_in_adj[idx] = Vec4<T>{mva[0], mva[1], mva[2], ma};      // vector part first: (x, y) is an aligned register pair for the packed gather
     if (defer && hf >= 0) { D.goa[0][idx] = va[0]; D.goa[1][idx] = va[1]; D.goa[2][idx] = va[2]; }
-    if (!defer) {
+    if (!defer && !KEEP) {
         D.goa[0][idx] = T(0); D.goa[1][idx] = T(0); D.goa[2][idx] = T(0);
         // this frame's grid is consumed: leave grid_in / flags clean for the next scatter into them.  grid_in_adj
         // is never cleared -- p2g.grad only reads nodes of active blocks, which are all rewritten every substep.
@@ -1181,9 +1308,8 @@ __global__ __launch_bounds__(kBlock, sizeof(T) == 4 ? PLB_GOG_WAVES : 1) void k_
 }
 
 // the pose-adjoint workgroups of the p2g.grad launch: blocks listed in D.contact, one wave each
-template <class T>
-__device__ __forceinline__ void pose_adjoint_blocks(const Dev<T>& D, int f, int wg, int nwg) {
-    __shared__ PrimT<T> sp[kMaxPrim];
+template <class T, bool KEEP = false>
+__device__ __forceinline__ void pose_adjoint_blocks(const Dev<T>& D, int f, int wg, int nwg, PrimT<T>* sp) {
     __shared__ double sacc[kMaxPrim * 15];
     __shared__ int shit;
     load_prims(D, f, sp);
@@ -1192,7 +1318,7 @@ __device__ __forceinline__ void pose_adjoint_blocks(const Dev<T>& D, int f, int 
     __syncthreads();
     const int lane = threadIdx.x & 63, count = D.contact[0];
     for (int i = wg * (kBlock / 64) + (threadIdx.x >> 6); i < count; i += nwg * (kBlock / 64))
-        grid_block_bwd<T, true>(D, HaloIn{}, D.contact[1 + i], lane, sp, sacc, &shit);
+        grid_block_bwd<T, true, KEEP>(D, HaloIn{}, D.contact[1 + i], lane, sp, sacc, &shit);
     __syncthreads();
     if (shit && threadIdx.x < D.nprim * 15) {
         int q = threadIdx.x / 15, c = threadIdx.x % 15;
@@ -1245,13 +1371,16 @@ __global__ __launch_bounds__(64) void k_pose_adjoint_det(Dev<T> D, int f) {
 
 // ------------------------------------------------------------------------------------------------
 // p2g.grad + svd_grad + compute_F_tmp.grad: gather grid_in_adj, finish adjoint frame `dst`
-template <class T>
+// FG (fused-grid engines): the pointwise part of grid_op.grad is evaluated in the tile fill (fg_node_gadj) from
+// grid_v_out.grad and the frame's grid_m / grid_v_in; the pose workgroups leave those inputs in place.
+template <class T, bool FG = false>
 __global__ __launch_bounds__(kBlock, sizeof(T) == 4 ? PLB_P2G_GRAD_WAVES : 1) void k_p2g_grad(Dev<T> D, int f, int src, int dst, int npose) {
     __shared__ Vec4<T> tile[TileCap<T>::nodes];
+    __shared__ PrimT<T> sp[kMaxPrim];
     // the first `npose` workgroups finish grid_op.grad (pose adjoints of the blocks in contact) under cover of the
     // particle workgroups
     const int chunk = (int)blockIdx.x - npose;
-    if (chunk < 0) { pose_adjoint_blocks(D, f, (int)blockIdx.x, npose); return; }
+    if (chunk < 0) { pose_adjoint_blocks<T, FG>(D, f, (int)blockIdx.x, npose, sp); return; }
     const int p = chunk * kBlock + threadIdx.x;
     const bool valid = p < D.N;
     const double* X = frame_x(D, f);
@@ -1262,7 +1391,18 @@ __global__ __launch_bounds__(kBlock, sizeof(T) == 4 ? PLB_P2G_GRAD_WAVES : 1) vo
     double x[3] = {0.5, 0.5, 0.5};
     if (valid) { x[0] = X[p]; x[1] = X[Np + p]; x[2] = X[2 * Np + p]; }
     const int ex = tl.e[0], exy = tl.e[0] * tl.e[1], tn = exy * tl.e[2];
-    if (tl.ok) {
+    if constexpr (FG) {
+        // the node adjoints of the whole box: into the LDS tile, or -- a box too large for it -- into grid_in_adj in HBM
+        load_prims(D, f, sp);
+        lds_barrier();
+        for (int i = threadIdx.x; i < tn; i += kBlock) {
+            int lz, ly, lx, idx;
+            tile_coords(i, ex, exy, lz, ly, lx);
+            const Vec4<T> a = fg_node_gadj(D, sp, tl.o[0] + lx, tl.o[1] + ly, tl.o[2] + lz, &idx);
+            if (tl.ok) tile[i] = a; else D.grid_in_adj[idx] = a;
+        }
+        __syncthreads();
+    } else if (tl.ok) {
         for (int i = threadIdx.x; i < tn; i += kBlock) {
             int lz, ly, lx;
                 tile_coords(i, ex, exy, lz, ly, lx);
