@@ -65,6 +65,108 @@
 
 namespace plb {
 
+// ---------------------------------------------------------------- lane packs
+// Everything below is written for a "lane value" T: a scalar (float, double) or a pack of TWO particles' values per
+// GPU lane (P2 = two floats; positions D2 = two doubles, stencil bases I2 = two ints, conditions M2 = two bools).  A
+// wave64 fp32 instruction takes 4 cycles on a 16-lane SIMD of this part and only the packed forms (v_pk_fma_f32,
+// v_pk_mul_f32, v_pk_add_f32: two fp32 operations per lane in ~5 cycles) reach the vector peak; with two particles
+// per lane every add / multiply / fma of the per-particle arithmetic pairs up for free (the operands of the two
+// particles sit in the two halves of one 64-bit register pair by construction).  Conditions are therefore never
+// branched on per value: `sel(cond, a, b)` picks per component, `any(cond)` guards work that is rare.
+#if defined(__HIPCC__)
+typedef float plb_f2 __attribute__((ext_vector_type(2)));
+#endif
+struct M2 { bool x, y; };
+struct I2 {
+    int x, y;
+    PLB_HD I2() {}
+    PLB_HD I2(int a) : x(a), y(a) {}
+    PLB_HD I2(int a, int b) : x(a), y(b) {}
+};
+struct D2 {
+    double x, y;
+    PLB_HD D2() {}
+    PLB_HD D2(double a) : x(a), y(a) {}
+    PLB_HD D2(double a, double b) : x(a), y(b) {}
+    PLB_HD double lo() const { return x; }
+    PLB_HD double hi() const { return y; }
+};
+struct P2 {
+#if defined(__HIPCC__)
+    plb_f2 v;
+    PLB_HD P2() {}
+    PLB_HD P2(float a) : v{a, a} {}
+    PLB_HD P2(float a, float b) : v{a, b} {}
+    PLB_HD explicit P2(plb_f2 a) : v(a) {}
+    PLB_HD float lo() const { return v.x; }
+    PLB_HD float hi() const { return v.y; }
+#else
+    float a_, b_;
+    PLB_HD P2() {}
+    PLB_HD P2(float a) : a_(a), b_(a) {}
+    PLB_HD P2(float a, float b) : a_(a), b_(b) {}
+    PLB_HD float lo() const { return a_; }
+    PLB_HD float hi() const { return b_; }
+#endif
+};
+#if defined(__HIPCC__)
+PLB_HD P2 operator+(P2 a, P2 b) { return P2(a.v + b.v); }
+PLB_HD P2 operator-(P2 a, P2 b) { return P2(a.v - b.v); }
+PLB_HD P2 operator*(P2 a, P2 b) { return P2(a.v * b.v); }
+PLB_HD P2 operator-(P2 a) { return P2(-a.v); }
+#else
+PLB_HD P2 operator+(P2 a, P2 b) { return P2(a.lo() + b.lo(), a.hi() + b.hi()); }
+PLB_HD P2 operator-(P2 a, P2 b) { return P2(a.lo() - b.lo(), a.hi() - b.hi()); }
+PLB_HD P2 operator*(P2 a, P2 b) { return P2(a.lo() * b.lo(), a.hi() * b.hi()); }
+PLB_HD P2 operator-(P2 a) { return P2(-a.lo(), -a.hi()); }
+#endif
+PLB_HD P2 operator/(P2 a, P2 b) { return P2(a.lo() / b.lo(), a.hi() / b.hi()); }
+PLB_HD P2& operator+=(P2& a, P2 b) { a = a + b; return a; }
+PLB_HD P2& operator-=(P2& a, P2 b) { a = a - b; return a; }
+PLB_HD P2& operator*=(P2& a, P2 b) { a = a * b; return a; }
+PLB_HD M2 operator<(P2 a, P2 b) { return M2{a.lo() < b.lo(), a.hi() < b.hi()}; }
+PLB_HD M2 operator>(P2 a, P2 b) { return M2{a.lo() > b.lo(), a.hi() > b.hi()}; }
+PLB_HD M2 operator<=(P2 a, P2 b) { return M2{a.lo() <= b.lo(), a.hi() <= b.hi()}; }
+PLB_HD M2 operator>=(P2 a, P2 b) { return M2{a.lo() >= b.lo(), a.hi() >= b.hi()}; }
+PLB_HD M2 operator==(P2 a, P2 b) { return M2{a.lo() == b.lo(), a.hi() == b.hi()}; }
+PLB_HD M2 operator!=(P2 a, P2 b) { return M2{a.lo() != b.lo(), a.hi() != b.hi()}; }
+PLB_HD D2 operator+(D2 a, D2 b) { return D2(a.x + b.x, a.y + b.y); }
+PLB_HD D2 operator-(D2 a, D2 b) { return D2(a.x - b.x, a.y - b.y); }
+PLB_HD D2 operator*(D2 a, D2 b) { return D2(a.x * b.x, a.y * b.y); }
+PLB_HD D2 operator/(D2 a, D2 b) { return D2(a.x / b.x, a.y / b.y); }
+PLB_HD M2 operator<(D2 a, D2 b) { return M2{a.x < b.x, a.y < b.y}; }
+PLB_HD M2 operator>(D2 a, D2 b) { return M2{a.x > b.x, a.y > b.y}; }
+PLB_HD M2 operator&&(M2 a, M2 b) { return M2{a.x && b.x, a.y && b.y}; }
+PLB_HD M2 operator||(M2 a, M2 b) { return M2{a.x || b.x, a.y || b.y}; }
+PLB_HD M2 operator!(M2 a) { return M2{!a.x, !a.y}; }
+PLB_HD I2 operator+(I2 a, I2 b) { return I2(a.x + b.x, a.y + b.y); }
+PLB_HD I2 operator-(I2 a, I2 b) { return I2(a.x - b.x, a.y - b.y); }
+
+// what belongs to a lane value T: its scalar, its condition type, the integer pack of its stencil base
+template <class T> struct Lane { typedef T scalar; typedef bool mask; typedef int ivec; };
+template <> struct Lane<P2> { typedef float scalar; typedef M2 mask; typedef I2 ivec; };
+template <> struct Lane<D2> { typedef double scalar; typedef M2 mask; typedef I2 ivec; };
+
+PLB_HD float sel(bool c, float a, float b) { return c ? a : b; }
+PLB_HD double sel(bool c, double a, double b) { return c ? a : b; }
+PLB_HD int sel(bool c, int a, int b) { return c ? a : b; }
+PLB_HD P2 sel(M2 c, P2 a, P2 b) { return P2(c.x ? a.lo() : b.lo(), c.y ? a.hi() : b.hi()); }
+PLB_HD D2 sel(M2 c, D2 a, D2 b) { return D2(c.x ? a.x : b.x, c.y ? a.y : b.y); }
+PLB_HD I2 sel(M2 c, I2 a, I2 b) { return I2(c.x ? a.x : b.x, c.y ? a.y : b.y); }
+PLB_HD bool any(bool c) { return c; }
+PLB_HD bool any(M2 c) { return c.x || c.y; }
+// conversions between the value kinds of one lane layout
+template <class To, class From> PLB_HD To cvt(From v) { return (To)v; }
+template <> PLB_HD D2 cvt<D2, P2>(P2 v) { return D2((double)v.lo(), (double)v.hi()); }
+template <> PLB_HD P2 cvt<P2, D2>(D2 v) { return P2((float)v.x, (float)v.y); }
+template <> PLB_HD D2 cvt<D2, I2>(I2 v) { return D2((double)v.x, (double)v.y); }
+template <> PLB_HD D2 cvt<D2, float>(float v) { return D2((double)v); }
+template <> PLB_HD D2 cvt<D2, double>(double v) { return D2(v); }
+template <> PLB_HD D2 cvt<D2, int>(int v) { return D2((double)v); }
+PLB_HD int to_int(double v) { return (int)v; }
+PLB_HD int to_int(float v) { return (int)v; }
+PLB_HD I2 to_int(D2 v) { return I2((int)v.x, (int)v.y); }
+
 // ---------------------------------------------------------------- scalar helpers
 template <class T> PLB_HD T t_sqrt(T x);
 template <> PLB_HD float t_sqrt<float>(float x) { return sqrtf(x); }
@@ -124,9 +226,15 @@ template <> PLB_HD float t_expm1_fast<float>(float e) {
     return __expf(e) - 1.0f;
 }
 #endif
-template <class T> PLB_HD T t_abs(T x) { return x < T(0) ? -x : x; }
-template <class T> PLB_HD T t_max(T a, T b) { return a > b ? a : b; }
-template <class T> PLB_HD T t_min(T a, T b) { return a < b ? a : b; }
+// the same helpers for a pack: component by component (the hardware has no packed transcendentals)
+#define PLB_P2_MAP1(fn) template <> PLB_HD P2 fn<P2>(P2 x) { return P2(fn<float>(x.lo()), fn<float>(x.hi())); }
+PLB_P2_MAP1(t_sqrt) PLB_P2_MAP1(t_exp) PLB_P2_MAP1(t_log) PLB_P2_MAP1(t_log1p) PLB_P2_MAP1(t_expm1)
+PLB_P2_MAP1(t_rcp) PLB_P2_MAP1(t_rsqrt) PLB_P2_MAP1(t_fsqrt) PLB_P2_MAP1(t_log1p_fast) PLB_P2_MAP1(t_expm1_fast)
+#undef PLB_P2_MAP1
+template <> PLB_HD D2 t_sqrt<D2>(D2 x) { return D2(sqrt(x.x), sqrt(x.y)); }
+template <class T> PLB_HD T t_abs(T x) { return sel(x < T(0), -x, x); }
+template <class T> PLB_HD T t_max(T a, T b) { return sel(a > b, a, b); }
+template <class T> PLB_HD T t_min(T a, T b) { return sel(a < b, a, b); }
 // pick one of three by a loop index that stays a run-time value (outer stencil loop is kept rolled on the GPU)
 template <class T> PLB_HD T sel3(int i, T a, T b, T c) { return i == 0 ? a : (i == 1 ? b : c); }
 
@@ -141,6 +249,7 @@ template <> struct Tol<double> {
     static PLB_HD double dd() { return 1e-4; }
     static PLB_HD double small_angle() { return 1e-12; }
 };
+template <> struct Tol<P2> : Tol<float> {};
 
 // ---------------------------------------------------------------- 3x3 helpers (row major)
 template <class T> PLB_HD void mat_mul(const T* a, const T* b, T* c) {          // c = a b
@@ -181,11 +290,11 @@ template <class T> struct SimP {
 // w[k][d] for offset k in {0,1,2}; dw = d w / d fx.      (mpm_simulator.py:160-163)
 // X is the position type: positions are carried in double even on the fp32 path, so that fx (and with
 // it every weight) keeps full fp32 relative precision instead of the ~4e-6 an fp32 x*inv_dx would leave.
-template <class T, class X> PLB_HD void stencil(const X* x, T inv_dx, int* base, T* fx, T (*w)[3], T (*dw)[3]) {
+template <class T, class X> PLB_HD void stencil(const X* x, typename Lane<T>::scalar inv_dx, typename Lane<T>::ivec* base, T* fx, T (*w)[3], T (*dw)[3]) {
     for (int d = 0; d < 3; ++d) {
-        X xs = x[d] * (X)inv_dx;
-        base[d] = (int)(xs - X(0.5));
-        T f = (T)(xs - (X)base[d]);
+        X xs = x[d] * cvt<X>(inv_dx);
+        base[d] = to_int(xs - X(0.5));
+        T f = cvt<T>(xs - cvt<X>(base[d]));
         fx[d] = f;
         w[0][d] = T(0.5) * (T(1.5) - f) * (T(1.5) - f);
         w[1][d] = T(0.75) - (f - T(1)) * (f - T(1));
@@ -213,8 +322,8 @@ template <class T> PLB_HD void jacobi_pair(T& app, T& aqq, T& apq, T& arp, T& ar
     // t = 0, c = 1, s = 0: an exact no-op.
     const T d = aqq - app;
     const T h = t_fsqrt(d * d + T(4) * apq * apq);
-    const T den = d + (d >= T(0) ? h : -h);
-    const T t = h > T(0) ? T(2) * apq * t_rcp(den) : T(0);
+    const T den = d + sel(d >= T(0), h, -h);
+    const T t = sel(h > T(0), T(2) * apq * t_rcp(den), T(0));
     const T c = t_rsqrt(t * t + T(1));
     const T s = t * c;
     app -= t * apq;
@@ -272,22 +381,23 @@ template <class T> PLB_HD void svd_finish(const T* Et, Svd3<T>& r) {
     // nearly singular F: rebuild the weakest column from the other two (constant indices only: a run-time
     // index into U/sig would push the whole decomposition into scratch memory on the GPU)
     T smin = t_min(r.sig[0], t_min(r.sig[1], r.sig[2]));
-    if (smin < T(1e-3)) {
+    typename Lane<T>::mask todo = smin < T(1e-3);
+    if (any(todo)) {
         T Fm[9];
         for (int i = 0; i < 9; ++i) Fm[i] = Et[i];
         Fm[0] += T(1); Fm[4] += T(1); Fm[8] += T(1);
-        T sgn = det3(Fm) < T(0) ? T(-1) : T(1);
-        bool done = false;
+        T sgn = sel(det3(Fm) < T(0), T(-1), T(1));
         PLB_UNROLL
         for (int k = 0; k < 3; ++k) {
-            if (!done && r.sig[k] == smin) {
+            const typename Lane<T>::mask hit = todo && (r.sig[k] == smin);        // the first such column only
+            if (any(hit)) {
                 const int a = (k + 1) % 3, b = (k + 2) % 3;
                 T ua[3] = {r.U[a], r.U[3 + a], r.U[6 + a]}, ub[3] = {r.U[b], r.U[3 + b], r.U[6 + b]}, uc[3];
                 cross3(ua, ub, uc);
                 T nrm = t_sqrt(dot3(uc, uc));
-                T sc = nrm > T(0) ? sgn / nrm : T(0);
-                r.U[k] = uc[0] * sc; r.U[3 + k] = uc[1] * sc; r.U[6 + k] = uc[2] * sc;
-                done = true;
+                T sc = sel(nrm > T(0), sgn / nrm, T(0));
+                r.U[k] = sel(hit, uc[0] * sc, r.U[k]); r.U[3 + k] = sel(hit, uc[1] * sc, r.U[3 + k]); r.U[6 + k] = sel(hit, uc[2] * sc, r.U[6 + k]);
+                todo = todo && !hit;
             }
         }
     }
@@ -302,14 +412,14 @@ template <class T> PLB_HD void svd_eform(const T* Et, Svd3<T>& r) {
 // compute_von_mises + stress of p2g               (mpm_simulator.py:124-141, :164-171)
 template <class T> struct Consti {
     Svd3<T> svd;
-    bool yield;
+    typename Lane<T>::mask yield;
     T g[3];      // singular values of new_F
     T gm1[3];    // g - 1
     T eps[3], eh[3], epsn[3];
     T nrm, c;    // ||dev eps|| (with the 1e-8 eps), yield_stress / (2 mu)
     T J, Jm1;    // det(new_F), det - 1
     T h[3];      // principal (unscaled) stress: 2 mu g (g-1) + lam J (J-1)
-    bool unc[3]; // sig > 0.05 (not clamped)
+    typename Lane<T>::mask unc[3]; // sig > 0.05 (not clamped)
 };
 
 // Et = F_tmp - I.  Outputs: En = new_F - I (what is stored as F[f+1]), stress (unscaled).
@@ -319,7 +429,7 @@ template <class T> PLB_HD void constitutive_fwd(const T* Et, T mu, T lam, T ys, 
     T mean = T(0);
     for (int i = 0; i < 3; ++i) {
         k.unc[i] = T(0.05) < S.sig[i];          // ti.max(sig, 0.05): adjoint to sig iff 0.05 < sig
-        k.eps[i] = k.unc[i] ? t_log1p_fast(S.s[i]) : T(-2.995732273553991);     // log(0.05)
+        k.eps[i] = sel(k.unc[i], t_log1p_fast(S.s[i]), T(-2.995732273553991));     // log(0.05)
         mean += k.eps[i];
     }
     mean *= T(1) / T(3);
@@ -328,35 +438,41 @@ template <class T> PLB_HD void constitutive_fwd(const T* Et, T mu, T lam, T ys, 
     k.nrm = t_fsqrt(n2);
     k.c = ys * t_rcp(T(2) * mu);
     k.yield = (k.nrm - k.c) > T(0);
-    T detsign = T(1);
-    if (k.yield) {
-        T f = (k.nrm - k.c) * t_rcp(k.nrm);
-        for (int i = 0; i < 3; ++i) {
-            k.epsn[i] = k.eps[i] - f * k.eh[i];
-            k.gm1[i] = t_expm1_fast(k.epsn[i]);
-            k.g[i] = T(1) + k.gm1[i];
-        }
-        T US[9];
-        for (int r = 0; r < 3; ++r)
-            for (int i = 0; i < 3; ++i) US[3 * r + i] = S.U[3 * r + i] * k.g[i];
-        mat_mul_nt(US, S.V, En);
-        En[0] -= T(1); En[4] -= T(1); En[8] -= T(1);
-        detsign = det3(S.U) < T(0) ? T(-1) : T(1);     // det V = +1
-    } else {
-        for (int i = 0; i < 3; ++i) { k.g[i] = S.sig[i]; k.gm1[i] = S.s[i]; k.epsn[i] = k.eps[i]; }
-        for (int i = 0; i < 9; ++i) En[i] = Et[i];
-        // det(F_tmp) sign: only negative for inverted elements
+    // elastic branch (every lane value starts from it; the values that yield are overwritten below)
+    for (int i = 0; i < 3; ++i) { k.g[i] = S.sig[i]; k.gm1[i] = S.s[i]; k.epsn[i] = k.eps[i]; }
+    for (int i = 0; i < 9; ++i) En[i] = Et[i];
+    T detsign;
+    {   // det(F_tmp) sign: only negative for inverted elements
         T Fm[9];
         for (int i = 0; i < 9; ++i) Fm[i] = Et[i];
         Fm[0] += T(1); Fm[4] += T(1); Fm[8] += T(1);
-        detsign = det3(Fm) < T(0) ? T(-1) : T(1);
+        detsign = sel(det3(Fm) < T(0), T(-1), T(1));
+    }
+    if (any(k.yield)) {
+        T f = (k.nrm - k.c) * t_rcp(k.nrm);
+        T gy[3];
+        for (int i = 0; i < 3; ++i) {
+            const T en = k.eps[i] - f * k.eh[i];
+            const T gm = t_expm1_fast(en);
+            gy[i] = T(1) + gm;
+            k.epsn[i] = sel(k.yield, en, k.epsn[i]);
+            k.gm1[i] = sel(k.yield, gm, k.gm1[i]);
+            k.g[i] = sel(k.yield, gy[i], k.g[i]);
+        }
+        T US[9], Ey[9];
+        for (int r = 0; r < 3; ++r)
+            for (int i = 0; i < 3; ++i) US[3 * r + i] = S.U[3 * r + i] * gy[i];
+        mat_mul_nt(US, S.V, Ey);
+        Ey[0] -= T(1); Ey[4] -= T(1); Ey[8] -= T(1);
+        for (int i = 0; i < 9; ++i) En[i] = sel(k.yield, Ey[i], En[i]);
+        detsign = sel(k.yield, sel(det3(S.U) < T(0), T(-1), T(1)), detsign);     // det V = +1
     }
     T e1 = k.gm1[0] + k.gm1[1] + k.gm1[2];
     T e2 = k.gm1[0] * k.gm1[1] + k.gm1[0] * k.gm1[2] + k.gm1[1] * k.gm1[2];
     T e3 = k.gm1[0] * k.gm1[1] * k.gm1[2];
     T Jp1m = e1 + e2 + e3;                      // prod(g) - 1
-    if (detsign > T(0)) { k.Jm1 = Jp1m; k.J = T(1) + Jp1m; }
-    else { k.J = -(T(1) + Jp1m); k.Jm1 = k.J - T(1); }
+    k.J = sel(detsign > T(0), T(1) + Jp1m, -(T(1) + Jp1m));
+    k.Jm1 = sel(detsign > T(0), Jp1m, k.J - T(1));
     T vol = lam * k.J * k.Jm1;
     for (int i = 0; i < 3; ++i) k.h[i] = T(2) * mu * k.g[i] * k.gm1[i] + vol;
     T UH[9];
@@ -378,11 +494,17 @@ template <class T> PLB_HD T dd_log(T a, T b) {       // (log a - log b)/(a - b),
     return t_log1p_fast(t) * t_rcp(t * b);
 }
 
+template <> PLB_HD P2 dd_exp<P2>(P2 a, P2 b) { return P2(dd_exp<float>(a.lo(), b.lo()), dd_exp<float>(a.hi(), b.hi())); }
+template <> PLB_HD P2 dd_log<P2>(P2 a, P2 b) { return P2(dd_log<float>(a.lo(), b.lo()), dd_log<float>(a.hi(), b.hi())); }
+
 // VJP of (new_F, stress) w.r.t. F_tmp: returns Ft_adj = d<GF,new_F>/dFt + d<GS,stress>/dFt.
 // Replaces p2g.grad's U/sig/V adjoints + svd_grad    (mpm_simulator.py:92-115, :276-277)
-template <class T> PLB_HD void constitutive_vjp(const Consti<T>& k, T mu, T lam, T svd_clamp,
+// One body for the elastic and the yielding branch: M (the adjoint in the singular basis) is built for the elastic
+// branch, the lane values that yield overwrite it -- that part only runs when some value of the wave yields.
+template <class T> PLB_HD void constitutive_vjp(const Consti<T>& k, T mu, T lam, typename Lane<T>::scalar svd_clamp_s,
                                                 const T* GS, const T* GF, T* Ft_adj) {
     const Svd3<T>& S = k.svd;
+    const T svd_clamp = T(svd_clamp_s);
     T tmp[9], Gs[9], Gf[9], M[9];
     mat_mul_tn(S.U, GS, tmp); mat_mul(tmp, S.U, Gs);            // U^T GS U
     const T* sig = S.sig;
@@ -390,25 +512,26 @@ template <class T> PLB_HD void constitutive_vjp(const Consti<T>& k, T mu, T lam,
     for (int i = 0; i < 3; ++i)
         for (int j = 0; j < 3; ++j) {
             T dl = t_abs(S.lam[j] - S.lam[i]);
-            att[i][j] = (svd_clamp > T(0) && dl < svd_clamp) ? dl * t_rcp(svd_clamp) : T(1);
+            att[i][j] = sel((svd_clamp > T(0)) && (dl < svd_clamp), dl * t_rcp(svd_clamp), T(1));
         }
     T J = k.J;
-    if (!k.yield) {
+    {
         T dvol = lam * (T(2) * J - T(1));
         for (int q = 0; q < 3; ++q) {
-            T Jq = J * t_rcp(sig[q]);      // dJ/dsig_q
-            if (sig[q] < T(1e-20)) Jq = T(0);
+            T Jq = sel(sig[q] < T(1e-20), T(0), J * t_rcp(sig[q]));      // dJ/dsig_q
             M[4 * q] = T(2) * mu * (T(2) * sig[q] - T(1)) * Gs[4 * q] + dvol * Jq * (Gs[0] + Gs[4] + Gs[8]);
         }
         for (int i = 0; i < 3; ++i)
             for (int j = 0; j < 3; ++j) {
                 if (i == j) continue;
                 T ssum = sig[i] + sig[j];
-                T inv = ssum > T(1e-20) ? t_rcp(ssum) : T(0);
+                T inv = sel(ssum > T(1e-20), t_rcp(ssum), T(0));
                 T kij = T(2) * mu * (ssum - T(1)) * inv;
                 M[3 * i + j] = kij * sig[j] * (Gs[3 * i + j] + Gs[3 * j + i])
                     + (T(1) - att[i][j]) * T(2) * mu * (Gs[3 * i + j] * sig[j] - Gs[3 * j + i] * sig[i]) * inv;
             }
+    }
+    if (!any(k.yield)) {
         T UM[9];
         mat_mul(S.U, M, UM); mat_mul_nt(UM, S.V, Ft_adj);
         for (int i = 0; i < 9; ++i) Ft_adj[i] += GF[i];
@@ -420,7 +543,7 @@ template <class T> PLB_HD void constitutive_vjp(const Consti<T>& k, T mu, T lam,
     T inrm = t_rcp(k.nrm);
     T cn = k.c * inrm, cn3 = k.c * inrm * inrm * inrm;
     for (int q = 0; q < 3; ++q) {
-        T dsc = k.unc[q] ? t_rcp(sig[q]) : T(0);                // d eps_q / d sig_q
+        T dsc = sel(k.unc[q], t_rcp(sig[q]), T(0));                // d eps_q / d sig_q
         dJ[q] = T(0);
         for (int i = 0; i < 3; ++i) {
             T de = T(1) / T(3) + cn * ((i == q ? T(1) : T(0)) - T(1) / T(3)) - cn3 * k.eh[i] * k.eh[q];
@@ -435,32 +558,30 @@ template <class T> PLB_HD void constitutive_vjp(const Consti<T>& k, T mu, T lam,
             T dh = T(2) * mu * (T(2) * k.g[i] - T(1)) * dg[i][q] + dvol * dJ[q];
             acc += dh * Gs[4 * i] + dg[i][q] * Gf[4 * i];
         }
-        M[4 * q] = acc;
+        M[4 * q] = sel(k.yield, acc, M[4 * q]);
     }
     for (int i = 0; i < 3; ++i)
         for (int j = 0; j < 3; ++j) {
             if (i == j) continue;
-            T ddg;
-            if (k.unc[i] && k.unc[j]) {
-                ddg = dd_exp(k.epsn[i], k.epsn[j]) * cn * dd_log(sig[i], sig[j]);
-            } else {
-                T ds = sig[i] - sig[j];
-                ddg = ds != T(0) ? (k.g[i] - k.g[j]) * t_rcp(ds) : T(0);
-            }
+            const typename Lane<T>::mask both = k.unc[i] && k.unc[j];
+            const T ds = sig[i] - sig[j];
+            T ddg = sel(ds != T(0), (k.g[i] - k.g[j]) * t_rcp(ds), T(0));
+            if (any(both)) ddg = sel(both, dd_exp(k.epsn[i], k.epsn[j]) * cn * dd_log(sig[i], sig[j]), ddg);
             T ssum = sig[i] + sig[j];
-            T inv = ssum > T(1e-20) ? t_rcp(ssum) : T(0);
+            T inv = sel(ssum > T(1e-20), t_rcp(ssum), T(0));
             T sumr = (k.g[i] + k.g[j]) * inv;
             T a = T(0.5) * (ddg + sumr), b = T(0.5) * (ddg - sumr);
             T kk = T(2) * mu * (k.g[i] + k.g[j] - T(1)) * ddg * inv;
-            M[3 * i + j] = att[i][j] * (kk * sig[j] * (Gs[3 * i + j] + Gs[3 * j + i]) + a * Gf[3 * i + j] + b * Gf[3 * j + i]);
+            M[3 * i + j] = sel(k.yield, att[i][j] * (kk * sig[j] * (Gs[3 * i + j] + Gs[3 * j + i]) + a * Gf[3 * i + j] + b * Gf[3 * j + i]), M[3 * i + j]);
         }
     T UM[9];
     mat_mul(S.U, M, UM); mat_mul_nt(UM, S.V, Ft_adj);
+    for (int i = 0; i < 9; ++i) Ft_adj[i] += sel(k.yield, T(0), GF[i]);
 }
 
 // ---------------------------------------------------------------- particle <-> grid
 // compute_F_tmp in E-form: Et = E + dt C + dt C E        (mpm_simulator.py:82-85)
-template <class T> PLB_HD void f_tmp_eform(const T* C, const T* E, T dt, T* Et) {
+template <class T> PLB_HD void f_tmp_eform(const T* C, const T* E, typename Lane<T>::scalar dt, T* Et) {
     T CE[9];
     mat_mul(C, E, CE);
     for (int i = 0; i < 9; ++i) Et[i] = E[i] + dt * (C[i] + CE[i]);
@@ -469,8 +590,8 @@ template <class T> PLB_HD void f_tmp_eform(const T* C, const T* E, T dt, T* Et) 
 // p2g body (mpm_simulator.py:157-184).  Emit(k0,k1,k2, mass, mom[3]) is called for the 27 offsets.
 // Returns new E (F[f+1] - I) in En.
 template <class T, class X, class Emit>
-PLB_HD void p2g_particle(const SimP<T>& P, const X* x, const T* v, const T* C, const T* E,
-                         T mu, T lam, T ys, T* En, int* base, Emit&& emit) {
+PLB_HD void p2g_particle(const SimP<typename Lane<T>::scalar>& P, const X* x, const T* v, const T* C, const T* E,
+                         T mu, T lam, T ys, T* En, typename Lane<T>::ivec* base, Emit&& emit) {
     T fx[3], w[3][3];
     stencil<T, X>(x, P.inv_dx, base, fx, w, nullptr);
     T Et[9], stress[9], A[9];
@@ -505,8 +626,8 @@ PLB_HD void p2g_particle(const SimP<T>& P, const X* x, const T* v, const T* C, c
 
 // g2p body (mpm_simulator.py:223-242).  Fetch(k0,k1,k2, gv[3]) reads grid_v_out.
 template <class T, class X, class Fetch>
-PLB_HD void g2p_particle(const SimP<T>& P, const X* x, X* xn, T* vn, T* Cn, Fetch&& fetch) {
-    int base[3];
+PLB_HD void g2p_particle(const SimP<typename Lane<T>::scalar>& P, const X* x, X* xn, T* vn, T* Cn, Fetch&& fetch) {
+    typename Lane<T>::ivec base[3];
     T fx[3], w[3][3];
     stencil<T, X>(x, P.inv_dx, base, fx, w, nullptr);
     for (int a = 0; a < 3; ++a) vn[a] = T(0);
@@ -557,8 +678,8 @@ PLB_HD void g2p_particle(const SimP<T>& P, const X* x, X* xn, T* vn, T* Cn, Fetc
 #endif
     for (int a = 0; a < 9; ++a) Cn[a] *= T(4) * P.inv_dx;
     for (int d = 0; d < 3; ++d) {
-        X y = x[d] + (X)P.dt * (X)vn[d];
-        X hi = X(1) - X(3) / (X)P.n;
+        X y = x[d] + cvt<X>(P.dt) * cvt<X>(vn[d]);
+        X hi = X(1) - X(3) / cvt<X>(P.n);
         xn[d] = t_max(t_min(y, hi), X(0));
     }
 }
@@ -567,17 +688,17 @@ PLB_HD void g2p_particle(const SimP<T>& P, const X* x, X* xn, T* vn, T* Cn, Fetc
 // (x,v,C)[f+1]; Fetch reads grid_v_out, Emit(k0,k1,k2, gv_adj[3]) scatters into grid_v_out.grad.
 // Output xa = contribution to x[f].grad.
 template <class T, class X, class Fetch, class Emit>
-PLB_HD void g2p_particle_grad(const SimP<T>& P, const X* x, const T* vn, const T* xn_a, const T* vn_a,
+PLB_HD void g2p_particle_grad(const SimP<typename Lane<T>::scalar>& P, const X* x, const T* vn, const T* xn_a, const T* vn_a,
                               const T* Cn_a, T* xa, Fetch&& fetch, Emit&& emit) {
-    int base[3];
+    typename Lane<T>::ivec base[3];
     T fx[3], w[3][3], dw[3][3];
     stencil<T, X>(x, P.inv_dx, base, fx, w, dw);
     T nva[3];
     for (int d = 0; d < 3; ++d) {
-        X y = x[d] + (X)P.dt * (X)vn[d];
-        X hi = X(1) - X(3) / (X)P.n;
+        X y = x[d] + cvt<X>(P.dt) * cvt<X>(vn[d]);
+        X hi = X(1) - X(3) / cvt<X>(P.n);
         // max(min(y, hi), 0): adjoint reaches y iff y < hi and 0 < min(y,hi)   (Taichi min/max rule)
-        T gate = (y < hi && X(0) < t_min(y, hi)) ? T(1) : T(0);
+        T gate = sel((y < hi) && (X(0) < t_min(y, hi)), T(1), T(0));
         xa[d] = gate * xn_a[d];
         nva[d] = vn_a[d] + P.dt * gate * xn_a[d];
     }
@@ -636,8 +757,8 @@ template <class T> struct P2GGather {
     T sv[9];     // sum_o gva_o[a] dw_o/dfx_d   ([3 d + a])
 };
 template <class T, class X, class Fetch>
-PLB_HD void p2g_gather_grad(const SimP<T>& P, const X* x, P2GGather<T>& G, Fetch&& fetch) {
-    int base[3];
+PLB_HD void p2g_gather_grad(const SimP<typename Lane<T>::scalar>& P, const X* x, P2GGather<T>& G, Fetch&& fetch) {
+    typename Lane<T>::ivec base[3];
     T fx[3], w[3][3], dw[3][3];
     stencil<T, X>(x, P.inv_dx, base, fx, w, dw);
     // Gather pass first, with accumulators that do not need the affine matrix A = kappa*stress + m C:
@@ -713,7 +834,7 @@ PLB_HD void p2g_gather_grad(const SimP<T>& P, const X* x, P2GGather<T>& G, Fetch
 }
 
 template <class T>
-PLB_HD void p2g_finish_grad(const SimP<T>& P, const P2GGather<T>& G, const T* v, const T* C, const T* E, T mu, T lam, T ys,
+PLB_HD void p2g_finish_grad(const SimP<typename Lane<T>::scalar>& P, const P2GGather<T>& G, const T* v, const T* C, const T* E, T mu, T lam, T ys,
                             const T* En_a, T* xa_io, T* va, T* Ca, T* Ea) {
     T Et[9], En[9], stress[9], A[9];
     f_tmp_eform(C, E, P.dt, Et);
@@ -729,7 +850,7 @@ PLB_HD void p2g_finish_grad(const SimP<T>& P, const P2GGather<T>& G, const T* v,
         T acc = P.p_mass * (G.sm[d] + G.sv[3 * d] * v[0] + G.sv[3 * d + 1] * v[1] + G.sv[3 * d + 2] * v[2]);
         for (int a = 0; a < 3; ++a) {
             for (int b = 0; b < 3; ++b) acc += A[3 * a + b] * M[9 * a + 3 * b + d];
-            acc -= P.dx * A[3 * a + d] * va[a] * t_rcp(P.p_mass);       // d/d dp: sum_o w_o A^T gva_o, dp = (k - fx) dx
+            acc -= P.dx * A[3 * a + d] * va[a] * t_rcp(T(P.p_mass));       // d/d dp: sum_o w_o A^T gva_o, dp = (k - fx) dx
         }
         fxa[d] = acc;
     }
@@ -750,7 +871,7 @@ PLB_HD void p2g_finish_grad(const SimP<T>& P, const P2GGather<T>& G, const T* v,
 
 
 template <class T, class X, class Fetch>
-PLB_HD void p2g_particle_grad(const SimP<T>& P, const X* x, const T* v, const T* C, const T* E,
+PLB_HD void p2g_particle_grad(const SimP<typename Lane<T>::scalar>& P, const X* x, const T* v, const T* C, const T* E,
                               T mu, T lam, T ys, const T* En_a, T* xa_io, T* va, T* Ca, T* Ea,
                               Fetch&& fetch) {
     P2GGather<T> G;

@@ -12,7 +12,7 @@
 #include <vector>
 
 #include "../../include/plmpm.h"
-#include "plmpm_kernels.h"
+#include "plmpm_kernels_pk.h"
 
 // plmpm_sort.hip
 extern "C" size_t plmpm_sort_temp_bytes(int n);
@@ -112,6 +112,8 @@ struct plmpm_sim {
     // (fg_pending) are cleared by the next g2p.grad, or by k_clear_boxes when something else comes first.
     bool fg = false;
     int fg_pending = -1;
+    // two particles per lane with packed fp32 arithmetic (plmpm_kernels_pk.h): fp32 engines, floating-point atomics
+    bool pk = false;
     char* grid_out_adj2 = nullptr;   // second grid_v_out.grad buffer (frames alternate)
     int* tiles = nullptr;        // per-frame stencil boxes of the particle workgroups: [(F+1)][Npad/256][8]
     // Per-env-step storage order ("epochs").  Epoch 0 is the order chosen at reset (perm_d).  With cfg.resort_steps,
@@ -168,13 +170,14 @@ static void prof_end(plmpm_sim* s) {
     (void)hipEventRecord(s->ev_pool[s->ev_used.back().second + 1], s->stream);
 }
 #define LAUNCHG_CLEAR(s, D) LAUNCH(s, K_CLEAR, (k_clear_active<T>), dim3(nblocks_grid(s)), D)
-#define LAUNCH(s, id, kern, grid, ...)                                                     \
+#define LAUNCHB(s, id, kern, grid, block, ...)                                             \
     do {                                                                                   \
         if (dim3(grid).x == 0) break;            /* a slab rank may hold no particles for a while */ \
         prof_begin(s, id);                                                                 \
-        hipLaunchKernelGGL(kern, grid, dim3(kBlock), 0, (s)->stream, __VA_ARGS__);        \
+        hipLaunchKernelGGL(kern, grid, dim3(block), 0, (s)->stream, __VA_ARGS__);         \
         prof_end(s);                                                                       \
     } while (0)
+#define LAUNCH(s, id, kern, grid, ...) LAUNCHB(s, id, kern, grid, kBlock, __VA_ARGS__)
 
 // Scatter launches.  Deterministic engines (cfg.deterministic) run the DET instantiation -- integer-limb accumulation,
 // plmpm_kernels.h -- followed by the sweep that turns the limbs into the T sums the next kernel reads.
@@ -796,6 +799,9 @@ static inline int nblocks_grid(const plmpm_sim* s) { return (s->nblk + (kBlock /
 static inline int nwg_grid(const plmpm_sim* s) { return s->gwg; }
 
 // clear arguments for the grids of frame `frame` (fused-grid engines)
+#ifndef PLB_PK_DEFAULT
+#define PLB_PK_DEFAULT 0
+#endif
 #ifndef PLB_FUSE_GRID_DEFAULT
 #define PLB_FUSE_GRID_DEFAULT 0      // measured (round 3, profiles/r03_notes.md): not yet faster than the grid kernels at config 3
 #endif
@@ -892,7 +898,10 @@ template <class T> static int step_fwd_fused(plmpm_sim* s, int first, int n) {
                 memset(&pg, 0, sizeof pg);
                 for (int c = 0; c < 4; ++c) pg.gin[c] = (const T*)(s->gstore + (size_t)(f - 1) * s->gstride) + (size_t)c * s->G;
                 pg.vout = (const Vec4<T>*)(s->vstore + (size_t)(f - 1) * s->gstride);      // only written / read by workgroups whose box exceeds the LDS tile
-                LAUNCH(s, K_FG_G2P_P2G, (k_g2p_p2g<T, false, true>), dim3(nblocks_particles(s, f)), D, f, pg);
+                if constexpr (sizeof(T) == 4) {
+                    if (s->pk) { LAUNCHB(s, K_FG_G2P_P2G, (k_g2p_p2g_pk<true>), dim3(nblocks_particles(s, f)), kBlockPk, D, f, pg); }
+                    else LAUNCH(s, K_FG_G2P_P2G, (k_g2p_p2g<T, false, true>), dim3(nblocks_particles(s, f)), D, f, pg);
+                } else LAUNCH(s, K_FG_G2P_P2G, (k_g2p_p2g<T, false, true>), dim3(nblocks_particles(s, f)), D, f, pg);
             }
             s->dirty[f] = 1;
         }
@@ -907,7 +916,17 @@ template <class T> static int step_fwd_fused(plmpm_sim* s, int first, int n) {
             LAUNCH_P2G(s, K_P2G, true, D, f);
         } else {
             const Vec4<T>* vprev = (const Vec4<T>*)(s->vstore + (size_t)(f - 1) * s->gstride);
-            LAUNCH_G2P_P2G(s, D, f, vprev);
+            bool done = false;
+            if constexpr (sizeof(T) == 4) {
+                if (s->pk) {
+                    PrevGrid<T> pg;
+                    memset(&pg, 0, sizeof pg);
+                    pg.vout = vprev;
+                    LAUNCHB(s, K_G2P_P2G, (k_g2p_p2g_pk<false>), dim3(nblocks_particles(s, f)), kBlockPk, D, f, pg);
+                    done = true;
+                }
+            }
+            if (!done) LAUNCH_G2P_P2G(s, D, f, vprev);
         }
         LAUNCH(s, K_GRID_OP, (k_grid_op<T, false>), dim3(nwg_grid(s)), D, f, s->halo_in[PLMPM_HALO_GRID_IN]);
         s->dirty[f] = 1;
@@ -1312,6 +1331,10 @@ int plmpm_create(const plmpm_config* cfg, const plmpm_primitive* prims, plmpm_ha
         s->fg = s->store && !s->dist && cfg->deterministic == 0 && want;
     }
     if (s->fg) s->ws.grid_bytes += align_up(s->G * 4 * s->tsz, 256);
+    {
+        const char* e = getenv("PLMPM_PK");
+        s->pk = cfg->dtype == PLMPM_F32 && cfg->deterministic == 0 && (e ? e[0] != '0' : (PLB_PK_DEFAULT != 0));
+    }
     s->dirty.assign(s->F + 1, 0);
     s->ws.misc_bytes = 2 * align_up((size_t)(s->F + 1) * P1 * 7 * 8, 256) + 2 * align_up((size_t)(s->F + 1) * P1 * 8 * 8, 256)  // poses(+adj), padded
                        + 4 * align_up((size_t)(s->F + 1) * P1 * 3 * 8, 256)                       // v,w (+adj)

@@ -66,6 +66,19 @@ template <> struct TileCap<double> { static constexpr int nodes = 512; };
 #define PT_END(D, slot0) do {} while (0)
 #endif
 
+// Workgroup barrier that only orders LDS traffic.  __syncthreads() also drains the wave's global-memory counter
+// (vmcnt(0)): every load still in flight AND every store just issued -- a full memory round trip per barrier for a wave
+// that has just written its particle state.  The barriers of the particle kernels only publish LDS data (tiles, box
+// reductions), so they wait for the LDS counter alone and leave loads / stores in flight across them.
+#ifndef PLB_LDS_BAR
+#define PLB_LDS_BAR 1
+#endif
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+__device__ __forceinline__ void wg_barrier() {
+    if (PLB_LDS_BAR) lds_barrier();
+    else __syncthreads();
+}
+
 template <class T> struct Vec4 { T x, y, z, w; };
 template <> struct __attribute__((aligned(16))) Vec4<float> { float x, y, z, w; };
 template <> struct __attribute__((aligned(32))) Vec4<double> { double x, y, z, w; };
@@ -507,9 +520,6 @@ template <class T> __device__ __forceinline__ Tile load_tile(const Dev<T>& D, in
     return t;
 }
 
-// Workgroup barrier that only orders LDS traffic: __syncthreads() also waits for every global load the wave has in
-// flight (vmcnt(0)), which would serialise the particle loads issued before it with the tile fill behind it.
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // ---- grid_op folded into the particle kernels (fused-grid engines: one GPU, per-frame grid store) ----------------------
 // grid_op (mpm_simulator.py:189-221) is pointwise per node: v_out = f(grid_m, grid_v_in, poses).  Instead of a kernel
@@ -895,7 +905,8 @@ __global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_g2p_p2g(Dev<T> D, int
         for (int d = 0; d < 9; ++d) E[d] = R[(12 + d) * Np + p];
         mu = D.mu[p]; lam = D.lam[p]; ys = D.ys[p];
     }
-    __syncthreads();                                                 // tile_v complete
+    if (FG && !ta.ok) __syncthreads();                               // v_out went through HBM
+    else wg_barrier();                                               // tile_v complete
     PT_MARK(1);
     double x[3] = {0.5, 0.5, 0.5};
     T v[3] = {T(0), T(0), T(0)}, C[9];
@@ -925,7 +936,7 @@ __global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_g2p_p2g(Dev<T> D, int
     for (int d = 0; d < 3; ++d) base[d] = (int)(x[d] * (double)D.P.inv_dx - 0.5);
     if (clamp_to_reach(D, base) && valid) atomicOr(D.err, 1);
     block_tile_publish(base, valid, sred);
-    __syncthreads();                                                     // everyone is done reading tile_v, and has published its box
+    wg_barrier();                                                        // everyone is done reading tile_v, and has published its box
     Tile tl = block_tile_collect(sred, DET ? TileCap<T>::nodes / 2 : TileCap<T>::nodes);
     store_tile(D, f, tl);
     const int tn = tl.e[0] * tl.e[1] * tl.e[2];
@@ -934,7 +945,7 @@ __global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_g2p_p2g(Dev<T> D, int
 #endif
     if (tl.ok) {
         for (int i = threadIdx.x; i < (DET ? 2 * tn : tn); i += kBlock) tile[i] = Vec4<double>{0.0, 0.0, 0.0, 0.0};
-        __syncthreads();
+        wg_barrier();
     }
     PT_MARK(3);
     {
@@ -984,7 +995,7 @@ __global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_g2p_p2g(Dev<T> D, int
     }
     PT_MARK(4);
     if (tl.ok && !(PLB_ABLATE & 2)) {
-        __syncthreads();
+        wg_barrier();
         const int ex = tl.e[0], exy = tl.e[0] * tl.e[1];
         for (int i = threadIdx.x; i < tn; i += kBlock) {
             if constexpr (DET) {

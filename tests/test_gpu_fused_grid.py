@@ -3,8 +3,8 @@ with the per-frame grid store) against the same engine with the grid kernels kep
 
 Both engines evaluate the same per-node arithmetic (mpm_grid.h: grid_node_fwd / grid_node_bwd, after
 mpm_simulator.py:189-221), so they must agree to the round-off of the atomic accumulation order: 1e-11 in float64,
-1e-5 / 1e-4 (loss / action gradient) in float32.  The oracle parity of the fused path itself is what every other
-GPU test checks -- those engines run it by default."""
+1e-5 / 1e-4 (loss / action gradient) in float32, and the fused engine is checked against the oracle's golden rollout
+as well.  Also here: the two-particles-per-lane forward kernel (PLMPM_PK=1) against the scalar one."""
 import os
 
 import numpy as np
@@ -111,3 +111,41 @@ def test_fused_grid_partial_sweeps_leave_clean_grids():
     assert relerr(g1, g0) < 1e-9
     assert abs(l1 - float(g["loss"])) / abs(float(g["loss"])) < 1e-10
     assert relerr(g1, g["grad"]) < 1e-7
+
+
+class packed_pairs:
+    """fp32 engines created inside this block run the two-particles-per-lane forward kernel (plmpm_kernels_pk.h)"""
+    def __init__(self, on):
+        self.on = on
+
+    def __enter__(self):
+        self.old = os.environ.get("PLMPM_PK")
+        os.environ["PLMPM_PK"] = "1" if self.on else "0"
+
+    def __exit__(self, *a):
+        if self.old is None:
+            del os.environ["PLMPM_PK"]
+        else:
+            os.environ["PLMPM_PK"] = self.old
+
+
+@pytest.mark.parametrize("fg", [False, True])
+def test_packed_pair_kernel_equals_scalar_kernel(fg):
+    """k_g2p_p2g_pk (two particles per lane, packed fp32: mpm_math.h instantiated for P2 / D2 / I2) against the scalar
+    kernel on the same rollout: the arithmetic per particle is the same sequence of operations (tests/test_host_emul.py
+    checks the two instantiations bit for bit on the host), so only the atomic accumulation order differs."""
+    g = np.load(os.path.join(GOLDEN, "rollout_small.npz"))
+    n = int(g["n_particles"])
+    with fuse_grid(fg):
+        with packed_pairs(False):
+            ref = make_env_sub("Move", n, "float32")
+        with packed_pairs(True):
+            pk = make_env_sub("Move", n, "float32")
+    l0, g0 = run_forward(ref, g["actions"])
+    l1, g1 = run_forward(pk, g["actions"])
+    f0, f1 = ref.simulator.engine.get_frame(ref.simulator.cur), pk.simulator.engine.get_frame(pk.simulator.cur)
+    print(f"\n[pk fg={fg}] loss rel {abs(l1 - l0) / abs(l0):.2e} grad rel {relerr(g1, g0):.2e} x {relerr(f1['x'], f0['x']):.2e}")
+    assert abs(l1 - l0) <= 1e-6 * abs(l0)
+    assert relerr(g1, g0) < 1e-4
+    assert relerr(f1["x"], f0["x"]) < 2e-6 and relerr(f1["F"], f0["F"]) < 2e-5
+    assert abs(l1 - float(g["loss"])) / abs(float(g["loss"])) < 1e-5 and relerr(g1, g["grad"]) < 1e-4

@@ -2,6 +2,7 @@
 mpm_grid.h) compiled for the host (tests/host_emul, test infrastructure only) against the oracle:
 forward substep and the hand-derived adjoint -- including the closed-form SVD-free constitutive VJP with the
 reference's 1e-6 clamp, quaternion pose adjoints and the primitive kinematics chain."""
+import os
 import numpy as np
 import pytest
 import torch
@@ -258,3 +259,14 @@ def test_node_between_two_manipulators():
     for k in range(P):
         ref = np.concatenate([gs[4 + 2 * k].numpy(), gs[5 + 2 * k].numpy(), gs[4 + 2 * P + 2 * k].numpy(), gs[5 + 2 * P + 2 * k].numpy()])
         assert np.abs(ref[:3]).max() > 0 and relerr(pose[k][:14], ref) < 1e-10
+
+
+def test_pack_instantiation_equals_scalar_bit_for_bit(tmp_path):
+    """mpm_math.h instantiated for two particles per lane (P2 / D2 / I2: what k_g2p_p2g_pk runs) against the scalar
+    float instantiation on 20 000 random particle pairs (elastic, yielding, nearly singular): identical bits."""
+    import subprocess
+    src = os.path.join(os.path.dirname(__file__), "host_emul", "pack_check.cpp")
+    exe = str(tmp_path / "pack_check")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-ffp-contract=off", src, "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0 and "mismatches: 0" in out.stdout, out.stdout + out.stderr
