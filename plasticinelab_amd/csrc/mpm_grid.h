@@ -361,16 +361,26 @@ PLB_HD float prim_bounding_radius(int shape, const double* par) {
     }
 }
 
+// conservative fp32 cull: sdf(p) >= |p - pos| - rb, and contact needs sdf <= max(0, ln(10)/softness).
+// Nodes that fail this test take exactly the branch the full evaluation would take (no contact);
+// the 1e-3 margin dwarfs fp32 rounding, so results are unchanged.  Skips the double-precision geometry
+// for the ~98 % of active nodes that are nowhere near a manipulator.
+template <class T> PLB_HD bool prim_within_reach(const PrimT<T>& pr, T softness, const double* gp) {
+    float dx = (float)(gp[0] - pr.pos[0]), dy = (float)(gp[1] - pr.pos[1]), dz = (float)(gp[2] - pr.pos[2]);
+    float reach = pr.rb + (softness > T(0) ? 2.302585093f / (float)softness : 0.0f) + 1e-3f;
+    return !(dx * dx + dy * dy + dz * dz > reach * reach);
+}
+// node I passes that cull for at least one primitive
+template <class T> PLB_HD bool node_near_any(const SimP<T>& P, const int* I, int nprim, const PrimT<T>* prims) {
+    const double inv_n = 1.0 / (double)P.n;
+    const double gp[3] = {I[0] * inv_n, I[1] * inv_n, I[2] * inv_n};
+    bool near = false;
+    for (int p = 0; p < nprim; ++p) near |= prim_within_reach(prims[p], P.softness, gp);
+    return near;
+}
 template <class T> PLB_HD bool collide_eval(const PrimT<T>& pr, T softness, T dt, const double* gp, const T* v,
                                             CollideTmp<T>& c, T* vnew) {
-    {   // conservative fp32 cull: sdf(p) >= |p - pos| - rb, and contact needs sdf <= max(0, ln(10)/softness).
-        // Nodes that fail this test take exactly the branch the full evaluation would take (no contact);
-        // the 1e-3 margin dwarfs fp32 rounding, so results are unchanged.  Skips the double-precision geometry
-        // for the ~98 % of active nodes that are nowhere near a manipulator.
-        float dx = (float)(gp[0] - pr.pos[0]), dy = (float)(gp[1] - pr.pos[1]), dz = (float)(gp[2] - pr.pos[2]);
-        float reach = pr.rb + (softness > T(0) ? 2.302585093f / (float)softness : 0.0f) + 1e-3f;
-        if (dx * dx + dy * dy + dz * dz > reach * reach) return false;
-    }
+    if (!prim_within_reach(pr, softness, gp)) return false;
     c.dist = prim_sdf(pr, gp);
     T ex = t_exp((T)(-c.dist * (double)softness));
     c.infl = ex < T(1) ? ex : T(1);
@@ -379,9 +389,10 @@ template <class T> PLB_HD bool collide_eval(const PrimT<T>& pr, T softness, T dt
     prim_normal(pr, gp, Dd);
     inv_trans(gp, pr.pos, pr.rot, c.rel, c.iq);                   // collider_v :82-89
     qrot(pr.rot1, c.rel, np);
+    const double inv_dt = 1.0 / (double)dt;               // one reciprocal instead of three double-precision divisions
     for (int i = 0; i < 3; ++i) {
         c.D[i] = (T)Dd[i];
-        c.cv[i] = (T)((np[i] + pr.pos1[i] - gp[i]) / (double)dt);
+        c.cv[i] = (T)((np[i] + pr.pos1[i] - gp[i]) * inv_dt);
         c.iv[i] = v[i] - c.cv[i];
     }
     c.nc = dot3(c.iv, c.D);
@@ -542,7 +553,10 @@ PLB_HD bool grid_node_fwd(const SimP<T>& P, const int* I, T m, const T* mv, int 
     if (!(m > T(1e-12))) { vout[0] = vout[1] = vout[2] = T(0); return false; }
     T inv = T(1) / m;
     T v[3] = {inv * mv[0] + P.grav[0], inv * mv[1] + P.grav[1], inv * mv[2] + P.grav[2]};
-    double gp[3] = {I[0] / (double)P.n, I[1] / (double)P.n, I[2] / (double)P.n};
+    // grid_pos = I * dx (mpm_simulator.py:197); one reciprocal (loop-invariant: the compiler hoists it out of a caller's node
+    // loop) instead of three double-precision divisions per node -- ~150 instructions each time a node is evaluated
+    const double inv_n = 1.0 / (double)P.n;
+    double gp[3] = {I[0] * inv_n, I[1] * inv_n, I[2] * inv_n};
     for (int p = 0; p < nprim; ++p) {
         CollideTmp<T> c;
         T vn[3];
@@ -570,7 +584,10 @@ PLB_HD void grid_node_bwd(const SimP<T>& P, const int* I, T m, const T* mv, int 
     const bool live = m > T(1e-12);
     const T inv = live ? T(1) / m : T(0);
     T v0[3] = {inv * mv[0] + P.grav[0], inv * mv[1] + P.grav[1], inv * mv[2] + P.grav[2]};
-    double gp[3] = {I[0] / (double)P.n, I[1] / (double)P.n, I[2] / (double)P.n};
+    // grid_pos = I * dx (mpm_simulator.py:197); one reciprocal (loop-invariant: the compiler hoists it out of a caller's node
+    // loop) instead of three double-precision divisions per node -- ~150 instructions each time a node is evaluated
+    const double inv_n = 1.0 / (double)P.n;
+    double gp[3] = {I[0] * inv_n, I[1] * inv_n, I[2] * inv_n};
     T a[3] = {T(0), T(0), T(0)};
     // the LAST primitive the node touches keeps its collide intermediates from the forward sweep, so the common case
     // (a node in contact with one manipulator) evaluates the double-precision geometry once, not three times

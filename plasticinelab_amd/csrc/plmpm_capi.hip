@@ -112,9 +112,12 @@ struct plmpm_sim {
     // (fg_pending) are cleared by the next g2p.grad, or by k_clear_boxes when something else comes first.
     bool fg = false;
     int fg_pending = -1;
+    std::vector<char> vnear;         // frame f: grid_v_out / contact bit of the nodes near a primitive are in the frame's grid_v_out store
     // two particles per lane with packed fp32 arithmetic (plmpm_kernels_pk.h): fp32 engines, floating-point atomics
     bool pk = false;
     char* grid_out_adj2 = nullptr;   // second grid_v_out.grad buffer (frames alternate)
+    int* contact_mark = nullptr;     // [nblk] stamp of the g2p.grad launch that last listed the block as in contact
+    int contact_stamp = 0;
     int* tiles = nullptr;        // per-frame stencil boxes of the particle workgroups: [(F+1)][Npad/256][8]
     // Per-env-step storage order ("epochs").  Epoch 0 is the order chosen at reset (perm_d).  With cfg.resort_steps,
     // plmpm_step re-sorts the step's first frame along the Hilbert curve before it starts (epoch = step index); the
@@ -267,6 +270,7 @@ template <class T> static Dev<T> make_dev(const plmpm_sim* s, int frame = -1, bo
     D.tiles = s->tiles;
     D.contact = s->contact + ((fg && (frame & 1)) ? s->nblk + 1 : 0);
     D.contact_next = s->contact + ((fg && (frame & 1)) ? 0 : s->nblk + 1);
+    D.contact_mark = s->contact_mark; D.stamp = s->contact_stamp;
     D.det = s->det_grid; D.det_stride = s->G;
     D.trace = (unsigned long long*)s->staging;      // profiling builds only (needs N * 24 * 8 >= 3 * 16384 * 128 bytes)
     D.ppos = s->ppos; D.prot = s->prot; D.pgap = s->pgap;
@@ -794,6 +798,7 @@ static const HaloIn kNoHalo = {0, {0, 0}, {0, 0}, {nullptr, nullptr}, 0};
 // workgroups at the head of every k_p2g_grad launch that finish grid_op.grad's pose adjoints (64 waves: the blocks in
 // contact with a manipulator number a few dozen)
 constexpr int kPoseWG = PLB_POSE_WG;
+constexpr int kClearWG = 64;
 static inline int nblocks_grid(const plmpm_sim* s) { return (s->nblk + (kBlock / 64) - 1) / (kBlock / 64); }
 // persistent grid kernels: a fixed number of workgroups, each striding over its share of the block flags
 static inline int nwg_grid(const plmpm_sim* s) { return s->gwg; }
@@ -812,6 +817,7 @@ template <class T> static ClearArgs<T> clear_args(const plmpm_sim* s, int frame)
     if (frame < 0) return A;
     const Dev<T> Df = make_dev<T>(s, frame, true);
     A.nwg = nblocks_particles(s, frame);
+    A.nwg_clear = 0;
     for (int c = 0; c < 4; ++c) A.gin[c] = Df.gin[c];
     for (int c = 0; c < 3; ++c) A.goa[c] = Df.goa[c];
     A.flags = Df.flags;
@@ -837,8 +843,10 @@ template <class T> static int substep_fwd(plmpm_sim* s, int f) {
         LAUNCH_P2G(s, K_P2G, true, D, f);
         s->dirty[f] = 1;
         LAUNCH(s, K_FG_G2P, (k_g2p<T, true>), dim3(nblocks_particles(s, f)), D, f);
+        s->vnear[f] = 1;
         return 0;
     }
+    s->vnear[f] = 0;
     if (s->store) {
         if (s->dirty[f]) LAUNCH(s, K_CLEAR, (k_clear_active<T>), dim3(nblocks_grid(s)), D);   // frame reused without a backward pass
         LAUNCH_P2G(s, K_P2G, true, D, f);
@@ -864,8 +872,13 @@ template <class T> static int substep_bwd(plmpm_sim* s, int f) {
             hipMemsetAsync(s->contact, 0, 4, s->stream);                          // both contact counters: no g2p.grad reset them
             hipMemsetAsync(s->contact + s->nblk + 1, 0, 4, s->stream);
         }
+        ++s->contact_stamp;                  // (the marks start at 0 and the first stamp is 1)
         Dev<T> Dg = make_dev<T>(s, f, true);
-        LAUNCH(s, K_FG_G2P_GRAD, (k_g2p_grad<T, false, true>), dim3(nblocks_particles(s, f)), Dg, f, src, dst, vnext, clear_args<T>(s, chained ? f + 1 : -1));
+        ClearArgs<T> ca = clear_args<T>(s, chained ? f + 1 : -1);
+        ca.nwg_clear = chained ? kClearWG : 0;                            // workgroups at the head of the launch do the clear
+        const int nwg = nblocks_particles(s, f) + ca.nwg_clear;
+        if (s->vnear[f]) LAUNCH(s, K_FG_G2P_GRAD, (k_g2p_grad<T, false, 1 + NEAR_LOAD>), dim3(nwg), Dg, f, src, dst, vnext, ca);
+        else LAUNCH(s, K_FG_G2P_GRAD, (k_g2p_grad<T, false, 1 + NEAR_EVAL>), dim3(nwg), Dg, f, src, dst, vnext, ca);
         if (chained) s->dirty[f + 1] = 0;
         LAUNCH(s, K_FG_P2G_GRAD, (k_p2g_grad<T, true>), dim3(nblocks_particles(s, f) + kPoseWG), Dg, f, src, dst, kPoseWG);
         s->fg_pending = f;                   // dirty[f] stays set until the frame's grids are cleared
@@ -897,7 +910,8 @@ template <class T> static int step_fwd_fused(plmpm_sim* s, int first, int n) {
                 PrevGrid<T> pg;
                 memset(&pg, 0, sizeof pg);
                 for (int c = 0; c < 4; ++c) pg.gin[c] = (const T*)(s->gstore + (size_t)(f - 1) * s->gstride) + (size_t)c * s->G;
-                pg.vout = (const Vec4<T>*)(s->vstore + (size_t)(f - 1) * s->gstride);      // only written / read by workgroups whose box exceeds the LDS tile
+                pg.vout = (const Vec4<T>*)(s->vstore + (size_t)(f - 1) * s->gstride);      // nodes near a primitive; all nodes of boxes that exceed the LDS tile
+                s->vnear[f - 1] = 1;
                 if constexpr (sizeof(T) == 4) {
                     if (s->pk) { LAUNCHB(s, K_FG_G2P_P2G, (k_g2p_p2g_pk<true>), dim3(nblocks_particles(s, f)), kBlockPk, D, f, pg); }
                     else LAUNCH(s, K_FG_G2P_P2G, (k_g2p_p2g<T, false, true>), dim3(nblocks_particles(s, f)), D, f, pg);
@@ -907,10 +921,12 @@ template <class T> static int step_fwd_fused(plmpm_sim* s, int first, int n) {
         }
         Dev<T> D = make_dev<T>(s, first + n - 1);
         LAUNCH(s, K_FG_G2P, (k_g2p<T, true>), dim3(nblocks_particles(s, first + n - 1)), D, first + n - 1);
+        s->vnear[first + n - 1] = 1;
         return 0;
     }
     for (int f = first; f < first + n; ++f) {
         Dev<T> D = make_dev<T>(s, f);
+        s->vnear[f] = 0;
         if (s->dirty[f]) LAUNCHG_CLEAR(s, D);
         if (f == first) {
             LAUNCH_P2G(s, K_P2G, true, D, f);
@@ -952,6 +968,7 @@ template <class T> static int phase_grid_g2p(plmpm_sim* s, int f, bool defer_g2p
     s->frame_epoch[f + 1] = s->frame_epoch[f];                 // g2p (now or fused into the next p2g) writes frame f + 1 in this order
     HaloIn H = s->halo_in[PLMPM_HALO_GRID_IN];
     H.part = part;
+    s->vnear[f] = 0;
     LAUNCH(s, K_GRID_OP, (k_grid_op<T, false>), dim3(nwg_grid(s)), D, f, H);
     if (part == 1) return 0;
     if (!defer_g2p) LAUNCH(s, K_G2P, (k_g2p<T>), dim3(nblocks_particles(s, f)), D, f);
@@ -1330,12 +1347,13 @@ int plmpm_create(const plmpm_config* cfg, const plmpm_primitive* prims, plmpm_ha
         const bool want = e ? e[0] != '0' : (PLB_FUSE_GRID_DEFAULT != 0);
         s->fg = s->store && !s->dist && cfg->deterministic == 0 && want;
     }
-    if (s->fg) s->ws.grid_bytes += align_up(s->G * 4 * s->tsz, 256);
+    if (s->fg) s->ws.grid_bytes += align_up(s->G * 4 * s->tsz, 256) + align_up((size_t)s->nblk * 4, 256);
     {
         const char* e = getenv("PLMPM_PK");
         s->pk = cfg->dtype == PLMPM_F32 && cfg->deterministic == 0 && (e ? e[0] != '0' : (PLB_PK_DEFAULT != 0));
     }
     s->dirty.assign(s->F + 1, 0);
+    s->vnear.assign(s->F + 1, 0);
     s->ws.misc_bytes = 2 * align_up((size_t)(s->F + 1) * P1 * 7 * 8, 256) + 2 * align_up((size_t)(s->F + 1) * P1 * 8 * 8, 256)  // poses(+adj), padded
                        + 4 * align_up((size_t)(s->F + 1) * P1 * 3 * 8, 256)                       // v,w (+adj)
                        + 4 * align_up((size_t)(s->F + 1) * P1 * 8, 256)                           // gap, gap_vel (+adj)
@@ -1409,7 +1427,7 @@ int plmpm_bind_workspace(plmpm_handle s, void* state, void* adjoint, void* grid,
     }
     s->tiles = (int*)take((size_t)(s->F + 1) * (s->Npad / kBlock) * 8 * 4);
     s->contact = (int*)take((size_t)2 * (s->nblk + 1) * 4);
-    if (s->fg) s->grid_out_adj2 = take(s->G * 4 * s->tsz);
+    if (s->fg) { s->grid_out_adj2 = take(s->G * 4 * s->tsz); s->contact_mark = (int*)take((size_t)s->nblk * 4); }
     s->det_grid = s->det ? (long long*)take(s->G * 8 * 8) : nullptr;
     REQUIRE((size_t)(p - s->gridw) <= s->ws.grid_bytes, "internal: grid workspace overflow");
     p = s->miscw;

@@ -113,6 +113,8 @@ template <class T> struct Dev {
     int* tiles;                      // [(F+1)][workgroups][8]: stencil box of each 256-particle workgroup, per frame
     int* contact;                    // [0] = n, [1..n] = blocks whose pose adjoints are still due (grid_op.grad -> p2g.grad)
     int* contact_next;               // fused-grid engines: the list of the frame before this one (its counter is reset here)
+    int* contact_mark;               // fused-grid engines: [n_blocks] stamp of the launch that last put the block on a contact list
+    int stamp;                       //   this launch's stamp
     unsigned long long* trace;       // profiling builds only
     long long* det;                  // deterministic mode only (else null): two-limb fixed-point accumulators, [8][det_stride]
     size_t det_stride;               //   component c of a node: hi limb det[c * stride + idx], lo limb det[(4 + c) * stride + idx]
@@ -189,9 +191,11 @@ template <class T> __device__ __forceinline__ void block_nodes(const Dev<T>& D, 
     I[0] = D.go[0] + ((bx << 2) | (lane & 3)); I[1] = D.go[1] + ((by << 2) | ((lane >> 2) & 3)); I[2] = D.go[2] + ((bz << 2) | (lane >> 4));
 }
 
-template <class T> __device__ __forceinline__ void load_prims(const Dev<T>& D, int f, PrimT<T>* sp) {
+// WAVE: every wave fills sp itself (lanes 0 .. nprim-1 of each wave write the same bytes) and only waits for its own
+// LDS writes -- no workgroup barrier, so no wave waits for another wave's loads before it may go on
+template <class T, bool WAVE = false> __device__ __forceinline__ void load_prims(const Dev<T>& D, int f, PrimT<T>* sp) {
     // called by all threads of a workgroup; sp in LDS
-    int t = threadIdx.x;
+    int t = WAVE ? (int)(threadIdx.x & 63) : (int)threadIdx.x;
     if (t < D.nprim) {
         PrimT<T> p;
         p.shape = D.prim[t].shape; p.movable = D.prim[t].movable; p.friction = (T)D.prim[t].friction;
@@ -206,6 +210,7 @@ template <class T> __device__ __forceinline__ void load_prims(const Dev<T>& D, i
         for (int i = 0; i < 4; ++i) { p.rot[i] = c[i]; p.rot1[i] = d[i]; }
         sp[t] = p;
     }
+    if (WAVE) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 }
 
 // Grid kernels run kGridWG persistent workgroups.  Workgroup g owns blocks g, g + G, g + 2G, ... (G = gridDim.x): the
@@ -537,17 +542,48 @@ template <class T> struct PrevGrid {
     const Vec4<T>* vout;             // grid_v_out of the previous substep (engines with grid kernels)
     const T* gin[4];                 // grid_m / grid_v_in of the previous substep (fused-grid engines)
 };
-// v_out of node (ix, iy, iz) from grid_m / grid_v_in; touch: the node is in contact with a movable primitive
-template <class T> __device__ __forceinline__ Vec4<T> fg_node_vout(const Dev<T>& D, const T* const* gin, const PrimT<T>* sp, int ix, int iy, int iz,
-                                                                    bool* touch = nullptr, int* index = nullptr) {
-    const int idx = node_index(D, ix, iy, iz);
-    if (index) *index = idx;
-    const T m = gin[0][idx];
-    const T mv[3] = {gin[1][idx], gin[2][idx], gin[3][idx]};
+// v_out of node (ix, iy, iz) from grid_m / grid_v_in; .w = 1: the node is in contact with a movable primitive (its
+// pose adjoints are due in the reverse pass).  The expensive part -- collide, double-precision rigid-body geometry -- only
+// concerns the nodes within reach of a primitive (prim_within_reach), and is evaluated in the FORWARD pass only:
+//   NEAR_STORE (forward fills): such a node's {v_out, contact bit} also goes to the frame's grid_v_out store `vnear`
+//                               (every workgroup whose box holds the node writes the same four words);
+//   NEAR_LOAD  (g2p.grad's fill): such a node is read back from there instead of being evaluated again;
+//   NEAR_EVAL: evaluate, touch nothing (a frame whose forward substep did not run through a fused-grid kernel).
+// In two halves so that a kernel can put independent work (its in-wave sort, its particle loads) between the issue of
+// the grid loads and their first use: fg_node_load issues them, fg_node_eval computes.
+enum { NEAR_EVAL = 0, NEAR_STORE = 1, NEAR_LOAD = 2 };
+template <class T> struct NodeIn { int idx; T m, mv[3]; };
+template <class T> __device__ __forceinline__ NodeIn<T> fg_node_load(const Dev<T>& D, const T* const* gin, int ix, int iy, int iz) {
+    NodeIn<T> n;
+    n.idx = node_index(D, ix, iy, iz);
+    n.m = gin[0][n.idx]; n.mv[0] = gin[1][n.idx]; n.mv[1] = gin[2][n.idx]; n.mv[2] = gin[3][n.idx];
+    return n;
+}
+template <int MODE, class T> __device__ __forceinline__ Vec4<T> fg_node_eval(const Dev<T>& D, const PrimT<T>* sp, int ix, int iy, int iz,
+                                                                              const NodeIn<T>& n, Vec4<T>* vnear) {
+    const int idx = n.idx;
+    const T m = n.m;
+    const T mv[3] = {n.mv[0], n.mv[1], n.mv[2]};
     T vo[3];
     const int I[3] = {ix, iy, iz};
-    grid_node_fwd<T>(D.P, I, m, mv, (PLB_FG_ABL & 1) ? 0 : D.nprim, sp, vo, touch);
-    return Vec4<T>{vo[0], vo[1], vo[2], T(0)};
+    const int np = (PLB_FG_ABL & 1) ? 0 : D.nprim;
+    bool touch = false;
+    if (MODE == NEAR_EVAL) {
+        grid_node_fwd<T>(D.P, I, m, mv, np, sp, vo, &touch);
+        return Vec4<T>{vo[0], vo[1], vo[2], touch ? T(1) : T(0)};
+    }
+    const bool near = m > T(1e-12) && node_near_any(D.P, I, np, sp);
+    if (MODE == NEAR_LOAD && near) return vnear[idx];
+    grid_node_fwd<T>(D.P, I, m, mv, near ? np : 0, sp, vo, &touch);       // far nodes: no primitive passes its cull anyway
+    const Vec4<T> a{vo[0], vo[1], vo[2], touch ? T(1) : T(0)};
+    if (MODE == NEAR_STORE && near) vnear[idx] = a;
+    return a;
+}
+template <int MODE, class T> __device__ __forceinline__ Vec4<T> fg_node_vout(const Dev<T>& D, const T* const* gin, const PrimT<T>* sp, int ix, int iy, int iz,
+                                                                              Vec4<T>* vnear, int* index = nullptr) {
+    const NodeIn<T> n = fg_node_load(D, gin, ix, iy, iz);
+    if (index) *index = n.idx;
+    return fg_node_eval<MODE>(D, sp, ix, iy, iz, n, vnear);
 }
 // {grid_v_in.grad, grid_m.grad} of node (ix, iy, iz) from grid_v_out.grad and the frame's grid_m / grid_v_in (the
 // pose adjoints of the nodes in contact are computed once per node elsewhere: pose_adjoint_blocks)
@@ -562,10 +598,15 @@ template <class T> __device__ __forceinline__ Vec4<T> fg_node_gadj(const Dev<T>&
     grid_node_bwd<T, false>(D.P, I, gm, mv, (PLB_FG_ABL & 1) ? 0 : D.nprim, sp, va, &ma, mva, [](int, const PoseAdj<T>&, bool) {});
     return Vec4<T>{mva[0], mva[1], mva[2], ma};
 }
-// a node in contact with a movable primitive: its block goes on the frame's contact list, once (bit 1 of the block flag)
+// a node in contact with a movable primitive: its block goes on the frame's contact list, once (the block's mark takes
+// this launch's stamp; stamps are never reused, so the marks are never cleared)
+// (a plain load first: a block in contact is marked by thousands of box nodes -- ~64 nodes x ~4.5 boxes -- and that many
+// same-address atomics serialise in the L2; only the first few arrivals still see the bit clear)
 template <class T> __device__ __forceinline__ void fg_mark_contact(const Dev<T>& D, int idx) {
     const int blk = idx >> 6;
-    if (!(atomicOr(&D.flags[flag_slot(D, blk)], 2) & 2)) D.contact[1 + atomicAdd(&D.contact[0], 1)] = blk;
+    int* mk = &D.contact_mark[blk];
+    if (__hip_atomic_load(mk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == D.stamp) return;      // read at the L2, where the atomics land
+    if (atomicExch(mk, D.stamp) != D.stamp) D.contact[1 + atomicAdd(&D.contact[0], 1)] = blk;
 }
 // The grids of a frame whose reverse substep is complete, cleared over the stencil boxes of its particle workgroups
 // (every scatter of the frame -- through a tile or direct -- stays inside its workgroup's box): grid_m / grid_v_in,
@@ -573,6 +614,7 @@ template <class T> __device__ __forceinline__ void fg_mark_contact(const Dev<T>&
 template <class T> struct ClearArgs {
     int frame;                       // < 0: nothing to clear
     int nwg;                         // particle workgroups of that frame
+    int nwg_clear;                   // workgroups at the head of the k_g2p_grad launch that do the clear (clear_blocks)
     T* gin[4];
     T* goa[3];
     int* flags;
@@ -592,20 +634,39 @@ template <class T> __device__ __forceinline__ void clear_boxes(const Dev<T>& D, 
     }
 }
 template <class T> __global__ __launch_bounds__(kBlock) void k_clear_boxes(Dev<T> D, ClearArgs<T> A) { clear_boxes(D, A); }
+// The same clear through the block flags (the scatters set them for every block they touch): wave `w` of `nw` takes the
+// flag rows of grid workgroups w, w + nw, ... (flags are stored per grid workgroup: flag_slot) and zeroes the 64 nodes of
+// each flagged block with one store per component.
+template <class T> __device__ __forceinline__ void clear_blocks(const Dev<T>& D, const ClearArgs<T>& A, int wg, int nwg) {
+    if (A.frame < 0 || (PLB_FG_ABL & 2)) return;
+    const int lane = threadIdx.x & 63, nblk = D.nbx * D.nby * D.nbz;
+    for (int g = wg * (kBlock / 64) + (threadIdx.x >> 6); g < (1 << D.fgl); g += nwg * (kBlock / 64))
+        for (int k0 = 0; k0 < D.fs; k0 += 64) {
+            const int k = k0 + lane, b = g + (k << D.fgl);
+            const bool in = k < D.fs && b < nblk;
+            const int fl = in ? A.flags[g * D.fs + k] : 0;
+            for (unsigned long long r = __ballot(fl != 0); r; r &= r - 1) {
+                const int kk = k0 + __ffsll((long long)r) - 1, blk = g + (kk << D.fgl), idx = (blk << 6) | lane;
+                A.gin[0][idx] = T(0); A.gin[1][idx] = T(0); A.gin[2][idx] = T(0); A.gin[3][idx] = T(0);
+                A.goa[0][idx] = T(0); A.goa[1][idx] = T(0); A.goa[2][idx] = T(0);
+                if (lane == 0) A.flags[g * D.fs + kk] = 0;
+            }
+        }
+}
 
 // Sorted particle load in two halves so that independent memory traffic can be issued in between.
 struct SortLoad { double x0[3]; long long key; };
-template <class T> __device__ __forceinline__ SortLoad sorted_begin(const Dev<T>& D, const double* X) {
+template <class T> __device__ __forceinline__ SortLoad sorted_begin(const Dev<T>& D, const double* X, int wg = blockIdx.x) {
     const int Np = D.Npad;
-    const int p0 = blockIdx.x * kBlock + threadIdx.x;
+    const int p0 = wg * kBlock + threadIdx.x;
     SortLoad s;
     s.x0[0] = s.x0[1] = s.x0[2] = 0.5;
     if (p0 < D.N) for (int d = 0; d < 3; ++d) s.x0[d] = X[d * Np + p0];
     return s;
 }
 template <class T>
-__device__ __forceinline__ bool sorted_finish(const Dev<T>& D, SortLoad& s, int& p, double* x, int* base, bool flag_err = false) {
-    const int p0 = blockIdx.x * kBlock + threadIdx.x;
+__device__ __forceinline__ bool sorted_finish(const Dev<T>& D, SortLoad& s, int& p, double* x, int* base, bool flag_err = false, int wg = blockIdx.x) {
+    const int p0 = wg * kBlock + threadIdx.x;
     s.key = (1LL << 40);                                            // padding lanes last
     if (p0 < D.N) {
         int b[3];
@@ -811,12 +872,11 @@ __global__ __launch_bounds__(kBlock) void k_g2p(Dev<T> D, int f) {
     if constexpr (FG) {
         // v_out of every node of the box: into the LDS tile, or -- a box too large for it -- into the frame's grid_v_out
         // in HBM, which the gather below then reads (workgroups with overlapping boxes write the same values)
-        load_prims(D, f, sp);
-        lds_barrier();
+        load_prims<T, true>(D, f, sp);
         for (int i = threadIdx.x; i < tn; i += kBlock) {
             int lz, ly, lx, idx;
             tile_coords(i, ex, exy, lz, ly, lx);
-            const Vec4<T> a = fg_node_vout(D, D.gin, sp, tl.o[0] + lx, tl.o[1] + ly, tl.o[2] + lz, nullptr, &idx);
+            const Vec4<T> a = fg_node_vout<NEAR_STORE>(D, D.gin, sp, tl.o[0] + lx, tl.o[1] + ly, tl.o[2] + lz, D.grid_out, &idx);
             if (tl.ok) tile[i] = a; else D.grid_out[idx] = a;
         }
         __syncthreads();
@@ -877,15 +937,16 @@ __global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_g2p_p2g(Dev<T> D, int
     // the tile fill is issued right behind the position loads and overlaps with them and with the sort
     const Tile ta = load_tile(D, f - 1, (int)(TileCap<T>::nodes * sizeof(Vec4<double>) / sizeof(Vec4<T>)));
     SortLoad sl = sorted_begin(D, X0);
-    if constexpr (FG) { load_prims(D, f - 1, sp); lds_barrier(); }       // poses of substep f-1 (issued behind the position loads)
+    if constexpr (FG) load_prims<T, true>(D, f - 1, sp);                 // poses of substep f-1 (issued behind the position loads)
+    NodeIn<T> fpre;
+    int flz = 0, fly = 0, flx = 0;
     {
         const int ex = ta.e[0], exy = ta.e[0] * ta.e[1], tn = exy * ta.e[2];
         if constexpr (FG) {
-            for (int i = threadIdx.x; i < tn; i += kBlock) {
-                int lz, ly, lx, idx;
-                tile_coords(i, ex, exy, lz, ly, lx);
-                const Vec4<T> a = fg_node_vout(D, G0.gin, sp, ta.o[0] + lx, ta.o[1] + ly, ta.o[2] + lz, nullptr, &idx);
-                if (ta.ok) tile_v[i] = a; else const_cast<Vec4<T>*>(vout_prev)[idx] = a;
+            // first pass of the fill (most boxes have <= 256 nodes): only the loads, their values are used behind the sort
+            if ((int)threadIdx.x < tn) {
+                tile_coords((int)threadIdx.x, ex, exy, flz, fly, flx);
+                fpre = fg_node_load(D, G0.gin, ta.o[0] + flx, ta.o[1] + fly, ta.o[2] + flz);
             }
         } else if (ta.ok)
             for (int i = threadIdx.x; i < tn; i += kBlock) {
@@ -904,6 +965,22 @@ __global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_g2p_p2g(Dev<T> D, int
         const T* R = frame_r(D, f);
         for (int d = 0; d < 9; ++d) E[d] = R[(12 + d) * Np + p];
         mu = D.mu[p]; lam = D.lam[p]; ys = D.ys[p];
+    }
+    if constexpr (FG) {
+        // grid_op of substep f-1 on the box: v_out into the tile, or -- a box too large for it -- into the previous frame's
+        // grid_v_out store, from where the gather below reads it
+        const int ex = ta.e[0], exy = ta.e[0] * ta.e[1], tn = exy * ta.e[2];
+        Vec4<T>* vst = const_cast<Vec4<T>*>(vout_prev);
+        if ((int)threadIdx.x < tn) {
+            const Vec4<T> a = fg_node_eval<NEAR_STORE>(D, sp, ta.o[0] + flx, ta.o[1] + fly, ta.o[2] + flz, fpre, vst);
+            if (ta.ok) tile_v[threadIdx.x] = a; else vst[fpre.idx] = a;
+        }
+        for (int i = threadIdx.x + kBlock; i < tn; i += kBlock) {
+            int lz, ly, lx, idx;
+            tile_coords(i, ex, exy, lz, ly, lx);
+            const Vec4<T> a = fg_node_vout<NEAR_STORE>(D, G0.gin, sp, ta.o[0] + lx, ta.o[1] + ly, ta.o[2] + lz, vst, &idx);
+            if (ta.ok) tile_v[i] = a; else vst[idx] = a;
+        }
     }
     if (FG && !ta.ok) __syncthreads();                               // v_out went through HBM
     else wg_barrier();                                               // tile_v complete
@@ -1046,9 +1123,18 @@ __global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_g2p_p2g(Dev<T> D, int
 // FG (fused-grid engines; never DET): v_out comes from grid_m / grid_v_in in the tile fill, which also finds the blocks
 // in contact with a movable primitive (D.contact, consumed by the pose workgroups of the k_p2g_grad launch behind this
 // one); the grids of the frame the previous reverse substep finished with are cleared at the end (CA).
-template <class T, bool DET = false, bool FG = false>
+// FGMODE: 0 grid kernels | 1 + NEAR_LOAD (the frame's forward substep ran through a fused-grid kernel) | 1 + NEAR_EVAL
+template <class T, bool DET = false, int FGMODE = 0>
 __global__ __launch_bounds__(kBlock, sizeof(T) == 4 ? PLB_G2PG_WAVES : 1) void k_g2p_grad(Dev<T> D, int f, int src, int dst, const T* vnext, ClearArgs<T> CA) {
+    constexpr bool FG = FGMODE != 0;
     __shared__ PrimT<T> sp[FG ? kMaxPrim : 1];
+    if constexpr (FG) {
+        // spare workgroups behind the particle workgroups: clear the grids of the frame the previous reverse substep
+        // finished with (one coalesced 256-byte row per block and component, found through the block flags)
+        // (they lead the launch, so they run under cover of the first particle workgroups)
+        if ((int)blockIdx.x < CA.nwg_clear) { clear_blocks(D, CA, (int)blockIdx.x, CA.nwg_clear); return; }
+    }
+    const int wg = FG ? (int)blockIdx.x - CA.nwg_clear : (int)blockIdx.x;
     // 960 nodes x (16 + 24) bytes = 37.5 KiB: four workgroups per CU (128 VGPRs = 4 waves per SIMD, see PLB_G2PG_WAVES)
     constexpr int CAP = sizeof(T) == 4 ? PLB_G2PG_CAP : 480;
     __shared__ Vec4<T> tile[CAP];                    // v_out values
@@ -1058,11 +1144,10 @@ __global__ __launch_bounds__(kBlock, sizeof(T) == 4 ? PLB_G2PG_WAVES : 1) void k
     int p, base[3];
     double x[3];
     PT_BEGIN();
-    if (blockIdx.x == 0 && threadIdx.x == 0) (FG ? D.contact_next : D.contact)[0] = 0;     // the list k_grid_op_grad(f) (FG: this kernel for frame f-1) is about to fill
-    const Tile tl = load_tile(D, f, DET ? CAP / 2 : CAP);           // stored by the scatter of this frame (DET: 6 limbs per node in tile_a)
-    SortLoad sl = sorted_begin(D, X);
-    if constexpr (FG) { load_prims(D, f, sp); lds_barrier(); }
-    // FG: v_out of a tile node, and the node's block on to the contact list if it touches a movable primitive
+    if (wg == 0 && threadIdx.x == 0) (FG ? D.contact_next : D.contact)[0] = 0;     // the list k_grid_op_grad(f) (FG: this kernel for frame f-1) is about to fill
+    const Tile tl = load_tile(D, f, DET ? CAP / 2 : CAP, wg);       // stored by the scatter of this frame (DET: 6 limbs per node in tile_a)
+    SortLoad sl = sorted_begin(D, X, wg);
+    if constexpr (FG) load_prims<T, true>(D, f, sp);
 
     const int ex = tl.e[0], exy = tl.e[0] * tl.e[1], tn = exy * tl.e[2];
     // Fixed-shape tile: a box of at most 8 nodes per axis (most are: the mean box is ~6^3 nodes) is laid out in LDS with
@@ -1073,18 +1158,13 @@ __global__ __launch_bounds__(kBlock, sizeof(T) == 4 ? PLB_G2PG_WAVES : 1) void k
     // cost 2 us (512 instead of ~230 tile slots to zero and flush), so only this kernel has it.
     const bool fix8 = PLB_G2PG_FIX8 && !DET && sizeof(T) == 4 && CAP >= 512 && tl.ok && tl.e[0] <= 8 && tl.e[1] <= 8 && tl.e[2] <= 8;
     const int n8 = tl.e[2] << 6;                                    // slots of the z planes in use
+    NodeIn<T> fpre;
+    int flz = 0, fly = 0, flx = 0;
     if constexpr (FG) {
-        // one loop over the box whatever the tile layout (fixed 8-strides, the box's own extents, or no tile at all: then
-        // v_out goes to the frame's grid_v_out in HBM and the gather reads it from there)
-        for (int i = threadIdx.x; i < tn; i += kBlock) {
-            int lz, ly, lx, idx;
-            tile_coords(i, ex, exy, lz, ly, lx);
-            bool touch = false;
-            const Vec4<T> a = fg_node_vout(D, D.gin, sp, tl.o[0] + lx, tl.o[1] + ly, tl.o[2] + lz, &touch, &idx);
-            if (touch) fg_mark_contact(D, idx);
-            if (fix8) tile[(lz << 6) + (ly << 3) + lx] = a;
-            else if (tl.ok) tile[i] = a;
-            else D.grid_out[idx] = a;
+        // first pass of the v_out fill: only the grid loads; they fly during the sort (fill_finish below)
+        if ((int)threadIdx.x < tn) {
+            tile_coords((int)threadIdx.x, ex, exy, flz, fly, flx);
+            fpre = fg_node_load(D, D.gin, tl.o[0] + flx, tl.o[1] + fly, tl.o[2] + flz);
         }
         if (tl.ok)
             for (int i = threadIdx.x; i < (fix8 ? n8 : tn); i += kBlock) { tile_a[3 * i] = 0.0; tile_a[3 * i + 1] = 0.0; tile_a[3 * i + 2] = 0.0; }
@@ -1104,7 +1184,7 @@ __global__ __launch_bounds__(kBlock, sizeof(T) == 4 ? PLB_G2PG_WAVES : 1) void k
             if (DET) { tile_a[3 * (tn + i)] = 0.0; tile_a[3 * (tn + i) + 1] = 0.0; tile_a[3 * (tn + i) + 2] = 0.0; }   // lo limbs
         }
     PT_MARK(0);
-    const bool valid = sorted_finish(D, sl, p, x, base);
+    const bool valid = sorted_finish(D, sl, p, x, base, false, wg);
     PT_MARK(1);
     {
         // v[f+1]: normally the stored frame; after a re-sort of frame f+1 the copy kept in this frame's particle order
@@ -1115,6 +1195,25 @@ __global__ __launch_bounds__(kBlock, sizeof(T) == 4 ? PLB_G2PG_WAVES : 1) void k
         if (valid) {
             for (int d = 0; d < 3; ++d) { vn[d] = R1[d * Np + p]; xna[d] = A1[d * Np + p]; vna[d] = A1[(3 + d) * Np + p]; }
             for (int d = 0; d < 9; ++d) Cna[d] = A1[(6 + d) * Np + p];
+        }
+        if constexpr (FG) {
+            // grid_op on the box, whatever the tile layout (fixed 8-strides, the box's own extents, or no tile at all: then
+            // v_out goes to the frame's grid_v_out in HBM and the gather reads it from there); nodes in contact with a
+            // movable primitive put their block on the contact list
+            auto put = [&](int i, int lx, int ly, int lz, int idx, const Vec4<T>& a) {
+                if (a.w != T(0)) fg_mark_contact(D, idx);
+                if (fix8) tile[(lz << 6) + (ly << 3) + lx] = a;
+                else if (tl.ok) tile[i] = a;
+                else D.grid_out[idx] = a;
+            };
+            if ((int)threadIdx.x < tn)
+                put((int)threadIdx.x, flx, fly, flz, fpre.idx, fg_node_eval<FGMODE - 1>(D, sp, tl.o[0] + flx, tl.o[1] + fly, tl.o[2] + flz, fpre, D.grid_out));
+            for (int i = threadIdx.x + kBlock; i < tn; i += kBlock) {
+                int lz, ly, lx, idx;
+                tile_coords(i, ex, exy, lz, ly, lx);
+                const Vec4<T> a = fg_node_vout<FGMODE - 1>(D, D.gin, sp, tl.o[0] + lx, tl.o[1] + ly, tl.o[2] + lz, D.grid_out, &idx);
+                put(i, lx, ly, lz, idx, a);
+            }
         }
         __syncthreads();                             // tile / tile_a complete (the loads above are in flight)
         PT_MARK(2);
@@ -1196,6 +1295,7 @@ __global__ __launch_bounds__(kBlock, sizeof(T) == 4 ? PLB_G2PG_WAVES : 1) void k
                     if (emitter) {
                         int idx = node_index(D, base[0] + i, base[1] + j, base[2] + l);
                         atomicAdd(&D.goa[0][idx], a0); atomicAdd(&D.goa[1][idx], a1); atomicAdd(&D.goa[2][idx], a2);
+                        if constexpr (FG) D.flags[flag_slot(D, idx >> 6)] = 1;
                     }
                 });
         }
@@ -1212,6 +1312,7 @@ __global__ __launch_bounds__(kBlock, sizeof(T) == 4 ? PLB_G2PG_WAVES : 1) void k
             if (ax != 0.0 || ay != 0.0 || az != 0.0) {
                 int idx = node_index(D, tl.o[0] + (i & 7), tl.o[1] + ((i >> 3) & 7), tl.o[2] + (i >> 6));
                 atomicAdd(&D.goa[0][idx], (T)ax); atomicAdd(&D.goa[1][idx], (T)ay); atomicAdd(&D.goa[2][idx], (T)az);
+                if constexpr (FG) D.flags[flag_slot(D, idx >> 6)] = 1;      // the clear goes by the flags
             }
         }
     } else if (tl.ok) {
@@ -1234,12 +1335,12 @@ __global__ __launch_bounds__(kBlock, sizeof(T) == 4 ? PLB_G2PG_WAVES : 1) void k
                 tile_coords(i, ex, exy, lz, ly, lx);
                 int idx = node_index(D, tl.o[0] + lx, tl.o[1] + ly, tl.o[2] + lz);
                 atomicAdd(&D.goa[0][idx], (T)ax); atomicAdd(&D.goa[1][idx], (T)ay); atomicAdd(&D.goa[2][idx], (T)az);
+                if constexpr (FG) D.flags[flag_slot(D, idx >> 6)] = 1;
             }
         }
     }
     PT_MARK(4);
     PT_END(D, 10);
-    if constexpr (FG) { if (CA.frame >= 0 && !(PLB_FG_ABL & 2)) clear_boxes(D, CA); }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1404,8 +1505,7 @@ __global__ __launch_bounds__(kBlock, sizeof(T) == 4 ? PLB_P2G_GRAD_WAVES : 1) vo
     const int ex = tl.e[0], exy = tl.e[0] * tl.e[1], tn = exy * tl.e[2];
     if constexpr (FG) {
         // the node adjoints of the whole box: into the LDS tile, or -- a box too large for it -- into grid_in_adj in HBM
-        load_prims(D, f, sp);
-        lds_barrier();
+        load_prims<T, true>(D, f, sp);
         for (int i = threadIdx.x; i < tn; i += kBlock) {
             int lz, ly, lx, idx;
             tile_coords(i, ex, exy, lz, ly, lx);
