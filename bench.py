@@ -15,10 +15,11 @@ touching opposite faces, seeded actions, own target grid (the cube's mass grid s
 
 Prints ONE JSON line (rank 0).  N > 1: one process per GPU; the SAME total workload is cut into z-slabs
 (plasticinelab_amd/distributed.py: windowed grids, zero-copy block-plane halo sum exchange over RCCL each substep
-forward and adjoint, particle migration every env step) -> "scaling": "strong".  If the slab path cannot run (body
-too thin for N slabs of >= 8 layers -- config 3's cube spans 40 layers, so at most 5 ranks --, a particle leaving the
-grid window, an RCCL error) the bench falls back to N independent replicas of the workload ("scaling": "weak") and
-says so in config.parallelism.
+forward and adjoint, particle migration every env step) -> "scaling": "strong".  Slabs are whole 4-layer block planes:
+two or more per rank while the body allows it (config 3's cube spans ten planes: N <= 5), one per rank beyond that
+(N = 8: slabs of one or two planes, the plane of a one-plane slab exchanged with both neighbours).  If the slab path
+cannot run at all (a particle leaving the grid window, an RCCL error, a hang caught by the watchdog) the bench falls
+back to N independent replicas of the workload ("scaling": "weak") and says so in `metric` and in config.parallelism.
 """
 from __future__ import annotations
 
@@ -130,8 +131,8 @@ def build_env(args, device, rank=0, world=1, slabs=False):
                                        xy_margin=XY_MARGIN, migrate_every=1)
         env.loss.set_weights(10, 10, 1, False)
         backend = dist.get_backend()
-        return env, (f"{world} z-slabs {list(layout.bounds)}, grid window = body + {XY_MARGIN} layers, zero-copy halo of one 4^3 block "
-                     f"plane per face side summed over {'RCCL' if backend == 'nccl' else backend} each substep (fwd + adjoint), "
+        return env, (f"{world} z-slabs {list(layout.bounds)} (reach {layout.halo} layers), grid window = body + {XY_MARGIN} layers, zero-copy halo of "
+                     f"one 4^3 block plane per face side summed over {'RCCL' if backend == 'nccl' else backend} each substep (fwd + adjoint), "
                      "particle migration every env step")
     if getattr(args, "window", -1) >= 0:
         from plasticinelab_amd.engine.shapes import Shapes
@@ -164,7 +165,8 @@ def cpu_baseline(args, env):
     its place: the C / OpenMP float64 restatement of one substep forward + reverse (oracle/mpm_substep_omp.c, kernel by
     kernel after mpm_simulator.py:60-278 in the reference's own layout -- AoS particles, dense n^3 grids, atomic
     scatters; checked against the torch oracle in tests/test_oracle_omp.py), timed on this box's host cores on the
-    workload's particle cloud: median of 5 runs on all cores (the value) and of 3 runs on one core.  kind = "port"."""
+    workload's particle cloud: median of 3 runs per thread count of a sweep (best count = the value) and of 3 runs on one
+    core.  kind = "port"."""
     from oracle.omp_substep import OmpSubstep
     sim_g = env.simulator
     x0 = np.ascontiguousarray(getattr(env, "all_particles", None) if getattr(env, "all_particles", None) is not None else env.init_particles)
@@ -354,8 +356,10 @@ def main():
     value = total_substeps / elapsed
 
     out = {
-        "metric": "MPM substeps/sec (fwd+bwd)", "value": value, "unit": "substeps/s", "n_gpus": world,
-        "steps": K, "warmup": W, "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True, "scaling": "strong" if slabs else "weak",
+        # N = 1 is the first point of the strong-scaling series (the whole workload on one GPU); replicas are not the metric
+        "metric": "MPM substeps/sec (fwd+bwd)" + ("" if slabs or world == 1 else f" -- FALLBACK: {world} independent replicas, not the sliced workload"),
+        "value": value, "unit": "substeps/s", "n_gpus": world,
+        "steps": K, "warmup": W, "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True, "scaling": "strong" if (slabs or world == 1) else "weak",
         "vs_baseline": None, "dtype": "f32" if args.dtype == "float32" else "f64", "data": "synthetic",
         "config": {"workload": ("config3_cube128" if (args.particles, args.quality) == (500_000, 2)
                                 else f"cube{sim.n_grid}_{args.particles}p"), "n_grid": sim.n_grid,

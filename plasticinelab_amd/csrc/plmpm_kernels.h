@@ -836,9 +836,14 @@ __global__ __launch_bounds__(kBlock) void k_grid_op(Dev<T> D, int f, HaloIn H) {
         if (hf >= 0) {
             // symmetric sum exchange: our partial sums + the neighbour's.  The complete sums go back into this
             // frame's stored grid_in (substep_grad recomputes grid_op from it), and a block that only the neighbour's
-            // particles reach becomes active here too
-            m += halo_value(D, H, hf, 0, blk, lane);
-            for (int c = 0; c < 3; ++c) mv[c] += halo_value(D, H, hf, 1 + c, blk, lane);
+            // particles reach becomes active here too.  (The block plane of a slab that is one plane thick lies in the
+            // exchange range of both faces: both neighbours' copies are added.)
+            const int bz = blk / (D.nbx * D.nby);
+            for (int hq = hf; hq < H.n; ++hq) {
+                if (bz < H.ba[hq] || bz >= H.bb[hq]) continue;
+                m += halo_value(D, H, hq, 0, blk, lane);
+                for (int c = 0; c < 3; ++c) mv[c] += halo_value(D, H, hq, 1 + c, blk, lane);
+            }
             if (!__any(m != T(0))) return;
             if (!CLEAR) {
                 D.gin[0][idx] = m; D.gin[1][idx] = mv[0]; D.gin[2][idx] = mv[1]; D.gin[3][idx] = mv[2];
@@ -1360,8 +1365,13 @@ __device__ __forceinline__ bool grid_block_bwd(const Dev<T>& D, const HaloIn& H,
     // multi-GPU: add the neighbour's share of grid_v_out.grad on the exchanged planes (POSE = false pass only: a
     // deferred block gets the sum written back below, so the POSE = true pass reads complete values)
     const int hf = (!POSE && H.n > 0) ? halo_face_of(D, H, blk) : -1;
-    if (hf >= 0)
-        for (int c = 0; c < 3; ++c) va[c] += halo_value(D, H, hf, c, blk, lane);
+    if (hf >= 0) {
+        const int bz = blk / (D.nbx * D.nby);
+        for (int hq = hf; hq < H.n; ++hq) {
+            if (bz < H.ba[hq] || bz >= H.bb[hq]) continue;
+            for (int c = 0; c < 3; ++c) va[c] += halo_value(D, H, hq, c, blk, lane);
+        }
+    }
     const bool owned = I[2] >= D.z0 && I[2] < D.z1;     // halo nodes are computed on two ranks: count once
     bool due = false;
     grid_node_bwd<T, POSE>(D.P, I, gm, mv, D.nprim, sp, va, &ma, mva, [&](int q, const PoseAdj<T>& pa, bool hit) {

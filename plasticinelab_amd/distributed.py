@@ -25,10 +25,13 @@ The reference has no multi-GPU path; this is new design.
   kinematics-chain adjoint runs redundantly everywhere, so every rank ends with the full action gradient.  The loss
   sums over owned nodes / local particles and all-reduces a 32-double record.
 
-Limits, stated plainly: slabs are at least 8 node layers thick (two block planes, so the two faces' exchange planes
-do not overlap), which caps the rank count for thin bodies (config 3's cube spans 40 layers: at most 5 ranks); a
-particle may drift at most 3 layers past its slab between two migrations (it raises otherwise); the exchange is
-issued by the host each substep and is not overlapped with the interior blocks yet.
+Limits, stated plainly: slabs are whole block planes.  At the default reach (a particle may drift 3 layers past its slab
+between two migrations; it raises otherwise) a slab is at least two planes thick; when a body is too thin for that --
+config 3's cube spans ten planes, so at most 5 such ranks -- the layout falls back to a reach of 2 layers (one of drift)
+and slabs of ONE plane, whose plane is exchanged with both neighbours (``min_thickness``): up to one rank per block plane
+of the body, at the price of a coarser load balance (8 ranks over ten planes: the largest slab holds 2/10 of the
+particles).  The exchange is issued by the host each substep; ``SlabEngine(overlap=True)`` runs the grid kernels of the
+blocks outside the exchanged planes while it is in flight.
 
 The communication layer is backend-agnostic (``nccl`` = RCCL on the GPUs; ``gloo`` for the CPU tests and for ranks
 sharing one GPU, staged through host memory).
@@ -47,7 +50,22 @@ _SUM_SLOTS = (0, 1, 3, 4)
 _MAX_SLOTS = (2,)
 
 HALO_PLANES = 1          # block planes exchanged either side of a face (4 node layers)
-MIN_THICKNESS = 8        # node layers: two block planes, so that the exchange planes of a slab's two faces are disjoint
+MIN_THICKNESS = 8        # node layers of a slab at the default reach (halo = 4); see min_thickness
+
+
+def min_thickness(halo: int) -> int:
+    """Thinnest slab (node layers, a multiple of 4) for particles that may reach ``halo`` layers beyond their slab.
+
+    A node layer must not collect contributions from more than two ranks -- the exchange is pairwise: each rank adds
+    the copy of its neighbour across the face, nothing is forwarded -- so the reach of the slab below and of the slab
+    above may not meet inside a slab: thickness >= 2 * halo.  halo = 4 (one layer of stencil + three of drift between
+    migrations): two block planes, the exchange planes of the two faces are disjoint.  halo = 2 (one of stencil + one
+    of drift: particles move a fraction of a cell per env step, so this holds with a migration every env step): a
+    slab may be a single block plane, which then lies in the exchange range of BOTH faces -- it is sent to both
+    neighbours and the grid kernels add both received copies."""
+    if halo not in (2, 4):
+        raise ValueError(f"slab reach must be 2 or 4 node layers (got {halo})")
+    return 4 * ((2 * halo + 3) // 4)
 
 
 @dataclass
@@ -83,13 +101,18 @@ class SlabLayout:
         return (np.asarray(x)[:, 2] * n_grid - 0.5).astype(np.int64)      # trunc, as in the kernels
 
     @classmethod
-    def balanced(cls, x: np.ndarray, n_grid: int, world: int, halo: int = 4) -> "SlabLayout":
+    def balanced(cls, x: np.ndarray, n_grid: int, world: int, halo: Optional[int] = 4) -> "SlabLayout":
         """Slab faces at particle-count quantiles of the stencil centre z, rounded to multiples of 4 and pushed apart
-        so that every slab is >= MIN_THICKNESS layers thick."""
+        so that every slab is >= min_thickness(halo) layers thick.  ``halo=None``: 4 if the body can be cut that way,
+        else 2 (thin slabs: up to one rank per block plane of the body)."""
         if world == 1:
             return cls(n_grid, (0, n_grid), 0)
-        if halo != 4 * HALO_PLANES:
-            raise ValueError(f"slab halos are whole block planes: halo = {4 * HALO_PLANES} node layers (got {halo})")
+        if halo is None:
+            try:
+                return cls.balanced(x, n_grid, world, 4)
+            except ValueError:
+                return cls.balanced(x, n_grid, world, 2)
+        thick = min_thickness(halo)
         cz = cls.stencil_base_z(x, n_grid) + 1                 # stencil centres
         # particles per block plane; a face may sit on any multiple of 4.  Choose the world - 1 faces, at least
         # MIN_THICKNESS apart, that minimise the largest slab's particle count (dynamic programme over the planes)
@@ -97,7 +120,7 @@ class SlabLayout:
         nbp = n_grid // 4
         cnt = np.bincount(np.clip(cz // 4, 0, nbp - 1), minlength=nbp).astype(np.int64)
         cum = np.concatenate([[0], np.cumsum(cnt)])           # cum[j] = particles in planes [0, j)
-        gap = MIN_THICKNESS // 4
+        gap = thick // 4
         INF = np.iinfo(np.int64).max
         # best[k][j]: smallest possible maximum load of k slabs covering planes [0, j), the k-th ending at face j
         best = np.full((world + 1, nbp + 1), INF, dtype=np.int64)
@@ -116,7 +139,7 @@ class SlabLayout:
                         best[k][j], prev[k][j] = m, i
         if best[world][nbp] == INF:
             raise ValueError(f"cannot cut the body (stencil centres z {int(cz.min())}..{int(cz.max())}) into {world} non-empty slabs of >= "
-                             f"{MIN_THICKNESS} layers with faces on multiples of 4")
+                             f"{thick} layers with faces on multiples of 4")
         faces, j = [n_grid], nbp
         for k in range(world, 0, -1):
             j = int(prev[k][j])
@@ -422,7 +445,7 @@ def slab_window(x_all: np.ndarray, n_grid: int, layout: SlabLayout, rank: int, x
     return [int(v) for v in lo], [int(v) for v in hi]
 
 
-def make_slab_env(cfg, rank: int, world: int, *, halo: int = 4, compute_dtype=None, device=None, group=None,
+def make_slab_env(cfg, rank: int, world: int, *, halo: Optional[int] = None, compute_dtype=None, device=None, group=None,
                   target_fn: Optional[Callable] = None, particles: Optional[np.ndarray] = None,
                   layout: Optional[SlabLayout] = None, comm: Optional[HaloComm] = None,
                   xy_margin: Optional[int] = 12, migrate_every: int = 1, capacity_factor: float = 1.5,

@@ -27,6 +27,7 @@ def main():
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     backend = os.environ.get("PLB_DIST_BACKEND", "gloo")
     overlap = os.environ.get("PLB_TEST_OVERLAP") == "1"      # interior grid blocks while the halos are in flight
+    halo = int(os.environ["PLB_TEST_HALO"]) if os.environ.get("PLB_TEST_HALO") else None     # 2: thin slabs (one block plane)
     dev = rank % torch.cuda.device_count() if backend == "nccl" else 0
     torch.cuda.set_device(dev)
     if backend == "nccl":
@@ -48,7 +49,7 @@ def main():
         x_all, _ = Shapes(cfg.SHAPES).get()
         n = 2000
         sub = np.ascontiguousarray(x_all[::len(x_all) // n][:n])
-        env, layout, mine = make_slab_env(cfg, rank, world, compute_dtype=dtype, particles=sub, xy_margin=xy_margin,
+        env, layout, mine = make_slab_env(cfg, rank, world, compute_dtype=dtype, particles=sub, xy_margin=xy_margin, halo=halo,
                                           migrate_every=migrate_every, target_fn=lambda x, sim: sparse_target("Move3D-v1"), overlap=overlap)
     else:
         import bench
@@ -59,7 +60,7 @@ def main():
         ys = None
         if scene.get("mixed"):                       # config 5: half the particles yield (50), half do not (1e9)
             ys = np.where(np.arange(scene["particles"]) % 2 == 0, 50.0, 1e9)
-        env, layout, mine = make_slab_env(cfg, rank, world, compute_dtype=dtype, xy_margin=xy_margin, migrate_every=migrate_every,
+        env, layout, mine = make_slab_env(cfg, rank, world, compute_dtype=dtype, xy_margin=xy_margin, migrate_every=migrate_every, halo=halo,
                                           target_fn=bench._target, yield_stress=ys, overlap=overlap)
     env.loss.set_weights(10, 10, 1, False)
     solver = Solver(env, None, None, softness=666.0, horizon=len(actions))

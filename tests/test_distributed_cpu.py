@@ -82,7 +82,8 @@ class ToyEngine:
 
     def error_flags(self):
         fr = self.frames[max(self.frames)]
-        bad = ((fr["bz"] < self.z0 - 4) & (self.rank > 0)) | ((fr["bz"] + 2 >= self.z1 + 4) & (self.rank < self.layout.world - 1))
+        h = self.layout.halo
+        bad = ((fr["bz"] < self.z0 - h) & (self.rank > 0)) | ((fr["bz"] + 2 >= self.z1 + h) & (self.rank < self.layout.world - 1))
         return int(bad.any())
 
     def check_error(self, flags=None):
@@ -256,8 +257,8 @@ def _world(rank, world, port, ids, bz_all, w_all, drift, out, overlap=False):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         x = np.zeros((len(bz_all), 3)); x[:, 2] = (np.asarray(bz_all) + 0.7) / N
-        layout = SlabLayout.balanced(x, N, world)
-        assert all(b - a >= 8 and a % 4 == 0 for a, b in zip(layout.bounds, layout.bounds[1:]))
+        layout = SlabLayout.balanced(x, N, world, None)
+        assert all(b - a >= 2 * layout.halo and a % 4 == 0 for a, b in zip(layout.bounds, layout.bounds[1:]))
         mine = np.nonzero(layout.owner_of(SlabLayout.stencil_base_z(x, N)) == rank)[0]
         toy = ToyEngine([ids[i] for i in mine], [bz_all[i] for i in mine], [w_all[i] for i in mine], drift, layout, rank)
         eng = SlabEngine(toy, layout, rank, migrate_every=1, overlap=overlap)
@@ -304,7 +305,16 @@ def test_layout_balanced_and_faces():
     with pytest.raises(ValueError):
         SlabLayout.balanced(x, 64, 9)                          # 64 layers cannot hold 9 slabs of >= 8
     with pytest.raises(ValueError):
-        SlabLayout.balanced(x, 64, 2, halo=2)                  # halos are whole block planes
+        SlabLayout.balanced(x, 64, 2, halo=3)                  # the reach is 4 layers (3 of drift) or 2 (1 of drift)
+    # thin slabs: a reach of 2 layers lets a slab be a single block plane, exchanged with both neighbours
+    thin = SlabLayout.balanced(x, 64, 9, halo=2)
+    assert thin.world == 9 and thin.halo == 2 and min(b - a for a, b in zip(thin.bounds, thin.bounds[1:])) == 4
+    assert SlabLayout.balanced(x, 64, 9, None).bounds == thin.bounds and SlabLayout.balanced(x, 64, 4, None).bounds == lay.bounds
+    one_plane = [r for r in range(1, 8) if thin.bounds[r + 1] - thin.bounds[r] == 4]
+    (_, a0, b0), (_, a1, b1) = thin.faces(one_plane[0])
+    assert (a1, b0) == (a0 + 1, a0 + 2)                        # the slab's own plane lies in both exchange ranges
+    with pytest.raises(ValueError):
+        SlabLayout.balanced(x, 64, 12, None)                   # the body spans ten block planes
     assert SlabLayout.balanced(x, 64, 1).bounds == (0, 64)
     # grid window of a middle rank: xy box of the cloud + margin, z = slab + one block plane either side
     x[:, 0] = 0.4 + 0.1 * rng.random(1000); x[:, 1] = 0.5
@@ -358,3 +368,41 @@ def test_ranks_equal_one_rank(WORLD, OVERLAP):
     assert many[0]["order"][0] == "fk" and many[0]["order"][-1] == "chain_grad"
     # g2p of every substep but an env step's last runs fused with the next p2g
     assert many[0]["fwd"][:4] == [("p2g", 0, False), ("grid_g2p", 0, True), ("p2g", 1, True), ("grid_g2p", 1, False)]
+
+
+def test_eight_thin_slabs_equal_one_rank():
+    """World size 8 on a body of eight block planes: every slab is ONE block plane (reach 2 layers: one of stencil, one of
+    drift), so a rank's plane is exchanged with both neighbours and both received copies are added -- the layout
+    `bench.py --gpus 8` needs for the 40-layer cube of config 3."""
+    rng = np.random.default_rng(2)
+    n = 96
+    ids = list(range(500, 500 + n))
+    bz = [int(v) for v in rng.integers(0, 29, n)] + []
+    bz[:8] = [4 * k + 1 for k in range(8)]                     # every plane holds a stencil centre
+    w = [float(v) for v in rng.random(n) + 0.5]
+    # one layer of drift per env step at most, away from the walls
+    drift = {i: (int(rng.integers(0, 2)) if b < 15 else -int(rng.integers(0, 2))) for i, b in zip(ids, bz)}
+    one = run(1, ids, bz, w, drift)[0]
+    many = run(8, ids, bz, w, drift)
+    b = many[0]["bounds"]
+    assert len(b) == 9 and all(hi - lo == 4 for lo, hi in zip(b, b[1:]))
+    assert sum(many[r]["moved"] for r in range(8)) > 0
+    for k in range(STEPS + 1):
+        assert sum(many[r]["counts"][k] for r in range(8)) == n
+    for f in range(STEPS * SUB):
+        got, adj = {}, {}
+        for r in range(8):
+            assert not set(got) & set(many[r]["read"][f])
+            got.update(many[r]["read"][f]); adj.update(many[r]["adj"][f])
+        assert set(got) == set(one["read"][f])
+        for i in one["read"][f]:
+            assert abs(got[i] - one["read"][f][i]) < 1e-12 * max(1.0, abs(got[i]))
+            assert abs(adj[i] - one["adj"][f][i]) < 1e-12 * max(1.0, abs(adj[i]))
+    fin = {}
+    for r in range(8):
+        fin.update(many[r]["final_adj"])
+    assert set(fin) == set(one["final_adj"]) and all(abs(fin[i] - one["final_adj"][i]) < 1e-12 * max(1.0, abs(fin[i])) for i in fin)
+    for a, c in zip(many[0]["chain"], one["chain"]):
+        assert abs(a[4] - c[4]) < 1e-12 * max(1.0, abs(c[4]))
+    for k in ("loss", "iou", "min_dist", "sum_m"):
+        assert abs(many[0]["info"][k] - one["info"][k]) < 1e-12 * max(1.0, abs(one["info"][k]))

@@ -24,7 +24,7 @@ def free_port():
         return s.getsockname()[1]
 
 
-def launch(tmp_path, world, dtype, actions, xy_margin, migrate_every, backend="gloo", scene=None, overlap=False, deterministic=False):
+def launch(tmp_path, world, dtype, actions, xy_margin, migrate_every, backend="gloo", scene=None, overlap=False, deterministic=False, halo=None):
     out = str(tmp_path / "r")
     act = str(tmp_path / "actions.npy")
     np.save(act, actions)
@@ -32,7 +32,8 @@ def launch(tmp_path, world, dtype, actions, xy_margin, migrate_every, backend="g
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   HSA_ENABLE_IPC_MODE_LEGACY="0", PLB_DIST_BACKEND=backend, PLB_TEST_OVERLAP="1" if overlap else "0", PLB_TEST_DETERMINISTIC="1" if deterministic else "0")
+                   HSA_ENABLE_IPC_MODE_LEGACY="0", PLB_DIST_BACKEND=backend, PLB_TEST_OVERLAP="1" if overlap else "0", PLB_TEST_DETERMINISTIC="1" if deterministic else "0",
+                   PLB_TEST_HALO="" if halo is None else str(halo))
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_gpu_worker.py"), out, dtype, act,
                                        "none" if xy_margin is None else str(xy_margin), str(migrate_every)]
                                       + ([json.dumps(scene)] if scene else []),
@@ -155,6 +156,38 @@ def test_config4_grid_in_four_slabs(tmp_path):
     assert sum(int(r["count"]) for r in res) == scene["particles"]
     print(f"\n[256^3 in 4 slabs] loss {loss:.9g}, rows moved {[int(r['rows_moved']) for r in res]}, grid store per rank "
           f"{[round(int(r['grid_bytes']) / 2**30, 2) for r in res]} GiB vs {single_grid_bytes / 2**30:.2f} GiB on one rank")
+
+
+def test_thin_slabs_one_block_plane_per_rank(tmp_path):
+    """The layout `bench.py --gpus 8` uses on config 3: a reach of 2 node layers (one of stencil, one of drift) lets a slab
+    be ONE block plane, which then lies in the exchange range of both its faces -- it goes to both neighbours, and
+    k_grid_op / k_grid_op_grad add both received copies.  Here: the benchmark's cube on a 64^3 grid (20 layers = 5-6 block
+    planes) cut into 5 slabs, 4 env steps with migration every step, against the single-rank run."""
+    import bench
+    import torch
+    from plasticinelab_amd.engine.taichi_env import TaichiEnv
+    from plasticinelab_amd.optimizer.solver import Solver
+    scene = dict(particles=20_000, quality=1, side=0.31, yield_stress=200.0)
+    H = 4
+    acts = bench.seeded_actions(H, 6)
+    cfg = bench.workload_cfg(scene["particles"], scene["quality"], max_steps=H * 19 + 1, yield_stress=200.0, side=0.31)
+    env = TaichiEnv(cfg, compute_dtype="float64")
+    env.initialize()
+    env.loss.load_target_density(grids=bench._target(env.init_particles, env.simulator))
+    env.loss.set_weights(10, 10, 1, False)
+    loss, grad = Solver(env, None, None, softness=666.0, horizon=H).forward(env.get_state()["state"], acts)
+    env.simulator.engine.close()
+    del env
+    torch.cuda.empty_cache()
+    res = launch(tmp_path, 5, "float64", acts, 10, 1, scene=scene, halo=2)
+    b = [int(v) for v in res[0]["bounds"]]
+    assert min(hi - lo for lo, hi in zip(b[1:-2], b[2:-1])) == 4, b          # the middle slabs are single block planes
+    for r in res:
+        assert abs(float(r["loss"]) - loss) / abs(loss) < 1e-9
+        assert relerr(r["grad"], grad) < 1e-7
+        assert int(r["migrations"]) == H - 1
+    assert sum(int(r["count"]) for r in res) == scene["particles"]
+    print(f"\n[thin slabs] bounds {b}, rows moved {[int(r['rows_moved']) for r in res]}")
 
 
 def test_config5_rank_fits_in_hbm():
