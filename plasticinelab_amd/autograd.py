@@ -126,7 +126,14 @@ class Observe(torch.autograd.Function):
     def backward(ctx, g):
         sess, f, idx = ctx.sess, ctx.f, ctx.idx
         sim = sess.env.simulator
-        # the adjoint of frame f is resident: the env step that starts there has just been differentiated
+        # the adjoint of frame f is resident: the env step that starts there has just been differentiated -- or f is the
+        # rollout's final frame (a terminal value / bootstrap on the last observation) and this is the first backward
+        # call of the sweep, which then starts here (grad_begin zeroes the adjoints: it must come BEFORE anything is added)
+        if not sess._grad_started:
+            if f != sim.cur:
+                raise RuntimeError(f"observation of frame {f} differentiated before the reverse sweep reached it (the sweep starts at frame {sim.cur})")
+            sim.grad_begin(sim.cur)
+            sess._grad_started, sess._pending = True, sess.steps - 1
         g = g.detach().cpu().double().numpy()
         n = sim.n_particles
         gp = g[:len(idx) * 6].reshape(len(idx), 6)

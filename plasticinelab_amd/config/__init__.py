@@ -86,9 +86,16 @@ def _arith(node):
         return [_arith(e) for e in node.elts]
     if isinstance(node, ast.BinOp) and type(node.op) in _BIN_OPS:
         a, b = _arith(node.left), _arith(node.right)
-        if isinstance(node.op, ast.Pow) and abs(b) > 64:
-            raise ValueError("exponent too large")
-        return _BIN_OPS[type(node.op)](a, b)
+        # numbers only on either side (no sequence repetition / concatenation), bounded exponents and shift counts, and a
+        # bounded result: a scene string such as '1<<(1<<36)' or '(0,)*10**10' must not be able to allocate gigabytes
+        if not all(isinstance(t, (int, float, bool)) for t in (a, b)):
+            raise ValueError("arithmetic on a sequence")
+        if isinstance(node.op, (ast.Pow, ast.LShift, ast.RShift)) and abs(b) > 64:
+            raise ValueError("exponent / shift count too large")
+        r = _BIN_OPS[type(node.op)](a, b)
+        if isinstance(r, int) and abs(r) > 1 << 128:
+            raise ValueError("result too large")
+        return r
     if isinstance(node, ast.UnaryOp) and type(node.op) in _UN_OPS:
         return _UN_OPS[type(node.op)](_arith(node.operand))
     raise ValueError(f"not plain arithmetic: {ast.dump(node)}")

@@ -1642,6 +1642,7 @@ __global__ void k_add_doubles(double* dst, double a0, double a1, double a2, doub
 }
 int plmpm_add_primitive_grad(plmpm_handle s, int prim, int frame, const double* g) {
     NEED_BOUND(s);
+    REQUIRE(s->adj_frame[0] >= 0 || s->adj_frame[1] >= 0, "add_primitive_grad: no reverse sweep has begun (plmpm_grad_begin clears the pose adjoints: call it first)");
     NEED_FRAME(s, frame);
     REQUIRE(prim >= 0 && prim < s->P && g, "bad primitive index");
     const size_t a = (size_t)frame * s->P + prim;
@@ -2462,6 +2463,9 @@ template <class T> static int migrate_finish_t(plmpm_sim* s, int frame, int e_ne
     REQUIRE(n_new >= 0 && n_new <= s->Npad, "migrate: %d particles after the exchange, capacity %d (raise particle_capacity)", n_new, s->Npad);
     const int total = n_old + n_in0 + n_in1;
     REQUIRE(total <= s->sort_cap, "migrate: %d candidate rows, room for %d", total, s->sort_cap);
+    // the reverse sweep packs the adjoint rows of these arrivals into this rank's own send buffers (mig_max_rows rows each)
+    REQUIRE(n_in0 <= s->mig_max_rows && n_in1 <= s->mig_max_rows, "migrate: %d / %d rows arrive at once, the row buffers hold %d (raise particle_capacity)",
+            n_in0, n_in1, s->mig_max_rows);
     int bits = 1;
     while ((1 << bits) < s->n) ++bits;
     if (total > 0) {

@@ -334,15 +334,36 @@ class SlabEngine:
         self.comm.all_reduce_(flags, op=dist.ReduceOp.MAX)
         self._e.check_error(int(flags.item()))
 
+    def _agree(self, err, where):
+        """Raise on every rank if any rank has an exception to report (``err``), the failing rank its own."""
+        bad = torch.tensor([0.0 if err is None else 1.0], dtype=torch.float64, device=self.comm.scalar_device)
+        self.comm.all_reduce_(bad, op=dist.ReduceOp.MAX)
+        if err is not None:
+            raise err
+        if bad.item() > 0:
+            raise RuntimeError(f"rank {self.rank}: another rank failed in {where}")
+
     # ---- migration
     def migrate(self, f):
         """Hand the rows of frame ``f`` whose stencil centre left this slab to the neighbours, take theirs, re-sort."""
         e = self._e
         self._check()                              # nobody migrates a state that is already wrong
-        (nd, nu), (rows_d, rows_u) = e.migrate_begin(f)
+        # A host-side failure inside migrate_begin / migrate_finish ("N rows leave at once", "out of storage epochs",
+        # "raise particle_capacity") happens on ONE rank; the others would wait for it forever in the row exchange or in
+        # the next halo.  So every rank learns of it before anyone raises (_agree), and all raise together.
+        err, nd, nu, rows_d, rows_u = None, 0, 0, None, None
+        try:
+            (nd, nu), (rows_d, rows_u) = e.migrate_begin(f)
+        except Exception as ex:                    # noqa: BLE001
+            err = ex
+        self._agree(err, "migrate_begin")
         in_d, in_u = self.comm.exchange_counts(nd, nu)
         got_d, got_u = self.comm.exchange_rows(rows_d, rows_u, in_d, in_u, e.MIG_ROW, e.device)
-        e.migrate_finish(f, got_d, got_u)
+        try:
+            e.migrate_finish(f, got_d, got_u)
+        except Exception as ex:                    # noqa: BLE001
+            err = ex
+        self._agree(err, "migrate_finish")
         self._since_migration = 0
         self.migrations += 1
         self.rows_moved += nd + nu

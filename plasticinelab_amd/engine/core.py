@@ -130,7 +130,9 @@ class Engine:
         L.check(self.lib.plmpm_set_materials(self.h, *[_ptr(v) for v in a]))
 
     def set_frame(self, f, x=None, v=None, F=None, C_=None, resort=False):
-        N = self.n_particles
+        # rows: the engine's own count at an episode reset (resort: a new epoch 0), else those of the frame's storage
+        # epoch (a slab rank gains and loses rows by migration)
+        N = self.n_particles if resort else self.frame_info(f)[0]
         x, v, F, C_ = _f64(x, (N, 3)), _f64(v, (N, 3)), _f64(F, (N, 3, 3)), _f64(C_, (N, 3, 3))
         L.check(self.lib.plmpm_set_frame(self.h, f, _ptr(x), _ptr(v), _ptr(F), _ptr(C_), int(resort)))
 
@@ -168,8 +170,12 @@ class Engine:
         return s
 
     def set_resort(self, on):
-        """Switch the per-env-step re-sort off / on (optimizer/checkpoint.py keeps one order across segments)."""
+        """Switch the per-env-step re-sort off / on (optimizer/checkpoint.py keeps one order across segments).  Returns
+        the previous setting, so that a caller can put it back."""
+        prev = getattr(self, "_resort_on", True)
         L.check(self.lib.plmpm_set_resort(self.h, int(bool(on))))
+        self._resort_on = bool(on)
+        return prev
 
     def add_primitive_grad(self, prim, f, grad8):
         g = np.zeros(8)

@@ -22,11 +22,11 @@ def forward_checkpointed(env, init_state, actions, segment: int, softness: float
     env.set_state(init_state, softness, False)          # sorts the storage order once ...
     # ... and it is kept for all segments: every segment reuses frames 0..T*sub, so a per-step re-sort would hand
     # out the same epoch numbers (and overwrite their permutations) while adjoints still carry those labels
-    eng.set_resort(False)
+    was_on = eng.set_resort(False)
     try:
         return _forward_checkpointed(env, init_state, actions, T, H, sub)
     finally:
-        eng.set_resort(True)
+        eng.set_resort(was_on)                          # as the owner had it (it may be off for an A/B run of its own)
 
 
 def _forward_checkpointed(env, init_state, actions, T, H, sub):

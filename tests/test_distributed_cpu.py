@@ -406,3 +406,38 @@ def test_eight_thin_slabs_equal_one_rank():
         assert abs(a[4] - c[4]) < 1e-12 * max(1.0, abs(c[4]))
     for k in ("loss", "iou", "min_dist", "sum_m"):
         assert abs(many[0]["info"][k] - one["info"][k]) < 1e-12 * max(1.0, abs(one["info"][k]))
+
+
+def _world_fail(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        bz_all = list(range(4, 24))
+        x = np.zeros((len(bz_all), 3)); x[:, 2] = (np.asarray(bz_all) + 0.7) / N
+        layout = SlabLayout.balanced(x, N, world)
+        mine = np.nonzero(layout.owner_of(SlabLayout.stencil_base_z(x, N)) == rank)[0]
+        toy = ToyEngine([100 + i for i in mine], [bz_all[i] for i in mine], [1.0] * len(mine), {100 + i: 0 for i in range(len(bz_all))}, layout, rank)
+        if rank == 1:
+            def boom(f):
+                raise RuntimeError("migrate: 99999 rows leave at once, the row buffers hold 4096")
+            toy.migrate_begin = boom
+        eng = SlabEngine(toy, layout, rank, migrate_every=1)
+        eng.step(0, SUB)
+        try:
+            eng.step(SUB, SUB)                     # migrates first: rank 1 fails inside migrate_begin
+            out[rank] = "no exception"
+        except RuntimeError as e:
+            out[rank] = str(e)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_a_migration_failure_on_one_rank_raises_on_every_rank():
+    """A host-side error inside plmpm_migrate_begin / _finish happens on one rank only; the others must not be left
+    waiting in the row exchange: the ok flag is all-reduced and every rank raises."""
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_world_fail, args=(2, free_port(), out), nprocs=2, join=True)
+    assert "rows leave at once" in out[1]
+    assert "another rank failed in migrate_begin" in out[0]

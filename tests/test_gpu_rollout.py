@@ -142,7 +142,7 @@ def test_checkpointed_gradient_long_horizon(segment):
     H = 3 * segment
     acts = np.random.default_rng(11).uniform(-1, 1, (H, env.primitives.action_dim)) * 0.5
     state0 = env.get_state()["state"]
-    loss, grad = run_forward(env, acts, state0)             # stored trajectory, re-sorted every 4 env steps
+    loss, grad = run_forward(env, acts, state0)             # stored trajectory, re-sorted every 2 env steps (cfg.resort_steps)
     loss2, grad2 = forward_checkpointed(env, state0, acts, segment)
     assert abs(loss2 - loss) / abs(loss) < 1e-10
     assert relerr(grad2, grad) < 1e-8
