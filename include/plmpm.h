@@ -89,6 +89,19 @@ typedef struct plmpm_config {
      * magnitude.  Slab engines: the rows that migrate leave in slot order, so a fixed rank layout reproduces too (the
      * host's reductions across ranks must be order-fixed as well: gloo and RCCL rings are).  0: fp atomics. */
     int32_t deterministic;
+    /* Two pieces of Taichi autodiff semantics that the reference's gradients depend on and that cannot be verified without
+     * a Taichi 0.7.14 installation are switches, so that a Taichi-generated golden vector that disagrees
+     * costs a flag, not a kernel edit (oracle/plb_oracle.py has the same two flags):
+     *   contact_min_adjoint  0: ti.atomic_min in the hard contact loss (loss.py:123-128) differentiated like an add --
+     *                           min_dist's adjoint goes to EVERY particle (the assumed Taichi 0.7.x behaviour, default);
+     *                        1: it goes to the particle(s) attaining the minimum (the mathematical derivative);
+     *   minmax_tie           0: the adjoint of max(a, b) / min(a, b) goes to the SECOND operand on an exact tie (assumed
+     *                           Taichi behaviour, default); 1: to the first.  Applies to every max / min on the
+     *                           differentiated path: position clamps (mpm_simulator.py:242, primive_base.py:119), the
+     *                           0.05 floor of the return mapping (:126), friction and normal-velocity clamps of collide
+     *                           (primive_base.py:100-103), the influence clamp, shape SDFs, the contact loss's max(sdf, 0). */
+    int32_t contact_min_adjoint;
+    int32_t minmax_tie;
 } plmpm_config;
 
 /* One rigid manipulator; mirrors Primitive.default_config + per-shape params

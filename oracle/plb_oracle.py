@@ -99,16 +99,23 @@ class PrimCfg:
 # --------------------------------------------------------------------------- #
 # Taichi autodiff semantics
 # --------------------------------------------------------------------------- #
+# The two unverified pieces of Taichi semantics are switches here as in the engine (plmpm_config.contact_min_adjoint /
+# minmax_tie, include/plmpm.h): when Taichi-generated vectors arrive (tests/golden/make_taichi_golden.py) and disagree,
+# the fix is a flag.  Defaults = what Taichi 0.7.x is remembered to do.
+SEMANTICS = {"minmax_tie": "second",            # adjoint of max / min on an exact tie: "second" operand | "first"
+             "contact_min_adjoint": "add"}      # ti.atomic_min in the hard contact loss: "add" (every particle) | "argmin"
+
+
 def ti_max(a, b):
-    """max(lhs, rhs): adjoint to lhs iff rhs < lhs, else to rhs."""
+    """max(lhs, rhs): adjoint to lhs iff rhs < lhs, else to rhs (ties to lhs with minmax_tie = "first")."""
     a, b = torch.broadcast_tensors(torch.as_tensor(a, dtype=DT), torch.as_tensor(b, dtype=DT))
-    return torch.where(b < a, a, b)
+    return torch.where(b <= a if SEMANTICS["minmax_tie"] == "first" else b < a, a, b)
 
 
 def ti_min(a, b):
-    """min(lhs, rhs): adjoint to lhs iff lhs < rhs, else to rhs."""
+    """min(lhs, rhs): adjoint to lhs iff lhs < rhs, else to rhs (ties to lhs with minmax_tie = "first")."""
     a, b = torch.broadcast_tensors(torch.as_tensor(a, dtype=DT), torch.as_tensor(b, dtype=DT))
-    return torch.where(a < b, a, b)
+    return torch.where(a <= b if SEMANTICS["minmax_tie"] == "first" else a < b, a, b)
 
 
 def _svd_clamp(a):
@@ -154,10 +161,14 @@ class AtomicMinAsAdd(torch.autograd.Function):
     @staticmethod
     def forward(ctx, init, vals):
         ctx.n = vals.shape[0]
-        return torch.minimum(torch.as_tensor(init, dtype=DT), vals.min())
+        out = torch.minimum(torch.as_tensor(init, dtype=DT), vals.min())
+        ctx.hit = (vals == out)                   # contact_min_adjoint = "argmin": only the particle(s) attaining the minimum
+        return out
 
     @staticmethod
     def backward(ctx, g):
+        if SEMANTICS["contact_min_adjoint"] == "argmin":
+            return None, g * ctx.hit.to(DT)
         return None, g.expand(ctx.n).clone()
 
 

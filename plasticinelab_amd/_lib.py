@@ -29,7 +29,7 @@ class Config(C.Structure):
                 ("svd_grad_clamp", C.c_double), ("slab_z0", C.c_int32), ("slab_z1", C.c_int32),
                 ("store_grid", C.c_int32), ("slab_halo", C.c_int32), ("resort_steps", C.c_int32),
                 ("grid_lo", C.c_int32 * 3), ("grid_hi", C.c_int32 * 3), ("particle_capacity", C.c_int32),
-                ("deterministic", C.c_int32)]
+                ("deterministic", C.c_int32), ("contact_min_adjoint", C.c_int32), ("minmax_tie", C.c_int32)]
 
 
 class Primitive(C.Structure):

@@ -102,10 +102,10 @@ template <class T> PLB_HD void capsule_normal(const T* par, const T* p, T* n) { 
     n[0] = p[0] * inv; n[1] = y * inv; n[2] = p[2] * inv;
 }
 // reverse mode of (capsule_sdf, capsule_normal) w.r.t. p; min/max follow Taichi's adjoint routing
-template <class T> PLB_HD void capsule_adj(const T* par, const T* p, T da, const T* na, T* pa) {
+template <class T> PLB_HD void capsule_adj(const T* par, const T* p, T da, const T* na, T* pa, int tf = 0) {
     T t = p[1] + par[0] / T(2);
     T mx = t_max(t, T(0));                          // max(t, 0): adjoint to t iff 0 < t
-    T dcl = (T(0) < t && mx < par[0]) ? T(1) : T(0);   // min(mx, h): adjoint to mx iff mx < h
+    T dcl = (max_to_lhs(t, T(0), tf) && min_to_lhs(mx, par[0], tf)) ? T(1) : T(0);   // min(mx, h): adjoint to mx iff mx < h
     T cl = t_min(mx, par[0]);
     T y = t - cl, dy = T(1) - dcl;                  // y' and dy'/dy
     T L = len14(p[0], y, p[2]);
@@ -194,17 +194,17 @@ template <class T> PLB_HD void shape_normal_local(int shape, const T* par, const
 
 // gradient of the Box distance (primitives.py:232-238) w.r.t. p, with Taichi's max/min adjoint routing:
 // g += scale * d sdf / d p
-template <class T> PLB_HD void box_sdf_grad(const T* par, const T* p, T scale, T* g) {
+template <class T> PLB_HD void box_sdf_grad(const T* par, const T* p, T scale, T* g, int tf = 0) {
     T q[3] = {t_abs(p[0]) - par[0], t_abs(p[1]) - par[1], t_abs(p[2]) - par[2]};
     T e[3] = {t_max(q[0], T(0)), t_max(q[1], T(0)), t_max(q[2], T(0))};
     T Le = len14(e[0], e[1], e[2]);
     T qa[3];
-    for (int i = 0; i < 3; ++i) qa[i] = (T(0) < q[i]) ? scale * e[i] / Le : T(0);     // max(q_i, 0): to q_i iff 0 < q_i
+    for (int i = 0; i < 3; ++i) qa[i] = max_to_lhs(q[i], T(0), tf) ? scale * e[i] / Le : T(0);     // max(q_i, 0): to q_i iff 0 < q_i
     T mm = t_max(q[1], q[2]);                        // max(q1, q2): to q1 iff q2 < q1, else to q2
     T m3 = t_max(q[0], mm);                          // max(q0, mm): to q0 iff mm < q0, else to mm
-    if (m3 < T(0)) {                                 // min(m3, 0): to m3 iff m3 < 0
-        if (mm < q[0]) qa[0] += scale;
-        else if (q[2] < q[1]) qa[1] += scale;
+    if (min_to_lhs(m3, T(0), tf)) {                  // min(m3, 0): to m3 iff m3 < 0
+        if (max_to_lhs(q[0], mm, tf)) qa[0] += scale;
+        else if (max_to_lhs(q[1], q[2], tf)) qa[1] += scale;
         else qa[2] += scale;
     }
     for (int i = 0; i < 3; ++i) g[i] += qa[i] * (p[i] > T(0) ? T(1) : (p[i] < T(0) ? T(-1) : T(0)));
@@ -216,7 +216,7 @@ template <class T> PLB_HD void box_sdf_grad(const T* par, const T* p, T scale, T
 // adjoint routing.  Returns false for shapes without a derived adjoint.  `ga` (Chopsticks only)
 // accumulates the adjoint of the gap par[2].
 template <class T> PLB_HD bool shape_local_adj(int shape, const T* par, const T* p, T da, const T* na, T* pa,
-                                               double* ga = nullptr) {
+                                               double* ga = nullptr, int tf = 0) {
     switch (shape) {
     case SHAPE_CHOPSTICKS: {
         // sdf = ti.min(a, b): adjoint to a iff a < b, else to b.  normal: m = (a <= b) carries no gradient and
@@ -225,15 +225,15 @@ template <class T> PLB_HD bool shape_local_adj(int shape, const T* par, const T*
         T qb[3] = {p[0] + par[2] / T(2), qa[1], p[2]};
         T a = capsule_sdf(par, qa), b = capsule_sdf(par, qb);
         const T zero3[3] = {T(0), T(0), T(0)};
-        const bool sdf_a = a < b, nrm_a = a <= b;
+        const bool sdf_a = min_to_lhs(a, b, tf), nrm_a = a <= b;
         T ga_[3] = {T(0), T(0), T(0)}, gb_[3] = {T(0), T(0), T(0)};
-        capsule_adj(par, qa, sdf_a ? da : T(0), nrm_a ? na : zero3, ga_);
-        capsule_adj(par, qb, sdf_a ? T(0) : da, nrm_a ? zero3 : na, gb_);
+        capsule_adj(par, qa, sdf_a ? da : T(0), nrm_a ? na : zero3, ga_, tf);
+        capsule_adj(par, qb, sdf_a ? T(0) : da, nrm_a ? zero3 : na, gb_, tf);
         for (int i = 0; i < 3; ++i) pa[i] += ga_[i] + gb_[i];
         if (ga) *ga += (double)((gb_[0] - ga_[0]) / T(2));
         return true;
     }
-    case SHAPE_CAPSULE: capsule_adj(par, p, da, na, pa); return true;
+    case SHAPE_CAPSULE: capsule_adj(par, p, da, na, pa, tf); return true;
     case SHAPE_TORUS: {
         T l = len14(p[0], p[2]);
         T q0 = l - par[0], q1 = p[1];
@@ -282,15 +282,15 @@ template <class T> PLB_HD bool shape_local_adj(int shape, const T* par, const T*
         const T n20a = ua[0] * x20 + ua[2] * x21, n21a = ua[1] * sgn;
         const T n2d = n20 * n20a + n21 * n21a;
         const T m0a = (n20a - n20 * n2d) / L2, m1a = (n21a - n21 * n2d) / L2;
-        T d0a = (T(0) < d0) ? m0a : T(0), d1a = (T(0) < d1) ? m1a : T(0);           // max(d, 0): to d iff 0 < d
+        T d0a = max_to_lhs(d0, T(0), tf) ? m0a : T(0), d1a = max_to_lhs(d1, T(0), tf) ? m1a : T(0);           // max(d, 0): to d iff 0 < d
         T xa = x20a / l, za = x21a / l;
         T la = -(x20a * p[0] + x21a * p[2]) / (l * l);
         // ---- distance: min(max(d0, d1), 0) + len14(max(d0, 0), max(d1, 0))
         const T e0 = t_max(d0, T(0)), e1 = t_max(d1, T(0));
         const T Le = len14(e0, e1);
-        if (T(0) < d0) d0a += da * e0 / Le;
-        if (T(0) < d1) d1a += da * e1 / Le;
-        if (t_max(d0, d1) < T(0)) { if (d1 < d0) d0a += da; else d1a += da; }       // min(mx, 0), max(d0, d1)
+        if (max_to_lhs(d0, T(0), tf)) d0a += da * e0 / Le;
+        if (max_to_lhs(d1, T(0), tf)) d1a += da * e1 / Le;
+        if (min_to_lhs(t_max(d0, d1), T(0), tf)) { if (max_to_lhs(d0, d1, tf)) d0a += da; else d1a += da; }       // min(mx, 0), max(d0, d1)
         la += d0a;                                        // d0 = |l| - h, l > 0
         xa += la * p[0] / l; za += la * p[2] / l;
         pa[0] += xa; pa[2] += za;
@@ -312,10 +312,10 @@ template <class T> PLB_HD bool shape_local_adj(int shape, const T* par, const T*
             const T gia = (na[i] - n[i] * nd) / Lg * (T(0.5) / d);
             for (int k = 0; k < 3; ++k) { pp[k] = p[k]; pm[k] = p[k]; }
             pp[i] += d; pm[i] -= d;
-            box_sdf_grad(par, pp, gia, pa);
-            box_sdf_grad(par, pm, -gia, pa);
+            box_sdf_grad(par, pp, gia, pa, tf);
+            box_sdf_grad(par, pm, -gia, pa, tf);
         }
-        box_sdf_grad(par, p, da, pa);
+        box_sdf_grad(par, p, da, pa, tf);
         return true;
     }
     default: return false;
@@ -345,7 +345,7 @@ template <class T> PLB_HD void prim_normal(const PrimT<T>& pr, const double* gp,
 
 // ------------------------------------------------------------------ collide (primive_base.py:82-115)
 template <class T> struct CollideTmp {
-    T infl, D[3], cv[3], iv[3], nc, gvt[3], gn, e, flag;
+    T infl, ex, D[3], cv[3], iv[3], nc, gvt[3], gn, e, flag;
     double dist, rel[3], iq[4];
 };
 
@@ -383,6 +383,7 @@ template <class T> PLB_HD bool collide_eval(const PrimT<T>& pr, T softness, T dt
     if (!prim_within_reach(pr, softness, gp)) return false;
     c.dist = prim_sdf(pr, gp);
     T ex = t_exp((T)(-c.dist * (double)softness));
+    c.ex = ex;
     c.infl = ex < T(1) ? ex : T(1);
     if (!((softness > T(0) && c.infl > T(0.1)) || c.dist <= 0.0)) return false;
     double Dd[3], np[3];
@@ -415,21 +416,21 @@ template <class T> PLB_HD bool collide_eval(const PrimT<T>& pr, T softness, T dt
 // Writes v_a; accumulates pose adjoints into pa (only for movable Spheres -- other movable
 // shapes need d sdf/d pose, d normal/d pose, which are not derived yet).
 template <class T> PLB_HD void collide_grad_from(const PrimT<T>& pr, T softness, T dt, const double* gp,
-                                                 const CollideTmp<T>& c, const T* vn_a, T* v_a, PoseAdj<T>* pa);
+                                                 const CollideTmp<T>& c, const T* vn_a, T* v_a, PoseAdj<T>* pa, int tf = 0);
 template <class T> PLB_HD bool collide_grad(const PrimT<T>& pr, T softness, T dt, const double* gp, const T* v,
-                                            const T* vn_a, T* v_a, PoseAdj<T>* pa) {
+                                            const T* vn_a, T* v_a, PoseAdj<T>* pa, int tf = 0) {
     CollideTmp<T> c;
     T vnew[3];
     if (!collide_eval(pr, softness, dt, gp, v, c, vnew)) {
         for (int i = 0; i < 3; ++i) v_a[i] = vn_a[i];
         return false;
     }
-    collide_grad_from(pr, softness, dt, gp, c, vn_a, v_a, pa);
+    collide_grad_from(pr, softness, dt, gp, c, vn_a, v_a, pa, tf);
     return true;
 }
 // the adjoint proper, from the intermediates `c` of a collide_eval that hit
 template <class T> PLB_HD void collide_grad_from(const PrimT<T>& pr, T softness, T dt, const double* gp,
-                                                 const CollideTmp<T>& c, const T* vn_a, T* v_a, PoseAdj<T>* pa) {
+                                                 const CollideTmp<T>& c, const T* vn_a, T* v_a, PoseAdj<T>* pa, int tf) {
     T m = c.e < T(0) ? T(0) : c.e;
     T cva[3], iva[3], g2a[3], gvta[3], Da[3] = {T(0), T(0), T(0)};
     T infla = T(0);
@@ -450,7 +451,7 @@ template <class T> PLB_HD void collide_grad_from(const PrimT<T>& pr, T softness,
     }
     T gna = -fra_dot_gvt * m / (c.gn * c.gn);
     T ma = fra_dot_gvt / c.gn;
-    T ea = c.e < T(0) ? T(0) : ma;            // max(0, e): adjoint to e unless e < 0
+    T ea = max_to_lhs(T(0), c.e, tf) ? T(0) : ma;            // max(0, e): e is the second operand -- it gets the adjoint unless 0 wins
     gna += ea;
     T nca = pr.friction * ea;
     for (int i = 0; i < 3; ++i) gvta[i] += gna * c.gvt[i] / c.gn;
@@ -458,14 +459,14 @@ template <class T> PLB_HD void collide_grad_from(const PrimT<T>& pr, T softness,
     T mn = c.nc < T(0) ? c.nc : T(0);
     T mna = T(0);
     for (int i = 0; i < 3; ++i) { iva[i] += gvta[i]; mna -= gvta[i] * c.D[i]; Da[i] -= mn * gvta[i]; }
-    if (c.nc < T(0)) nca += mna;
+    if (min_to_lhs(c.nc, T(0), tf)) nca += mna;              // min(nc, 0)
     for (int i = 0; i < 3; ++i) { iva[i] += nca * c.D[i]; Da[i] += nca * c.iv[i]; }
     for (int i = 0; i < 3; ++i) { v_a[i] = iva[i]; cva[i] -= iva[i]; }
     if (!pa || !pr.movable) return;
     // ---- pose adjoints
     // influence = min(exp(-dist*soft), 1): adjoint to the exp iff exp < 1
     double dista = 0.0;
-    if (c.infl < T(1)) dista = -(double)softness * (double)c.infl * (double)infla;     // infl = exp(..) when < 1
+    if (min_to_lhs(c.ex, T(1), tf)) dista = -(double)softness * (double)c.infl * (double)infla;     // infl = min(exp(..), 1)
     // collider velocity
     const double inv_dt = 1.0 / (double)dt;
     double npa[3] = {(double)cva[0] * inv_dt, (double)cva[1] * inv_dt, (double)cva[2] * inv_dt};
@@ -494,7 +495,7 @@ template <class T> PLB_HD void collide_grad_from(const PrimT<T>& pr, T softness,
         qrot_adj_q(pr.rot, nl, Dad, pa->rot);            // d D / d rot (direct)
         qconj(pr.rot, cr);
         qrot(cr, Dad, nla);                              // adjoint of n_local (qrot is linear in its vector argument)
-        shape_local_adj(pr.shape, pr.par, c.rel, dista, nla, loca, &pa->gap);
+        shape_local_adj(pr.shape, pr.par, c.rel, dista, nla, loca, &pa->gap, tf);
         inv_trans_adj(gp, pr.pos, pr.rot, c.iq, loca, pa->pos, pa->rot);
     }
 }
@@ -535,7 +536,7 @@ template <class T> PLB_HD void boundary_axis_grad(const SimP<T>& P, const int* I
     else if (mode == 2) {
         T sa = a[0] * vb[0] + a[2] * vb[2];
         T ax = s * a[0], az = s * a[2];
-        T ea = (T(0) < e) ? sa : T(0);            // max(e, 0): adjoint to e iff 0 < e
+        T ea = max_to_lhs(e, T(0), P.tie_first) ? sa : T(0);            // max(e, 0): adjoint to e iff 0 < e
         T lina = P.ground_friction * ea / lit;
         T lita = -P.ground_friction * vb[1] * ea / (lit * lit);
         ax += lita * vb[0] / lit;
@@ -634,7 +635,7 @@ PLB_HD void grid_node_bwd(const SimP<T>& P, const int* I, T m, const T* mv, int 
         }
         if (hit) {
             T va[3];
-            collide_grad_from(prims[p], P.softness, P.dt, gp, c, a, va, POSE ? &pa : nullptr);
+            collide_grad_from(prims[p], P.softness, P.dt, gp, c, a, va, POSE ? &pa : nullptr, P.tie_first);
             a[0] = va[0]; a[1] = va[1]; a[2] = va[2];
         }
         sink(p, pa, hit && prims[p].movable);
@@ -713,12 +714,12 @@ PLB_HD void w2quat_adj_d(const double* a, const double* qa, double* a_a) {
 // adjoint: pos1_a, rot1_a in; accumulates pos_a, rot_a (pose at f); writes v_a, w_a (overwrite)
 PLB_HD void fk_bwd_d(const double* pos, const double* rot, const double* v, const double* w,
                      const double* lo, const double* hi, const double* pos1_a, const double* rot1_a,
-                     double* pos_a, double* rot_a, double* v_a, double* w_a) {
+                     double* pos_a, double* rot_a, double* v_a, double* w_a, int tf = 0) {
     for (int i = 0; i < 3; ++i) {
         double y = pos[i] + v[i];
         double mn = y < hi[i] ? y : hi[i];
         // max(min(y,hi),lo): to y iff y < hi and lo < min
-        double gate = (y < hi[i] && lo[i] < mn) ? 1.0 : 0.0;
+        double gate = (min_to_lhs(y, hi[i], tf) && max_to_lhs(mn, lo[i], tf)) ? 1.0 : 0.0;
         pos_a[i] += gate * pos1_a[i];
         v_a[i] = gate * pos1_a[i];
     }
@@ -748,15 +749,15 @@ PLB_HD void fk_chopsticks_fwd_d(const double* pos, const double* rot, const doub
 PLB_HD void fk_chopsticks_bwd_d(const double* pos, const double* rot, const double* v, const double* w, double gap,
                                 double gap_vel, double min_gap, const double* lo, const double* hi,
                                 const double* pos1_a, const double* rot1_a, double gap1_a, double* pos_a,
-                                double* rot_a, double* gap_a, double* v_a, double* w_a, double* gap_vel_a) {
+                                double* rot_a, double* gap_a, double* v_a, double* w_a, double* gap_vel_a, int tf = 0) {
     for (int i = 0; i < 3; ++i) {
         double y = pos[i] + v[i];
         double mn = y < hi[i] ? y : hi[i];
-        double gate = (y < hi[i] && lo[i] < mn) ? 1.0 : 0.0;
+        double gate = (min_to_lhs(y, hi[i], tf) && max_to_lhs(mn, lo[i], tf)) ? 1.0 : 0.0;
         pos_a[i] += gate * pos1_a[i];
         v_a[i] = gate * pos1_a[i];
     }
-    double ggate = (min_gap < gap - gap_vel) ? 1.0 : 0.0;      // max(lhs, rhs): adjoint to lhs iff rhs < lhs
+    double ggate = max_to_lhs(gap - gap_vel, min_gap, tf) ? 1.0 : 0.0;      // max(lhs, rhs): adjoint to lhs iff rhs < lhs
     *gap_a += ggate * gap1_a;
     *gap_vel_a = -ggate * gap1_a;
     double q[4], qa[4] = {0, 0, 0, 0};
@@ -787,7 +788,7 @@ PLB_HD void fk_rollingpin_fwd_d(const double* pos, const double* rot, const doub
 }
 PLB_HD void fk_rollingpin_bwd_d(const double* pos, const double* rot, const double* v, const double* lo,
                                 const double* hi, const double* pos1_a, const double* rot1_a,
-                                double* pos_a, double* rot_a, double* v_a) {
+                                double* pos_a, double* rot_a, double* v_a, int tf = 0) {
     const double dw = v[0], dth = v[1], dy = v[2];
     const double e[3] = {0.0, -1.0, 0.0};
     double yd[3];
@@ -797,7 +798,7 @@ PLB_HD void fk_rollingpin_bwd_d(const double* pos, const double* rot, const doub
     for (int i = 0; i < 3; ++i) {
         double y = pos[i] + xd[i];
         double mn = y < hi[i] ? y : hi[i];
-        double gate = (y < hi[i] && lo[i] < mn) ? 1.0 : 0.0;
+        double gate = (min_to_lhs(y, hi[i], tf) && max_to_lhs(mn, lo[i], tf)) ? 1.0 : 0.0;
         pos_a[i] += gate * pos1_a[i];
         xda[i] = gate * pos1_a[i];
     }

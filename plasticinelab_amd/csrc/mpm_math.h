@@ -283,7 +283,15 @@ template <class T> struct SimP {
     T ground_friction;  //                                        (:204-217)
     T svd_clamp;        // 1e-6 reproduces backward_svd's clamp; 0 = exact derivative
     T softness;         // Primitive.softness                     (primive_base.py:29)
+    int tie_first;      // adjoint routing of max / min on exact ties (plmpm_config.minmax_tie): 0 second operand, 1 first
 };
+
+// Adjoint routing of Taichi's max(lhs, rhs) / min(lhs, rhs): the adjoint goes to ONE operand.  tie_first = 0: to lhs iff
+// it is strictly the winner, ties to rhs (what Taichi 0.7.x's auto_diff.cpp is remembered to do -- unverified);
+// tie_first = 1: ties to lhs.  Every max / min on the differentiated path routes through these two, so that a
+// Taichi-generated golden vector that disagrees costs a flag (plmpm_config.minmax_tie), not a rewrite.
+template <class A> PLB_HD auto max_to_lhs(A lhs, A rhs, int tie_first) -> decltype(lhs < rhs) { return tie_first ? !(lhs < rhs) : (rhs < lhs); }
+template <class A> PLB_HD auto min_to_lhs(A lhs, A rhs, int tie_first) -> decltype(lhs < rhs) { return tie_first ? !(rhs < lhs) : (lhs < rhs); }
 
 // ---------------------------------------------------------------- quadratic B-spline stencil
 // base = trunc(x*inv_dx - 0.5) (Taichi cast(int) truncates); fx = x*inv_dx - base;
@@ -423,12 +431,12 @@ template <class T> struct Consti {
 };
 
 // Et = F_tmp - I.  Outputs: En = new_F - I (what is stored as F[f+1]), stress (unscaled).
-template <class T> PLB_HD void constitutive_fwd(const T* Et, T mu, T lam, T ys, Consti<T>& k, T* En, T* stress) {
+template <class T> PLB_HD void constitutive_fwd(const T* Et, T mu, T lam, T ys, Consti<T>& k, T* En, T* stress, int tie_first = 0) {
     svd_eform(Et, k.svd);
     const Svd3<T>& S = k.svd;
     T mean = T(0);
     for (int i = 0; i < 3; ++i) {
-        k.unc[i] = T(0.05) < S.sig[i];          // ti.max(sig, 0.05): adjoint to sig iff 0.05 < sig
+        k.unc[i] = max_to_lhs(S.sig[i], T(0.05), tie_first);          // ti.max(sig, 0.05): adjoint to sig iff 0.05 < sig (ties: Q10)
         k.eps[i] = sel(k.unc[i], t_log1p_fast(S.s[i]), T(-2.995732273553991));     // log(0.05)
         mean += k.eps[i];
     }
@@ -597,7 +605,7 @@ PLB_HD void p2g_particle(const SimP<typename Lane<T>::scalar>& P, const X* x, co
     T Et[9], stress[9], A[9];
     f_tmp_eform(C, E, P.dt, Et);
     Consti<T> k;
-    constitutive_fwd(Et, mu, lam, ys, k, En, stress);
+    constitutive_fwd(Et, mu, lam, ys, k, En, stress, P.tie_first);
     for (int i = 0; i < 9; ++i) A[i] = P.kappa * stress[i] + P.p_mass * C[i];
     // momentum per unit weight at stencil offset o is affine in o:  q(o) = m v + A (o - fx) dx
     //   = q0 + o_x ax + o_y ay + o_z az,   q0 = m v - A fx dx,  a_d = A[:,d] dx   (3 adds per node instead of a mat-vec)
@@ -698,7 +706,7 @@ PLB_HD void g2p_particle_grad(const SimP<typename Lane<T>::scalar>& P, const X* 
         X y = x[d] + cvt<X>(P.dt) * cvt<X>(vn[d]);
         X hi = X(1) - X(3) / cvt<X>(P.n);
         // max(min(y, hi), 0): adjoint reaches y iff y < hi and 0 < min(y,hi)   (Taichi min/max rule)
-        T gate = sel((y < hi) && (X(0) < t_min(y, hi)), T(1), T(0));
+        T gate = sel(min_to_lhs(y, hi, P.tie_first) && max_to_lhs(t_min(y, hi), X(0), P.tie_first), T(1), T(0));
         xa[d] = gate * xn_a[d];
         nva[d] = vn_a[d] + P.dt * gate * xn_a[d];
     }
@@ -839,7 +847,7 @@ PLB_HD void p2g_finish_grad(const SimP<typename Lane<T>::scalar>& P, const P2GGa
     T Et[9], En[9], stress[9], A[9];
     f_tmp_eform(C, E, P.dt, Et);
     Consti<T> k;
-    constitutive_fwd(Et, mu, lam, ys, k, En, stress);
+    constitutive_fwd(Et, mu, lam, ys, k, En, stress, P.tie_first);
     for (int i = 0; i < 9; ++i) A[i] = P.kappa * stress[i] + P.p_mass * C[i];
     const T* M = G.M;
     const T* Aa = G.Aa;

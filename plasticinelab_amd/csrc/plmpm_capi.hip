@@ -237,6 +237,7 @@ template <class T> static Dev<T> make_dev(const plmpm_sim* s, int frame = -1, bo
     D.P.ground_friction = (T)c.ground_friction;
     D.P.svd_clamp = (T)c.svd_grad_clamp;
     D.P.softness = (T)s->softness;
+    D.P.tie_first = c.minmax_tie != 0;
     const int epoch = frame >= 0 ? s->frame_epoch[frame] : 0;
     D.N = frame >= 0 ? s->epochN[epoch] : s->N; D.Npad = s->Npad; D.nprim = s->P;
     D.twg = s->Npad / kBlock;
@@ -364,6 +365,7 @@ __global__ void k_merge_pose_adj(double* g, double* l, size_t n) {
 
 struct PrimChainArgs {
     int P;
+    int tie_first;                   // plmpm_config.minmax_tie (adjoint routing of the clamps)
     int action_dim[kMaxPrim];
     int kin[kMaxPrim];
     double scale[kMaxPrim][PLMPM_MAX_ACTION_DIM];
@@ -498,14 +500,14 @@ __global__ __launch_bounds__(kChainThreads) void k_fk_chain_grad(PrimChainArgs A
         double va[3], wa[3] = {0.0, 0.0, 0.0}, pa[3] = {own_p[0], own_p[1], own_p[2]}, ra[4] = {own_r[0], own_r[1], own_r[2], own_r[3]}, ga = own_g;
         if (A.kin[p] == PLMPM_KIN_CHOPSTICKS) {
             double gva = 0.0;
-            fk_chopsticks_bwd_d(pos, rot, v, w, gap, gv, A.min_gap[p], A.lo[p], A.hi[p], pos1_a, rot1_a, gap1_a, pa, ra, &ga, va, wa, &gva);
+            fk_chopsticks_bwd_d(pos, rot, v, w, gap, gv, A.min_gap[p], A.lo[p], A.hi[p], pos1_a, rot1_a, gap1_a, pa, ra, &ga, va, wa, &gva, A.tie_first);
             B.pgv_a[a] = gva;
             B.pgap_a[a] = ga;
             ga_sum += gva;
         } else if (A.kin[p] == PLMPM_KIN_ROLLINGPIN)
-            fk_rollingpin_bwd_d(pos, rot, v, A.lo[p], A.hi[p], pos1_a, rot1_a, pa, ra, va);
+            fk_rollingpin_bwd_d(pos, rot, v, A.lo[p], A.hi[p], pos1_a, rot1_a, pa, ra, va, A.tie_first);
         else
-            fk_bwd_d(pos, rot, v, w, A.lo[p], A.hi[p], pos1_a, rot1_a, pa, ra, va, wa);
+            fk_bwd_d(pos, rot, v, w, A.lo[p], A.hi[p], pos1_a, rot1_a, pa, ra, va, wa, A.tie_first);
         for (int k = 0; k < 3; ++k) {
             B.pv_a[a * 3 + k] = va[k]; B.pw_a[a * 3 + k] = wa[k]; va_sum[k] += va[k]; wa_sum[k] += wa[k];
             B.ppos_a[a * 3 + k] = pa[k]; pos1_a[k] = pa[k];
@@ -618,7 +620,7 @@ template <class T> __global__ void k_contact(Dev<T> D, int f, int mode, double* 
 // compute_loss_kernel_grad (loss.py:210-237) per particle: density + sdf through grid_m, contact through sdf.
 template <class T>
 __global__ void k_loss_grad(Dev<T> D, int f, int which, const T* gm, const T* td, const T* ts, const double* ls,
-                            double w_sdf, double w_density, double w_contact, int soft, long long* dl) {
+                            double w_sdf, double w_density, double w_contact, int soft, long long* dl, int argmin) {
     __shared__ double sacc[kMaxPrim * 8];
     __shared__ long long sdet[kMaxPrim * 8 * 2];          // deterministic mode: integer limbs instead of sacc
     if (threadIdx.x < kMaxPrim * 8) { sacc[threadIdx.x] = 0.0; sdet[2 * threadIdx.x] = 0; sdet[2 * threadIdx.x + 1] = 0; }
@@ -648,10 +650,13 @@ __global__ void k_loss_grad(Dev<T> D, int f, int which, const T* gm, const T* td
             if (!D.prim[q].movable) continue;
             PrimT<T> pr = prim_at(D, q, f);
             double sd = prim_sdf(pr, x);
-            if (!(0.0 < sd)) continue;                      // max(sdf, 0): adjoint to sdf iff 0 < sdf
+            if (!max_to_lhs(sd, 0.0, D.P.tie_first)) continue;          // max(sdf, 0): adjoint to sdf iff 0 < sdf
             double md = ls[LS_MIND + q];
             double coef;
-            if (!soft) coef = w_contact * 2.0 * md;         // atomic_min differentiated as add (Taichi 0.7.x)
+            // hard contact, ti.atomic_min(min_dist, d) (loss.py:123-128): differentiated as an add by Taichi 0.7.x as far as
+            // it is known (unverified) -- every particle gets min_dist's adjoint; plmpm_config.contact_min_adjoint
+            // = 1 sends it to the particle(s) that attain the minimum instead (the mathematical derivative)
+            if (!soft) { if (argmin && fmax(sd, 0.0) != md) continue; coef = w_contact * 2.0 * md; }
             else {
                 double dn = ls[LS_DNORM + q];
                 double den = 1.0 + sd * sd * 10000.0;
@@ -774,6 +779,7 @@ static PrimChainArgs chain_args(const plmpm_sim* s) {
     PrimChainArgs A;
     memset(&A, 0, sizeof A);
     A.P = s->P;
+    A.tie_first = s->cfg.minmax_tie != 0;
     for (int p = 0; p < s->P; ++p) {
         A.action_dim[p] = s->prims[p].action_dim;
         A.kin[p] = s->prims[p].kinematics;
@@ -1226,7 +1232,8 @@ template <class T> static int loss_reduce_t(plmpm_sim* s) {
 template <class T> static int loss_grad_t(plmpm_sim* s, int f) {
     Dev<T> D = make_dev<T>(s, f);
     hipLaunchKernelGGL((k_loss_grad<T>), dim3(s->Npad / 256), dim3(256), 0, s->stream, D, f, f & 1, (const T*)s->loss_gm,
-                       (const T*)s->loss_td, (const T*)s->loss_ts, s->lscal, s->w_sdf, s->w_density, s->w_contact, s->soft_contact, s->det_small);
+                       (const T*)s->loss_td, (const T*)s->loss_ts, s->lscal, s->w_sdf, s->w_density, s->w_contact, s->soft_contact, s->det_small,
+                       s->cfg.contact_min_adjoint);
     if (s->det) hipLaunchKernelGGL((k_det_small_resolve<T>), dim3(1), dim3(128), 0, s->stream, D, f, s->det_small, s->lscal);
     return 0;
 }

@@ -35,7 +35,7 @@ class Engine:
                  dtype: str = "float32", svd_grad_clamp: float = 1e-6, device: Optional[torch.device] = None,
                  slab: Optional[Sequence[int]] = None, store_grid="auto", slab_halo: int = 0, resort_steps: int = 2,
                  grid_window: Optional[Sequence[Sequence[int]]] = None, particle_capacity: Optional[int] = None,
-                 allocate: bool = True, deterministic: bool = False):
+                 allocate: bool = True, deterministic: bool = False, contact_min_adjoint: str = "add", minmax_tie: str = "second"):
         self.lib = L.load()
         if not torch.cuda.is_available():
             raise L.EngineError("no ROCm device visible: the MPM engine has no CPU path")
@@ -72,6 +72,9 @@ class Engine:
         self.store_grid = bool(store_grid)
         # bit-reproducible runs: integer-limb accumulation instead of floating-point atomics (include/plmpm.h)
         cfg.deterministic = int(bool(deterministic))
+        # unverified Taichi autodiff semantics as switches (include/plmpm.h)
+        cfg.contact_min_adjoint = {"add": 0, "argmin": 1}[contact_min_adjoint]
+        cfg.minmax_tie = {"second": 0, "first": 1}[minmax_tie]
         self.deterministic = bool(deterministic)
         parr = (L.Primitive * max(len(primitives), 1))()
         self.action_dims = []

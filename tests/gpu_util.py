@@ -8,13 +8,13 @@ from tests import emul
 from tests.util import O
 
 
-def engine_for(sim, prims, dtype="float64", max_frames=64, svd_grad_clamp=1e-6):
+def engine_for(sim, prims, dtype="float64", max_frames=64, svd_grad_clamp=1e-6, **engine_kw):
     from plasticinelab_amd.engine.core import Engine
     plist = [dict(shape=p.shape, action_dim=p.action_dim, params=emul.prim_par(p), friction=p.friction,
                   action_scale=p.action_scale, lower_bound=p.lower_bound, upper_bound=p.upper_bound) for p in prims]
     return Engine(n_grid=sim.n_grid, n_particles=sim.n_particles, max_frames=max_frames, substeps=sim.substeps,
                   dt=sim.dt, p_vol=sim.p_vol, p_mass=sim.p_mass, gravity=sim.gravity,
-                  ground_friction=sim.ground_friction, primitives=plist, dtype=dtype, svd_grad_clamp=svd_grad_clamp)
+                  ground_friction=sim.ground_friction, primitives=plist, dtype=dtype, svd_grad_clamp=svd_grad_clamp, **engine_kw)
 
 
 def preroll(sim, prims, x0, actions, softness=666.0):

@@ -30,6 +30,7 @@ template <class T> static SimP<T> make_simp(const emul_cfg& c) {
     for (int i = 0; i < 3; ++i) P.grav[i] = (T)(c.dt * c.gravity[i] * 30);
     P.x_hi = (T)(1.0 - 3 * dx);
     P.ground_friction = (T)c.ground_friction; P.svd_clamp = (T)c.svd_clamp; P.softness = (T)c.softness;
+    P.tie_first = 0;
     return P;
 }
 template <class T> static std::vector<PrimT<T>> make_prims(const emul_cfg& c, const emul_prim* p) {

@@ -12,7 +12,7 @@ using namespace plb;
 // host check: the P2 instantiation must equal two scalar float evaluations bit for bit
 static float rnd() { return (float)rand() / RAND_MAX * 2 - 1; }
 int main() {
-    SimP<float> P; P.n = 64; P.dx = 1.f/64; P.inv_dx = 64; P.dt = 1e-4f; P.p_mass = 1e-4f; P.kappa = -1e-4f*1e-6f*4*64*64; P.grav[0]=0;P.grav[1]=-3e-2f;P.grav[2]=0; P.x_hi = 1-3.f/64; P.ground_friction=0; P.svd_clamp=1e-6f; P.softness=666;
+    SimP<float> P; P.n = 64; P.dx = 1.f/64; P.inv_dx = 64; P.dt = 1e-4f; P.p_mass = 1e-4f; P.kappa = -1e-4f*1e-6f*4*64*64; P.grav[0]=0;P.grav[1]=-3e-2f;P.grav[2]=0; P.x_hi = 1-3.f/64; P.ground_friction=0; P.svd_clamp=1e-6f; P.softness=666; P.tie_first=0;
     int bad = 0;
     for (int it = 0; it < 20000; ++it) {
         double x[2][3]; float v[2][3], C[2][9], E[2][9], mu[2], lam[2], ys[2];
