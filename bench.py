@@ -87,6 +87,26 @@ def workload_cfg(n_particles=500_000, quality=2, max_steps=1024, yield_stress=20
     return cfg
 
 
+def scene_cfg(name, n_particles=500_000, quality=2, max_steps=1024):
+    """BASELINE configs[2] as it names the scenes: the reference's TripleMove-v1 (three boxes, six Sphere manipulators,
+    plb/envs/triplemove.yml:3-64) or Rope-v1 (one bar, two Spheres + a static Cylinder, ground_friction 0.3,
+    plb/envs/rope.yml:1-32) geometry on the 128^3 grid with the particle count raised to ~n_particles (split evenly over
+    the scene's shapes; the reference samples 10k per shape)."""
+    from plasticinelab_amd.envs.scenes import load_scene
+    cfg = load_scene(name, 1)
+    shapes = [dict(sh) for sh in cfg.SHAPES]
+    per = -(-n_particles // len(shapes))
+    for sh in shapes:
+        sh["n_particles"] = per
+    cfg.merge({"SIMULATOR": {"quality": quality, "max_steps": max_steps, "n_particles": per * len(shapes)}, "SHAPES": shapes}, strict=True)
+    cfg.ENV.loss.target_path = ""
+    cfg["VARIANTS"] = None
+    return cfg
+
+
+WORKLOADS = {"config3_cube128": None, "triplemove128": "TripleMove", "rope128": "Rope"}
+
+
 def mass_grid(x, n, p_mass):
     """host copy of compute_grid_m_kernel (only used to synthesise the benchmark's own target grid)."""
     xs = x * n
@@ -120,8 +140,12 @@ def build_env(args, device, rank=0, world=1, slabs=False):
     from plasticinelab_amd.engine.taichi_env import TaichiEnv
     sub = int(2e-3 // (0.5e-4 / (args.quality * 0.5)))
     frames = max(args.steps, args.warmup, 1) * sub + 1
-    cfg = workload_cfg(args.particles, args.quality, max_steps=frames, yield_stress=getattr(args, "yield_stress", 200.0),
-                       side=getattr(args, "side", 0.31))
+    scene = WORKLOADS.get(getattr(args, "workload", "config3_cube128"))
+    if scene is not None:
+        cfg = scene_cfg(scene, args.particles, args.quality, max_steps=frames)
+    else:
+        cfg = workload_cfg(args.particles, args.quality, max_steps=frames, yield_stress=getattr(args, "yield_stress", 200.0),
+                           side=getattr(args, "side", 0.31))
     if getattr(args, "deterministic", False) and not slabs:
         cfg.SIMULATOR["deterministic"] = True
     if slabs:
@@ -222,6 +246,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--dtype", default="float32")
     ap.add_argument("--particles", type=int, default=500_000)
+    ap.add_argument("--workload", default="config3_cube128", choices=sorted(WORKLOADS),
+                    help="config3_cube128: the headline (SURVEY 8d's synthetic cube, two spheres); triplemove128 / rope128: the reference's "
+                         "TripleMove-v1 / Rope-v1 geometry (6 spheres / 2 spheres + static cylinder + ground friction) at 128^3 with ~500k "
+                         "particles -- BASELINE configs[2] as it names the scenes")
     ap.add_argument("--quality", type=float, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -361,10 +389,12 @@ def main():
         "value": value, "unit": "substeps/s", "n_gpus": world,
         "steps": K, "warmup": W, "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True, "scaling": "strong" if (slabs or world == 1) else "weak",
         "vs_baseline": None, "dtype": "f32" if args.dtype == "float32" else "f64", "data": "synthetic",
-        "config": {"workload": ("config3_cube128" if (args.particles, args.quality) == (500_000, 2)
-                                else f"cube{sim.n_grid}_{args.particles}p"), "n_grid": sim.n_grid,
+        "config": {"workload": ((args.workload if (args.particles, args.quality) == (500_000, 2) else f"{args.workload.rstrip('0123456789')}{sim.n_grid}_{args.particles}p")
+                                if args.workload != "config3_cube128" else
+                                ("config3_cube128" if (args.particles, args.quality) == (500_000, 2) else f"cube{sim.n_grid}_{args.particles}p")),
+                   "n_grid": sim.n_grid,
                    "n_particles": args.particles if slabs else sim.n_particles,
-                   "substeps_per_step": sub, "primitives": 2, "positions": "f64", "loss": "sdf+density+hard contact",
+                   "substeps_per_step": sub, "primitives": len(env.primitives), "positions": "f64", "loss": "sdf+density+hard contact",
                    "parallelism": parallelism},
         "final_loss": float(loss),
     }
@@ -424,7 +454,7 @@ def main():
                            "job_alg_MB_per_substep": alg_unit * 1e-6,
                            "job_frac": alg_unit * value / (world * HBM_PEAK_GBS * 1e9),
                            "kernels": kernels}
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and not args.no_cpu_baseline and args.workload == "config3_cube128":      # the C / OpenMP restatement knows Sphere manipulators only
         out["cpu_baseline"] = cpu_baseline(args, env)
     if rank == 0:
         print(json.dumps(out))

@@ -20,6 +20,24 @@ import numpy as np
 from .core import Engine
 
 
+class _FrameField:
+    """`field[f]` -> (N, ...) array of frame f, `field[f, i]` -> one particle's value, `field.to_numpy()` -> frames
+    0 .. cur stacked (what `ti.field.to_numpy()` of the reference's (max_steps, n_particles) fields holds, up to the frames
+    computed so far).  Reads go through plmpm_get_frame (a device -> host copy): for inspection, not for hot loops."""
+
+    def __init__(self, sim, name):
+        self._sim, self._name = sim, name
+
+    def __getitem__(self, key):
+        if isinstance(key, tuple):
+            f, rest = key[0], key[1:]
+            return self._sim.engine.get_frame(int(f), want=(self._name,))[self._name][rest if len(rest) > 1 else rest[0]]
+        return self._sim.engine.get_frame(int(key), want=(self._name,))[self._name]
+
+    def to_numpy(self):
+        return np.stack([self[f] for f in range(self._sim.cur + 1)])
+
+
 class MPMSimulator:
     def __init__(self, cfg, primitives=(), compute_dtype=None, device=None, slab=None, slab_halo=0, grid_window=None,
                  particle_capacity=None):
@@ -122,6 +140,24 @@ class MPMSimulator:
         if self._mats is not None:
             self.engine.set_materials(*self._mats)
         self.cur = 0
+
+    # The reference exposes its particle state as Taichi fields (`sim.x[f, i]`, `sim.v`, `sim.C`, `sim.F`: mpm_simulator.py:35-38)
+    # and a few callers read them as such (losses/loss.py:18-19, the notebook).  Read-only views with the same indexing:
+    @property
+    def x(self):
+        return _FrameField(self, "x")
+
+    @property
+    def v(self):
+        return _FrameField(self, "v")
+
+    @property
+    def C(self):
+        return _FrameField(self, "C")
+
+    @property
+    def F(self):
+        return _FrameField(self, "F")
 
     def get_x(self, f):                                        # :349-352
         return self.engine.get_frame(f, want=("x",))["x"]

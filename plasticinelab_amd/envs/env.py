@@ -79,6 +79,12 @@ class PlasticineEnv(_Base):
         obs = self._get_obs()
         r = loss_info["reward"]
         if np.isnan(obs).any() or np.isnan(r):
+            if np.isnan(r):
+                print("nan in r")
+            import datetime
+            import pickle
+            with open(f"{self.cfg_path}_nan_action_{str(datetime.datetime.now())}", "wb") as f:     # env.py:50-56: the episode's actions, for a replay
+                pickle.dump(self._recorded_actions, f)
             raise Exception("NaN..")
         return obs, r, False, loss_info
 

@@ -284,3 +284,73 @@ def test_config5_workload_full_size():
     assert np.abs(x32 - x64).max() < 1e-7
     assert abs(L32 - L64) / abs(L64) < 1e-4
     assert relerr(g32, g64) < 1e-4
+
+
+@pytest.mark.parametrize("workload", ["triplemove128", "rope128"])
+def test_reference_scene_geometries_full_size(workload):
+    """BASELINE configs[2] as it NAMES the scenes: TripleMove-v1 (three boxes, six Sphere manipulators,
+    plb/envs/triplemove.yml:3-64) and Rope-v1 (a bar, two Spheres, a static Cylinder, ground_friction 0.3,
+    plb/envs/rope.yml:1-32) on the 128^3 grid with ~500k particles (`bench.py --workload ...`).  Same size-independent
+    properties as the synthetic cube: mass = N p_mass; the fp32 engine against the fp64 engine on a two-env-step rollout
+    (78 substeps fwd + bwd): loss and action gradient within the north star's 1e-4; the adjoint against central finite
+    differences along a random action direction.
+
+    The finite differences need contact_min_adjoint = "argmin": in Rope-v1 the manipulators start clear of the bar
+    (min_dist ~ 0.03), and the reference's gradient of the hard contact loss -- ti.atomic_min differentiated as an add
+    (SURVEY Q10), the engine's default -- hands min_dist's adjoint to EVERY particle: d loss / d action ~ -90 where the
+    derivative of the minimum itself is ~2e-5 (measured).  A finite difference sees the latter."""
+    import torch
+    import bench
+
+    class A:
+        particles, quality, steps, warmup = 500_000, 2, 2, 0
+    A.workload = workload
+    orig = bench.scene_cfg
+
+    def argmin_cfg(*a, **k):
+        c = orig(*a, **k)
+        c.SIMULATOR["contact_min_adjoint"] = "argmin"
+        return c
+    bench.scene_cfg = argmin_cfg
+    try:
+        _reference_scene_body(A, workload, bench, torch)
+    finally:
+        bench.scene_cfg = orig
+
+
+def _reference_scene_body(A, workload, bench, torch):
+    out = {}
+    for dtype in ("float64", "float32"):
+        A.dtype = dtype
+        env, _ = bench.build_env(A, torch.device("cuda", 0))
+        sim = env.simulator
+        assert len(env.primitives) == (6 if workload == "triplemove128" else 3) and abs(sim.n_particles - 500_000) <= 3
+        if dtype == "float32":
+            gm = sim.engine.grid_mass(0)
+            assert abs(gm.sum() / (sim.n_particles * sim.p_mass) - 1.0) < 1e-5
+        acts = bench.seeded_actions(2, env.primitives.action_dim)
+        st = env.get_state()["state"]
+        env.set_state(st, 666.0, False)
+        loss = bench.rollout(env, acts)
+        grad = env.primitives.get_grad(2).copy()
+        out[dtype] = (loss, grad)
+        if dtype == "float64":                                      # finite differences, forward only
+            d = np.random.default_rng(1).standard_normal(acts.shape)
+            d /= np.abs(d).max()
+            eps, fl = 1e-5, []
+            for sgn in (1, -1):
+                env.set_state(st, 666.0, False)
+                env.loss.clear_loss()
+                for ai in acts + sgn * eps * d:
+                    env.step(ai)
+                    env.compute_loss()
+                fl.append(env.loss.loss)
+            fd, an = (fl[0] - fl[1]) / (2 * eps), float((grad * d).sum())
+            assert abs(fd) > 0 and abs(an - fd) / abs(fd) < 2e-4, (an, fd)
+        env.simulator.engine.close()
+        del env
+        torch.cuda.empty_cache()
+    (l64, g64), (l32, g32) = out["float64"], out["float32"]
+    print(f"\n[{workload}] loss {l64:.9g}; fp32 vs fp64: loss {abs(l32 - l64) / abs(l64):.2e}, action gradient {relerr(g32, g64):.2e}")
+    assert abs(l32 - l64) / abs(l64) < 1e-4
+    assert relerr(g32, g64) < 1e-4

@@ -52,14 +52,36 @@ def test_gym_episode_matches_oracle(dtype, tol):
     assert abs(r1 - rewards[0]) <= 1e-12 * scale + (0 if dtype == "float64" else 1e-6 * scale)
 
 
-def test_nan_guard_raises():
+def test_nan_guard_raises(tmp_path):
+    """env.py:43-57: NaN in the observation or the reward raises, after the episode's actions were pickled next to the
+    scene file (`<cfg_path>_nan_action_<timestamp>`) for a replay."""
+    import glob
+    import pickle
     env = make_env("float32")
+    env.cfg_path = str(tmp_path / "move.yml")                        # where the dump goes
     env.reset()
+    env.step(np.full(6, 0.25))
     st = env.taichi_env.get_state()
     st["state"][1][7, 1] = np.nan                                    # one particle's velocity
     env.taichi_env.set_state(**st)
     with pytest.raises(Exception, match="NaN"):
         env.step(np.zeros(6))
+    dumps = glob.glob(str(tmp_path / "move.yml_nan_action_*"))
+    assert len(dumps) == 1
+    acts = pickle.load(open(dumps[0], "rb"))
+    assert len(acts) == 2 and np.allclose(acts[0], 0.25) and np.allclose(acts[1], 0.0)
+
+
+def test_simulator_state_fields():
+    """mpm_simulator.py:35-38: x / v / C / F read as fields (`sim.x[f, i]`, `sim.x[f]`, `.to_numpy()`), as loss.py:18-19 and
+    the notebook do."""
+    env = make_env("float64")
+    env.reset()
+    sim = env.taichi_env.simulator
+    x0 = sim.get_x(0)
+    assert np.array_equal(sim.x[0], x0) and np.array_equal(sim.x[0, 5], x0[5]) and sim.x[0, 5, 1] == x0[5, 1]
+    assert sim.v[0].shape == (len(x0), 3) and sim.F[0].shape == (len(x0), 3, 3) and np.allclose(sim.F[0, 3], np.eye(3))
+    assert sim.x.to_numpy().shape == (sim.cur + 1, len(x0), 3)
 
 
 def test_primitive_queries():
