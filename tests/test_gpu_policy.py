@@ -21,7 +21,7 @@ def make_policy(obs_dim, act_dim):
     return net
 
 
-@pytest.mark.parametrize("dtype,ltol,gtol", [("float64", 1e-10, 1e-6), ("float32", 1e-5, 5e-3)])
+@pytest.mark.parametrize("dtype,ltol,gtol", [("float64", 1e-10, 1e-9), ("float32", 1e-5, 1e-4)]      # measured (round 3): 6e-15 / 8e-7)
 def test_policy_gradient_matches_oracle(oracle_c, dtype, ltol, gtol):
     from plasticinelab_amd.engine import taichi_env as te
     from plasticinelab_amd.envs.scenes import load_scene
@@ -71,6 +71,7 @@ def test_policy_gradient_matches_oracle(oracle_c, dtype, ltol, gtol):
     total.backward()
     ref = np.concatenate([p.grad.numpy().reshape(-1) for p in ref_policy.parameters()])
     assert abs(loss - float(total)) / abs(float(total)) < ltol
+    print(f"\n[policy {dtype}] loss rel {abs(loss - float(total)) / abs(float(total)):.2e}  d loss / d parameters max-norm rel {relerr(grad, ref):.2e}")
     assert np.abs(ref).max() > 0 and relerr(grad, ref) < gtol
 
 
