@@ -49,18 +49,18 @@ ALG = {
     "gridop+g2p": (15, 14), "gridop+g2p_p2g": (51, 18), "gridop+g2p_grad": (18, 16), "gridop_grad+p2g_grad": (54, 15),
 }
 HBM_PEAK_GBS = 8000.0          # MI355X spec (MI355X_MICROARCH.md); the copy / read rates this box reaches are measured live
-PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc.json")
 
 
-def pmc_traffic(kernel, workload, dtype):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/r02_pmc.json, written by
+def pmc_traffic(kernel, workload, dtype, steps, warmup):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/r03_pmc.json, written by
     profiles/tools/pmc_summary.py from separate --pmc FETCH_SIZE / WRITE_SIZE runs of this very command: 2 x
     FETCH_SIZE + WRITE_SIZE, the gfx950 correction of MI355X_MICROARCH.md's HBM section).  None when the file is
-    missing or was taken on another workload / dtype -- a stale number is worse than none."""
+    missing or was taken on another workload / dtype / --steps / --warmup -- a stale number is worse than none."""
     try:
         with open(PMC_FILE) as f:
             d = json.load(f)
-        if d.get("workload") != workload or d.get("dtype") != dtype:
+        if d.get("workload") != workload or d.get("dtype") != dtype or d.get("steps") != steps or d.get("warmup") != warmup:
             return None, None
         k = d["kernels"].get(kernel)
         return (None, None) if k is None else (float(k["hbm_bytes_per_launch"]), d.get("source"))
@@ -433,7 +433,9 @@ def main():
         alg_substep = 4.0 * (150 * N + 57 * nodes)            # this rank's share
         alg_unit = 4.0 * (150 * float(tot[0]) + 57 * float(tot[1]))     # bytes of one substep as counted in `value`
         sum_us = sum(v["avg_us"] * v["launches"] for v in kernels.values()) / (K * sub)     # per fwd+bwd substep
-        traffic, traffic_src = pmc_traffic(dom, workload, out["dtype"]) if world == 1 else (None, None)
+        traffic, traffic_src = pmc_traffic(dom, workload, out["dtype"], K, W) if world == 1 else (None, None)
+        for name in kernels:                      # per-kernel HBM bytes per launch from the same PMC passes (null when they do not apply)
+            kernels[name]["traffic"] = pmc_traffic(name, workload, out["dtype"], K, W)[0] if world == 1 else None
         out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": kernels[dom]["GBps"], "peak": HBM_PEAK_GBS,
                            "unit": "GB/s", "frac": kernels[dom]["GBps"] / HBM_PEAK_GBS,
                            "traffic": traffic, "traffic_unit": "HBM bytes per launch", "traffic_source": traffic_src,

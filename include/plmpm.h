@@ -277,6 +277,16 @@ int plmpm_halo_apply(plmpm_handle h, int field, int frame);
  * the rows. */
 int plmpm_set_ids(plmpm_handle h, const int32_t* ids);                      /* global ids of the epoch-0 rows (caller order) */
 int plmpm_get_ids(plmpm_handle h, int frame, int32_t* ids);
+/* Slab engines, segment-checkpointed rollouts (plb/optimizer/long_term_gradient.ipynb cells 2-4 on a population that
+ * changes with every migration): plmpm_set_population re-enters the engine with a NEW set of rows -- call it, then
+ * plmpm_set_ids, plmpm_set_frame(0, ..., resort = 1) and plmpm_set_materials with the rows of a checkpoint (what
+ * plmpm_get_ids / plmpm_get_frame / plmpm_get_materials returned for the checkpointed frame). */
+int plmpm_set_population(plmpm_handle h, int n_rows);
+/* rows of the resident adjoint of `frame` (those of the storage epoch the adjoint is in: after plmpm_migrate_adjoint_* at a
+ * frame that migrated, the epoch BEFORE the migration -- not the frame's own row count): what plmpm_get_frame_grad writes */
+int plmpm_adjoint_rows(plmpm_handle h, int frame, int32_t* rows);
+/* mu, lam, yield stress of the rows of `frame`, in the row order plmpm_get_frame uses for it */
+int plmpm_get_materials(plmpm_handle h, int frame, double* mu, double* lam, double* yield_stress);
 int plmpm_frame_info(plmpm_handle h, int frame, int32_t* count, int32_t* epoch, int32_t* adjoint_epoch /* -1: not resident */);
 int plmpm_migrate_begin(plmpm_handle h, int frame, int32_t* out2, void** rows_down, void** rows_up);
 int plmpm_migrate_finish(plmpm_handle h, int frame, int n_in_down, const void* rows_down, int n_in_up, const void* rows_up,

@@ -97,6 +97,9 @@ SYMBOLS = {
     "plmpm_halo_apply": (_I, [_P, _I, _I]),
     "plmpm_set_ids": (_I, [_P, _P]),
     "plmpm_get_ids": (_I, [_P, _I, _P]),
+    "plmpm_set_population": (_I, [_P, _I]),
+    "plmpm_adjoint_rows": (_I, [_P, _I, C.POINTER(C.c_int32)]),
+    "plmpm_get_materials": (_I, [_P, _I, _P, _P, _P]),
     "plmpm_frame_info": (_I, [_P, _I, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "plmpm_migrate_begin": (_I, [_P, _I, _P, C.POINTER(_P), C.POINTER(_P)]),
     "plmpm_migrate_finish": (_I, [_P, _I, _I, _P, _I, _P, C.POINTER(C.c_int32)]),

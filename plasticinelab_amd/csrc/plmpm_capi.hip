@@ -1567,6 +1567,7 @@ int plmpm_set_frame(plmpm_handle s, int frame, const double* x, const double* v,
         s->epochN[0] = s->N;
         s->next_epoch = 1;
         s->steps_since_sort = 0;
+        s->mats_epoch = 0;                       // whatever epoch the last rollout ended in: the materials that follow are epoch 0's
         if (s->dist) {       // global ids in the reset order
             std::vector<int32_t> g(s->N);
             for (int i = 0; i < s->N; ++i) g[i] = s->ids0[s->perm[i]];
@@ -2534,6 +2535,49 @@ int plmpm_frame_info(plmpm_handle s, int frame, int32_t* count, int32_t* epoch, 
     if (count) *count = s->epochN[e];
     if (epoch) *epoch = e;
     if (adjoint_epoch) *adjoint_epoch = s->adj_frame[frame & 1] == frame ? s->adj_epoch[frame & 1] : -1;
+    return 0;
+}
+int plmpm_set_population(plmpm_handle s, int n_rows) {
+    NEED_BOUND(s);
+    REQUIRE(s->dist, "set_population: slab engines only (a single-GPU engine keeps its particle count)");
+    REQUIRE(n_rows >= 0 && n_rows <= s->Npad, "set_population: %d rows, capacity %d (raise particle_capacity)", n_rows, s->Npad);
+    s->N = n_rows;
+    s->perm.resize(n_rows);
+    for (int i = 0; i < n_rows; ++i) s->perm[i] = i;
+    s->ids0.assign(n_rows, 0);
+    s->have_mats = false;                       // the caller sets ids, frame 0 (resort) and materials of the new population next
+    return 0;
+}
+int plmpm_get_materials(plmpm_handle s, int frame, double* mu, double* lam, double* ys) {
+    NEED_BOUND(s);
+    NEED_FRAME(s, frame);
+    REQUIRE(mu && lam && ys, "null argument");
+    REQUIRE(s->have_mats, "get_materials: no materials were set");
+    const int e = s->frame_epoch[frame];
+    const size_t n = s->epochN[e];
+    if (!(s->dist && e > 0)) {                 // rows in caller order: the master copy
+        HIPCHK(hipMemcpyAsync(mu, s->mats_master, n * 8, hipMemcpyDeviceToHost, s->stream));
+        HIPCHK(hipMemcpyAsync(lam, s->mats_master + s->N, n * 8, hipMemcpyDeviceToHost, s->stream));
+        HIPCHK(hipMemcpyAsync(ys, s->mats_master + 2 * (size_t)s->N, n * 8, hipMemcpyDeviceToHost, s->stream));
+        HIPCHK(hipStreamSynchronize(s->stream));
+        return 0;
+    }
+    // a migrated epoch of a slab engine: the materials travelled with the rows, storage order, engine scalar type
+    std::vector<char> h((size_t)3 * s->Npad * s->tsz);
+    HIPCHK(hipMemcpyAsync(h.data(), s->mats_store + (size_t)e * 3 * s->Npad * s->tsz, h.size(), hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    double* out[3] = {mu, lam, ys};
+    for (int c = 0; c < 3; ++c)
+        for (size_t i = 0; i < n; ++i)
+            out[c][i] = s->tsz == 8 ? ((const double*)h.data())[(size_t)c * s->Npad + i] : (double)((const float*)h.data())[(size_t)c * s->Npad + i];
+    return 0;
+}
+int plmpm_adjoint_rows(plmpm_handle s, int frame, int32_t* rows) {
+    NEED_BOUND(s);
+    NEED_FRAME(s, frame);
+    REQUIRE(rows, "null argument");
+    REQUIRE(s->adj_frame[frame & 1] == frame, "adjoint_rows: adjoint of frame %d is not resident", frame);
+    *rows = s->epochN[s->adj_epoch[frame & 1]];
     return 0;
 }
 int plmpm_get_ids(plmpm_handle s, int frame, int32_t* ids) {

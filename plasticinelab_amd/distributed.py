@@ -334,6 +334,32 @@ class SlabEngine:
         self.comm.all_reduce_(flags, op=dist.ReduceOp.MAX)
         self._e.check_error(int(flags.item()))
 
+    # ---- segment checkpoints (optimizer/checkpoint.py): this rank's population at a frame, and re-entry with it
+    def checkpoint(self, f):
+        """Host copy of everything that defines this rank's rows at frame ``f``: global ids, state, materials, and how
+        long ago the last migration was.  Rows are in the frame's own row order (``get_frame`` / ``get_ids``)."""
+        e = self._e
+        fr = e.get_frame(f)
+        mu, lam, ys = e.get_materials(f)
+        return dict(ids=e.get_ids(f).copy(), x=fr["x"], v=fr["v"], F=fr["F"], C=fr["C"], mu=mu, lam=lam, ys=ys,
+                    since=self._since_migration)
+
+    def reenter(self, ck):
+        """Make frame 0 the checkpointed population (a new episode for the engine: epoch 0 again, rows in the checkpoint's
+        order, Hilbert-sorted storage); the next ``step`` migrates exactly as the run the checkpoint was taken from did."""
+        e = self._e
+        e.set_population(len(ck["ids"]))
+        e.set_ids(ck["ids"])
+        e.set_frame(0, x=ck["x"], v=ck["v"], F=ck["F"], C_=ck["C"], resort=True)
+        e.set_materials(ck["mu"], ck["lam"], ck["ys"])
+        self._since_migration = ck["since"]
+
+    def adjoint_to_reentry_rows(self, f=0):
+        """After the reverse sweep has reached frame ``f`` = the frame a segment re-entered at: undo the migration the
+        segment's first step began with, so that ``get_frame_grad(f)`` is in the checkpoint's rows (collective)."""
+        if self.layout.world > 1 and self._e.frame_info(f)[2] > 0:
+            self._migrate_adjoint(f)
+
     def _agree(self, err, where):
         """Raise on every rank if any rank has an exception to report (``err``), the failing rank its own."""
         bad = torch.tensor([0.0 if err is None else 1.0], dtype=torch.float64, device=self.comm.scalar_device)

@@ -226,7 +226,9 @@ class Engine:
         L.check(self.lib.plmpm_add_frame_grad(self.h, f, _ptr(xa), _ptr(va), _ptr(Fa), _ptr(Ca)))
 
     def get_frame_grad(self, f):
-        N = self.frame_info(f)[0]
+        n = C.c_int32(0)                                # rows of the epoch the adjoint is in (a slab frame that migrated: the epoch before)
+        L.check(self.lib.plmpm_adjoint_rows(self.h, f, C.byref(n)))
+        N = n.value
         out = {"x": np.empty((N, 3)), "v": np.empty((N, 3)), "F": np.empty((N, 3, 3)), "C": np.empty((N, 3, 3))}
         L.check(self.lib.plmpm_get_frame_grad(self.h, f, _ptr(out["x"]), _ptr(out["v"]), _ptr(out["F"]), _ptr(out["C"])))
         return out
@@ -356,6 +358,19 @@ class Engine:
         ids = np.ascontiguousarray(ids, np.int32)
         assert len(ids) == self.n_particles
         L.check(self.lib.plmpm_set_ids(self.h, _ptr(ids)))
+
+    def set_population(self, n_rows):
+        """Slab engines: re-enter with a new set of ``n_rows`` rows (then ``set_ids``, ``set_frame(0, ..., resort=True)``,
+        ``set_materials``): a segment checkpoint of a population that migration has changed."""
+        L.check(self.lib.plmpm_set_population(self.h, int(n_rows)))
+        self.n_particles = int(n_rows)
+
+    def get_materials(self, f):
+        """(mu, lam, yield_stress) of the rows of frame f, in ``get_frame``'s row order."""
+        n = self.frame_info(f)[0]
+        out = [np.empty(n) for _ in range(3)]
+        L.check(self.lib.plmpm_get_materials(self.h, f, *[_ptr(a) for a in out]))
+        return out
 
     def get_ids(self, f):
         ids = np.empty(self.frame_info(f)[0], np.int32)

@@ -2,11 +2,11 @@
 """rocprofv3 PMC passes of `python bench.py` -> profiles/rNN_pmc.json, the file bench.py reads roofline.traffic from.
 
     # on the GPU box, separate passes (a --pmc run must not be combined with the trace domains):
-    rocprofv3 --pmc FETCH_SIZE -d gpurun_out/pmc_fetch -o r --  python bench.py --steps 2 --warmup 0 --no-cpu-baseline --no-roofline
-    rocprofv3 --pmc WRITE_SIZE -d gpurun_out/pmc_write -o r --  python bench.py --steps 2 --warmup 0 --no-cpu-baseline --no-roofline
+    rocprofv3 --pmc FETCH_SIZE -d gpurun_out/pmc_fetch -o r --  python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline
+    rocprofv3 --pmc WRITE_SIZE -d gpurun_out/pmc_write -o r --  python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline
     rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES -d gpurun_out/pmc_sq -o r -- ...
     # here:
-    python profiles/tools/pmc_summary.py --workload config3_cube128 --dtype f32 --out profiles/r02_pmc.json \\
+    python profiles/tools/pmc_summary.py --workload config3_cube128 --dtype f32 --steps 20 --warmup 5 --out profiles/r03_pmc.json \\
         gpurun_out/pmc_fetch/*/r_results.db gpurun_out/pmc_write/*/r_results.db [gpurun_out/pmc_sq/*/r_results.db]
 
 HBM bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE (both reported in KB): on gfx950 FETCH_SIZE tallies 128-byte
@@ -53,6 +53,8 @@ def main():
     ap.add_argument("--workload", required=True)
     ap.add_argument("--dtype", required=True)
     ap.add_argument("--out", required=True)
+    ap.add_argument("--steps", type=int, required=True, help="--steps of the profiled bench.py command")
+    ap.add_argument("--warmup", type=int, required=True, help="--warmup of the profiled bench.py command")
     a = ap.parse_args()
     merged = defaultdict(dict)
     for p in a.dbs:
@@ -83,7 +85,7 @@ def main():
             if (m.group(2) == "float") != (a.dtype == "f32"):
                 continue
         kernels[key] = v
-    out = {"workload": a.workload, "dtype": a.dtype, "source": "profiles/" + os.path.basename(a.out) + " <- rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `python bench.py` (profiles/tools/pmc_summary.py)",
+    out = {"workload": a.workload, "dtype": a.dtype, "steps": a.steps, "warmup": a.warmup, "source": "profiles/" + os.path.basename(a.out) + " <- rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `python bench.py --steps " + str(a.steps) + " --warmup " + str(a.warmup) + "` (profiles/tools/pmc_summary.py)",
            "formula": "hbm_bytes_per_launch = (2 * FETCH_SIZE + WRITE_SIZE) KB, averaged per dispatch", "kernels": kernels}
     with open(a.out, "w") as f:
         json.dump(out, f, indent=1, sort_keys=True)

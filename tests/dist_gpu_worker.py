@@ -65,7 +65,14 @@ def main():
     env.loss.set_weights(10, 10, 1, False)
     solver = Solver(env, None, None, softness=666.0, horizon=len(actions))
     state0 = env.get_state()["state"]
-    loss, grad = solver.forward(state0, actions)
+    segment = int(os.environ.get("PLB_TEST_SEGMENT") or 0)
+    if segment:                                         # segment-checkpointed backward on the slab ranks (optimizer/checkpoint.py)
+        from plasticinelab_amd.optimizer.checkpoint import forward_checkpointed
+        loss, grad = forward_checkpointed(env, state0, actions, segment)
+        loss2, grad2 = forward_checkpointed(env, state0, actions, segment)      # the engine is left ready for another call
+        assert abs(loss2 - loss) <= 1e-9 * abs(loss) and np.abs(grad2 - grad).max() <= 1e-7 * np.abs(grad).max()
+    else:
+        loss, grad = solver.forward(state0, actions)
     sim = env.simulator
     eng = sim.engine
     ids, fr = eng.get_frame_by_id(sim.cur, want=("x", "v"))

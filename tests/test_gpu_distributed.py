@@ -24,7 +24,8 @@ def free_port():
         return s.getsockname()[1]
 
 
-def launch(tmp_path, world, dtype, actions, xy_margin, migrate_every, backend="gloo", scene=None, overlap=False, deterministic=False, halo=None):
+def launch(tmp_path, world, dtype, actions, xy_margin, migrate_every, backend="gloo", scene=None, overlap=False, deterministic=False, halo=None,
+           segment=0):
     out = str(tmp_path / "r")
     act = str(tmp_path / "actions.npy")
     np.save(act, actions)
@@ -33,7 +34,7 @@ def launch(tmp_path, world, dtype, actions, xy_margin, migrate_every, backend="g
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    HSA_ENABLE_IPC_MODE_LEGACY="0", PLB_DIST_BACKEND=backend, PLB_TEST_OVERLAP="1" if overlap else "0", PLB_TEST_DETERMINISTIC="1" if deterministic else "0",
-                   PLB_TEST_HALO="" if halo is None else str(halo))
+                   PLB_TEST_HALO="" if halo is None else str(halo), PLB_TEST_SEGMENT=str(segment) if segment else "")
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_gpu_worker.py"), out, dtype, act,
                                        "none" if xy_margin is None else str(xy_margin), str(migrate_every)]
                                       + ([json.dumps(scene)] if scene else []),
@@ -156,6 +157,26 @@ def test_config4_grid_in_four_slabs(tmp_path):
     assert sum(int(r["count"]) for r in res) == scene["particles"]
     print(f"\n[256^3 in 4 slabs] loss {loss:.9g}, rows moved {[int(r['rows_moved']) for r in res]}, grid store per rank "
           f"{[round(int(r['grid_bytes']) / 2**30, 2) for r in res]} GiB vs {single_grid_bytes / 2**30:.2f} GiB on one rank")
+
+
+@pytest.mark.parametrize("world,segment", [(2, 2), (3, 1)])
+def test_segment_checkpointed_backward_on_slab_ranks(tmp_path, world, segment):
+    """optimizer/checkpoint.py on z-slab ranks (long_term_gradient.ipynb cells 2-4 on a population that migration keeps
+    changing): 6 env steps in segments of 2 (3 segments) / 1 (6 segments), migration before every env step; a checkpoint
+    is the rank's rows at the boundary (ids, state, materials), a segment re-enters the engine with them as a new
+    population, the carried adjoint is matched by global id.  Loss and action gradient equal the single-rank
+    stored-trajectory run."""
+    H = 6
+    acts = np.zeros((H, 6))
+    acts[:, 2] = 0.9; acts[:, 5] = 0.9              # both spheres push +z: rows cross the slab faces
+    acts[:, 0] = 0.5; acts[:, 3] = -0.5
+    acts += np.random.default_rng(5).uniform(-0.1, 0.1, acts.shape)
+    loss, grad, x1, v1 = single_rank(acts, "float64")
+    res = launch(tmp_path, world, "float64", acts, 10, 1, segment=segment)
+    assert sum(int(r["rows_moved"]) for r in res) > 0
+    for r in res:
+        assert abs(float(r["loss"]) - loss) / abs(loss) < 1e-9
+        assert relerr(r["grad"], grad) < 1e-7
 
 
 def test_thin_slabs_one_block_plane_per_rank(tmp_path):
