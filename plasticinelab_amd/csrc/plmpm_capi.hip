@@ -116,6 +116,7 @@ struct plmpm_sim {
     // two particles per lane with packed fp32 arithmetic (plmpm_kernels_pk.h): fp32 engines, floating-point atomics
     bool pk = false;
     char* grid_out_adj2 = nullptr;   // second grid_v_out.grad buffer (frames alternate)
+    char* ptab = nullptr;            // [(F+1)][kMaxPrim] PrimT<T>: the primitives per substep, for the fills (k_build_prims)
     int* contact_mark = nullptr;     // [nblk] stamp of the g2p.grad launch that last listed the block as in contact
     int contact_stamp = 0;
     int* tiles = nullptr;        // per-frame stencil boxes of the particle workgroups: [(F+1)][Npad/256][8]
@@ -272,6 +273,7 @@ template <class T> static Dev<T> make_dev(const plmpm_sim* s, int frame = -1, bo
     D.contact = s->contact + ((fg && (frame & 1)) ? s->nblk + 1 : 0);
     D.contact_next = s->contact + ((fg && (frame & 1)) ? 0 : s->nblk + 1);
     D.contact_mark = s->contact_mark; D.stamp = s->contact_stamp;
+    D.ptab = (const PrimT<T>*)s->ptab;
     D.det = s->det_grid; D.det_stride = s->G;
     D.trace = (unsigned long long*)s->staging;      // profiling builds only (needs N * 24 * 8 >= 3 * 16384 * 128 bytes)
     D.ppos = s->ppos; D.prot = s->prot; D.pgap = s->pgap;
@@ -1010,6 +1012,11 @@ template <class T> static int phase_grad_gather(plmpm_sim* s, int f, int part = 
     return 0;
 }
 
+template <class T> static int build_prims_t(plmpm_sim* s, int first, int n) {
+    Dev<T> D = make_dev<T>(s);
+    hipLaunchKernelGGL((k_build_prims<T>), dim3((n * s->P + 63) / 64), dim3(64), 0, s->stream, D, first, n, (PrimT<T>*)s->ptab);
+    return 0;
+}
 #define DISPATCH(s, fn, ...) ((s)->cfg.dtype == PLMPM_F64 ? fn<double>(__VA_ARGS__) : fn<float>(__VA_ARGS__))
 
 // ---------------------------------------------------------------------------------------------
@@ -1354,7 +1361,8 @@ int plmpm_create(const plmpm_config* cfg, const plmpm_primitive* prims, plmpm_ha
         const bool want = e ? e[0] != '0' : (PLB_FUSE_GRID_DEFAULT != 0);
         s->fg = s->store && !s->dist && cfg->deterministic == 0 && want;
     }
-    if (s->fg) s->ws.grid_bytes += align_up(s->G * 4 * s->tsz, 256) + align_up((size_t)s->nblk * 4, 256);
+    if (s->fg) s->ws.grid_bytes += align_up(s->G * 4 * s->tsz, 256) + align_up((size_t)s->nblk * 4, 256)
+                                   + align_up((size_t)(s->F + 1) * kMaxPrim * sizeof(PrimT<double>), 256);
     {
         const char* e = getenv("PLMPM_PK");
         s->pk = cfg->dtype == PLMPM_F32 && cfg->deterministic == 0 && (e ? e[0] != '0' : (PLB_PK_DEFAULT != 0));
@@ -1434,7 +1442,11 @@ int plmpm_bind_workspace(plmpm_handle s, void* state, void* adjoint, void* grid,
     }
     s->tiles = (int*)take((size_t)(s->F + 1) * (s->Npad / kBlock) * 8 * 4);
     s->contact = (int*)take((size_t)2 * (s->nblk + 1) * 4);
-    if (s->fg) { s->grid_out_adj2 = take(s->G * 4 * s->tsz); s->contact_mark = (int*)take((size_t)s->nblk * 4); }
+    if (s->fg) {
+        s->grid_out_adj2 = take(s->G * 4 * s->tsz);
+        s->contact_mark = (int*)take((size_t)s->nblk * 4);
+        s->ptab = take((size_t)(s->F + 1) * kMaxPrim * sizeof(PrimT<double>));
+    }
     s->det_grid = s->det ? (long long*)take(s->G * 8 * 8) : nullptr;
     REQUIRE((size_t)(p - s->gridw) <= s->ws.grid_bytes, "internal: grid workspace overflow");
     p = s->miscw;
@@ -1799,6 +1811,9 @@ static int launch_fk(plmpm_sim* s, int first, int n) {
         const size_t lds = (size_t)n * kChainFwdWords * 8;
         if (lds <= kChainMaxLds) hipLaunchKernelGGL(k_fk_chain<true>, dim3(s->P), dim3(kChainThreads), lds, s->stream, chain_args(s), first, n, chain_bufs(s));
         else hipLaunchKernelGGL(k_fk_chain<false>, dim3(s->P), dim3(kChainThreads), 0, s->stream, chain_args(s), first, n, chain_bufs(s));
+        if (s->fg) {          // the primitives of substeps first .. first+n-1 as the fused-grid fills read them
+            if (s->cfg.dtype == PLMPM_F64) build_prims_t<double>(s, first, n); else build_prims_t<float>(s, first, n);
+        }
     }
     return 0;
 }

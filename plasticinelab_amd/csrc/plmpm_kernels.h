@@ -113,6 +113,9 @@ template <class T> struct Dev {
     int* tiles;                      // [(F+1)][workgroups][8]: stencil box of each 256-particle workgroup, per frame
     int* contact;                    // [0] = n, [1..n] = blocks whose pose adjoints are still due (grid_op.grad -> p2g.grad)
     int* contact_next;               // fused-grid engines: the list of the frame before this one (its counter is reset here)
+    const PrimT<T>* ptab;            // fused-grid engines: [(F+1)][kMaxPrim] the primitives as a grid node sees them during substep f
+                                     // (k_build_prims, once per env step behind the kinematics chain): the fills read them
+                                     // straight from here -- uniform addresses, no LDS copy, no per-wave set-up
     int* contact_mark;               // fused-grid engines: [n_blocks] stamp of the launch that last put the block on a contact list
     int stamp;                       //   this launch's stamp
     unsigned long long* trace;       // profiling builds only
@@ -211,6 +214,25 @@ template <class T, bool WAVE = false> __device__ __forceinline__ void load_prims
         sp[t] = p;
     }
     if (WAVE) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
+// one record per (frame, primitive): what load_prims assembles, kept in HBM for the fused-grid fills
+template <class T> __global__ void k_build_prims(Dev<T> D, int first, int n, PrimT<T>* ptab) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * D.nprim) return;
+    const int f = first + i / D.nprim, t = i % D.nprim;
+    PrimT<T> p;
+    p.shape = D.prim[t].shape; p.movable = D.prim[t].movable; p.friction = (T)D.prim[t].friction;
+    for (int k = 0; k < 3; ++k) p.par[k] = D.prim[t].par[k];
+    if (p.shape == SHAPE_CHOPSTICKS) p.par[2] = D.pgap[(size_t)f * D.nprim + t];
+    p.rb = prim_bounding_radius(p.shape, p.par);
+    const double* a = D.ppos + ((size_t)f * D.nprim + t) * 3;
+    const double* b = D.ppos + ((size_t)(f + 1) * D.nprim + t) * 3;
+    const double* c = D.prot + ((size_t)f * D.nprim + t) * 4;
+    const double* d = D.prot + ((size_t)(f + 1) * D.nprim + t) * 4;
+    for (int k = 0; k < 3; ++k) { p.pos[k] = a[k]; p.pos1[k] = b[k]; }
+    for (int k = 0; k < 4; ++k) { p.rot[k] = c[k]; p.rot1[k] = d[k]; }
+    ptab[(size_t)f * kMaxPrim + t] = p;
 }
 
 // Grid kernels run kGridWG persistent workgroups.  Workgroup g owns blocks g, g + G, g + 2G, ... (G = gridDim.x): the
@@ -545,13 +567,34 @@ template <class T> struct PrevGrid {
 // v_out of node (ix, iy, iz) from grid_m / grid_v_in; .w = 1: the node is in contact with a movable primitive (its
 // pose adjoints are due in the reverse pass).  The expensive part -- collide, double-precision rigid-body geometry -- only
 // concerns the nodes within reach of a primitive (prim_within_reach), and is evaluated in the FORWARD pass only:
-//   NEAR_STORE (forward fills): such a node's {v_out, contact bit} also goes to the frame's grid_v_out store `vnear`
-//                               (every workgroup whose box holds the node writes the same four words);
-//   NEAR_LOAD  (g2p.grad's fill): such a node is read back from there instead of being evaluated again;
+//   NEAR_STORE (forward fills): every box node's {v_out, contact bit} also goes to the frame's grid_v_out store `vnear`
+//                               (every workgroup whose box holds the node writes the same four words: 16 B x ~4.5 per
+//                               node -- cheaper than evaluating v_out a second time in g2p.grad, measured round 3);
+//   NEAR_LOAD  (g2p.grad's fill): reads them back, exactly as an engine with grid kernels reads grid_v_out -- no
+//                               primitives, no grid_m / grid_v_in there -- and takes the contact bit from .w;
 //   NEAR_EVAL: evaluate, touch nothing (a frame whose forward substep did not run through a fused-grid kernel).
 // In two halves so that a kernel can put independent work (its in-wave sort, its particle loads) between the issue of
 // the grid loads and their first use: fg_node_load issues them, fg_node_eval computes.
 enum { NEAR_EVAL = 0, NEAR_STORE = 1, NEAR_LOAD = 2 };
+// Number of primitives a workgroup's fill has to look at: 0 when its whole stencil box lies outside every primitive's
+// reach (prim_within_reach, the same bound, taken for the box's nearest point) -- workgroup-uniform, so the ~95 % of the
+// workgroups that are nowhere near a manipulator skip the per-node culls altogether.
+template <class T> __device__ __forceinline__ int fg_box_prims(const Dev<T>& D, const PrimT<T>* sp, const Tile& t) {
+    if (PLB_FG_ABL & 1) return 0;
+    const float inv_n = 1.0f / (float)D.P.n;
+    bool near = false;
+    for (int p = 0; p < D.nprim; ++p) {
+        float d2 = 0.f;
+        for (int d = 0; d < 3; ++d) {
+            const float c = (float)sp[p].pos[d], lo = (float)t.o[d] * inv_n, hi = (float)(t.o[d] + t.e[d] - 1) * inv_n;
+            const float q = c < lo ? lo - c : (c > hi ? c - hi : 0.f);
+            d2 += q * q;
+        }
+        const float reach = sp[p].rb + (D.P.softness > T(0) ? 2.302585093f / (float)D.P.softness : 0.0f) + 2e-3f;     // node test: + 1e-3
+        near |= !(d2 > reach * reach);
+    }
+    return near ? D.nprim : 0;
+}
 template <class T> struct NodeIn { int idx; T m, mv[3]; };
 template <class T> __device__ __forceinline__ NodeIn<T> fg_node_load(const Dev<T>& D, const T* const* gin, int ix, int iy, int iz) {
     NodeIn<T> n;
@@ -560,43 +603,50 @@ template <class T> __device__ __forceinline__ NodeIn<T> fg_node_load(const Dev<T
     return n;
 }
 template <int MODE, class T> __device__ __forceinline__ Vec4<T> fg_node_eval(const Dev<T>& D, const PrimT<T>* sp, int ix, int iy, int iz,
-                                                                              const NodeIn<T>& n, Vec4<T>* vnear) {
+                                                                              const NodeIn<T>& n, Vec4<T>* vnear, int np) {
     const int idx = n.idx;
     const T m = n.m;
     const T mv[3] = {n.mv[0], n.mv[1], n.mv[2]};
     T vo[3];
     const int I[3] = {ix, iy, iz};
-    const int np = (PLB_FG_ABL & 1) ? 0 : D.nprim;
     bool touch = false;
     if (MODE == NEAR_EVAL) {
         grid_node_fwd<T>(D.P, I, m, mv, np, sp, vo, &touch);
         return Vec4<T>{vo[0], vo[1], vo[2], touch ? T(1) : T(0)};
     }
-    const bool near = m > T(1e-12) && node_near_any(D.P, I, np, sp);
+    const bool near = np > 0 && m > T(1e-12) && node_near_any(D.P, I, np, sp);
     if (MODE == NEAR_LOAD && near) return vnear[idx];
     grid_node_fwd<T>(D.P, I, m, mv, near ? np : 0, sp, vo, &touch);       // far nodes: no primitive passes its cull anyway
     const Vec4<T> a{vo[0], vo[1], vo[2], touch ? T(1) : T(0)};
-    if (MODE == NEAR_STORE && near) vnear[idx] = a;
+    if (MODE == NEAR_STORE) vnear[idx] = a;            // every box node (see above: g2p.grad gathers from the store)
     return a;
 }
 template <int MODE, class T> __device__ __forceinline__ Vec4<T> fg_node_vout(const Dev<T>& D, const T* const* gin, const PrimT<T>* sp, int ix, int iy, int iz,
-                                                                              Vec4<T>* vnear, int* index = nullptr) {
+                                                                              Vec4<T>* vnear, int np, int* index = nullptr) {
     const NodeIn<T> n = fg_node_load(D, gin, ix, iy, iz);
     if (index) *index = n.idx;
-    return fg_node_eval<MODE>(D, sp, ix, iy, iz, n, vnear);
+    return fg_node_eval<MODE>(D, sp, ix, iy, iz, n, vnear, np);
 }
 // {grid_v_in.grad, grid_m.grad} of node (ix, iy, iz) from grid_v_out.grad and the frame's grid_m / grid_v_in (the
 // pose adjoints of the nodes in contact are computed once per node elsewhere: pose_adjoint_blocks)
-template <class T> __device__ __forceinline__ Vec4<T> fg_node_gadj(const Dev<T>& D, const PrimT<T>* sp, int ix, int iy, int iz, int* index = nullptr) {
-    const int idx = node_index(D, ix, iy, iz);
-    if (index) *index = idx;
-    const T gm = D.gin[0][idx];
-    const T mv[3] = {D.gin[1][idx], D.gin[2][idx], D.gin[3][idx]};
-    const T va[3] = {D.goa[0][idx], D.goa[1][idx], D.goa[2][idx]};
+template <class T> struct NodeAdjIn { int idx; T gm, mv[3], va[3]; };
+template <class T> __device__ __forceinline__ NodeAdjIn<T> fg_node_gadj_load(const Dev<T>& D, int ix, int iy, int iz) {
+    NodeAdjIn<T> n;
+    n.idx = node_index(D, ix, iy, iz);
+    n.gm = D.gin[0][n.idx];
+    for (int c = 0; c < 3; ++c) { n.mv[c] = D.gin[1 + c][n.idx]; n.va[c] = D.goa[c][n.idx]; }
+    return n;
+}
+template <class T> __device__ __forceinline__ Vec4<T> fg_node_gadj_eval(const Dev<T>& D, const PrimT<T>* sp, int ix, int iy, int iz, int np, const NodeAdjIn<T>& n) {
     T ma, mva[3];
     const int I[3] = {ix, iy, iz};
-    grid_node_bwd<T, false>(D.P, I, gm, mv, (PLB_FG_ABL & 1) ? 0 : D.nprim, sp, va, &ma, mva, [](int, const PoseAdj<T>&, bool) {});
+    grid_node_bwd<T, false>(D.P, I, n.gm, n.mv, np, sp, n.va, &ma, mva, [](int, const PoseAdj<T>&, bool) {});
     return Vec4<T>{mva[0], mva[1], mva[2], ma};
+}
+template <class T> __device__ __forceinline__ Vec4<T> fg_node_gadj(const Dev<T>& D, const PrimT<T>* sp, int ix, int iy, int iz, int np, int* index = nullptr) {
+    const NodeAdjIn<T> n = fg_node_gadj_load(D, ix, iy, iz);
+    if (index) *index = n.idx;
+    return fg_node_gadj_eval(D, sp, ix, iy, iz, np, n);
 }
 // a node in contact with a movable primitive: its block goes on the frame's contact list, once (the block's mark takes
 // this launch's stamp; stamps are never reused, so the marks are never cleared)
@@ -865,7 +915,7 @@ __global__ __launch_bounds__(kBlock) void k_grid_op(Dev<T> D, int f, HaloIn H) {
 template <class T, bool FG = false>
 __global__ __launch_bounds__(kBlock) void k_g2p(Dev<T> D, int f) {
     __shared__ Vec4<T> tile[TileCap<T>::nodes];
-    __shared__ PrimT<T> sp[FG ? kMaxPrim : 1];
+    const PrimT<T>* sp = D.ptab + (size_t)f * kMaxPrim;
     const int p = blockIdx.x * kBlock + threadIdx.x;
     const bool valid = p < D.N;
     const double* X = frame_x(D, f);
@@ -877,11 +927,11 @@ __global__ __launch_bounds__(kBlock) void k_g2p(Dev<T> D, int f) {
     if constexpr (FG) {
         // v_out of every node of the box: into the LDS tile, or -- a box too large for it -- into the frame's grid_v_out
         // in HBM, which the gather below then reads (workgroups with overlapping boxes write the same values)
-        load_prims<T, true>(D, f, sp);
+        const int np = fg_box_prims(D, sp, tl);
         for (int i = threadIdx.x; i < tn; i += kBlock) {
             int lz, ly, lx, idx;
             tile_coords(i, ex, exy, lz, ly, lx);
-            const Vec4<T> a = fg_node_vout<NEAR_STORE>(D, D.gin, sp, tl.o[0] + lx, tl.o[1] + ly, tl.o[2] + lz, D.grid_out, &idx);
+            const Vec4<T> a = fg_node_vout<NEAR_STORE>(D, D.gin, sp, tl.o[0] + lx, tl.o[1] + ly, tl.o[2] + lz, D.grid_out, np, &idx);
             if (tl.ok) tile[i] = a; else D.grid_out[idx] = a;
         }
         __syncthreads();
@@ -927,7 +977,7 @@ template <class T, bool DET = false, bool FG = false>
 __global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_g2p_p2g(Dev<T> D, int f, PrevGrid<T> G0) {
     __shared__ int sred[32];
     __shared__ Vec4<double> tile[TileCap<T>::nodes];
-    __shared__ PrimT<T> sp[FG ? kMaxPrim : 1];
+    const PrimT<T>* sp = D.ptab + (size_t)(f - 1) * kMaxPrim;      // FG: the primitives during substep f-1
     const Vec4<T>* vout_prev = G0.vout;          // FG: the previous frame's grid_v_out store, written here for boxes too large for the tile
     Vec4<T>* tile_v = reinterpret_cast<Vec4<T>*>(tile);          // first use of the same LDS
     const int Np = D.Npad;
@@ -942,7 +992,6 @@ __global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_g2p_p2g(Dev<T> D, int
     // the tile fill is issued right behind the position loads and overlaps with them and with the sort
     const Tile ta = load_tile(D, f - 1, (int)(TileCap<T>::nodes * sizeof(Vec4<double>) / sizeof(Vec4<T>)));
     SortLoad sl = sorted_begin(D, X0);
-    if constexpr (FG) load_prims<T, true>(D, f - 1, sp);                 // poses of substep f-1 (issued behind the position loads)
     NodeIn<T> fpre;
     int flz = 0, fly = 0, flx = 0;
     {
@@ -976,14 +1025,15 @@ __global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_g2p_p2g(Dev<T> D, int
         // grid_v_out store, from where the gather below reads it
         const int ex = ta.e[0], exy = ta.e[0] * ta.e[1], tn = exy * ta.e[2];
         Vec4<T>* vst = const_cast<Vec4<T>*>(vout_prev);
+        const int np = fg_box_prims(D, sp, ta);
         if ((int)threadIdx.x < tn) {
-            const Vec4<T> a = fg_node_eval<NEAR_STORE>(D, sp, ta.o[0] + flx, ta.o[1] + fly, ta.o[2] + flz, fpre, vst);
+            const Vec4<T> a = fg_node_eval<NEAR_STORE>(D, sp, ta.o[0] + flx, ta.o[1] + fly, ta.o[2] + flz, fpre, vst, np);
             if (ta.ok) tile_v[threadIdx.x] = a; else vst[fpre.idx] = a;
         }
         for (int i = threadIdx.x + kBlock; i < tn; i += kBlock) {
             int lz, ly, lx, idx;
             tile_coords(i, ex, exy, lz, ly, lx);
-            const Vec4<T> a = fg_node_vout<NEAR_STORE>(D, G0.gin, sp, ta.o[0] + lx, ta.o[1] + ly, ta.o[2] + lz, vst, &idx);
+            const Vec4<T> a = fg_node_vout<NEAR_STORE>(D, G0.gin, sp, ta.o[0] + lx, ta.o[1] + ly, ta.o[2] + lz, vst, np, &idx);
             if (ta.ok) tile_v[i] = a; else vst[idx] = a;
         }
     }
@@ -1132,7 +1182,8 @@ __global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_g2p_p2g(Dev<T> D, int
 template <class T, bool DET = false, int FGMODE = 0>
 __global__ __launch_bounds__(kBlock, sizeof(T) == 4 ? PLB_G2PG_WAVES : 1) void k_g2p_grad(Dev<T> D, int f, int src, int dst, const T* vnext, ClearArgs<T> CA) {
     constexpr bool FG = FGMODE != 0;
-    __shared__ PrimT<T> sp[FG ? kMaxPrim : 1];
+    constexpr bool EVAL = FGMODE == 1 + NEAR_EVAL;     // v_out evaluated here (a frame whose forward ran through the grid kernels' engine path)
+    const PrimT<T>* sp = D.ptab + (size_t)f * kMaxPrim;
     if constexpr (FG) {
         // spare workgroups behind the particle workgroups: clear the grids of the frame the previous reverse substep
         // finished with (one coalesced 256-byte row per block and component, found through the block flags)
@@ -1152,7 +1203,6 @@ __global__ __launch_bounds__(kBlock, sizeof(T) == 4 ? PLB_G2PG_WAVES : 1) void k
     if (wg == 0 && threadIdx.x == 0) (FG ? D.contact_next : D.contact)[0] = 0;     // the list k_grid_op_grad(f) (FG: this kernel for frame f-1) is about to fill
     const Tile tl = load_tile(D, f, DET ? CAP / 2 : CAP, wg);       // stored by the scatter of this frame (DET: 6 limbs per node in tile_a)
     SortLoad sl = sorted_begin(D, X, wg);
-    if constexpr (FG) load_prims<T, true>(D, f, sp);
 
     const int ex = tl.e[0], exy = tl.e[0] * tl.e[1], tn = exy * tl.e[2];
     // Fixed-shape tile: a box of at most 8 nodes per axis (most are: the mean box is ~6^3 nodes) is laid out in LDS with
@@ -1165,7 +1215,13 @@ __global__ __launch_bounds__(kBlock, sizeof(T) == 4 ? PLB_G2PG_WAVES : 1) void k
     const int n8 = tl.e[2] << 6;                                    // slots of the z planes in use
     NodeIn<T> fpre;
     int flz = 0, fly = 0, flx = 0;
-    if constexpr (FG) {
+    // a stored v_out whose .w is set: the node touches a movable primitive -- its block goes on the contact list
+    auto stored = [&](int idx) -> Vec4<T> {
+        const Vec4<T> a = D.grid_out[idx];
+        if constexpr (FG) { if (a.w != T(0)) fg_mark_contact(D, idx); }
+        return a;
+    };
+    if constexpr (EVAL) {
         // first pass of the v_out fill: only the grid loads; they fly during the sort (fill_finish below)
         if ((int)threadIdx.x < tn) {
             tile_coords((int)threadIdx.x, ex, exy, flz, fly, flx);
@@ -1177,16 +1233,22 @@ __global__ __launch_bounds__(kBlock, sizeof(T) == 4 ? PLB_G2PG_WAVES : 1) void k
         for (int i = threadIdx.x; i < n8; i += kBlock) {
             const int lx = i & 7, ly = (i >> 3) & 7, lz = i >> 6;
             if (lx < tl.e[0] && ly < tl.e[1] && lz < tl.e[2])
-                tile[i] = D.grid_out[node_index(D, tl.o[0] + lx, tl.o[1] + ly, tl.o[2] + lz)];
+                tile[i] = stored(node_index(D, tl.o[0] + lx, tl.o[1] + ly, tl.o[2] + lz));
             tile_a[3 * i] = 0.0; tile_a[3 * i + 1] = 0.0; tile_a[3 * i + 2] = 0.0;
         }
     } else if (tl.ok)
         for (int i = threadIdx.x; i < tn; i += kBlock) {
             int lz, ly, lx;
                 tile_coords(i, ex, exy, lz, ly, lx);
-            tile[i] = D.grid_out[node_index(D, tl.o[0] + lx, tl.o[1] + ly, tl.o[2] + lz)];
+            tile[i] = stored(node_index(D, tl.o[0] + lx, tl.o[1] + ly, tl.o[2] + lz));
             tile_a[3 * i] = 0.0; tile_a[3 * i + 1] = 0.0; tile_a[3 * i + 2] = 0.0;
             if (DET) { tile_a[3 * (tn + i)] = 0.0; tile_a[3 * (tn + i) + 1] = 0.0; tile_a[3 * (tn + i) + 2] = 0.0; }   // lo limbs
+        }
+    else if (FG)                                    // no tile: the gather reads the store itself; the box still reports its contacts
+        for (int i = threadIdx.x; i < tn; i += kBlock) {
+            int lz, ly, lx;
+            tile_coords(i, ex, exy, lz, ly, lx);
+            (void)stored(node_index(D, tl.o[0] + lx, tl.o[1] + ly, tl.o[2] + lz));
         }
     PT_MARK(0);
     const bool valid = sorted_finish(D, sl, p, x, base, false, wg);
@@ -1201,7 +1263,7 @@ __global__ __launch_bounds__(kBlock, sizeof(T) == 4 ? PLB_G2PG_WAVES : 1) void k
             for (int d = 0; d < 3; ++d) { vn[d] = R1[d * Np + p]; xna[d] = A1[d * Np + p]; vna[d] = A1[(3 + d) * Np + p]; }
             for (int d = 0; d < 9; ++d) Cna[d] = A1[(6 + d) * Np + p];
         }
-        if constexpr (FG) {
+        if constexpr (EVAL) {
             // grid_op on the box, whatever the tile layout (fixed 8-strides, the box's own extents, or no tile at all: then
             // v_out goes to the frame's grid_v_out in HBM and the gather reads it from there); nodes in contact with a
             // movable primitive put their block on the contact list
@@ -1212,11 +1274,11 @@ __global__ __launch_bounds__(kBlock, sizeof(T) == 4 ? PLB_G2PG_WAVES : 1) void k
                 else D.grid_out[idx] = a;
             };
             if ((int)threadIdx.x < tn)
-                put((int)threadIdx.x, flx, fly, flz, fpre.idx, fg_node_eval<FGMODE - 1>(D, sp, tl.o[0] + flx, tl.o[1] + fly, tl.o[2] + flz, fpre, D.grid_out));
+                put((int)threadIdx.x, flx, fly, flz, fpre.idx, fg_node_eval<NEAR_EVAL>(D, sp, tl.o[0] + flx, tl.o[1] + fly, tl.o[2] + flz, fpre, D.grid_out, D.nprim));
             for (int i = threadIdx.x + kBlock; i < tn; i += kBlock) {
                 int lz, ly, lx, idx;
                 tile_coords(i, ex, exy, lz, ly, lx);
-                const Vec4<T> a = fg_node_vout<FGMODE - 1>(D, D.gin, sp, tl.o[0] + lx, tl.o[1] + ly, tl.o[2] + lz, D.grid_out, &idx);
+                const Vec4<T> a = fg_node_vout<NEAR_EVAL>(D, D.gin, sp, tl.o[0] + lx, tl.o[1] + ly, tl.o[2] + lz, D.grid_out, D.nprim, &idx);
                 put(i, lx, ly, lz, idx, a);
             }
         }
@@ -1515,11 +1577,22 @@ __global__ __launch_bounds__(kBlock, sizeof(T) == 4 ? PLB_P2G_GRAD_WAVES : 1) vo
     const int ex = tl.e[0], exy = tl.e[0] * tl.e[1], tn = exy * tl.e[2];
     if constexpr (FG) {
         // the node adjoints of the whole box: into the LDS tile, or -- a box too large for it -- into grid_in_adj in HBM
-        load_prims<T, true>(D, f, sp);
-        for (int i = threadIdx.x; i < tn; i += kBlock) {
+        NodeAdjIn<T> pre;
+        int plz = 0, ply = 0, plx = 0;
+        if ((int)threadIdx.x < tn) {
+            tile_coords((int)threadIdx.x, ex, exy, plz, ply, plx);
+            pre = fg_node_gadj_load(D, tl.o[0] + plx, tl.o[1] + ply, tl.o[2] + plz);
+        }
+        const PrimT<T>* gp = D.ptab + (size_t)f * kMaxPrim;
+        const int np = fg_box_prims(D, gp, tl);
+        if ((int)threadIdx.x < tn) {
+            const Vec4<T> a = fg_node_gadj_eval(D, gp, tl.o[0] + plx, tl.o[1] + ply, tl.o[2] + plz, np, pre);
+            if (tl.ok) tile[threadIdx.x] = a; else D.grid_in_adj[pre.idx] = a;
+        }
+        for (int i = threadIdx.x + kBlock; i < tn; i += kBlock) {
             int lz, ly, lx, idx;
             tile_coords(i, ex, exy, lz, ly, lx);
-            const Vec4<T> a = fg_node_gadj(D, sp, tl.o[0] + lx, tl.o[1] + ly, tl.o[2] + lz, &idx);
+            const Vec4<T> a = fg_node_gadj(D, gp, tl.o[0] + lx, tl.o[1] + ly, tl.o[2] + lz, np, &idx);
             if (tl.ok) tile[i] = a; else D.grid_in_adj[idx] = a;
         }
         __syncthreads();

@@ -88,7 +88,7 @@ __global__ __launch_bounds__(kBlockPk, 2) void k_g2p_p2g_pk(Dev<float> D, int f,
     typedef float T;
     __shared__ int sred[32];
     __shared__ Vec4<double> tile[TileCap<T>::nodes];
-    __shared__ PrimT<T> sp[FG ? kMaxPrim : 1];
+    const PrimT<T>* sp = D.ptab + (size_t)(f - 1) * kMaxPrim;
     Vec4<T>* tile_v = reinterpret_cast<Vec4<T>*>(tile);
     const Vec4<T>* vout_prev = G0.vout;
     const int Np = D.Npad;
@@ -97,14 +97,13 @@ __global__ __launch_bounds__(kBlockPk, 2) void k_g2p_p2g_pk(Dev<float> D, int f,
     PT_BEGIN();
     const Tile ta = load_tile(D, f - 1, (int)(TileCap<T>::nodes * sizeof(Vec4<double>) / sizeof(Vec4<T>)));
     const SlotLoad sl0 = slot_begin(D, X0, 0), sl1 = slot_begin(D, X0, 1);
-    if constexpr (FG) load_prims<T, true>(D, f - 1, sp);
     {
         const int ex = ta.e[0], exy = ta.e[0] * ta.e[1], tn = exy * ta.e[2];
         if constexpr (FG) {
             for (int i = threadIdx.x; i < tn; i += kBlockPk) {
                 int lz, ly, lx, idx;
                 tile_coords(i, ex, exy, lz, ly, lx);
-                const Vec4<T> a = fg_node_vout<NEAR_STORE>(D, G0.gin, sp, ta.o[0] + lx, ta.o[1] + ly, ta.o[2] + lz, const_cast<Vec4<T>*>(vout_prev), &idx);
+                const Vec4<T> a = fg_node_vout<NEAR_STORE>(D, G0.gin, sp, ta.o[0] + lx, ta.o[1] + ly, ta.o[2] + lz, const_cast<Vec4<T>*>(vout_prev), D.nprim, &idx);
                 if (ta.ok) tile_v[i] = a; else const_cast<Vec4<T>*>(vout_prev)[idx] = a;
             }
         } else if (ta.ok)
