@@ -1361,8 +1361,8 @@ int plmpm_create(const plmpm_config* cfg, const plmpm_primitive* prims, plmpm_ha
         const bool want = e ? e[0] != '0' : (PLB_FUSE_GRID_DEFAULT != 0);
         s->fg = s->store && !s->dist && cfg->deterministic == 0 && want;
     }
-    if (s->fg) s->ws.grid_bytes += align_up(s->G * 4 * s->tsz, 256) + align_up((size_t)s->nblk * 4, 256)
-                                   + align_up((size_t)(s->F + 1) * kMaxPrim * sizeof(PrimT<double>), 256);
+    if (s->fg) s->ws.grid_bytes += align_up(s->G * 4 * s->tsz, 256) + align_up((size_t)s->nblk * 4, 256);
+    s->ws.grid_bytes += align_up((size_t)(s->F + 1) * kMaxPrim * sizeof(PrimT<double>), 256);
     {
         const char* e = getenv("PLMPM_PK");
         s->pk = cfg->dtype == PLMPM_F32 && cfg->deterministic == 0 && (e ? e[0] != '0' : (PLB_PK_DEFAULT != 0));
@@ -1445,8 +1445,8 @@ int plmpm_bind_workspace(plmpm_handle s, void* state, void* adjoint, void* grid,
     if (s->fg) {
         s->grid_out_adj2 = take(s->G * 4 * s->tsz);
         s->contact_mark = (int*)take((size_t)s->nblk * 4);
-        s->ptab = take((size_t)(s->F + 1) * kMaxPrim * sizeof(PrimT<double>));
     }
+    s->ptab = take((size_t)(s->F + 1) * kMaxPrim * sizeof(PrimT<double>));
     s->det_grid = s->det ? (long long*)take(s->G * 8 * 8) : nullptr;
     REQUIRE((size_t)(p - s->gridw) <= s->ws.grid_bytes, "internal: grid workspace overflow");
     p = s->miscw;
@@ -1633,6 +1633,10 @@ int plmpm_set_primitive_state(plmpm_handle s, int prim, int frame, const double*
     HIPCHK(hipMemcpyAsync(s->ppos + ((size_t)frame * s->P + prim) * 3, st, 3 * 8, hipMemcpyHostToDevice, s->stream));
     HIPCHK(hipMemcpyAsync(s->prot + ((size_t)frame * s->P + prim) * 4, st + 3, 4 * 8, hipMemcpyHostToDevice, s->stream));
     HIPCHK(hipMemcpyAsync(s->pgap + (size_t)frame * s->P + prim, st + 7, 8, hipMemcpyHostToDevice, s->stream));
+    {   // the per-substep primitive records that hold this pose (substeps frame-1 and frame)
+        const int a = std::max(frame - 1, 0), b = std::min(frame, s->F - 1);
+        if (b >= a) { if (s->cfg.dtype == PLMPM_F64) build_prims_t<double>(s, a, b - a + 1); else build_prims_t<float>(s, a, b - a + 1); }
+    }
     HIPCHK(hipStreamSynchronize(s->stream));
     return 0;
 }
@@ -1811,9 +1815,8 @@ static int launch_fk(plmpm_sim* s, int first, int n) {
         const size_t lds = (size_t)n * kChainFwdWords * 8;
         if (lds <= kChainMaxLds) hipLaunchKernelGGL(k_fk_chain<true>, dim3(s->P), dim3(kChainThreads), lds, s->stream, chain_args(s), first, n, chain_bufs(s));
         else hipLaunchKernelGGL(k_fk_chain<false>, dim3(s->P), dim3(kChainThreads), 0, s->stream, chain_args(s), first, n, chain_bufs(s));
-        if (s->fg) {          // the primitives of substeps first .. first+n-1 as the fused-grid fills read them
-            if (s->cfg.dtype == PLMPM_F64) build_prims_t<double>(s, first, n); else build_prims_t<float>(s, first, n);
-        }
+        // the primitives of substeps first .. first+n-1 as the grid kernels / fused-grid fills read them
+        if (s->cfg.dtype == PLMPM_F64) build_prims_t<double>(s, first, n); else build_prims_t<float>(s, first, n);
     }
     return 0;
 }

@@ -113,9 +113,9 @@ template <class T> struct Dev {
     int* tiles;                      // [(F+1)][workgroups][8]: stencil box of each 256-particle workgroup, per frame
     int* contact;                    // [0] = n, [1..n] = blocks whose pose adjoints are still due (grid_op.grad -> p2g.grad)
     int* contact_next;               // fused-grid engines: the list of the frame before this one (its counter is reset here)
-    const PrimT<T>* ptab;            // fused-grid engines: [(F+1)][kMaxPrim] the primitives as a grid node sees them during substep f
-                                     // (k_build_prims, once per env step behind the kinematics chain): the fills read them
-                                     // straight from here -- uniform addresses, no LDS copy, no per-wave set-up
+    const PrimT<T>* ptab;            // [(F+1)][kMaxPrim] the primitives as a grid node sees them during substep f (k_build_prims, once
+                                     // per env step behind the kinematics chain): the grid kernels and the fused-grid fills read them
+                                     // straight from here -- uniform addresses, no LDS copy, no per-workgroup set-up
     int* contact_mark;               // fused-grid engines: [n_blocks] stamp of the launch that last put the block on a contact list
     int stamp;                       //   this launch's stamp
     unsigned long long* trace;       // profiling builds only
@@ -871,10 +871,11 @@ __global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_p2g(Dev<T> D, int f) 
 // CLEAR: forward pass -- consume grid_in (zero it and the flag for the next substep).
 template <class T, bool CLEAR>
 __global__ __launch_bounds__(kBlock) void k_grid_op(Dev<T> D, int f, HaloIn H) {
-    __shared__ PrimT<T> sp[kMaxPrim];
+    // the primitives of this substep: ready-made records in HBM (k_build_prims), read through uniform addresses -- no
+    // assembly from the pose arrays, no LDS copy and no barrier in front of the first block (this kernel is one chain of
+    // latencies: flags -> grid loads -> node arithmetic -> stores)
+    const PrimT<T>* sp = D.ptab + (size_t)f * kMaxPrim;
     const int fl0 = first_flags(D);
-    load_prims(D, f, sp);
-    __syncthreads();
     const int lane = threadIdx.x & 63;
     for_each_active_block<true>(D, H, fl0, [&](int blk) {
         const int idx = (blk << 6) | lane;
@@ -1478,10 +1479,8 @@ __device__ __forceinline__ bool grid_block_bwd(const Dev<T>& D, const HaloIn& H,
 #endif
 template <class T>
 __global__ __launch_bounds__(kBlock, sizeof(T) == 4 ? PLB_GOG_WAVES : 1) void k_grid_op_grad(Dev<T> D, int f, HaloIn H) {
-    __shared__ PrimT<T> sp[kMaxPrim];
+    const PrimT<T>* sp = D.ptab + (size_t)f * kMaxPrim;          // see k_grid_op
     const int fl0 = first_flags(D);
-    load_prims(D, f, sp);
-    __syncthreads();
     const int lane = threadIdx.x & 63;
     // the forward grid_op marked every block of the exchanged planes that carries mass, so the flags alone are
     // complete here: no halo candidates
