@@ -18,14 +18,12 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "mpm_grid.h"
+#include "plmpm_profiling.h"
 
 namespace plb {
 
 constexpr int kBlock = 256;          // threads per workgroup in particle kernels
 // minimum waves per SIMD the register allocator must leave room for (second __launch_bounds__ argument)
-#ifndef PLB_ABLATE
-#define PLB_ABLATE 0          // profiling only: 1 no LDS atomics, 2 no tile flush, 4 no scatter at all
-#endif
 #ifndef PLB_P2G_WAVES
 #define PLB_P2G_WAVES 4
 #endif
@@ -45,26 +43,6 @@ template <class T> struct TileCap;
 template <> struct TileCap<float> { static constexpr int nodes = PLB_TILECAP; };
 template <> struct TileCap<double> { static constexpr int nodes = 512; };
 
-// profiling builds only (-DPLB_PHASE_TIMING): PT_MARK(k) stamps s_memtime at the end of phase k; for the launch of
-// frame PLB_TRACE_FRAME every wave stores its stamps and its hardware id (XCC / SE / CU / SIMD) with plain stores to
-// D.trace[(kernel slot) * 16384 * 16 + wave * 16 + ...] (plmpm_debug_trace).  No atomics: same-address atomics from
-// every wave clog the memory pipeline and become the thing being measured.  Nothing is emitted in normal builds.
-#ifdef PLB_PHASE_TIMING
-#ifndef PLB_TRACE_FRAME
-#define PLB_TRACE_FRAME 20
-#endif
-#define PT_BEGIN() unsigned long long pt_abs[11] = {__builtin_readcyclecounter(), 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
-#define PT_MARK(k) do { pt_abs[1 + (k)] = __builtin_readcyclecounter(); } while (0)
-#define PT_END(D, slot0) do { if ((threadIdx.x & 63) == 0 && f == PLB_TRACE_FRAME) { \
-            unsigned long long* q_ = D.trace + ((size_t)((slot0) / 10) * 16384 + blockIdx.x * 4 + (threadIdx.x >> 6)) * 16; \
-            for (int k_ = 0; k_ < 11; ++k_) q_[k_] = pt_abs[k_]; \
-            q_[11] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)); \
-            q_[12] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)); } } while (0)
-#else
-#define PT_BEGIN() do {} while (0)
-#define PT_MARK(k) do {} while (0)
-#define PT_END(D, slot0) do {} while (0)
-#endif
 
 // Workgroup barrier that only orders LDS traffic.  __syncthreads() also drains the wave's global-memory counter
 // (vmcnt(0)): every load still in flight AND every store just issued -- a full memory round trip per barrier for a wave
@@ -557,9 +535,6 @@ template <class T> __device__ __forceinline__ Tile load_tile(const Dev<T>& D, in
 // and the frame's own grid_m / grid_v_in.  Nothing is written back, so nothing can be cleared by the kernel that
 // reads it (other workgroups read the same nodes): frame f's grids are cleared by g2p.grad of frame f - 1, over the
 // stencil boxes of frame f's workgroups (clear_boxes), and the two grid_v_out.grad buffers alternate between frames.
-#ifndef PLB_FG_ABL
-#define PLB_FG_ABL 0          // profiling only: 1 tile fills ignore the primitives, 2 no clear of the previous frame's grids
-#endif
 template <class T> struct PrevGrid {
     const Vec4<T>* vout;             // grid_v_out of the previous substep (engines with grid kernels)
     const T* gin[4];                 // grid_m / grid_v_in of the previous substep (fused-grid engines)
@@ -798,9 +773,9 @@ __global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_p2g(Dev<T> D, int f) 
             const int ex = tl.e[0], exy = tl.e[0] * tl.e[1];
             p2g_particle<T, double>(D.P, x, v, C, E, mu, lam, ys, En, b2, [&](int i, int j, int l, T mass, const T* mom) {
                 T a0 = mass, a1 = mom[0], a2 = mom[1], a3 = mom[2];
-                if (PLB_ABLATE & 4) { if (a0 + a1 + a2 + a3 == T(-1e30)) tile[0].x = 1.0; return; }
+                PLB_ABLATE_STOP(4, a0 + a1 + a2 + a3, tile);
                 seg_sum4(a0, a1, a2, a3, sg);
-                if (PLB_ABLATE & 1) { if (a0 + a1 + a2 + a3 == T(-1e30)) tile[0].x = 1.0; return; }
+                PLB_ABLATE_STOP(1, a0 + a1 + a2 + a3, tile);
                 if (emitter) {
                     if constexpr (DET) {          // node: 4 hi limbs, then 4 lo limbs
                         long long* q = reinterpret_cast<long long*>(tile) + 8 * ((oz + l) * exy + (oy + j) * ex + (ox + i));
@@ -1091,9 +1066,9 @@ __global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_g2p_p2g(Dev<T> D, int
             const int ex = tl.e[0], exy = tl.e[0] * tl.e[1];
             p2g_particle<T, double>(D.P, x, v, C, E, mu, lam, ys, En, b2, [&](int i, int j, int l, T mass, const T* mom) {
                 T a0 = mass, a1 = mom[0], a2 = mom[1], a3 = mom[2];
-                if (PLB_ABLATE & 4) { if (a0 + a1 + a2 + a3 == T(-1e30)) tile[0].x = 1.0; return; }
+                PLB_ABLATE_STOP(4, a0 + a1 + a2 + a3, tile);
                 seg_sum4(a0, a1, a2, a3, sg);
-                if (PLB_ABLATE & 1) { if (a0 + a1 + a2 + a3 == T(-1e30)) tile[0].x = 1.0; return; }
+                PLB_ABLATE_STOP(1, a0 + a1 + a2 + a3, tile);
                 if (emitter) {
                     if constexpr (DET) {          // node: 4 hi limbs, then 4 lo limbs
                         long long* q = reinterpret_cast<long long*>(tile) + 8 * ((oz + l) * exy + (oy + j) * ex + (ox + i));

@@ -192,10 +192,10 @@ __global__ __launch_bounds__(kBlockPk, 2) void k_g2p_p2g_pk(Dev<float> D, int f,
             p2g_particle<P2, D2>(D.P, x, v, C, E, mu, lam, ys, En, b2, [&](int i, int j, int l, P2 mass, const P2* mom) {
                 T a0 = mass.lo(), a1 = mom[0].lo(), a2 = mom[1].lo(), a3 = mom[2].lo();
                 T c0 = mass.hi(), c1 = mom[0].hi(), c2 = mom[1].hi(), c3 = mom[2].hi();
-                if (PLB_ABLATE & 4) { if (a0 + a1 + a2 + a3 + c0 + c1 + c2 + c3 == T(-1e30)) tile[0].x = 1.0; return; }
+                PLB_ABLATE_STOP(4, a0 + a1 + a2 + a3 + c0 + c1 + c2 + c3, tile);
                 seg_sum4(a0, a1, a2, a3, sg0);
                 seg_sum4(c0, c1, c2, c3, sg1);
-                if (PLB_ABLATE & 1) { if (a0 + a1 + a2 + a3 + c0 + c1 + c2 + c3 == T(-1e30)) tile[0].x = 1.0; return; }
+                PLB_ABLATE_STOP(1, a0 + a1 + a2 + a3 + c0 + c1 + c2 + c3, tile);
                 const int o = l * exy + j * ex + i;
                 if (em0) {
                     double* q = reinterpret_cast<double*>(t0 + o);

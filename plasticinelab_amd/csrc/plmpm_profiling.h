@@ -1,0 +1,37 @@
+// Profiling-only hooks of the particle kernels.  Nothing here emits code in a normal build: the macros expand to
+// nothing (or to a constant-false test) unless libplmpm.so is compiled with -DPLB_PHASE_TIMING / -DPLB_ABLATE=... /
+// -DPLB_FG_ABL=... (profiles/r0N_notes.md name the builds that were measured this way; the Makefile's EXTRA carries the flags).
+#pragma once
+
+// profiling builds only (-DPLB_PHASE_TIMING): PT_MARK(k) stamps s_memtime at the end of phase k; for the launch of
+// frame PLB_TRACE_FRAME every wave stores its stamps and its hardware id (XCC / SE / CU / SIMD) with plain stores to
+// D.trace[(kernel slot) * 16384 * 16 + wave * 16 + ...] (plmpm_debug_trace).  No atomics: same-address atomics from
+// every wave clog the memory pipeline and become the thing being measured.  Nothing is emitted in normal builds.
+#ifdef PLB_PHASE_TIMING
+#ifndef PLB_TRACE_FRAME
+#define PLB_TRACE_FRAME 20
+#endif
+#define PT_BEGIN() unsigned long long pt_abs[11] = {__builtin_readcyclecounter(), 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
+#define PT_MARK(k) do { pt_abs[1 + (k)] = __builtin_readcyclecounter(); } while (0)
+#define PT_END(D, slot0) do { if ((threadIdx.x & 63) == 0 && f == PLB_TRACE_FRAME) { \
+            unsigned long long* q_ = D.trace + ((size_t)((slot0) / 10) * 16384 + blockIdx.x * 4 + (threadIdx.x >> 6)) * 16; \
+            for (int k_ = 0; k_ < 11; ++k_) q_[k_] = pt_abs[k_]; \
+            q_[11] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)); \
+            q_[12] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)); } } while (0)
+#else
+#define PT_BEGIN() do {} while (0)
+#define PT_MARK(k) do {} while (0)
+#define PT_END(D, slot0) do {} while (0)
+#endif
+
+// Ablations (timing only -- results are wrong): PLB_ABLATE bits 1 no LDS atomics, 2 no tile flush, 4 no scatter at all;
+// PLB_FG_ABL bits 1 the fused-grid tile fills ignore the primitives, 2 no clear of the previous frame's grids.
+#ifndef PLB_ABLATE
+#define PLB_ABLATE 0
+#endif
+#ifndef PLB_FG_ABL
+#define PLB_FG_ABL 0
+#endif
+// inside a scatter lambda: stop here when ablation bit `bit` is set, keeping `sum` alive so the arithmetic before it is not
+// optimised away
+#define PLB_ABLATE_STOP(bit, sum, tile) do { if (PLB_ABLATE & (bit)) { if ((sum) == T(-1e30)) (tile)[0].x = 1.0; return; } } while (0)
