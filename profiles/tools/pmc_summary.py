@@ -66,7 +66,7 @@ def main():
     for k, v in merged.items():
         if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
             v["hbm_bytes_per_launch"] = (2.0 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024.0
-        m = re.match(r"k_([a-z0-9_]+)<(float|double)((?:, (?:true|false))*)>", k)
+        m = re.match(r"k_([a-z0-9_]+)<(float|double)((?:, (?:true|false|-?\d+))*)>", k)
         key = k
         if m:
             key = m.group(1)
