@@ -262,6 +262,29 @@ int plmpm_halo_set_recv(plmpm_handle h, int field, int n_faces, const int* bz_a,
  * grid_op / grid_op.grad themselves) */
 int plmpm_halo_apply(plmpm_handle h, int field, int frame);
 
+/* ---- device-side halo exchange (peer writes) and the native slab substep loops -------------------------------------
+ * The host-driven exchange above costs a communication-library call per neighbour, component and substep.  This form
+ * takes the host out of the substep loop: every rank allocates, per halo field and face, a RECEIVE AREA in fine-grained
+ * device memory (plmpm_peer_area_bytes, plmpm_peer_alloc -> pointer + 64-byte IPC handle), sends the handle to the
+ * neighbour on that face by whatever means the host has (once), maps the neighbour's area (plmpm_peer_open) and
+ * registers both (plmpm_halo_peer_setup).  plmpm_halo_peer_exchange is then ONE kernel on the engine's stream: copy this
+ * rank's exchange planes into the neighbours' areas (xGMI peer writes on a multi-GPU node), publish an arrival counter
+ * behind them, wait (bounded: PLMPM_PEER_TIMEOUT seconds, default 20) for the neighbours' counters; the grid kernels
+ * that follow add the received planes as before.  plmpm_slab_step / plmpm_slab_step_grad are the substep loops of one
+ * env step for a slab rank -- mpm_simulator.py:245-278, 365-376 with one exchange per grid phase -- and only enqueue.
+ * All ranks must run the same sequence of exchanges per field.  An arrival that timed out is reported by the next
+ * exchange call and by plmpm_peer_status (0 = fine). */
+int plmpm_peer_area_bytes(plmpm_handle h, int field, int bz_a, int bz_b, size_t* bytes);
+int plmpm_peer_alloc(plmpm_handle h, size_t bytes, void** dev_ptr, void* ipc_handle64);   /* owned by the engine, zeroed */
+int plmpm_peer_open(plmpm_handle h, const void* ipc_handle64, void** dev_ptr);            /* unmapped at plmpm_destroy */
+/* local[i]: this rank's area for face i; remote[i]: the area the neighbour on face i allocated for ITS face towards this
+ * rank, mapped here (a loop-back run may pass its own areas).  n_faces = 0 unregisters. */
+int plmpm_halo_peer_setup(plmpm_handle h, int field, int n_faces, const int* bz_a, const int* bz_b, void* const* local, void* const* remote);
+int plmpm_halo_peer_exchange(plmpm_handle h, int field, int frame);
+int plmpm_peer_status(plmpm_handle h, int* status);
+int plmpm_slab_step(plmpm_handle h, int first_frame, int n_substeps);         /* fk + n x (p2g | exchange | grid_op + g2p) */
+int plmpm_slab_step_grad(plmpm_handle h, int first_frame, int n_substeps);    /* n x (g2p.grad | exchange | grid_op.grad + p2g.grad), in reverse */
+
 /* ---- particle migration between z-slabs --------------------------------------------------------------
  * A rank owns the particles whose stencil centre node lies in its slab.  At the first frame of an env step:
  *   plmpm_migrate_begin  classifies the rows of `frame`, packs the leavers (28 doubles per row: global id, x, v, C,

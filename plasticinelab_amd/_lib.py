@@ -95,6 +95,14 @@ SYMBOLS = {
     "plmpm_halo_region": (_I, [_P, _I, _I, _I, _I, _I, C.POINTER(_P), C.POINTER(C.c_size_t)]),
     "plmpm_halo_set_recv": (_I, [_P, _I, _I, _P, _P, _P]),
     "plmpm_halo_apply": (_I, [_P, _I, _I]),
+    "plmpm_peer_area_bytes": (_I, [_P, _I, _I, _I, C.POINTER(C.c_size_t)]),
+    "plmpm_peer_alloc": (_I, [_P, C.c_size_t, C.POINTER(_P), _P]),
+    "plmpm_peer_open": (_I, [_P, _P, C.POINTER(_P)]),
+    "plmpm_halo_peer_setup": (_I, [_P, _I, _I, _P, _P, _P, _P]),
+    "plmpm_halo_peer_exchange": (_I, [_P, _I, _I]),
+    "plmpm_peer_status": (_I, [_P, C.POINTER(_I)]),
+    "plmpm_slab_step": (_I, [_P, _I, _I]),
+    "plmpm_slab_step_grad": (_I, [_P, _I, _I]),
     "plmpm_set_ids": (_I, [_P, _P]),
     "plmpm_get_ids": (_I, [_P, _I, _P]),
     "plmpm_set_population": (_I, [_P, _I]),

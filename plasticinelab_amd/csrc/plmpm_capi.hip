@@ -589,7 +589,13 @@ int plmpm_create(const plmpm_config* cfg, const plmpm_primitive* prims, plmpm_ha
 }
 
 int plmpm_destroy(plmpm_handle s) {
-    if (s) for (auto e : s->ev_pool) (void)hipEventDestroy(e);
+    if (s) {
+        for (auto e : s->ev_pool) (void)hipEventDestroy(e);
+        for (void* p : s->peer_mapped) (void)hipIpcCloseMemHandle(p);
+        for (void* p : s->peer_allocs) (void)hipFree(p);
+        if (s->peer_done) (void)hipFree(s->peer_done);
+        if (s->peer_status) (void)hipHostFree(s->peer_status);
+    }
     delete s;
     return 0;
 }
@@ -1121,7 +1127,8 @@ int plmpm_grad_gather(plmpm_handle s, int frame) {
     return 0;
 }
 // ---- halos: zero-copy exchange of whole block planes ---------------------------------------------------------------
-static int halo_field(plmpm_sim* s, int field, int frame, char** base, int* ncomp) {
+}  // extern "C"
+int plmpm_halo_field(plmpm_sim* s, int field, int frame, char** base, int* ncomp) {
     if (field == PLMPM_HALO_GRID_IN) {
         REQUIRE(s->store && frame >= 0 && frame < s->F, "halo: grid_in needs store_grid and a valid frame");
         *base = s->gstore + (size_t)frame * s->gstride; *ncomp = 4;
@@ -1130,6 +1137,8 @@ static int halo_field(plmpm_sim* s, int field, int frame, char** base, int* ncom
     else return fail("unknown halo field %d", field);
     return 0;
 }
+#define halo_field plmpm_halo_field
+extern "C" {
 int plmpm_grid_window(plmpm_handle s, int32_t* origin3, int32_t* blocks3) {
     REQUIRE(s && origin3 && blocks3, "null argument");
     for (int d = 0; d < 3; ++d) { origin3[d] = s->go[d]; blocks3[d] = s->nbw[d]; }

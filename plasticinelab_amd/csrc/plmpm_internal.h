@@ -1,7 +1,8 @@
 // Shared by the translation units of libplmpm.so: the engine object, the launch / error macros and the device view
 // (Dev<T>) of an engine.  plmpm_capi.hip: object life cycle, state I/O, the hot path and its phase-split form, halos,
 // profiling | plmpm_kinematics.hip: actions, the serial kinematics chain and its adjoint, primitive queries |
-// plmpm_loss.hip: the loss and its adjoint | plmpm_migrate.hip: particle migration between z-slabs.
+// plmpm_loss.hip: the loss and its adjoint | plmpm_migrate.hip: particle migration between z-slabs | plmpm_peer.hip: the
+// device-side halo exchange (peer writes) and the slab substep loops that use it.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -139,6 +140,19 @@ struct plmpm_sim {
     int steps_since_sort = 0;             // env steps since the order of the current frames was chosen
     size_t gstride = 0;
     std::vector<char> dirty;          // frame f holds a scattered grid that has not been consumed/cleared
+    // Device-side halo exchange (plmpm_peer.hip): per halo field and face a receive area in fine-grained device memory
+    // that the neighbour on that face has mapped (IPC) -- [arrival counter | 2 x ncomp x count scalars] -- and the
+    // neighbour's area for this rank's planes, mapped here.  seq counts the exchanges of a field; half seq & 1 is written.
+    struct PeerField {
+        int n = 0, ba[2] = {0, 0}, bb[2] = {0, 0};
+        size_t count[2] = {0, 0};
+        char *local[2] = {nullptr, nullptr}, *remote[2] = {nullptr, nullptr};
+        unsigned seq = 0;
+    };
+    PeerField peer[3];
+    unsigned* peer_done = nullptr;        // device: workgroups of the running exchange kernel that have finished their copies
+    int* peer_status = nullptr;           // pinned host: 0, or field << 16 | face << 8 | 1 of an arrival that timed out
+    std::vector<void*> peer_allocs, peer_mapped;
     // optional per-kernel timing with HIP events on the launch stream (plmpm_profile_*)
     bool prof = false;
     std::vector<hipEvent_t> ev_pool;
@@ -148,10 +162,10 @@ struct plmpm_sim {
 
 enum KernelId { K_P2G = 0, K_GRID_OP, K_G2P, K_P2G_RE, K_GRID_OP_RE, K_G2P_GRAD, K_GRID_OP_GRAD, K_P2G_GRAD, K_CLEAR, K_G2P_P2G,
                 // fused-grid engines: the same particle kernels with grid_op / grid_op.grad evaluated in their tile fills
-                K_FG_G2P, K_FG_G2P_P2G, K_FG_G2P_GRAD, K_FG_P2G_GRAD, K_COUNT };
+                K_FG_G2P, K_FG_G2P_P2G, K_FG_G2P_GRAD, K_FG_P2G_GRAD, K_HALO_XCHG, K_COUNT };
 static const char* kKernelNames[K_COUNT] = {"p2g", "grid_op", "g2p", "p2g_recompute", "grid_op_recompute",
                                             "g2p_grad", "grid_op_grad", "p2g_grad", "clear_active", "g2p_p2g",
-                                            "gridop+g2p", "gridop+g2p_p2g", "gridop+g2p_grad", "gridop_grad+p2g_grad"};
+                                            "gridop+g2p", "gridop+g2p_p2g", "gridop+g2p_grad", "gridop_grad+p2g_grad", "halo_exchange"};
 
 static void prof_begin(plmpm_sim* s, int id) {
     if (!s->prof) return;
@@ -338,5 +352,6 @@ __device__ __forceinline__ unsigned hilbert_key_dev(unsigned x0, unsigned x1, un
 // cross-unit entry points
 extern "C" int plmpm_launch_fk(plmpm_sim* s, int first, int n);                      // plmpm_kinematics.hip
 extern "C" void plmpm_launch_fk_grad(plmpm_sim* s, int first, int n, int step);
+int plmpm_halo_field(plmpm_sim* s, int field, int frame, char** base, int* ncomp);   // plmpm_capi.hip: base of a halo field's SoA components
 int plmpm_convert_adjoint(plmpm_sim* s, int which, int from, int to);                 // plmpm_capi.hip: adjoint frame `which` into another storage epoch
 

@@ -1,0 +1,235 @@
+// Device-side halo exchange for z-slab ranks: a rank WRITES its copy of the exchanged block planes straight into the
+// neighbour's receive area (fine-grained device memory the neighbour allocated and this rank mapped through an IPC
+// handle -- across xGMI on a multi-GPU node, inside one GPU when test ranks share it), publishes an arrival counter
+// behind the data, and waits for the neighbour's counter -- all inside ONE kernel on the engine's stream.  The host
+// only enqueues: no torch.distributed call, no request object and no stream hand-over per substep, so the slab substep
+// loops themselves (plmpm_slab_step / plmpm_slab_step_grad) are native and the Python driver is out of them.
+//
+//   receive area of a face:  [256 B: arrival counter][half 0: ncomp x count scalars][half 1: ...]
+//
+// Exchange k of a field writes half k & 1.  Why two halves are enough: rank A starts exchange k + 1 only behind its grid
+// kernel of exchange k, which ran behind A's wait for the neighbour's arrival k, which the neighbour published behind
+// ITS grid kernel of exchange k - 1 -- the last reader of half (k + 1) & 1 there.
+#include <type_traits>
+
+#include "plmpm_internal.h"
+
+namespace {
+
+constexpr size_t kPeerHeader = 256;
+
+struct PeerXchg {
+    int n, ncomp;
+    const void* src[2][4];       // this rank's planes, one range per SoA component
+    void* dst[2];                // the half of the neighbour's receive area this exchange writes
+    size_t count[2];             // scalars per component
+    unsigned* arrive_remote[2];  // the neighbour's counter for this rank's planes
+    unsigned* arrive_local[2];   // this rank's counters
+    unsigned seq;
+    unsigned* done;
+    int* status;
+    int code;                    // field << 16 | 1
+    long long timeout_ticks;     // of the 100 MHz wall clock
+};
+
+// 16 bytes per lane, written THROUGH the L2 (sc0 sc1: system-scope write-through): once the store is acknowledged the data
+// is where the neighbour -- another XCD, another process, another GPU -- reads it, and no L2 write-back is needed before the
+// arrival counter moves.  (A release fence at system scope writes back everything the PREVIOUS kernels left dirty in this
+// XCD's L2 -- megabytes of particle state after a particle kernel: 11 us per exchange instead of 6.)
+typedef float __attribute__((ext_vector_type(4))) vec16;
+__device__ __forceinline__ void store_through(vec16* p, vec16 v) {
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void store_through(unsigned* p, unsigned v) {
+    asm volatile("global_store_dword %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+}
+
+template <class T>
+__global__ __launch_bounds__(256) void k_halo_xchg(PeerXchg X) {
+    constexpr int per = 16 / sizeof(T);
+    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (size_t)gridDim.x * blockDim.x;
+    for (int i = 0; i < X.n; ++i) {
+        const size_t nv = X.count[i] / per;          // a block plane is a multiple of 64 scalars
+        for (int c = 0; c < X.ncomp; ++c) {
+            const vec16* s = (const vec16*)X.src[i][c];
+            vec16* d = (vec16*)((T*)X.dst[i] + (size_t)c * X.count[i]);
+            for (size_t j = tid; j < nv; j += nth) store_through(d + j, s[j]);
+        }
+    }
+    // every wave waits for the acknowledgements of its own stores; the workgroup then counts itself done
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    __shared__ int last;
+    if (threadIdx.x == 0) last = __hip_atomic_fetch_add(X.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+    __syncthreads();
+    if (!last) return;
+    // the last workgroup: every copy of this launch has landed.  Publish, then wait for the neighbours.
+    if (threadIdx.x == 0) __hip_atomic_store(X.done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // the next launch is stream-ordered behind this one
+    if (threadIdx.x < X.n) {
+        const int i = threadIdx.x;
+        store_through(X.arrive_remote[i], X.seq);
+        const long long t0 = wall_clock64();
+        for (;;) {
+            const unsigned got = __hip_atomic_load(X.arrive_local[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if ((int)(got - X.seq) >= 0) break;
+            if (wall_clock64() - t0 > X.timeout_ticks) {         // the neighbour is gone: report, do not hang the GPU
+                __hip_atomic_store(X.status, X.code | (i << 8), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(2);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    // the grid kernel that consumes the received planes is a later launch on this stream: its start is the acquire
+}
+
+int peer_init(plmpm_sim* s) {
+    if (s->peer_done) return 0;
+    HIPCHK(hipMalloc((void**)&s->peer_done, 256));
+    HIPCHK(hipMemsetAsync(s->peer_done, 0, 256, s->stream));
+    HIPCHK(hipHostMalloc((void**)&s->peer_status, 64, hipHostMallocMapped));
+    *s->peer_status = 0;
+    return 0;
+}
+
+double peer_timeout_seconds() {
+    const char* e = getenv("PLMPM_PEER_TIMEOUT");
+    const double v = e ? atof(e) : 20.0;
+    return v > 0 ? v : 20.0;
+}
+
+}  // namespace
+
+extern "C" {
+
+// ---- memory a neighbour can map ---------------------------------------------------------------------------------------
+int plmpm_peer_area_bytes(plmpm_handle s, int field, int bz_a, int bz_b, size_t* bytes) {
+    NEED_BOUND(s);
+    REQUIRE(bytes, "null argument");
+    char* base; int nc;
+    if (plmpm_halo_field(s, field, 0, &base, &nc)) return -1;
+    REQUIRE(bz_a < bz_b, "peer_area_bytes: empty range of block planes");
+    const size_t cnt = (size_t)(bz_b - bz_a) * s->nbw[0] * s->nbw[1] * 64;
+    *bytes = kPeerHeader + 2 * (size_t)nc * cnt * s->tsz;
+    return 0;
+}
+int plmpm_peer_alloc(plmpm_handle s, size_t bytes, void** dev_ptr, void* ipc_handle64) {
+    REQUIRE(s && dev_ptr && ipc_handle64 && bytes > 0, "peer_alloc: bad argument");
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "IPC handles travel as 64 bytes");
+    if (peer_init(s)) return -1;
+    void* p = nullptr;
+    // fine-grained: coherent at system scope -- a neighbour's stores are visible here once it has released them (k_halo_xchg),
+    // this rank's polling loads see the counter move, and the grid kernels launched behind the exchange read what arrived
+    HIPCHK(hipExtMallocWithFlags(&p, bytes, hipDeviceMallocFinegrained));
+    s->peer_allocs.push_back(p);
+    HIPCHK(hipMemsetAsync(p, 0, bytes, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));         // zeroed (counter = 0) before anybody learns the handle
+    hipIpcMemHandle_t hnd;
+    HIPCHK(hipIpcGetMemHandle(&hnd, p));
+    memcpy(ipc_handle64, &hnd, 64);
+    *dev_ptr = p;
+    return 0;
+}
+int plmpm_peer_open(plmpm_handle s, const void* ipc_handle64, void** dev_ptr) {
+    REQUIRE(s && dev_ptr && ipc_handle64, "peer_open: bad argument");
+    hipIpcMemHandle_t hnd;
+    memcpy(&hnd, ipc_handle64, 64);
+    void* p = nullptr;
+    HIPCHK(hipIpcOpenMemHandle(&p, hnd, hipIpcMemLazyEnablePeerAccess));
+    s->peer_mapped.push_back(p);
+    *dev_ptr = p;
+    return 0;
+}
+
+// local[i]: this rank's receive area for face i (plmpm_peer_alloc); remote[i]: the area the neighbour on face i allocated
+// for ITS face towards this rank, mapped here (plmpm_peer_open) -- or any device pointer of that layout (loop-back runs)
+int plmpm_halo_peer_setup(plmpm_handle s, int field, int n_faces, const int* bz_a, const int* bz_b, void* const* local, void* const* remote) {
+    NEED_BOUND(s);
+    REQUIRE(field >= 0 && field < 3 && n_faces >= 0 && n_faces <= 2, "halo_peer_setup: a z-slab has at most 2 faces");
+    if (peer_init(s)) return -1;
+    plmpm_sim::PeerField& F = s->peer[field];
+    F = plmpm_sim::PeerField();
+    for (int i = 0; i < n_faces; ++i) {
+        const int ra = bz_a[i] - s->go[2] / 4, rb = bz_b[i] - s->go[2] / 4;
+        REQUIRE(local[i] && remote[i] && ra >= 0 && rb <= s->nbw[2] && ra < rb, "halo_peer_setup: block planes [%d,%d) outside the grid window", bz_a[i], bz_b[i]);
+        F.ba[i] = ra; F.bb[i] = rb;
+        F.count[i] = (size_t)(rb - ra) * s->nbw[0] * s->nbw[1] * 64;
+        F.local[i] = (char*)local[i]; F.remote[i] = (char*)remote[i];
+    }
+    F.n = n_faces;
+    return 0;
+}
+
+// One exchange of `field` (frame: which frame's grid_m / grid_v_in for PLMPM_HALO_GRID_IN): push, publish, wait -- one
+// launch on the engine's stream -- and point the grid kernels' halo input at the half that is being filled.
+int plmpm_halo_peer_exchange(plmpm_handle s, int field, int frame) {
+    NEED_BOUND(s);
+    REQUIRE(field >= 0 && field < 3, "halo_peer_exchange: unknown field %d", field);
+    plmpm_sim::PeerField& F = s->peer[field];
+    HaloIn& H = s->halo_in[field];
+    if (F.n == 0) { memset(&H, 0, sizeof H); return 0; }
+    REQUIRE(*s->peer_status == 0, "halo exchange: an earlier arrival timed out (status 0x%x: field %d, face %d) -- a neighbouring rank has stopped",
+            *s->peer_status, *s->peer_status >> 16, (*s->peer_status >> 8) & 255);
+    char* base; int nc;
+    if (plmpm_halo_field(s, field, frame, &base, &nc)) return -1;
+    const unsigned seq = ++F.seq;
+    const size_t plane = (size_t)s->nbw[0] * s->nbw[1] * 64;
+    PeerXchg X;
+    memset(&X, 0, sizeof X);
+    X.n = F.n; X.ncomp = nc; X.seq = seq; X.done = s->peer_done; X.status = s->peer_status; X.code = (field << 16) | 1;
+    X.timeout_ticks = (long long)(peer_timeout_seconds() * 1e8);
+    size_t total = 0;
+    memset(&H, 0, sizeof H);
+    for (int i = 0; i < F.n; ++i) {
+        const size_t half = (size_t)nc * F.count[i] * s->tsz;
+        for (int c = 0; c < nc; ++c) X.src[i][c] = base + ((size_t)c * s->G + (size_t)F.ba[i] * plane) * s->tsz;
+        X.dst[i] = F.remote[i] + kPeerHeader + (seq & 1) * half;
+        X.count[i] = F.count[i];
+        X.arrive_remote[i] = (unsigned*)F.remote[i];
+        X.arrive_local[i] = (unsigned*)F.local[i];
+        total += (size_t)nc * F.count[i] * s->tsz;
+        H.ba[i] = F.ba[i]; H.bb[i] = F.bb[i]; H.buf[i] = F.local[i] + kPeerHeader + (seq & 1) * half;
+    }
+    H.n = F.n;
+    const unsigned nwg = (unsigned)std::min<size_t>(64, std::max<size_t>(1, total / (256 * 16 * 4)));      // the copy is latency, not bandwidth
+    if (s->cfg.dtype == PLMPM_F64) LAUNCHB(s, K_HALO_XCHG, (k_halo_xchg<double>), dim3(nwg), 256, X);
+    else LAUNCHB(s, K_HALO_XCHG, (k_halo_xchg<float>), dim3(nwg), 256, X);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+int plmpm_peer_status(plmpm_handle s, int* status) {
+    REQUIRE(s && status, "null argument");
+    *status = s->peer_status ? *s->peer_status : 0;
+    return 0;
+}
+
+// ---- the slab substep loops, host side: enqueue only ---------------------------------------------------------------
+// plmpm_fk(first, n), then per substep  p2g | exchange of grid_m, grid_v_in | grid_op + g2p  (g2p deferred into the next
+// substep's particle kernel, as on one GPU).  mpm_simulator.py:245-257, 365-376 for one slab.
+int plmpm_slab_step(plmpm_handle s, int first, int n) {
+    NEED_BOUND(s);
+    REQUIRE(n >= 1 && first >= 0 && first + n < s->F + 1, "slab_step: frames [%d, %d] out of range", first, first + n);
+    if (plmpm_fk(s, first, n)) return -1;
+    int pending = 0;
+    for (int f = first; f < first + n; ++f) {
+        if (plmpm_p2g(s, f, pending)) return -1;
+        if (plmpm_halo_peer_exchange(s, PLMPM_HALO_GRID_IN, f)) return -1;
+        pending = f + 1 < first + n;
+        if (plmpm_grid_g2p(s, f, pending)) return -1;
+    }
+    return 0;
+}
+// reverse: per substep  g2p.grad | exchange of grid_v_out.grad | grid_op.grad + p2g.grad  (mpm_simulator.py:260-278); the
+// caller then sums the pose adjoints over the ranks (plmpm_pose_grad_region) and runs plmpm_chain_grad
+int plmpm_slab_step_grad(plmpm_handle s, int first, int n) {
+    NEED_BOUND(s);
+    REQUIRE(n >= 1 && first >= 0 && first + n < s->F + 1, "slab_step_grad: frames [%d, %d] out of range", first, first + n);
+    for (int f = first + n - 1; f >= first; --f) {
+        if (plmpm_grad_scatter(s, f)) return -1;
+        if (plmpm_halo_peer_exchange(s, PLMPM_HALO_GRID_OUT_ADJ, f)) return -1;
+        if (plmpm_grad_gather(s, f)) return -1;
+    }
+    return 0;
+}
+
+}  // extern "C"

@@ -30,8 +30,17 @@ between two migrations; it raises otherwise) a slab is at least two planes thick
 config 3's cube spans ten planes, so at most 5 such ranks -- the layout falls back to a reach of 2 layers (one of drift)
 and slabs of ONE plane, whose plane is exchanged with both neighbours (``min_thickness``): up to one rank per block plane
 of the body, at the price of a coarser load balance (8 ranks over ten planes: the largest slab holds 2/10 of the
-particles).  The exchange is issued by the host each substep; ``SlabEngine(overlap=True)`` runs the grid kernels of the
-blocks outside the exchanged planes while it is in flight.
+particles).
+
+* **Who drives the exchange.**  Two transports, same planes, same kernels consuming them.  *Peer writes* (default when
+  they can be set up, ``PLB_PEER_HALOS=0`` turns them off): every rank allocates its receive areas in fine-grained
+  device memory, the neighbours map them through IPC handles (exchanged once, over ``torch.distributed``), and an
+  exchange is ONE kernel on the engine's stream -- copy into the neighbours' areas, publish an arrival counter, wait
+  for theirs (``csrc/plmpm_peer.hip``).  The substep loops of an env step are then native (``plmpm_slab_step`` /
+  ``plmpm_slab_step_grad``) and only enqueue: no Python, no communication-library call, no request object per substep.
+  *torch.distributed point-to-point* (``batch_isend_irecv`` of zero-copy views; the fallback, and what gloo-staged test
+  ranks without IPC use): issued by the host each substep; ``SlabEngine(overlap=True)`` runs the grid kernels of the
+  blocks outside the exchanged planes while it is in flight.
 
 The communication layer is backend-agnostic (``nccl`` = RCCL on the GPUs; ``gloo`` for the CPU tests and for ranks
 sharing one GPU, staged through host memory).
@@ -40,6 +49,8 @@ from __future__ import annotations
 
 from dataclasses import dataclass
 from typing import Callable, List, Optional, Tuple
+
+import os
 
 import numpy as np
 import torch
@@ -153,8 +164,12 @@ class HaloComm:
     exchange of block planes (zero-copy send views, persistent receive buffers, op lists cached per frame) and the
     row exchanges of particle migration."""
 
-    def __init__(self, layout: SlabLayout, rank: int, group=None):
+    def __init__(self, layout: SlabLayout, rank: int, group=None, peer: Optional[bool] = None):
         self.layout, self.rank, self.group = layout, rank, group
+        # peer writes: asked for explicitly, or by default on the GPUs' own backend (PLB_PEER_HALOS=0/1 overrides both)
+        env = os.environ.get("PLB_PEER_HALOS", "")
+        self.want_peer = (env == "1") if env in ("0", "1") else (bool(peer) if peer is not None else dist.get_backend(group) == "nccl")
+        self.peer_ready = False
         self.stage_host = dist.get_backend(group) == "gloo"      # gloo P2P wants host tensors
         # small host records (loss sums) are reduced on the device when the backend is RCCL
         self.scalar_device = torch.device("cpu") if self.stage_host else torch.device("cuda", torch.cuda.current_device())
@@ -175,9 +190,53 @@ class HaloComm:
         engine.halo_set_recv(field, [(a, b) for _n, a, b in faces], bufs)
         self._recv[field] = bufs
 
+    def setup_peer(self, engine):
+        """Collective, once: receive areas for the three halo fields in fine-grained device memory, IPC handles swapped
+        with the neighbours, their areas mapped here.  True if EVERY rank got through (otherwise nobody uses the peer
+        path: the point-to-point exchange below works without it)."""
+        if self.peer_ready or not self.want_peer or self.layout.world < 2:
+            return self.peer_ready
+        faces = self.layout.faces(self.rank)
+        fields = (engine.HALO_GRID_IN, engine.HALO_GRID_OUT_ADJ, engine.HALO_LOSS_MASS)
+        mine, local, err = {}, {}, ""
+        try:
+            for field in fields:
+                for nbr, a, b in faces:
+                    ptr, handle = engine.peer_alloc(field, a, b)
+                    local[(field, nbr)] = ptr
+                    mine[(field, nbr)] = (handle, a, b)
+        except Exception as e:                                   # noqa: BLE001 -- e.g. no IPC in this environment
+            err = f"{type(e).__name__}: {e}"
+        everyone = [None] * self.layout.world
+        dist.all_gather_object(everyone, {"rank": self.rank, "areas": mine, "err": err}, group=self.group)
+        ok = not any(r["err"] for r in everyone)
+        remote = {}
+        if ok:
+            try:
+                for field in fields:
+                    for nbr, a, b in faces:
+                        handle, ra, rb = everyone[nbr]["areas"][(field, self.rank)]
+                        assert (ra, rb) == (a, b), "both sides of a face exchange the same block planes"
+                        remote[(field, nbr)] = engine.peer_open(handle)
+            except Exception as e:                               # noqa: BLE001
+                err = f"{type(e).__name__}: {e}"
+        flags = [None] * self.layout.world
+        dist.all_gather_object(flags, err, group=self.group)
+        if any(flags):
+            self.peer_error = next(f for f in flags if f)
+            return False
+        for field in fields:
+            engine.halo_peer_setup(field, [(a, b) for _n, a, b in faces], [local[(field, n)] for n, _a, _b in faces],
+                                   [remote[(field, n)] for n, _a, _b in faces])
+        self.peer_ready = True
+        return True
+
     def exchange(self, engine, field, f):
         """Send this rank's copy of the exchanged block planes of ``field`` (frame ``f``) to the neighbours and receive
         theirs into the registered buffers.  The grid kernels (or ``halo_apply``) add them."""
+        if self.peer_ready:
+            engine.halo_peer_exchange(field, f)          # one kernel on the engine's stream: push, publish, wait
+            return
         self.exchange_finish(self.exchange_start(engine, field, f))
 
     def exchange_finish(self, reqs):
@@ -192,6 +251,9 @@ class HaloComm:
         test transport, goes through host memory and is complete on return.)"""
         faces = self.layout.faces(self.rank)
         if not faces:
+            return []
+        if self.peer_ready:
+            engine.halo_peer_exchange(field, f)
             return []
         if field not in self._recv:
             self.attach(engine, field, f)
@@ -299,13 +361,17 @@ class SlabEngine:
     halo-exchanging, migrating versions.  ``MPMSimulator``, ``Loss`` and ``Tape`` work on it unchanged."""
 
     def __init__(self, engine, layout: SlabLayout, rank: int, group=None, comm: Optional[HaloComm] = None, migrate_every: int = 1,
-                 overlap: bool = False):
+                 overlap: bool = False, peer: Optional[bool] = None):
         self._e, self.layout, self.rank = engine, layout, rank
         # overlap: grid_op / grid_op.grad of the blocks outside the exchanged planes run while the halos are in flight
         # (one more launch per phase: worth it when a rank's kernels are long against the exchange -- configs 4 and 5 --
         # not when the host is what bounds the substep, as at 128^3 cut four ways)
         self.overlap = bool(overlap) and bool(layout.faces(rank))
-        self.comm = comm if comm is not None else HaloComm(layout, rank, group)
+        self.comm = comm if comm is not None else HaloComm(layout, rank, group, peer=peer)
+        # device-side exchange (peer writes): the substep loops are then the native ones and the host only enqueues
+        self.native_loops = bool(getattr(self.comm, "setup_peer", None) and self.comm.setup_peer(engine))
+        if self.native_loops:
+            self.overlap = False                   # the exchange is a kernel in the engine's own stream
         self.soft_contact = False
         self.migrate_every = int(migrate_every)        # env steps between two migrations (0: never -- fixed ownership)
         self._since_migration = 0
@@ -330,9 +396,14 @@ class SlabEngine:
     def _check(self):
         """Combine the device error word over the ranks before anyone raises: a rank that bailed out alone would
         leave the others waiting in their next exchange."""
-        flags = torch.tensor([float(self._e.error_flags())], dtype=torch.float64, device=self.comm.scalar_device)
+        flags = torch.tensor([float(self._e.error_flags()), float(self._e.peer_status() if self.native_loops else 0)],
+                             dtype=torch.float64, device=self.comm.scalar_device)
         self.comm.all_reduce_(flags, op=dist.ReduceOp.MAX)
-        self._e.check_error(int(flags.item()))
+        if flags[1].item():
+            st = int(flags[1].item())
+            raise RuntimeError(f"halo exchange: an arrival timed out on some rank (status 0x{st:x}: field {st >> 16}, face {(st >> 8) & 255}) "
+                               "-- a neighbouring rank stopped enqueueing; results of this env step are not valid")
+        self._e.check_error(int(flags[0].item()))
 
     # ---- segment checkpoints (optimizer/checkpoint.py): this rank's population at a frame, and re-entry with it
     def checkpoint(self, f):
@@ -406,6 +477,9 @@ class SlabEngine:
         if self.layout.world > 1 and self.migrate_every > 0 and self._since_migration >= self.migrate_every:
             self.migrate(first)
         self._since_migration += 1
+        if self.native_loops:
+            e.slab_step(first, n)
+            return
         e.fk(first, n)
         pending = False                         # g2p(f - 1) deferred: it runs fused with p2g(f), as on one GPU
         for f in range(first, first + n):
@@ -429,15 +503,18 @@ class SlabEngine:
             adj_epoch = e.frame_info(last)[2]
             if adj_epoch >= 0 and adj_epoch != e.frame_info(last - 1)[1]:
                 self._migrate_adjoint(last)     # particles migrated at `last`: adjoint rows go back where they came from
-        for f in range(last - 1, first - 1, -1):
-            e.grad_scatter(f)
-            if self.overlap:
-                reqs = self.comm.exchange_start(e, e.HALO_GRID_OUT_ADJ, f)
-                e.grad_gather_interior(f)
-                self.comm.exchange_finish(reqs)
-            else:
-                self.comm.exchange(e, e.HALO_GRID_OUT_ADJ, f)
-            e.grad_gather(f)
+        if self.native_loops:
+            e.slab_step_grad(first, n)
+        else:
+            for f in range(last - 1, first - 1, -1):
+                e.grad_scatter(f)
+                if self.overlap:
+                    reqs = self.comm.exchange_start(e, e.HALO_GRID_OUT_ADJ, f)
+                    e.grad_gather_interior(f)
+                    self.comm.exchange_finish(reqs)
+                else:
+                    self.comm.exchange(e, e.HALO_GRID_OUT_ADJ, f)
+                e.grad_gather(f)
         for view in e.pose_grad_views(first, n + 1):      # position, rotation, (Chopsticks) gap adjoints
             self.comm.all_reduce_(view)
         e.chain_grad(first, n, step)
@@ -496,7 +573,7 @@ def make_slab_env(cfg, rank: int, world: int, *, halo: Optional[int] = None, com
                   target_fn: Optional[Callable] = None, particles: Optional[np.ndarray] = None,
                   layout: Optional[SlabLayout] = None, comm: Optional[HaloComm] = None,
                   xy_margin: Optional[int] = 12, migrate_every: int = 1, capacity_factor: float = 1.5,
-                  yield_stress: Optional[np.ndarray] = None, overlap: bool = False):
+                  yield_stress: Optional[np.ndarray] = None, overlap: bool = False, peer: Optional[bool] = None):
     """Build this rank's ``TaichiEnv`` over its slab of the scene in ``cfg`` (every rank samples the same seed-0
     particle cloud and keeps its own part).  ``target_fn(all_particles, sim) -> (n,n,n) grid`` may supply the loss
     target.  ``xy_margin`` (node layers): the grid window is the bounding box of the whole cloud at reset plus that
@@ -505,7 +582,8 @@ def make_slab_env(cfg, rank: int, world: int, *, halo: Optional[int] = None, com
     values for the WHOLE cloud (each rank keeps its part).  ``layout`` / ``comm`` override the balanced cut and the
     torch.distributed communicator (measurement tools: profiles/tools/slab_host_cost.py).  ``overlap``: run grid_op /
     grid_op.grad of the blocks outside the exchanged planes while the halos are in flight (``SlabEngine.overlap``).
-    Returns (env, layout, owned_index)."""
+    ``peer``: device-side halo exchange by peer writes + native substep loops (None: on for the ``nccl`` backend, off for
+    gloo; the environment variable PLB_PEER_HALOS=0/1 overrides).  Returns (env, layout, owned_index)."""
     from .engine import taichi_env as te
     from .engine.losses import Loss
     from .engine.mpm_simulator import MPMSimulator
@@ -547,7 +625,7 @@ def make_slab_env(cfg, rank: int, world: int, *, halo: Optional[int] = None, com
                        particle_capacity=capacity)
     if world > 1:
         sim.engine.set_ids(mine)
-        sim.engine = SlabEngine(sim.engine, layout, rank, group, comm, migrate_every=migrate_every, overlap=overlap)
+        sim.engine = SlabEngine(sim.engine, layout, rank, group, comm, migrate_every=migrate_every, overlap=overlap, peer=peer)
         env.primitives._bind(sim.engine)
     if yield_stress is not None:
         sim._yield_stress = np.ascontiguousarray(np.asarray(yield_stress, np.float64)[mine])

@@ -353,6 +353,44 @@ class Engine:
     def halo_apply(self, field, f):
         L.check(self.lib.plmpm_halo_apply(self.h, field, f))
 
+    # ---- device-side halo exchange (plmpm_peer.hip)
+    def peer_alloc(self, field, bz_a, bz_b):
+        """A receive area for block planes [bz_a, bz_b) of ``field`` in fine-grained device memory owned by the engine:
+        (device pointer, 64-byte IPC handle a neighbouring process maps with ``peer_open``)."""
+        nbytes, p = C.c_size_t(), C.c_void_p()
+        L.check(self.lib.plmpm_peer_area_bytes(self.h, field, bz_a, bz_b, C.byref(nbytes)))
+        handle = C.create_string_buffer(64)
+        L.check(self.lib.plmpm_peer_alloc(self.h, nbytes, C.byref(p), handle))
+        return p.value, handle.raw
+
+    def peer_open(self, handle: bytes):
+        p = C.c_void_p()
+        L.check(self.lib.plmpm_peer_open(self.h, C.create_string_buffer(handle, 64), C.byref(p)))
+        return p.value
+
+    def halo_peer_setup(self, field, planes, local, remote):
+        nf = len(planes)
+        za = (C.c_int * max(nf, 1))(*[p[0] for p in planes])
+        zb = (C.c_int * max(nf, 1))(*[p[1] for p in planes])
+        lo = (C.c_void_p * max(nf, 1))(*local)
+        re = (C.c_void_p * max(nf, 1))(*remote)
+        L.check(self.lib.plmpm_halo_peer_setup(self.h, field, nf, za, zb, lo, re))
+
+    def halo_peer_exchange(self, field, f):
+        L.check(self.lib.plmpm_halo_peer_exchange(self.h, field, f))
+
+    def peer_status(self):
+        st = C.c_int()
+        L.check(self.lib.plmpm_peer_status(self.h, C.byref(st)))
+        return st.value
+
+    def slab_step(self, first, n):
+        """fk + the forward substeps of one env step of a slab rank, exchanges included: enqueue only."""
+        L.check(self.lib.plmpm_slab_step(self.h, first, n))
+
+    def slab_step_grad(self, first, n):
+        L.check(self.lib.plmpm_slab_step_grad(self.h, first, n))
+
     # ---- migration (slab engines)
     def set_ids(self, ids):
         ids = np.ascontiguousarray(ids, np.int32)

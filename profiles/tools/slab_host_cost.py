@@ -26,8 +26,9 @@ class LoopbackComm(D.HaloComm):
     """No neighbours: the registered receive buffers stay zero (one memset per face and exchange stands in for the
     arrival of a message), so the physics is that of a body with free faces; rows that leave are dropped."""
 
-    def __init__(self, layout, rank):
+    def __init__(self, layout, rank, peer=False):
         self.layout, self.rank, self.group = layout, rank, None
+        self.want_peer, self.peer_ready = bool(peer), False
         self.stage_host = False
         self.backend = "loopback"
         self.scalar_device = torch.device("cuda", torch.cuda.current_device())
@@ -35,8 +36,23 @@ class LoopbackComm(D.HaloComm):
         self.down = rank - 1 if rank > 0 else None
         self.up = rank + 1 if rank < layout.world - 1 else None
 
+    def setup_peer(self, engine):
+        """--peer: the device-side exchange with this rank's own receive areas as the "neighbours'" (the kernel copies the
+        planes, publishes the counter it then waits for): same launches and host work per substep as a real run."""
+        if not self.want_peer:
+            return False
+        faces = self.layout.faces(self.rank)
+        for field in (engine.HALO_GRID_IN, engine.HALO_GRID_OUT_ADJ, engine.HALO_LOSS_MASS):
+            local = [engine.peer_alloc(field, a, b)[0] for _n, a, b in faces]
+            engine.halo_peer_setup(field, [(a, b) for _n, a, b in faces], local, local)
+        self.peer_ready = True
+        return True
+
     def exchange_start(self, engine, field, f):
         if not self.layout.faces(self.rank):
+            return []
+        if self.peer_ready:
+            engine.halo_peer_exchange(field, f)
             return []
         if field not in self._recv:
             self.attach(engine, field, f)
@@ -69,6 +85,8 @@ def main():
     ap.add_argument("--migrate-every", type=int, default=1)
     ap.add_argument("--overlap", action="store_true", help="interior grid blocks launched before the exchange is waited for")
     ap.add_argument("--profile", action="store_true", help="cProfile one rollout (top functions by own time)")
+    ap.add_argument("--kernels", action="store_true", help="per-kernel HIP-event durations of one more rollout")
+    ap.add_argument("--peer", action="store_true", help="device-side exchange (one kernel per exchange) + native substep loops")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(0)
@@ -82,10 +100,11 @@ def main():
         from plasticinelab_amd.engine.shapes import Shapes
         x_all, _ = Shapes(cfg.SHAPES).get()
         world, rank = args.world, args.world // 2
-        layout = D.SlabLayout.balanced(x_all, n, world)
+        layout = D.SlabLayout.balanced(x_all, n, world, None)      # reach 4, or 2 (one-plane slabs) when the body is too thin for that
     env, _, mine = D.make_slab_env(cfg, rank, world, compute_dtype=args.dtype, device=dev, target_fn=bench._target,
-                                   layout=layout, comm=LoopbackComm(layout, rank), xy_margin=args.xy_margin, migrate_every=args.migrate_every,
+                                   layout=layout, comm=LoopbackComm(layout, rank, args.peer), xy_margin=args.xy_margin, migrate_every=args.migrate_every,
                                    overlap=args.overlap)
+    print(f"native substep loops: {env.simulator.engine.native_loops}")
     print(f"rank {rank}/{world}: slab {layout.slab(rank)}, halo {layout.halo}, {len(mine)} particles, "
           f"grid window {[list(map(int, a)) for a in env.simulator.engine.grid_window()]}")
     env.loss.set_weights(10, 10, 1, False)
@@ -105,6 +124,16 @@ def main():
             k = args.steps * sub
             print(f"issue {1e6 * (t1 - t0) / k:7.1f} us/substep   wall {1e6 * (t2 - t0) / k:7.1f} us/substep   "
                   f"({k} fwd+bwd substeps)")
+    if args.kernels:
+        env.set_state(state0, 666.0, False)
+        sim.engine.profile_enable(True)
+        bench.rollout(env, acts)
+        prof = sim.engine.profile_read()
+        sim.engine.profile_enable(False)
+        k = args.steps * sub
+        print("kernels (HIP events), us per launch / us per fwd+bwd substep: " +
+              ", ".join(f"{name} {1e3 * ms / cnt:.1f} / {1e3 * ms / k:.1f}" for name, (ms, cnt) in prof.items() if cnt))
+        print(f"sum {sum(1e3 * ms / k for ms, cnt in prof.values()):.1f} us per fwd+bwd substep")
     if args.profile:
         import cProfile
         import pstats

@@ -28,6 +28,7 @@ def main():
     backend = os.environ.get("PLB_DIST_BACKEND", "gloo")
     overlap = os.environ.get("PLB_TEST_OVERLAP") == "1"      # interior grid blocks while the halos are in flight
     halo = int(os.environ["PLB_TEST_HALO"]) if os.environ.get("PLB_TEST_HALO") else None     # 2: thin slabs (one block plane)
+    peer = os.environ.get("PLB_TEST_PEER") == "1"            # device-side halo exchange (peer writes through IPC-mapped areas)
     dev = rank % torch.cuda.device_count() if backend == "nccl" else 0
     torch.cuda.set_device(dev)
     if backend == "nccl":
@@ -49,7 +50,7 @@ def main():
         x_all, _ = Shapes(cfg.SHAPES).get()
         n = 2000
         sub = np.ascontiguousarray(x_all[::len(x_all) // n][:n])
-        env, layout, mine = make_slab_env(cfg, rank, world, compute_dtype=dtype, particles=sub, xy_margin=xy_margin, halo=halo,
+        env, layout, mine = make_slab_env(cfg, rank, world, compute_dtype=dtype, particles=sub, xy_margin=xy_margin, halo=halo, peer=peer,
                                           migrate_every=migrate_every, target_fn=lambda x, sim: sparse_target("Move3D-v1"), overlap=overlap)
     else:
         import bench
@@ -60,8 +61,11 @@ def main():
         ys = None
         if scene.get("mixed"):                       # config 5: half the particles yield (50), half do not (1e9)
             ys = np.where(np.arange(scene["particles"]) % 2 == 0, 50.0, 1e9)
-        env, layout, mine = make_slab_env(cfg, rank, world, compute_dtype=dtype, xy_margin=xy_margin, migrate_every=migrate_every, halo=halo,
+        env, layout, mine = make_slab_env(cfg, rank, world, compute_dtype=dtype, xy_margin=xy_margin, migrate_every=migrate_every, halo=halo, peer=peer,
                                           target_fn=bench._target, yield_stress=ys, overlap=overlap)
+    if peer:
+        comm = env.simulator.engine.comm
+        assert env.simulator.engine.native_loops, f"peer halos were asked for and could not be set up: {getattr(comm, 'peer_error', '?')}"
     env.loss.set_weights(10, 10, 1, False)
     solver = Solver(env, None, None, softness=666.0, horizon=len(actions))
     state0 = env.get_state()["state"]
@@ -79,7 +83,8 @@ def main():
     ws = eng.workspace_bytes
     np.savez(f"{out_path}.{rank}.npz", loss=loss, grad=grad, mine=mine, ids=ids, x=fr["x"], v=fr["v"], bounds=np.array(layout.bounds),
              migrations=eng.migrations, rows_moved=eng.rows_moved, window=np.concatenate(eng.grid_window()),
-             grid_bytes=ws["grid_bytes"], total_bytes=sum(ws.values()), count=eng.frame_info(sim.cur)[0])
+             grid_bytes=ws["grid_bytes"], total_bytes=sum(ws.values()), count=eng.frame_info(sim.cur)[0],
+             native_loops=int(getattr(eng, "native_loops", False)))
     dist.barrier()
     dist.destroy_process_group()
 

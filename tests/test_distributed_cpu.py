@@ -76,6 +76,75 @@ class ToyEngine:
         assert field == 2
         self._add_recv(2, f)
 
+    # ---- device-side exchange (csrc/plmpm_peer.hip), emulated: a receive area is a file in /dev/shm that the neighbour
+    # maps by name -- what fine-grained device memory behind an IPC handle is on the GPUs.  Same layout (arrival counter,
+    # two halves written alternately) and same protocol: write the neighbour's half, publish the counter, wait for ours.
+    HEADER = 32
+
+    def peer_alloc(self, field, a, b):
+        cnt = self.halo_ncomp(field) * 4 * (b - a) * N * N
+        self._areas = getattr(self, "_areas", [])
+        name = f"/dev/shm/plb_toy_{os.getpid()}_{len(self._areas)}"
+        arr = np.memmap(name, dtype=np.float64, mode="w+", shape=(self.HEADER + 2 * cnt,))
+        arr[:] = 0
+        self._areas.append(arr)
+        self._owned = getattr(self, "_owned", []) + [name]
+        return len(self._areas) - 1, name.encode().ljust(64, b"\0")
+
+    def peer_open(self, handle):
+        assert len(handle) == 64
+        self._areas.append(np.memmap(handle.rstrip(b"\0").decode(), dtype=np.float64, mode="r+"))
+        return len(self._areas) - 1
+
+    def halo_peer_setup(self, field, planes, local, remote):
+        self.peer = getattr(self, "peer", {})
+        self.peer[field] = dict(planes=list(planes), local=[self._areas[i] for i in local], remote=[self._areas[i] for i in remote], seq=0)
+
+    def halo_peer_exchange(self, field, f):
+        import time
+        P = self.peer[field]
+        P["seq"] += 1
+        seq, half, g = P["seq"], P["seq"] & 1, self._field(field, f)
+        for (a, b), rem in zip(P["planes"], P["remote"]):
+            data = g[:, 4 * a:4 * b].reshape(-1).numpy()
+            rem[self.HEADER + half * data.size:self.HEADER + (half + 1) * data.size] = data
+            rem[0] = seq                                        # published behind the data
+        recv = []
+        for (a, b), loc in zip(P["planes"], P["local"]):
+            t0 = time.time()
+            while loc[0] < seq:
+                assert time.time() - t0 < 120, "the neighbour's arrival never came"
+                time.sleep(1e-4)
+            cnt = g.shape[0] * 4 * (b - a) * N * N
+            recv.append(((a, b), torch.from_numpy(np.array(loc[self.HEADER + half * cnt:self.HEADER + (half + 1) * cnt]))))
+        self.recv[field] = recv
+        self.calls.append(("peer_exchange", field, f))
+
+    def peer_status(self):
+        return 0
+
+    def slab_step(self, first, n):                              # plmpm_slab_step
+        self.fk(first, n)
+        pending = False
+        for f in range(first, first + n):
+            self.p2g(f, chain=pending)
+            self.halo_peer_exchange(0, f)
+            pending = f + 1 < first + n
+            self.grid_g2p(f, chain=pending)
+
+    def slab_step_grad(self, first, n):                         # plmpm_slab_step_grad
+        for f in range(first + n - 1, first - 1, -1):
+            self.grad_scatter(f)
+            self.halo_peer_exchange(1, f)
+            self.grad_gather(f)
+
+    def close(self):
+        for name in getattr(self, "_owned", []):
+            try:
+                os.unlink(name)
+            except OSError:
+                pass
+
     def frame_info(self, f):
         fr = self.frames[f]
         return len(fr["ids"]), self.epoch_of[f], (self.adj_epoch if self.adj_frame == f else -1)
@@ -252,16 +321,17 @@ class ToyEngine:
         self.calls.append(("loss_backward_local", f))
 
 
-def _world(rank, world, port, ids, bz_all, w_all, drift, out, overlap=False):
+def _world(rank, world, port, ids, bz_all, w_all, drift, out, overlap=False, peer=False, halo=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         x = np.zeros((len(bz_all), 3)); x[:, 2] = (np.asarray(bz_all) + 0.7) / N
-        layout = SlabLayout.balanced(x, N, world, None)
+        layout = SlabLayout.balanced(x, N, world, halo)
         assert all(b - a >= 2 * layout.halo and a % 4 == 0 for a, b in zip(layout.bounds, layout.bounds[1:]))
         mine = np.nonzero(layout.owner_of(SlabLayout.stencil_base_z(x, N)) == rank)[0]
         toy = ToyEngine([ids[i] for i in mine], [bz_all[i] for i in mine], [w_all[i] for i in mine], drift, layout, rank)
-        eng = SlabEngine(toy, layout, rank, migrate_every=1, overlap=overlap)
+        eng = SlabEngine(toy, layout, rank, migrate_every=1, overlap=overlap, peer=peer)
+        assert eng.native_loops == (peer and world > 1), getattr(eng.comm, "peer_error", None)
         last = STEPS * SUB
         for k in range(STEPS):
             eng.step(k * SUB, SUB)
@@ -275,14 +345,16 @@ def _world(rank, world, port, ids, bz_all, w_all, drift, out, overlap=False):
                          order=[c[0] for c in toy.calls], moved=eng.rows_moved, migrations=eng.migrations,
                          counts=[len(toy.frames[k * SUB]["ids"]) for k in range(STEPS + 1)],
                          fwd=[c for c in toy.calls if c[0] in ("p2g", "grid_g2p")])
+        dist.barrier()                                          # nobody unmaps an area a neighbour may still write
+        toy.close()
     finally:
         dist.destroy_process_group()
 
 
-def run(world, ids, bz, w, drift, overlap=False):
+def run(world, ids, bz, w, drift, overlap=False, peer=False, halo=None):
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_world, args=(world, free_port(), ids, bz, w, drift, out, overlap), nprocs=world, join=True)
+    mp.spawn(_world, args=(world, free_port(), ids, bz, w, drift, out, overlap, peer, halo), nprocs=world, join=True)
     return dict(out)
 
 
@@ -325,8 +397,10 @@ def test_layout_balanced_and_faces():
     assert hi0[2] == lay.bounds[1] + 4 and lo0[2] < lay.bounds[1] - 8 and lo0[:2] == lo[:2]   # same xy window on every rank
 
 
-@pytest.mark.parametrize("WORLD,OVERLAP", [(2, False), (3, False), (3, True)])
-def test_ranks_equal_one_rank(WORLD, OVERLAP):
+@pytest.mark.parametrize("WORLD,OVERLAP,PEER", [(2, False, False), (3, False, False), (3, True, False), (2, False, True), (3, False, True)])
+def test_ranks_equal_one_rank(WORLD, OVERLAP, PEER):
+    """PEER: the device-side exchange protocol (receive areas mapped by name, two halves, arrival counters) and the native
+    substep loops it enables, with shared-memory files standing in for IPC-mapped device memory."""
     rng = np.random.default_rng(1)
     n = 48
     ids = list(range(100, 100 + n))
@@ -334,8 +408,10 @@ def test_ranks_equal_one_rank(WORLD, OVERLAP):
     w = [float(v) for v in rng.random(n) + 0.5]
     drift = {i: int(d) for i, d in zip(ids, rng.integers(-1, 2, n))}        # -1 / 0 / +1 layers per env step
     one = run(1, ids, bz, w, drift)[0]
-    many = run(WORLD, ids, bz, w, drift, OVERLAP)
+    many = run(WORLD, ids, bz, w, drift, OVERLAP, PEER)
     assert many[0]["bounds"] == many[1]["bounds"]
+    if PEER:          # one exchange per grid phase, inside the native loops
+        assert many[0]["order"].count("peer_exchange") == 2 * STEPS * SUB + 1              # + the loss mass grid
     if OVERLAP:       # every substep ran its interior pass between the scatter and the face pass, forward and reverse
         for r in range(WORLD):
             o = many[r]["order"]
@@ -370,7 +446,8 @@ def test_ranks_equal_one_rank(WORLD, OVERLAP):
     assert many[0]["fwd"][:4] == [("p2g", 0, False), ("grid_g2p", 0, True), ("p2g", 1, True), ("grid_g2p", 1, False)]
 
 
-def test_eight_thin_slabs_equal_one_rank():
+@pytest.mark.parametrize("PEER", [False, True])
+def test_eight_thin_slabs_equal_one_rank(PEER):
     """World size 8 on a body of eight block planes: every slab is ONE block plane (reach 2 layers: one of stencil, one of
     drift), so a rank's plane is exchanged with both neighbours and both received copies are added -- the layout
     `bench.py --gpus 8` needs for the 40-layer cube of config 3."""
@@ -383,7 +460,7 @@ def test_eight_thin_slabs_equal_one_rank():
     # one layer of drift per env step at most, away from the walls
     drift = {i: (int(rng.integers(0, 2)) if b < 15 else -int(rng.integers(0, 2))) for i, b in zip(ids, bz)}
     one = run(1, ids, bz, w, drift)[0]
-    many = run(8, ids, bz, w, drift)
+    many = run(8, ids, bz, w, drift, peer=PEER)        # PEER: a one-plane slab's plane goes into BOTH neighbours' receive areas
     b = many[0]["bounds"]
     assert len(b) == 9 and all(hi - lo == 4 for lo, hi in zip(b, b[1:]))
     assert sum(many[r]["moved"] for r in range(8)) > 0

@@ -25,7 +25,7 @@ def free_port():
 
 
 def launch(tmp_path, world, dtype, actions, xy_margin, migrate_every, backend="gloo", scene=None, overlap=False, deterministic=False, halo=None,
-           segment=0):
+           segment=0, peer=False):
     out = str(tmp_path / "r")
     act = str(tmp_path / "actions.npy")
     np.save(act, actions)
@@ -34,7 +34,7 @@ def launch(tmp_path, world, dtype, actions, xy_margin, migrate_every, backend="g
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    HSA_ENABLE_IPC_MODE_LEGACY="0", PLB_DIST_BACKEND=backend, PLB_TEST_OVERLAP="1" if overlap else "0", PLB_TEST_DETERMINISTIC="1" if deterministic else "0",
-                   PLB_TEST_HALO="" if halo is None else str(halo), PLB_TEST_SEGMENT=str(segment) if segment else "")
+                   PLB_TEST_HALO="" if halo is None else str(halo), PLB_TEST_SEGMENT=str(segment) if segment else "", PLB_TEST_PEER="1" if peer else "0", PLMPM_PEER_TIMEOUT="60")
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_gpu_worker.py"), out, dtype, act,
                                        "none" if xy_margin is None else str(xy_margin), str(migrate_every)]
                                       + ([json.dumps(scene)] if scene else []),
@@ -159,8 +159,62 @@ def test_config4_grid_in_four_slabs(tmp_path):
           f"{[round(int(r['grid_bytes']) / 2**30, 2) for r in res]} GiB vs {single_grid_bytes / 2**30:.2f} GiB on one rank")
 
 
-@pytest.mark.parametrize("world,segment", [(2, 2), (3, 1)])
-def test_segment_checkpointed_backward_on_slab_ranks(tmp_path, world, segment):
+def test_config4_full_size_split_over_two_ranks(tmp_path):
+    """BASELINE configs[3] at its own size -- 256^3 grid, 2M elastic particles, 79 substeps per env step -- as the
+    config names it: split into z-slabs over 2 ranks (both on the box's one GPU, halos over gloo), 2 env steps fwd+bwd
+    with a migration in between, against the single-rank run of the same workload (float64 engine: the comparison is
+    then a statement about the decomposition, not about summation order)."""
+    import bench
+    import torch
+    from plasticinelab_amd.engine.shapes import Shapes
+    from plasticinelab_amd.engine.taichi_env import TaichiEnv
+    from plasticinelab_amd.optimizer.solver import Solver
+    scene = dict(particles=2_000_000, quality=4, side=0.25, yield_stress=1e9)
+    H, margin = 2, 16
+    acts = bench.seeded_actions(H, 6)
+    cfg = bench.workload_cfg(scene["particles"], scene["quality"], max_steps=H * 79 + 1, yield_stress=1e9, side=0.25)
+    x_all, _ = Shapes(cfg.SHAPES).get()
+    b = (x_all * 256 - 0.5).astype(np.int64)
+    cfg.SIMULATOR["grid_window"] = ([int(v) for v in np.maximum(b.min(0) - margin, 0)], [int(v) for v in np.minimum(b.max(0) + 3 + margin, 256)])
+    env = TaichiEnv(cfg, compute_dtype="float64")
+    env.initialize()
+    env.loss.load_target_density(grids=bench._target(env.init_particles, env.simulator))
+    env.loss.set_weights(10, 10, 1, False)
+    loss, grad = Solver(env, None, None, softness=666.0, horizon=H).forward(env.get_state()["state"], acts)
+    env.simulator.engine.close()
+    del env
+    torch.cuda.empty_cache()
+    res = launch(tmp_path, 2, "float64", acts, margin, 1, scene=scene)
+    for r in res:
+        assert abs(float(r["loss"]) - loss) / abs(loss) < 1e-9
+        assert relerr(r["grad"], grad) < 1e-7
+        assert int(r["migrations"]) == H - 1
+    assert sum(int(r["count"]) for r in res) == scene["particles"]
+    print(f"\n[256^3 / 2M particles in 2 slabs] loss {loss:.9g}, particles per rank {[int(r['count']) for r in res]}, rows moved {[int(r['rows_moved']) for r in res]}")
+
+
+@pytest.mark.parametrize("dtype,world", [("float64", 2), ("float64", 3), ("float32", 3)])
+def test_peer_write_halos_match_golden_rollout(tmp_path, dtype, world):
+    """Device-side halo exchange (csrc/plmpm_peer.hip): receive areas in fine-grained device memory mapped by the
+    neighbours through IPC handles, one kernel per exchange (copy into the neighbours' areas, publish the arrival counter,
+    wait for theirs), the substep loops native (plmpm_slab_step / plmpm_slab_step_grad) -- no host-side communication per
+    substep.  Same planes and same consuming kernels as the torch.distributed transport, so the same results: the golden
+    rollout with migration every env step, a middle rank with two faces included."""
+    g = np.load(os.path.join(GOLDEN, "rollout_small.npz"))
+    res = launch(tmp_path, world, dtype, g["actions"], 6, migrate_every=1, peer=True)
+    ltol, gtol, xtol = (1e-10, 1e-7, 1e-10) if dtype == "float64" else (1e-5, 1e-4, 2e-5)
+    assert all(int(r["native_loops"]) == 1 for r in res)
+    for r in res:
+        assert abs(float(r["loss"]) - float(g["loss"])) / abs(float(g["loss"])) < ltol
+        assert relerr(r["grad"], g["grad"]) < gtol
+        assert int(r["migrations"]) == len(g["actions"]) - 1
+    x, v = gather(res, int(g["n_particles"]))
+    assert relerr(x, g["x_final"]) < xtol
+    assert relerr(v, g["v_final"]) < (1e-8 if dtype == "float64" else 2e-3)
+
+
+@pytest.mark.parametrize("world,segment,peer", [(2, 2, False), (3, 1, False), (3, 2, True)])
+def test_segment_checkpointed_backward_on_slab_ranks(tmp_path, world, segment, peer):
     """optimizer/checkpoint.py on z-slab ranks (long_term_gradient.ipynb cells 2-4 on a population that migration keeps
     changing): 6 env steps in segments of 2 (3 segments) / 1 (6 segments), migration before every env step; a checkpoint
     is the rank's rows at the boundary (ids, state, materials), a segment re-enters the engine with them as a new
@@ -172,14 +226,15 @@ def test_segment_checkpointed_backward_on_slab_ranks(tmp_path, world, segment):
     acts[:, 0] = 0.5; acts[:, 3] = -0.5
     acts += np.random.default_rng(5).uniform(-0.1, 0.1, acts.shape)
     loss, grad, x1, v1 = single_rank(acts, "float64")
-    res = launch(tmp_path, world, "float64", acts, 10, 1, segment=segment)
+    res = launch(tmp_path, world, "float64", acts, 10, 1, segment=segment, peer=peer)
     assert sum(int(r["rows_moved"]) for r in res) > 0
     for r in res:
         assert abs(float(r["loss"]) - loss) / abs(loss) < 1e-9
         assert relerr(r["grad"], grad) < 1e-7
 
 
-def test_thin_slabs_one_block_plane_per_rank(tmp_path):
+@pytest.mark.parametrize("peer", [False, True])
+def test_thin_slabs_one_block_plane_per_rank(tmp_path, peer):
     """The layout `bench.py --gpus 8` uses on config 3: a reach of 2 node layers (one of stencil, one of drift) lets a slab
     be ONE block plane, which then lies in the exchange range of both its faces -- it goes to both neighbours, and
     k_grid_op / k_grid_op_grad add both received copies.  Here: the benchmark's cube on a 64^3 grid (20 layers = 5-6 block
@@ -200,7 +255,8 @@ def test_thin_slabs_one_block_plane_per_rank(tmp_path):
     env.simulator.engine.close()
     del env
     torch.cuda.empty_cache()
-    res = launch(tmp_path, 5, "float64", acts, 10, 1, scene=scene, halo=2)
+    res = launch(tmp_path, 5, "float64", acts, 10, 1, scene=scene, halo=2, peer=peer)
+    assert all(int(r["native_loops"]) == int(peer) for r in res)
     b = [int(v) for v in res[0]["bounds"]]
     assert min(hi - lo for lo, hi in zip(b[1:-2], b[2:-1])) == 4, b          # the middle slabs are single block planes
     for r in res:
