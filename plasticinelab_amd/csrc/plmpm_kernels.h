@@ -227,6 +227,8 @@ struct HaloIn {
     int n;                           // faces with a neighbour (0 on a single GPU)
     int ba[2], bb[2];
     const void* buf[2];
+    const int* valid[2];             // device-side exchange: one word per block of the face's planes -- 0: the neighbour sent nothing
+                                     // for it (its copy of the block is empty; buf holds stale values there); nullptr: all sent
     int part;                        // 0: every active block | 1: only blocks outside the exchanged planes (they do not
                                      // need the neighbours' values: this pass can run while the halos are in flight) | 2: only
                                      // the blocks of the exchanged planes
@@ -236,6 +238,10 @@ template <class T> __device__ __forceinline__ int halo_face_of(const Dev<T>& D, 
     for (int f = 0; f < H.n; ++f)
         if (bz >= H.ba[f] && bz < H.bb[f]) return f;
     return -1;
+}
+// did the neighbour on face f send block blk (which must lie in face f's planes)?
+template <class T> __device__ __forceinline__ bool halo_sent(const Dev<T>& D, const HaloIn& H, int f, int blk) {
+    return !H.valid[f] || H.valid[f][blk - H.ba[f] * D.nbx * D.nby] != 0;
 }
 // received value of component c at node (blk, lane); blk must lie in face f's planes
 template <class T> __device__ __forceinline__ T halo_value(const Dev<T>& D, const HaloIn& H, int f, int c, int blk, int lane) {
@@ -866,7 +872,7 @@ __global__ __launch_bounds__(kBlock) void k_grid_op(Dev<T> D, int f, HaloIn H) {
             // exchange range of both faces: both neighbours' copies are added.)
             const int bz = blk / (D.nbx * D.nby);
             for (int hq = hf; hq < H.n; ++hq) {
-                if (bz < H.ba[hq] || bz >= H.bb[hq]) continue;
+                if (bz < H.ba[hq] || bz >= H.bb[hq] || !halo_sent(D, H, hq, blk)) continue;
                 m += halo_value(D, H, hq, 0, blk, lane);
                 for (int c = 0; c < 3; ++c) mv[c] += halo_value(D, H, hq, 1 + c, blk, lane);
             }
@@ -1406,7 +1412,7 @@ __device__ __forceinline__ bool grid_block_bwd(const Dev<T>& D, const HaloIn& H,
     if (hf >= 0) {
         const int bz = blk / (D.nbx * D.nby);
         for (int hq = hf; hq < H.n; ++hq) {
-            if (bz < H.ba[hq] || bz >= H.bb[hq]) continue;
+            if (bz < H.ba[hq] || bz >= H.bb[hq] || !halo_sent(D, H, hq, blk)) continue;
             for (int c = 0; c < 3; ++c) va[c] += halo_value(D, H, hq, c, blk, lane);
         }
     }

@@ -5,7 +5,13 @@
 // only enqueues: no torch.distributed call, no request object and no stream hand-over per substep, so the slab substep
 // loops themselves (plmpm_slab_step / plmpm_slab_step_grad) are native and the Python driver is out of them.
 //
-//   receive area of a face:  [256 B: arrival counter][half 0: ncomp x count scalars][half 1: ...]
+//   receive area of a face:  [256 B: arrival counter][half 0][half 1],  half = [one validity word per 4^3 block, padded to
+//                            256 B][ncomp x count scalars]
+//
+// Only the blocks that carry something are sent: a wave per block of the exchange planes looks at the block's activity flag
+// (the flag the scatter kernels set), writes the validity word, and copies the block's 64 nodes per component if it is set.
+// The body's cross-section covers about a quarter of the xy window's blocks at config 3, so about a quarter of the plane
+// crosses the link (a 24 x 18-block window: 442 KB per block plane and face dense, ~110 KB as sent).
 //
 // Exchange k of a field writes half k & 1.  Why two halves are enough: rank A starts exchange k + 1 only behind its grid
 // kernel of exchange k, which ran behind A's wait for the neighbour's arrival k, which the neighbour published behind
@@ -20,9 +26,12 @@ constexpr size_t kPeerHeader = 256;
 
 struct PeerXchg {
     int n, ncomp;
-    const void* src[2][4];       // this rank's planes, one range per SoA component
-    void* dst[2];                // the half of the neighbour's receive area this exchange writes
-    size_t count[2];             // scalars per component
+    const void* src[2][4];       // component c of this rank's grid array (block 0 of the window)
+    char* dst[2];                // the half of the neighbour's receive area this exchange writes: validity words, then data
+    size_t data_ofs[2];          // bytes from dst to the data
+    int blk0[2], nblk[2];        // first block and number of blocks of the face's planes
+    const int* flags;            // activity flags of the frame's blocks (flag_slot layout); nullptr: every block is sent
+    int fgl, fs;
     unsigned* arrive_remote[2];  // the neighbour's counter for this rank's planes
     unsigned* arrive_local[2];   // this rank's counters
     unsigned seq;
@@ -32,28 +41,47 @@ struct PeerXchg {
     long long timeout_ticks;     // of the 100 MHz wall clock
 };
 
-// 16 bytes per lane, written THROUGH the L2 (sc0 sc1: system-scope write-through): once the store is acknowledged the data
-// is where the neighbour -- another XCD, another process, another GPU -- reads it, and no L2 write-back is needed before the
-// arrival counter moves.  (A release fence at system scope writes back everything the PREVIOUS kernels left dirty in this
-// XCD's L2 -- megabytes of particle state after a particle kernel: 11 us per exchange instead of 6.)
-typedef float __attribute__((ext_vector_type(4))) vec16;
-__device__ __forceinline__ void store_through(vec16* p, vec16 v) {
-    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
-}
-__device__ __forceinline__ void store_through(unsigned* p, unsigned v) {
-    asm volatile("global_store_dword %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
-}
+// Stores written THROUGH the L2 (sc0 sc1: system-scope write-through): once the store is acknowledged the data is where the
+// neighbour -- another XCD, another process, another GPU -- reads it, and no L2 write-back is needed before the arrival
+// counter moves.  (A release fence at system scope writes back everything the PREVIOUS kernels left dirty in this XCD's L2
+// -- megabytes of particle state after a particle kernel: 11 us per exchange instead of 6; a system fence per thread: 25.)
+__device__ __forceinline__ void store_through(float* p, float v) { asm volatile("global_store_dword %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ void store_through(double* p, double v) { asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ void store_through(int* p, int v) { asm volatile("global_store_dword %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ void store_through(unsigned* p, unsigned v) { asm volatile("global_store_dword %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory"); }
 
 template <class T>
 __global__ __launch_bounds__(256) void k_halo_xchg(PeerXchg X) {
-    constexpr int per = 16 / sizeof(T);
-    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (size_t)gridDim.x * blockDim.x;
+    const int lane = threadIdx.x & 63, wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwave = gridDim.x * 4;
     for (int i = 0; i < X.n; ++i) {
-        const size_t nv = X.count[i] / per;          // a block plane is a multiple of 64 scalars
-        for (int c = 0; c < X.ncomp; ++c) {
-            const vec16* s = (const vec16*)X.src[i][c];
-            vec16* d = (vec16*)((T*)X.dst[i] + (size_t)c * X.count[i]);
-            for (size_t j = tid; j < nv; j += nth) store_through(d + j, s[j]);
+        int* valid = (int*)X.dst[i];
+        T* data = (T*)(X.dst[i] + X.data_ofs[i]);
+        const size_t count = (size_t)X.nblk[i] << 6;
+        // a wave owns blocks wave, wave + nwave, ... of the face's planes (at most 64: the launch is sized for that).  Lane k
+        // fetches the activity flag of the wave's k-th block and writes its validity word; the set bits are the blocks to copy
+        const int bl = wave + lane * nwave;
+        int on = 0;
+        if (bl < X.nblk[i]) {
+            const int blk = X.blk0[i] + bl;
+            on = X.flags ? (X.flags[(blk & ((1 << X.fgl) - 1)) * X.fs + (blk >> X.fgl)] != 0) : 1;      // flag_slot
+            store_through(valid + bl, on);
+        }
+        unsigned long long todo = __ballot(on);
+        while (todo) {                                   // two blocks per trip: their loads fly together
+            const int k0 = __ffsll((long long)todo) - 1;
+            todo &= todo - 1;
+            const int k1 = todo ? __ffsll((long long)todo) - 1 : -1;
+            if (k1 >= 0) todo &= todo - 1;
+            const int b0 = wave + k0 * nwave, b1 = k1 >= 0 ? wave + k1 * nwave : b0;
+            T v0[4], v1[4];
+            for (int c = 0; c < X.ncomp; ++c) {
+                v0[c] = ((const T*)X.src[i][c])[((size_t)(X.blk0[i] + b0) << 6) + lane];
+                v1[c] = ((const T*)X.src[i][c])[((size_t)(X.blk0[i] + b1) << 6) + lane];
+            }
+            for (int c = 0; c < X.ncomp; ++c) {
+                store_through(data + (size_t)c * count + ((size_t)b0 << 6) + lane, v0[c]);
+                if (k1 >= 0) store_through(data + (size_t)c * count + ((size_t)b1 << 6) + lane, v1[c]);
+            }
         }
     }
     // every wave waits for the acknowledgements of its own stores; the workgroup then counts itself done
@@ -109,8 +137,8 @@ int plmpm_peer_area_bytes(plmpm_handle s, int field, int bz_a, int bz_b, size_t*
     char* base; int nc;
     if (plmpm_halo_field(s, field, 0, &base, &nc)) return -1;
     REQUIRE(bz_a < bz_b, "peer_area_bytes: empty range of block planes");
-    const size_t cnt = (size_t)(bz_b - bz_a) * s->nbw[0] * s->nbw[1] * 64;
-    *bytes = kPeerHeader + 2 * (size_t)nc * cnt * s->tsz;
+    const size_t nblk = (size_t)(bz_b - bz_a) * s->nbw[0] * s->nbw[1];
+    *bytes = kPeerHeader + 2 * (align_up(nblk * 4, 256) + (size_t)nc * (nblk << 6) * s->tsz);
     return 0;
 }
 int plmpm_peer_alloc(plmpm_handle s, size_t bytes, void** dev_ptr, void* ipc_handle64) {
@@ -173,25 +201,35 @@ int plmpm_halo_peer_exchange(plmpm_handle s, int field, int frame) {
     char* base; int nc;
     if (plmpm_halo_field(s, field, frame, &base, &nc)) return -1;
     const unsigned seq = ++F.seq;
-    const size_t plane = (size_t)s->nbw[0] * s->nbw[1] * 64;
+    const size_t pblk = (size_t)s->nbw[0] * s->nbw[1];              // blocks per plane
     PeerXchg X;
     memset(&X, 0, sizeof X);
     X.n = F.n; X.ncomp = nc; X.seq = seq; X.done = s->peer_done; X.status = s->peer_status; X.code = (field << 16) | 1;
     X.timeout_ticks = (long long)(peer_timeout_seconds() * 1e8);
-    size_t total = 0;
+    // the substep fields are sparse in the blocks the frame's scatter flagged; the loss mass grid is sent whole
+    X.flags = field == PLMPM_HALO_LOSS_MASS ? nullptr : s->fstore + (size_t)frame * s->nflag;
+    X.fgl = s->gwg_log2; X.fs = s->fs;
+    size_t blocks = 0;
     memset(&H, 0, sizeof H);
+    for (int c = 0; c < nc; ++c) X.src[0][c] = X.src[1][c] = base + (size_t)c * s->G * s->tsz;
     for (int i = 0; i < F.n; ++i) {
-        const size_t half = (size_t)nc * F.count[i] * s->tsz;
-        for (int c = 0; c < nc; ++c) X.src[i][c] = base + ((size_t)c * s->G + (size_t)F.ba[i] * plane) * s->tsz;
+        const size_t nblk = (size_t)(F.bb[i] - F.ba[i]) * pblk, vbytes = align_up(nblk * 4, 256);
+        const size_t half = vbytes + (size_t)nc * F.count[i] * s->tsz;
         X.dst[i] = F.remote[i] + kPeerHeader + (seq & 1) * half;
-        X.count[i] = F.count[i];
+        X.data_ofs[i] = vbytes;
+        X.blk0[i] = (int)(F.ba[i] * pblk); X.nblk[i] = (int)nblk;
         X.arrive_remote[i] = (unsigned*)F.remote[i];
         X.arrive_local[i] = (unsigned*)F.local[i];
-        total += (size_t)nc * F.count[i] * s->tsz;
-        H.ba[i] = F.ba[i]; H.bb[i] = F.bb[i]; H.buf[i] = F.local[i] + kPeerHeader + (seq & 1) * half;
+        blocks += nblk;
+        H.ba[i] = F.ba[i]; H.bb[i] = F.bb[i];
+        H.valid[i] = (const int*)(F.local[i] + kPeerHeader + (seq & 1) * half);
+        H.buf[i] = F.local[i] + kPeerHeader + (seq & 1) * half + vbytes;
     }
     H.n = F.n;
-    const unsigned nwg = (unsigned)std::min<size_t>(64, std::max<size_t>(1, total / (256 * 16 * 4)));      // the copy is latency, not bandwidth
+    size_t most = 0;
+    for (int i = 0; i < F.n; ++i) most = std::max<size_t>(most, (size_t)(F.bb[i] - F.ba[i]) * pblk);
+    // 64 workgroups (the kernel is three memory latencies long whatever its size), more when a face has more than 64 blocks per wave
+    const unsigned nwg = (unsigned)std::max<size_t>(std::min<size_t>(64, std::max<size_t>(1, (blocks + 3) / 4)), (most + 255) / 256);
     if (s->cfg.dtype == PLMPM_F64) LAUNCHB(s, K_HALO_XCHG, (k_halo_xchg<double>), dim3(nwg), 256, X);
     else LAUNCHB(s, K_HALO_XCHG, (k_halo_xchg<float>), dim3(nwg), 256, X);
     HIPCHK(hipGetLastError());
