@@ -267,6 +267,47 @@ def test_thin_slabs_one_block_plane_per_rank(tmp_path, peer):
     print(f"\n[thin slabs] bounds {b}, rows moved {[int(r['rows_moved']) for r in res]}")
 
 
+def test_peer_exchange_wait_is_bounded(monkeypatch):
+    """A neighbour that never publishes its arrival must not hang the GPU: the exchange kernel gives up after
+    PLMPM_PEER_TIMEOUT seconds, leaves a status word, and SlabEngine._check (or the next exchange call) raises.  One
+    process, middle rank of a 3-slab layout, "neighbours'" areas that nobody ever writes a counter into."""
+    import sys
+    import time
+    import torch
+    import bench
+    sys.path.insert(0, os.path.join(ROOT, "profiles", "tools"))
+    import slab_host_cost as shc
+    from plasticinelab_amd import distributed as D
+
+    class Silent(shc.LoopbackComm):
+        def setup_peer(self, engine):
+            faces = self.layout.faces(self.rank)
+            for field in (engine.HALO_GRID_IN, engine.HALO_GRID_OUT_ADJ, engine.HALO_LOSS_MASS):
+                local = [engine.peer_alloc(field, a, b)[0] for _n, a, b in faces]
+                remote = [engine.peer_alloc(field, a, b)[0] for _n, a, b in faces]      # written to, never answered from
+                engine.halo_peer_setup(field, [(a, b) for _n, a, b in faces], local, remote)
+            self.peer_ready = True
+            return True
+
+    monkeypatch.setenv("PLMPM_PEER_TIMEOUT", "0.3")
+    cfg = bench.workload_cfg(20_000, 1, max_steps=40)
+    layout = D.SlabLayout(64, (0, 16, 36, 64))
+    env, _, _ = D.make_slab_env(cfg, 1, 3, compute_dtype="float32", target_fn=bench._target, layout=layout,
+                                comm=Silent(layout, 1, True), xy_margin=8, migrate_every=0)
+    eng = env.simulator.engine
+    assert eng.native_loops and eng.peer_status() == 0
+    t0 = time.time()
+    # the first exchange -- the loss mass grid, when set_state evaluates the initial loss -- already times out
+    with pytest.raises(RuntimeError, match="timed out.*field 2"):
+        env.set_state(env.get_state()["state"], 666.0, False)
+    assert 0.25 < time.time() - t0 < 30
+    torch.cuda.synchronize()                                   # the GPU is still there
+    st = eng.peer_status()
+    assert st & 1 and (st >> 16) == eng.HALO_LOSS_MASS
+    with pytest.raises(RuntimeError, match="earlier arrival timed out"):       # and the engine refuses to go on exchanging
+        eng.halo_peer_exchange(eng.HALO_GRID_IN, 0)
+
+
 def test_config5_rank_fits_in_hbm():
     """BASELINE configs[4]: 512^3 grid, 16M particles in a cube of side 0.25, 8 z-slabs.  What one rank has to allocate
     for a whole env step (159 substeps) in store mode, as plmpm_workspace_bytes reports it -- nothing is allocated
