@@ -1045,6 +1045,7 @@ __global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_g2p_p2g(Dev<T> D, int
         for (int d = 0; d < 9; ++d) R1[(3 + d) * Np + p] = C[d];
     }
     PT_MARK(2);
+    PLB_PAD(x[0], D.err);
     // ---------------- p2g(f): scatter
     int base[3];
     for (int d = 0; d < 3; ++d) base[d] = (int)(x[d] * (double)D.P.inv_dx - 0.5);

@@ -35,3 +35,20 @@
 // inside a scatter lambda: stop here when ablation bit `bit` is set, keeping `sum` alive so the arithmetic before it is not
 // optimised away
 #define PLB_ABLATE_STOP(bit, sum, tile) do { if (PLB_ABLATE & (bit)) { if ((sum) == T(-1e30)) (tile)[0].x = 1.0; return; } } while (0)
+
+// Experiment (profiles/r03_notes.md): PLB_PAD_VALU=N inserts N extra fp32 FMAs (four independent chains) per lane into
+// k_g2p_p2g behind its gather -- does the kernel's time follow its VALU instruction count?
+#ifndef PLB_PAD_VALU
+#define PLB_PAD_VALU 0
+#endif
+#define PLB_PAD(seed, errp)                                                                    \
+    do {                                                                                       \
+        if (PLB_PAD_VALU > 0) {                                                                \
+            float a0_ = (float)(seed), a1_ = a0_ + 1.f, a2_ = a0_ + 2.f, a3_ = a0_ + 3.f;      \
+            _Pragma("unroll") for (int i_ = 0; i_ < PLB_PAD_VALU / 4; ++i_) {                  \
+                a0_ = __builtin_fmaf(a0_, 1.0001f, 0.5f); a1_ = __builtin_fmaf(a1_, 1.0002f, 0.25f);   \
+                a2_ = __builtin_fmaf(a2_, 0.9999f, 0.125f); a3_ = __builtin_fmaf(a3_, 0.9998f, 0.75f); \
+            }                                                                                  \
+            if (a0_ + a1_ + a2_ + a3_ == 123456.789f) atomicOr((errp), 64);                    \
+        }                                                                                      \
+    } while (0)
