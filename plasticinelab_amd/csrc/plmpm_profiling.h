@@ -52,3 +52,4 @@
             if (a0_ + a1_ + a2_ + a3_ == 123456.789f) atomicOr((errp), 64);                    \
         }                                                                                      \
     } while (0)
+
