@@ -16,8 +16,6 @@
 // Exchange k of a field writes half k & 1.  Why two halves are enough: rank A starts exchange k + 1 only behind its grid
 // kernel of exchange k, which ran behind A's wait for the neighbour's arrival k, which the neighbour published behind
 // ITS grid kernel of exchange k - 1 -- the last reader of half (k + 1) & 1 there.
-#include <type_traits>
-
 #include "plmpm_internal.h"
 
 namespace {
