@@ -1,0 +1,51 @@
+"""-m gpu: bench.py as the driver runs it -- `python bench.py --gpus 1 ...` and `python -m torch.distributed.run
+--nproc-per-node 2 ... bench.py --gpus 2 ...` -- prints ONE JSON line with the contract's keys, the N = 2 run is the SAME
+workload cut into z-slabs ("strong", the loss equals the single-GPU run's), and its halos go through the device-side
+exchange.  (Both ranks share the box's one GPU, so the per-env-step collectives use gloo: PLB_DIST_BACKEND.)  Reduced
+particle count: this checks the contract, not the number."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+from tests.util import ROOT
+
+pytestmark = pytest.mark.gpu
+
+KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+        "data", "config", "roofline", "phases_s")
+
+
+def run(cmd, extra_env=None):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **(extra_env or {}))
+    p = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    lines = [ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, "exactly one JSON line on stdout"
+    return json.loads(lines[0])
+
+
+def test_bench_lines_single_gpu_and_two_slabs():
+    common = ["--steps", "2", "--warmup", "1", "--particles", "60000", "--no-cpu-baseline"]
+    one = run([sys.executable, "bench.py", "--gpus", "1"] + common)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    two = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), "bench.py", "--gpus", "2"] + common,
+              {"PLB_DIST_BACKEND": "gloo", "PLB_PEER_HALOS": "1", "PLB_SLAB_TIMEOUT": "300"})
+    for d, n in ((one, 1), (two, 2)):
+        assert all(k in d for k in KEYS), [k for k in KEYS if k not in d]
+        assert d["n_gpus"] == n and d["steps"] == 2 and d["warmup"] == 1 and d["unit"] == "substeps/s" and d["higher_is_better"] is True
+        assert d["scaling"] == "strong" and d["dtype"] == "f32" and d["data"] == "synthetic" and d["vs_baseline"] is None
+        assert "model" not in d["config"] and d["config"]["n_particles"] == 60000
+        r = d["roofline"]
+        assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+        assert abs(d["value"] - d["steps"] * d["config"]["substeps_per_step"] / (1e-3 * d["ms_per_step"] * d["steps"])) < 1e-6 * d["value"]
+    assert "FALLBACK" not in two["metric"] and "z-slabs" in two["config"]["parallelism"] and "IPC-mapped" in two["config"]["parallelism"]
+    assert "halo_exchange" in two["roofline"]["kernels"] and two["roofline"]["kernel"] != "halo_exchange"
+    # the same workload: the two-slab run ends with the single-GPU run's loss (fp32 engines, different summation order)
+    assert abs(two["final_loss"] - one["final_loss"]) < 1e-5 * abs(one["final_loss"])
