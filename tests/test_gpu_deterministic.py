@@ -111,8 +111,7 @@ def test_deterministic_slab_ranks_are_bit_reproducible(tmp_path):
         for k in range(2):
             d = tmp_path / f"w{world}_{k}"
             d.mkdir()
-            # three ranks: with the device-side halo exchange (peer writes), two ranks: torch.distributed point-to-point
-            runs.append(launch(d, world, "float32", acts, 10, 1, deterministic=True, peer=(world == 3)))
+            runs.append(launch(d, world, "float32", acts, 10, 1, deterministic=True))
         assert sum(int(r["rows_moved"]) for r in runs[0]) > 0
         for a, b in zip(*runs):
             for key in ("loss", "grad", "ids", "x", "v"):
