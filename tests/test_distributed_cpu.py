@@ -321,7 +321,7 @@ class ToyEngine:
         self.calls.append(("loss_backward_local", f))
 
 
-def _world(rank, world, port, ids, bz_all, w_all, drift, out, overlap=False, peer=False, halo=None):
+def _world(rank, world, port, ids, bz_all, w_all, drift, out, overlap=False, peer=False, halo=None, peer_broken_on=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -330,8 +330,14 @@ def _world(rank, world, port, ids, bz_all, w_all, drift, out, overlap=False, pee
         assert all(b - a >= 2 * layout.halo and a % 4 == 0 for a, b in zip(layout.bounds, layout.bounds[1:]))
         mine = np.nonzero(layout.owner_of(SlabLayout.stencil_base_z(x, N)) == rank)[0]
         toy = ToyEngine([ids[i] for i in mine], [bz_all[i] for i in mine], [w_all[i] for i in mine], drift, layout, rank)
+        if peer_broken_on == rank:                              # this rank cannot map its neighbour's area (no IPC, say)
+            def no_ipc(handle):
+                raise RuntimeError("hipIpcOpenMemHandle failed: invalid argument")
+            toy.peer_open = no_ipc
         eng = SlabEngine(toy, layout, rank, migrate_every=1, overlap=overlap, peer=peer)
-        assert eng.native_loops == (peer and world > 1), getattr(eng.comm, "peer_error", None)
+        assert eng.native_loops == (peer and world > 1 and peer_broken_on is None), getattr(eng.comm, "peer_error", None)
+        if peer_broken_on is not None:
+            assert "hipIpcOpenMemHandle" in eng.comm.peer_error   # every rank knows why
         last = STEPS * SUB
         for k in range(STEPS):
             eng.step(k * SUB, SUB)
@@ -351,10 +357,10 @@ def _world(rank, world, port, ids, bz_all, w_all, drift, out, overlap=False, pee
         dist.destroy_process_group()
 
 
-def run(world, ids, bz, w, drift, overlap=False, peer=False, halo=None):
+def run(world, ids, bz, w, drift, overlap=False, peer=False, halo=None, peer_broken_on=None):
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_world, args=(world, free_port(), ids, bz, w, drift, out, overlap, peer, halo), nprocs=world, join=True)
+    mp.spawn(_world, args=(world, free_port(), ids, bz, w, drift, out, overlap, peer, halo, peer_broken_on), nprocs=world, join=True)
     return dict(out)
 
 
@@ -481,6 +487,28 @@ def test_eight_thin_slabs_equal_one_rank(PEER):
     assert set(fin) == set(one["final_adj"]) and all(abs(fin[i] - one["final_adj"][i]) < 1e-12 * max(1.0, abs(fin[i])) for i in fin)
     for a, c in zip(many[0]["chain"], one["chain"]):
         assert abs(a[4] - c[4]) < 1e-12 * max(1.0, abs(c[4]))
+    for k in ("loss", "iou", "min_dist", "sum_m"):
+        assert abs(many[0]["info"][k] - one["info"][k]) < 1e-12 * max(1.0, abs(one["info"][k]))
+
+
+def test_peer_setup_failure_on_one_rank_falls_back_everywhere():
+    """One rank cannot map its neighbour's receive area: the peer path is off on EVERY rank (agreed collectively, with the
+    reason), the torch.distributed point-to-point exchange takes over, and the results are still those of one rank."""
+    rng = np.random.default_rng(3)
+    n = 40
+    ids = list(range(300, 300 + n))
+    bz = [int(v) for v in rng.integers(3, 26, n)]
+    w = [float(v) for v in rng.random(n) + 0.5]
+    drift = {i: int(d) for i, d in zip(ids, rng.integers(-1, 2, n))}
+    one = run(1, ids, bz, w, drift)[0]
+    many = run(3, ids, bz, w, drift, peer=True, peer_broken_on=1)
+    assert all("peer_exchange" not in many[r]["order"] for r in range(3))
+    for f in range(STEPS * SUB):
+        got = {}
+        for r in range(3):
+            got.update(many[r]["read"][f])
+        assert set(got) == set(one["read"][f])
+        assert all(abs(got[i] - one["read"][f][i]) < 1e-12 * max(1.0, abs(got[i])) for i in got)
     for k in ("loss", "iou", "min_dist", "sum_m"):
         assert abs(many[0]["info"][k] - one["info"][k]) < 1e-12 * max(1.0, abs(one["info"][k]))
 
