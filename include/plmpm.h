@@ -348,6 +348,10 @@ int plmpm_profile_enable(plmpm_handle h, int on);
 int plmpm_profile_kernel_count(void);
 const char* plmpm_profile_kernel_name(int id);
 int plmpm_profile_read(plmpm_handle h, double* total_ms, int64_t* launches);
+/* profiling aid: launch one hot-path kernel `reps` times on the engine's current state, mean duration in microseconds
+ * (kind 0: fused g2p(frame-1)+p2g(frame), 1: g2p.grad(frame), 2: p2g.grad(frame), 3: p2g(frame)).  The rollout is not
+ * usable afterwards (the replays accumulate into the grids).  profiles/tools/replay_ab.py */
+int plmpm_replay(plmpm_handle h, int kind, int frame, int reps, double* mean_us);
 /* Measured HBM roof of the device the buffers live on: a 16-byte-per-lane copy src -> dst and a read-only sweep of
  * `bytes` bytes, best of `reps` runs, in GB/s of bytes moved (bench.py reports it next to the 8 TB/s spec). */
 int plmpm_measure_hbm(void* src, void* dst, size_t bytes, int reps, void* hip_stream, double* copy_gbs, double* read_gbs);

@@ -20,6 +20,7 @@
 #pragma once
 #include <math.h>
 #include <stdint.h>
+#include <type_traits>
 
 #if defined(__HIPCC__)
 #define PLB_HD __host__ __device__ __forceinline__
@@ -416,6 +417,203 @@ template <class T> PLB_HD void svd_eform(const T* Et, Svd3<T>& r) {
     svd_finish(Et, r);
 }
 
+// ---------------------------------------------------------------- elastic fast path (round 4)
+// A wave in which NO lane can yield does not need the singular value decomposition at all.  Without yielding
+// compute_von_mises (mpm_simulator.py:124-141) returns F_tmp itself (sig >= 0.05 cannot bind either), and the stress of
+// p2g (:164-171), 2 mu (F - R) F^T + lam J (J - 1) I, needs only the rotation R = U V^T of the polar decomposition
+// F = R S -- a 3-step Newton iteration on I + E instead of 12 Jacobi rotations, log / exp and the U h U^T product -- and
+// its VJP has a closed form in (R, S) (elastic_vjp below) instead of the divided differences in the singular basis.
+// The decision is wave-uniform (one vote per wave, both code paths stay free of divergence) and made from
+// A = F^T F - I alone, with SUFFICIENT conditions:
+//   no yield:   ||dev eps|| <= ||dev A||_F / (2 (1 + lam_min)),  eps = log sig = log(1 + lam) / 2,  lam_min >= -||A||_F,
+//               and the reference adds 1e-8 under the root (norm <= ||dev eps|| + 1e-4);
+//   backward_svd's clamp (mpm_simulator.py:143-151) inactive: every pair of eigenvalues of A at least `clamp` apart.
+//               With B = dev A, p = ||B||_F^2, q = det B the eigenvalues are 2 r cos(theta + 2 pi k / 3), r = sqrt(p / 6),
+//               cos 3 theta = q / (2 r^3), and the smallest gap is >= (2 / 3) sqrt(p t), t = 1 - |q| / (2 r^3);
+//   or the clamp removes the rotation term altogether (all gaps << clamp: F_tmp a multiple of a rotation, e.g. the
+//               undeformed state): the divided-difference VJP then equals the closed form WITHOUT its dR term.
+// Everything in between (and every wave with an inverted, crushed or possibly yielding particle) takes the Jacobi path.
+#ifndef PLB_FAST
+#define PLB_FAST 0          // measured (round 4, profiles/r04_notes.md): parity-green and not faster -- the kernels do not follow their
+#endif                      // constitutive instruction count (the whole block is 3.3 us of the forward kernel's 48.5); opt-in: -DPLB_FAST=1
+#ifndef PLB_ABL_CONST
+#define PLB_ABL_CONST 0
+#endif
+template <class T> struct TolFast;
+template <> struct TolFast<float> {
+    static constexpr int it_small = 3, it_big = 5;          // Newton steps for ||A|| <= 0.1 / < 0.9: error e -> e^2 / 2
+    static PLB_HD float gap_margin() { return 4e-6f; }      // round-off of p t, relative to (||A|| + ||dev A||) ||dev A||
+    static PLB_HD float pristine() { return 1e-6f; }        // largest attenuation factor treated as 0
+};
+template <> struct TolFast<double> {
+    static constexpr int it_small = 4, it_big = 7;
+    static PLB_HD double gap_margin() { return 1e-13; }
+    static PLB_HD double pristine() { return 1e-11; }
+};
+PLB_HD bool wave_all(bool c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __all(c ? 1 : 0) != 0;
+#else
+    return c;
+#endif
+}
+template <class T> struct Elastic {
+    T Y[9];      // R - I, R the rotation of the polar decomposition of F_tmp = R S
+    T D[6];      // S - I (symmetric): 00 11 22 01 02 12
+    T Jm1;       // det F_tmp - 1 (= det S - 1)
+    T rotw;      // 1, or 0 where the reference's clamp removes the dR term of the VJP
+};
+// per-lane test; `small`: ||A||_F <= 0.1 (three Newton steps suffice)
+template <class T> PLB_HD bool elastic_lane_ok(const T* Et, T mu, T ys, T svd_clamp, bool need_gap, T* A6, T& rotw, bool& small) {
+    const T a00 = T(2) * Et[0] + Et[0] * Et[0] + Et[3] * Et[3] + Et[6] * Et[6];
+    const T a11 = T(2) * Et[4] + Et[1] * Et[1] + Et[4] * Et[4] + Et[7] * Et[7];
+    const T a22 = T(2) * Et[8] + Et[2] * Et[2] + Et[5] * Et[5] + Et[8] * Et[8];
+    const T a01 = Et[1] + Et[3] + Et[0] * Et[1] + Et[3] * Et[4] + Et[6] * Et[7];
+    const T a02 = Et[2] + Et[6] + Et[0] * Et[2] + Et[3] * Et[5] + Et[6] * Et[8];
+    const T a12 = Et[5] + Et[7] + Et[1] * Et[2] + Et[4] * Et[5] + Et[7] * Et[8];
+    const T off2 = T(2) * (a01 * a01 + a02 * a02 + a12 * a12);
+    const T a = t_fsqrt(a00 * a00 + a11 * a11 + a22 * a22 + off2);
+    const T m = (a00 + a11 + a22) * (T(1) / T(3));
+    const T b00 = a00 - m, b11 = a11 - m, b22 = a22 - m;
+    const T p = b00 * b00 + b11 * b11 + b22 * b22 + off2;
+    const T sp = t_fsqrt(p);
+    // det F_tmp - 1 = tr E + tr cof E + det E
+    const T c00 = Et[4] * Et[8] - Et[5] * Et[7], c11 = Et[0] * Et[8] - Et[2] * Et[6], c22 = Et[0] * Et[4] - Et[1] * Et[3];
+    const T detE = Et[0] * c00 - Et[1] * (Et[3] * Et[8] - Et[5] * Et[6]) + Et[2] * (Et[3] * Et[7] - Et[4] * Et[6]);
+    const T Jm1 = (Et[0] + Et[4] + Et[8]) + (c00 + c11 + c22) + detE;          // only its sign matters here (an inverted particle)
+    A6[0] = a00; A6[1] = a11; A6[2] = a22; A6[3] = a01; A6[4] = a02; A6[5] = a12;
+    small = a <= T(0.1);
+    rotw = T(1);
+    const T c = ys * t_rcp(T(2) * mu);
+    bool ok = a < T(0.9) && Jm1 > T(-0.9) && sp < (c * T(1 - 1e-5) - T(1e-4)) * T(2) * (T(1) - a);
+    if (need_gap && svd_clamp > T(0)) {
+        const T q = b00 * (b11 * b22 - a12 * a12) - a01 * (a01 * b22 - a12 * a02) + a02 * (a01 * a12 - b11 * a02);
+        const T pt = p > T(0) ? p - T(7.348469228349534) * t_abs(q) * t_rsqrt(p) : T(0);     // p t, 6^1.5 / 2
+        const bool apart = pt >= T(2.25) * svd_clamp * svd_clamp + TolFast<T>::gap_margin() * (a + sp) * sp;
+        const T lim = svd_clamp * TolFast<T>::pristine();
+        const bool pristine = T(2) * p <= lim * lim;               // largest gap <= sqrt(2 p)
+        rotw = apart ? T(1) : T(0);
+        ok = ok && (apart || pristine);
+    }
+    return ok;
+}
+// Newton iteration for the polar rotation in deviation form: X = I + Y, Y <- (Y + (X^-T - I)) / 2 with
+// X^-T - I = (cof Y - Y^T - (tr cof Y + det Y) I) / det X -- every term is O(Y), so R - I keeps its relative precision.
+template <class T> PLB_HD void polar_newton(const T* Et, int iters, T* Y) {
+    for (int i = 0; i < 9; ++i) Y[i] = Et[i];
+    PLB_ROLL
+    for (int it = 0; it < iters; ++it) {
+        T cf[9];
+        cf[0] = Y[4] * Y[8] - Y[5] * Y[7]; cf[1] = Y[5] * Y[6] - Y[3] * Y[8]; cf[2] = Y[3] * Y[7] - Y[4] * Y[6];
+        cf[3] = Y[2] * Y[7] - Y[1] * Y[8]; cf[4] = Y[0] * Y[8] - Y[2] * Y[6]; cf[5] = Y[1] * Y[6] - Y[0] * Y[7];
+        cf[6] = Y[1] * Y[5] - Y[2] * Y[4]; cf[7] = Y[2] * Y[3] - Y[0] * Y[5]; cf[8] = Y[0] * Y[4] - Y[1] * Y[3];
+        const T trc = cf[0] + cf[4] + cf[8];
+        const T det = Y[0] * cf[0] + Y[1] * cf[1] + Y[2] * cf[2];
+        const T half_inv = T(0.5) * t_rcp(T(1) + (Y[0] + Y[4] + Y[8]) + trc + det);
+        const T s = -(trc + det);
+        T Z[9];
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c) Z[3 * r + c] = (cf[3 * r + c] - Y[3 * c + r] + (r == c ? s : T(0))) * half_inv;
+        for (int i = 0; i < 9; ++i) Y[i] = T(0.5) * Y[i] + Z[i];
+    }
+}
+// wave-uniform: true when every lane may take the fast path; then e holds the lane's rotation and stretch.
+// The stretch deviation D = S - I: D0 = sym(R^T F) - I carries the round-off of R (eps x the rotation angle); one
+// correction step against A = S^2 - I = 2 D + D^2, which the E-form gives to eps x angle^2, brings it down to that
+// (D = D0 + (A - 2 D0 - D0^2) / 2) -- so a rotated, barely strained particle keeps the accuracy of the Jacobi path.
+template <class T> PLB_HD bool elastic_try(const T* Et, T mu, T ys, T svd_clamp, bool need_gap, Elastic<T>& e) {
+    bool small;
+    T A[6];
+    const bool ok = elastic_lane_ok(Et, mu, ys, svd_clamp, need_gap, A, e.rotw, small);
+    if (!wave_all(ok)) return false;
+    polar_newton(Et, wave_all(small) ? TolFast<T>::it_small : TolFast<T>::it_big, e.Y);
+    const T* Y = e.Y;
+    T M[9];
+    mat_mul_tn(Y, Et, M);
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) M[3 * r + c] += Y[3 * c + r] + Et[3 * r + c];
+    const T d00 = M[0], d11 = M[4], d22 = M[8], d01 = T(0.5) * (M[1] + M[3]), d02 = T(0.5) * (M[2] + M[6]), d12 = T(0.5) * (M[5] + M[7]);
+    T* D = e.D;
+    D[0] = d00 + T(0.5) * (A[0] - T(2) * d00 - (d00 * d00 + d01 * d01 + d02 * d02));
+    D[1] = d11 + T(0.5) * (A[1] - T(2) * d11 - (d01 * d01 + d11 * d11 + d12 * d12));
+    D[2] = d22 + T(0.5) * (A[2] - T(2) * d22 - (d02 * d02 + d12 * d12 + d22 * d22));
+    D[3] = d01 + T(0.5) * (A[3] - T(2) * d01 - (d00 * d01 + d01 * d11 + d02 * d12));
+    D[4] = d02 + T(0.5) * (A[4] - T(2) * d02 - (d00 * d02 + d01 * d12 + d02 * d22));
+    D[5] = d12 + T(0.5) * (A[5] - T(2) * d12 - (d01 * d02 + d11 * d12 + d12 * d22));
+    // det S - 1 = tr D + tr cof D + det D
+    const T c00 = D[1] * D[2] - D[5] * D[5], c11 = D[0] * D[2] - D[4] * D[4], c22 = D[0] * D[1] - D[3] * D[3];
+    const T detD = D[0] * c00 - D[3] * (D[3] * D[2] - D[5] * D[4]) + D[4] * (D[3] * D[5] - D[1] * D[4]);
+    e.Jm1 = (D[0] + D[1] + D[2]) + (c00 + c11 + c22) + detD;
+    return true;
+}
+// stress of p2g (unscaled, as constitutive_fwd returns it): 2 mu (F - R) F^T + lam J (J - 1) I with
+// (F - R) F^T = R D (R S)^T = R (D + D^2) R^T
+template <class T> PLB_HD void elastic_stress(const T* Et, const Elastic<T>& e, T mu, T lam, T* stress) {
+    const T* D = e.D;
+    const T* Y = e.Y;
+    T Tm[9];
+    Tm[0] = D[0] + (D[0] * D[0] + D[3] * D[3] + D[4] * D[4]);
+    Tm[4] = D[1] + (D[3] * D[3] + D[1] * D[1] + D[5] * D[5]);
+    Tm[8] = D[2] + (D[4] * D[4] + D[5] * D[5] + D[2] * D[2]);
+    Tm[1] = Tm[3] = D[3] + (D[0] * D[3] + D[3] * D[1] + D[4] * D[5]);
+    Tm[2] = Tm[6] = D[4] + (D[0] * D[4] + D[3] * D[5] + D[4] * D[2]);
+    Tm[5] = Tm[7] = D[5] + (D[3] * D[4] + D[1] * D[5] + D[5] * D[2]);
+    T YT[9], YTY[9];
+    mat_mul(Y, Tm, YT);
+    mat_mul_nt(YT, Y, YTY);
+    const T vol = lam * (T(1) + e.Jm1) * e.Jm1;
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) stress[3 * r + c] = T(2) * mu * (Tm[3 * r + c] + YT[3 * r + c] + YT[3 * c + r] + YTY[3 * r + c]);
+    stress[0] += vol; stress[4] += vol; stress[8] += vol;
+}
+// VJP of (new_F = F_tmp, stress) w.r.t. F_tmp on the elastic branch, G = GS:
+//   d<G, F F^T>  = ((G + G^T) F) : dF
+//   d<G, R F^T>  = <G F, dR> + (G^T R) : dF,   <Q, dR> = (2 R [y]x) : dF,  (tr S I - S) y = axl(skw(R^T Q)),  S = R^T F
+//   d<G, J (J - 1) I> = tr G (2 J - 1) cof F : dF
+// (dR = R W with W S + S W = R^T dF - dF^T R; the solve is the 3x3 system above.)  rotw = 0 drops the dR term.
+template <class T> PLB_HD void elastic_vjp(const T* Et, const Elastic<T>& e, T mu, T lam, const T* GS, const T* GF, T* Ft_adj) {
+    const T* Y = e.Y;
+    T Q[9], t9[9];
+    mat_mul(GS, Et, t9);
+    for (int i = 0; i < 9; ++i) Q[i] = GS[i] + t9[i];                         // G F
+    // skew part of R^T Q = Q + Y^T Q (only the three axial components)
+    T M[9];
+    mat_mul_tn(Y, Q, M);
+    for (int i = 0; i < 9; ++i) M[i] += Q[i];
+    const T tx = T(0.5) * (M[7] - M[5]), ty = T(0.5) * (M[2] - M[6]), tz = T(0.5) * (M[3] - M[1]);
+    // H = tr S I - S = (2 + tr D) I - D,  D = S - I
+    const T trD = e.D[0] + e.D[1] + e.D[2];
+    const T h00 = T(2) + trD - e.D[0], h11 = T(2) + trD - e.D[1], h22 = T(2) + trD - e.D[2], h01 = -e.D[3], h02 = -e.D[4], h12 = -e.D[5];
+    // y = H^-1 t by the adjugate (H is symmetric positive definite: its eigenvalues are the pairwise sums of the stretches)
+    const T k00 = h11 * h22 - h12 * h12, k01 = h02 * h12 - h01 * h22, k02 = h01 * h12 - h02 * h11;
+    const T k11 = h00 * h22 - h02 * h02, k12 = h01 * h02 - h00 * h12, k22 = h00 * h11 - h01 * h01;
+    const T idet = e.rotw * t_rcp(h00 * k00 + h01 * k01 + h02 * k02);
+    const T y0 = (k00 * tx + k01 * ty + k02 * tz) * idet, y1 = (k01 * tx + k11 * ty + k12 * tz) * idet, y2 = (k02 * tx + k12 * ty + k22 * tz) * idet;
+    // W = [y]x ;  R W = W + Y W
+    const T W[9] = {T(0), -y2, y1, y2, T(0), -y0, -y1, y0, T(0)};
+    T YW[9], GtY[9], SF[9];
+    mat_mul(Y, W, YW);
+    mat_mul_tn(GS, Y, GtY);                                                 // G^T Y
+    T Sg[9];
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) Sg[3 * r + c] = GS[3 * r + c] + GS[3 * c + r];
+    mat_mul(Sg, Et, SF);                                                    // (G + G^T) E
+    // cof F = (1 + tr E) I - E^T + cof E
+    T cf[9];
+    cf[0] = Et[4] * Et[8] - Et[5] * Et[7]; cf[1] = Et[5] * Et[6] - Et[3] * Et[8]; cf[2] = Et[3] * Et[7] - Et[4] * Et[6];
+    cf[3] = Et[2] * Et[7] - Et[1] * Et[8]; cf[4] = Et[0] * Et[8] - Et[2] * Et[6]; cf[5] = Et[1] * Et[6] - Et[0] * Et[7];
+    cf[6] = Et[1] * Et[5] - Et[2] * Et[4]; cf[7] = Et[2] * Et[3] - Et[0] * Et[5]; cf[8] = Et[0] * Et[4] - Et[1] * Et[3];
+    const T trE = Et[0] + Et[4] + Et[8];
+    const T kv = lam * (GS[0] + GS[4] + GS[8]) * (T(2) * (T(1) + e.Jm1) - T(1));
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) {
+            const int i = 3 * r + c;
+            const T cofF = cf[i] - Et[3 * c + r] + (r == c ? T(1) + trE : T(0));
+            //        (G + G^T) F          - 2 R W                 - G^T R
+            Ft_adj[i] = GF[i] + T(2) * mu * ((Sg[i] + SF[i]) - T(2) * (W[i] + YW[i]) - (GS[3 * c + r] + GtY[i])) + kv * cofF;
+        }
+}
+
 // ---------------------------------------------------------------- constitutive model
 // compute_von_mises + stress of p2g               (mpm_simulator.py:124-141, :164-171)
 template <class T> struct Consti {
@@ -604,8 +802,25 @@ PLB_HD void p2g_particle(const SimP<typename Lane<T>::scalar>& P, const X* x, co
     stencil<T, X>(x, P.inv_dx, base, fx, w, nullptr);
     T Et[9], stress[9], A[9];
     f_tmp_eform(C, E, P.dt, Et);
-    Consti<T> k;
-    constitutive_fwd(Et, mu, lam, ys, k, En, stress, P.tie_first);
+    bool fast = false;
+#if PLB_ABL_CONST        /* timing experiment only (wrong results): no constitutive model at all */
+    fast = true;
+    for (int i = 0; i < 9; ++i) { En[i] = Et[i]; stress[i] = mu * Et[i]; }
+#endif
+    if constexpr (PLB_FAST && !PLB_ABL_CONST && std::is_floating_point<T>::value) {
+        // a wave without a lane that can yield: polar rotation instead of the SVD (elastic fast path above); the forward
+        // pass has no use for the eigenvalue gaps
+        Elastic<T> el;
+        fast = elastic_try(Et, mu, ys, T(0), false, el);
+        if (fast) {
+            for (int i = 0; i < 9; ++i) En[i] = Et[i];
+            elastic_stress(Et, el, mu, lam, stress);
+        }
+    }
+    if (!fast) {
+        Consti<T> k;
+        constitutive_fwd(Et, mu, lam, ys, k, En, stress, P.tie_first);
+    }
     for (int i = 0; i < 9; ++i) A[i] = P.kappa * stress[i] + P.p_mass * C[i];
     // momentum per unit weight at stencil offset o is affine in o:  q(o) = m v + A (o - fx) dx
     //   = q0 + o_x ax + o_y ay + o_z az,   q0 = m v - A fx dx,  a_d = A[:,d] dx   (3 adds per node instead of a mat-vec)
@@ -846,8 +1061,17 @@ PLB_HD void p2g_finish_grad(const SimP<typename Lane<T>::scalar>& P, const P2GGa
                             const T* En_a, T* xa_io, T* va, T* Ca, T* Ea) {
     T Et[9], En[9], stress[9], A[9];
     f_tmp_eform(C, E, P.dt, Et);
+    bool fast = false;
+    Elastic<T> el;
     Consti<T> k;
-    constitutive_fwd(Et, mu, lam, ys, k, En, stress, P.tie_first);
+#if PLB_ABL_CONST        /* timing experiment only (wrong results): no constitutive model at all */
+    for (int i = 0; i < 9; ++i) stress[i] = mu * Et[i];
+#else
+    if constexpr (PLB_FAST && std::is_floating_point<T>::value)
+        fast = elastic_try(Et, mu, ys, T(P.svd_clamp), true, el);         // wave-uniform (elastic fast path above)
+    if (fast) elastic_stress(Et, el, mu, lam, stress);
+    else constitutive_fwd(Et, mu, lam, ys, k, En, stress, P.tie_first);
+#endif
     for (int i = 0; i < 9; ++i) A[i] = P.kappa * stress[i] + P.p_mass * C[i];
     const T* M = G.M;
     const T* Aa = G.Aa;
@@ -865,7 +1089,14 @@ PLB_HD void p2g_finish_grad(const SimP<typename Lane<T>::scalar>& P, const P2GGa
     for (int d = 0; d < 3; ++d) xa_io[d] += P.inv_dx * fxa[d];
     T GS[9], Fta[9];
     for (int i = 0; i < 9; ++i) { Ca[i] = P.p_mass * Aa[i]; GS[i] = P.kappa * Aa[i]; }
-    constitutive_vjp(k, mu, lam, P.svd_clamp, GS, En_a, Fta);
+#if PLB_ABL_CONST
+    for (int i = 0; i < 9; ++i) Fta[i] = mu * GS[i] + En_a[i];
+#else
+    if constexpr (PLB_FAST && std::is_floating_point<T>::value) {
+        if (fast) elastic_vjp(Et, el, mu, lam, GS, En_a, Fta);
+        else constitutive_vjp(k, mu, lam, P.svd_clamp, GS, En_a, Fta);
+    } else constitutive_vjp(k, mu, lam, P.svd_clamp, GS, En_a, Fta);
+#endif
     // F_tmp = (I + dt C) F :  C.grad += dt Fta F^T ;  F.grad = (I + dt C)^T Fta
     T Fm[9];
     for (int i = 0; i < 9; ++i) Fm[i] = E[i];

@@ -1241,6 +1241,51 @@ int plmpm_profile_read(plmpm_handle s, double* total_ms, int64_t* launches) {
     return 0;
 }
 
+}  // extern "C"
+// Profiling aid: launch ONE hot-path kernel `reps` times on the state the engine is in and return its mean duration
+// (HIP events on the launch stream).  Every build of the library lays plmpm_sim out identically, so a handle created
+// by the default build can be replayed through an experiment build loaded next to it (profiles/tools/replay_ab.py):
+// variants of a kernel are timed on bit-identical inputs, in one process.  The replayed launches accumulate into the
+// grids they scatter to and overwrite the frame they produce -- the rollout is not usable afterwards.
+//   kind 0: g2p(f-1)+p2g(f) fused forward kernel   1: g2p.grad(f)   2: p2g.grad(f)   3: p2g(f) alone
+template <class T> static int replay_t(plmpm_sim* s, int kind, int f, int reps, double* us) {
+    Dev<T> D = make_dev<T>(s, f);
+    const int src = (f + 1) & 1, dst = f & 1;
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0));
+    HIPCHK(hipEventCreate(&e1));
+    for (int r = -2; r < reps; ++r) {                     // two untimed launches first
+        if (r == 0) HIPCHK(hipEventRecord(e0, s->stream));
+        if (kind == 0) {
+            const Vec4<T>* vprev = (const Vec4<T>*)(s->vstore + (size_t)(f - 1) * s->gstride);
+            LAUNCH_G2P_P2G(s, D, f, vprev);
+        } else if (kind == 1) {
+            LAUNCH_G2P_GRAD(s, D, f, src, dst, (const T*)nullptr);
+        } else if (kind == 2) {
+            LAUNCH_P2G_GRAD(s, D, f, src, dst);
+        } else {
+            LAUNCH_P2G(s, K_P2G, true, D, f);
+        }
+    }
+    HIPCHK(hipEventRecord(e1, s->stream));
+    HIPCHK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+    *us = 1e3 * ms / reps;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+extern "C" {
+int plmpm_replay(plmpm_handle s, int kind, int frame, int reps, double* mean_us) {
+    NEED_BOUND(s);
+    REQUIRE(mean_us && reps > 0 && kind >= 0 && kind <= 3, "replay: bad arguments");
+    REQUIRE(frame >= (kind == 0 ? 1 : 0) && frame < s->F, "replay: frame %d out of range", frame);
+    REQUIRE(s->store && !s->fg && !s->pk, "replay: needs the per-frame grid store and the default engine");
+    return DISPATCH(s, replay_t, s, kind, frame, reps, mean_us);
+}
+
 int plmpm_get_order(plmpm_handle s, int32_t* perm) {
     REQUIRE(s && perm, "null argument");
     memcpy(perm, s->perm.data(), (size_t)s->N * 4);

@@ -182,12 +182,36 @@ static void prof_end(plmpm_sim* s) {
     if (!s->prof) return;
     (void)hipEventRecord(s->ev_pool[s->ev_used.back().second + 1], s->stream);
 }
+// Experiment hook (profiles/r04_notes.md): PLB_DYNLDS="kernel:bytes,..." adds dynamic LDS to a kernel's launches, which
+// lowers the workgroups a CU can hold -- how much does each kernel's time depend on its occupancy?  Read once; 0 otherwise.
+static inline unsigned dyn_lds(int id) {
+    static unsigned tab[K_COUNT];
+    static bool init = false;
+    if (!init) {
+        init = true;
+        if (const char* e = getenv("PLB_DYNLDS")) {
+            std::string v(e);
+            size_t pos = 0;
+            while (pos < v.size()) {
+                size_t c = v.find(',', pos);
+                if (c == std::string::npos) c = v.size();
+                const std::string item = v.substr(pos, c - pos);
+                const size_t q = item.find(':');
+                if (q != std::string::npos)
+                    for (int k = 0; k < K_COUNT; ++k)
+                        if (item.substr(0, q) == kKernelNames[k]) tab[k] = (unsigned)atoi(item.c_str() + q + 1);
+                pos = c + 1;
+            }
+        }
+    }
+    return tab[id];
+}
 #define LAUNCHG_CLEAR(s, D) LAUNCH(s, K_CLEAR, (k_clear_active<T>), dim3(nblocks_grid(s)), D)
 #define LAUNCHB(s, id, kern, grid, block, ...)                                             \
     do {                                                                                   \
         if (dim3(grid).x == 0) break;            /* a slab rank may hold no particles for a while */ \
         prof_begin(s, id);                                                                 \
-        hipLaunchKernelGGL(kern, grid, dim3(block), 0, (s)->stream, __VA_ARGS__);         \
+        hipLaunchKernelGGL(kern, grid, dim3(block), dyn_lds(id), (s)->stream, __VA_ARGS__); \
         prof_end(s);                                                                       \
     } while (0)
 #define LAUNCH(s, id, kern, grid, ...) LAUNCHB(s, id, kern, grid, kBlock, __VA_ARGS__)

@@ -285,6 +285,20 @@ template <class T> __device__ __forceinline__ bool clamp_to_reach(const Dev<T>& 
     return out;
 }
 
+// XCD-aware workgroup -> particle chunk map.  Workgroup b of a launch runs on XCD b % 8 (observed, MI355X_MICROARCH.md:
+// "block b runs on XCD b % 8"; a speed assumption only -- the map is a bijection whatever the placement), and every XCD
+// has its own L2.  Particles are stored along the Hilbert curve, so neighbouring 256-particle chunks have overlapping
+// stencil boxes; with the identity map those neighbours sit on eight different L2s.  Here XCD k takes the k-th
+// CONTIGUOUS eighth of the chunks: the tile fills of neighbouring workgroups hit the same L2.
+#ifndef PLB_XCD_MAP
+#define PLB_XCD_MAP 0
+#endif
+__device__ __forceinline__ int xcd_chunk(int b, int n) {
+    if (!PLB_XCD_MAP) return b;
+    const int q = n >> 3, r = n & 7, k = b & 7;
+    return k * q + min(k, r) + (b >> 3);
+}
+
 // ------------------------------------------------------------------------------------------------
 // workgroup bounding box of stencil bases -> LDS tile geometry
 struct Tile {
@@ -516,9 +530,9 @@ __device__ __forceinline__ Tile block_tile(const int* base, bool valid, int* sre
 // anyway), and kept per frame: every later kernel over the same frame -- g2p, g2p.grad, p2g.grad -- reads 6 ints
 // and can start filling its LDS tile at once, in parallel with its particle loads, instead of load -> reduce ->
 // barrier -> fill.
-template <class T> __device__ __forceinline__ void store_tile(const Dev<T>& D, int f, const Tile& t) {
+template <class T> __device__ __forceinline__ void store_tile(const Dev<T>& D, int f, const Tile& t, int wg = blockIdx.x) {
     if (threadIdx.x < 6) {
-        int* q = D.tiles + ((size_t)f * D.twg + blockIdx.x) * 8;
+        int* q = D.tiles + ((size_t)f * D.twg + wg) * 8;
         q[threadIdx.x] = threadIdx.x < 3 ? t.o[threadIdx.x] : t.e[threadIdx.x - 3];
     }
 }
@@ -707,7 +721,7 @@ __device__ __forceinline__ bool sorted_finish(const Dev<T>& D, SortLoad& s, int&
     // padding lanes carry the largest key either way; the 32-bit network needs (cells << 6) to fit
     // (skipping the sort when the lanes already come in few runs of equal keys was measured in round 2: the extra LDS
     // atomics of the shorter runs cost more than the sort, profiles/r02_notes.md)
-    const int src = D.P.n <= 256 ? wave_sort_lanes32(p0 < D.N ? (unsigned)s.key : 0x3ffffffu) : wave_sort_lanes(s.key);
+    const int src = PLB_ABL_NOSORT ? (int)(threadIdx.x & 63) : (D.P.n <= 256 ? wave_sort_lanes32(p0 < D.N ? (unsigned)s.key : 0x3ffffffu) : wave_sort_lanes(s.key));
     p = (p0 & ~63) + src;
     for (int d = 0; d < 3; ++d) x[d] = __shfl(s.x0[d], src);       // the position travels with the sort
     for (int d = 0; d < 3; ++d) base[d] = (int)(x[d] * (double)D.P.inv_dx - 0.5);
@@ -718,9 +732,9 @@ __device__ __forceinline__ bool sorted_finish(const Dev<T>& D, SortLoad& s, int&
 // Load this lane's particle after the wave-local sort by stencil base: p = particle index, x = position,
 // base = stencil base.  Padding lanes (beyond N) sort to the end and return false.
 template <class T>
-__device__ __forceinline__ bool load_sorted_particle(const Dev<T>& D, const double* X, int& p, double* x, int* base, bool flag_err = false) {
+__device__ __forceinline__ bool load_sorted_particle(const Dev<T>& D, const double* X, int& p, double* x, int* base, bool flag_err = false, int wg = blockIdx.x) {
     const int Np = D.Npad;
-    const int p0 = blockIdx.x * kBlock + threadIdx.x;
+    const int p0 = wg * kBlock + threadIdx.x;
     long long key = (1LL << 40);                                    // padding lanes last
     double x0[3] = {0.5, 0.5, 0.5};
     if (p0 < D.N) {
@@ -753,9 +767,10 @@ __global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_p2g(Dev<T> D, int f) 
     const int Np = D.Npad;
     int p, base[3];
     double x[3];
-    const bool valid = load_sorted_particle(D, X, p, x, base, WRITE_F);
+    const int wgi = xcd_chunk((int)blockIdx.x, (int)gridDim.x);
+    const bool valid = load_sorted_particle(D, X, p, x, base, WRITE_F, wgi);
     Tile tl = block_tile(base, valid, sred, DET ? TileCap<T>::nodes / 2 : TileCap<T>::nodes);
-    store_tile(D, f, tl);
+    store_tile(D, f, tl, wgi);
     const int tn = tl.e[0] * tl.e[1] * tl.e[2];
     if (tl.ok) {
         for (int i = threadIdx.x; i < (DET ? 2 * tn : tn); i += kBlock) tile[i] = Vec4<double>{0.0, 0.0, 0.0, 0.0};
@@ -788,7 +803,13 @@ __global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_p2g(Dev<T> D, int f) 
                         det_add(q, q + 4, (double)a0); det_add(q + 1, q + 5, (double)a1); det_add(q + 2, q + 6, (double)a2); det_add(q + 3, q + 7, (double)a3);
                     } else {
                         double* q = reinterpret_cast<double*>(&tile[(oz + l) * exy + (oy + j) * ex + (ox + i)]);
+                        if (PLB_ABL_PACK) {          // timing experiment (wrong sums): two 64-bit integer atomics per node instead of four f64
+                            unsigned long long* qi = reinterpret_cast<unsigned long long*>(q);
+                            atomicAdd(qi, ((unsigned long long)(unsigned)(int)(a0 * 1e6f) << 32) | (unsigned)(int)(a1 * 1e6f));
+                            atomicAdd(qi + 1, ((unsigned long long)(unsigned)(int)(a2 * 1e6f) << 32) | (unsigned)(int)(a3 * 1e6f));
+                        } else {
                         atomicAdd(q, (double)a0); atomicAdd(q + 1, (double)a1); atomicAdd(q + 2, (double)a2); atomicAdd(q + 3, (double)a3);
+                        }
                     }
                 }
             });
@@ -898,11 +919,12 @@ template <class T, bool FG = false>
 __global__ __launch_bounds__(kBlock) void k_g2p(Dev<T> D, int f) {
     __shared__ Vec4<T> tile[TileCap<T>::nodes];
     const PrimT<T>* sp = D.ptab + (size_t)f * kMaxPrim;
-    const int p = blockIdx.x * kBlock + threadIdx.x;
+    const int wgi = xcd_chunk((int)blockIdx.x, (int)gridDim.x);
+    const int p = wgi * kBlock + threadIdx.x;
     const bool valid = p < D.N;
     const double* X = frame_x(D, f);
     const int Np = D.Npad;
-    const Tile tl = load_tile(D, f, TileCap<T>::nodes);             // written by the scatter of this frame
+    const Tile tl = load_tile(D, f, TileCap<T>::nodes, wgi);        // written by the scatter of this frame
     double x[3] = {0.5, 0.5, 0.5};
     if (valid) { x[0] = X[p]; x[1] = X[Np + p]; x[2] = X[2 * Np + p]; }
     const int ex = tl.e[0], exy = tl.e[0] * tl.e[1], tn = exy * tl.e[2];
@@ -972,8 +994,9 @@ __global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_g2p_p2g(Dev<T> D, int
     PT_BEGIN();
     // box of frame f-1 (stored by the kernel that scattered it; capacity: the same LDS bytes in Vec4<T> nodes):
     // the tile fill is issued right behind the position loads and overlaps with them and with the sort
-    const Tile ta = load_tile(D, f - 1, (int)(TileCap<T>::nodes * sizeof(Vec4<double>) / sizeof(Vec4<T>)));
-    SortLoad sl = sorted_begin(D, X0);
+    const int wgi = xcd_chunk((int)blockIdx.x, (int)gridDim.x);
+    const Tile ta = load_tile(D, f - 1, (int)(TileCap<T>::nodes * sizeof(Vec4<double>) / sizeof(Vec4<T>)), wgi);
+    SortLoad sl = sorted_begin(D, X0, wgi);
     NodeIn<T> fpre;
     int flz = 0, fly = 0, flx = 0;
     {
@@ -992,7 +1015,7 @@ __global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_g2p_p2g(Dev<T> D, int
             }
     }
     PT_MARK(0);
-    const bool valid = sorted_finish(D, sl, p, x0, base0);
+    const bool valid = sorted_finish(D, sl, p, x0, base0, false, wgi);
     // state that does not depend on the gather: issue these loads now so they fly during the gather
     T E[9];
     for (int d = 0; d < 9; ++d) E[d] = T(0);
@@ -1053,7 +1076,7 @@ __global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_g2p_p2g(Dev<T> D, int
     block_tile_publish(base, valid, sred);
     wg_barrier();                                                        // everyone is done reading tile_v, and has published its box
     Tile tl = block_tile_collect(sred, DET ? TileCap<T>::nodes / 2 : TileCap<T>::nodes);
-    store_tile(D, f, tl);
+    store_tile(D, f, tl, wgi);
     const int tn = tl.e[0] * tl.e[1] * tl.e[2];
 #ifdef PLB_DEBUG_COUNTERS      // tile statistics for plmpm_debug_counters (same-address atomics: keep out of production builds)
     if (threadIdx.x == 0) { atomicAdd(D.err + (tl.ok ? 2 : 1), 1); if (tl.ok) atomicAdd(D.err + 3, tn); }
@@ -1082,7 +1105,13 @@ __global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_g2p_p2g(Dev<T> D, int
                         det_add(q, q + 4, (double)a0); det_add(q + 1, q + 5, (double)a1); det_add(q + 2, q + 6, (double)a2); det_add(q + 3, q + 7, (double)a3);
                     } else {
                         double* q = reinterpret_cast<double*>(&tile[(oz + l) * exy + (oy + j) * ex + (ox + i)]);
+                        if (PLB_ABL_PACK) {          // timing experiment (wrong sums): two 64-bit integer atomics per node instead of four f64
+                            unsigned long long* qi = reinterpret_cast<unsigned long long*>(q);
+                            atomicAdd(qi, ((unsigned long long)(unsigned)(int)(a0 * 1e6f) << 32) | (unsigned)(int)(a1 * 1e6f));
+                            atomicAdd(qi + 1, ((unsigned long long)(unsigned)(int)(a2 * 1e6f) << 32) | (unsigned)(int)(a3 * 1e6f));
+                        } else {
                         atomicAdd(q, (double)a0); atomicAdd(q + 1, (double)a1); atomicAdd(q + 2, (double)a2); atomicAdd(q + 3, (double)a3);
+                        }
                     }
                 }
             });
@@ -1173,7 +1202,7 @@ __global__ __launch_bounds__(kBlock, sizeof(T) == 4 ? PLB_G2PG_WAVES : 1) void k
         // (they lead the launch, so they run under cover of the first particle workgroups)
         if ((int)blockIdx.x < CA.nwg_clear) { clear_blocks(D, CA, (int)blockIdx.x, CA.nwg_clear); return; }
     }
-    const int wg = FG ? (int)blockIdx.x - CA.nwg_clear : (int)blockIdx.x;
+    const int wg = FG ? (int)blockIdx.x - CA.nwg_clear : xcd_chunk((int)blockIdx.x, (int)gridDim.x);
     // 960 nodes x (16 + 24) bytes = 37.5 KiB: four workgroups per CU (128 VGPRs = 4 waves per SIMD, see PLB_G2PG_WAVES)
     constexpr int CAP = sizeof(T) == 4 ? PLB_G2PG_CAP : 480;
     __shared__ Vec4<T> tile[CAP];                    // v_out values
@@ -1544,8 +1573,8 @@ __global__ __launch_bounds__(kBlock, sizeof(T) == 4 ? PLB_P2G_GRAD_WAVES : 1) vo
     __shared__ PrimT<T> sp[kMaxPrim];
     // the first `npose` workgroups finish grid_op.grad (pose adjoints of the blocks in contact) under cover of the
     // particle workgroups
-    const int chunk = (int)blockIdx.x - npose;
-    if (chunk < 0) { pose_adjoint_blocks<T, FG>(D, f, (int)blockIdx.x, npose, sp); return; }
+    if ((int)blockIdx.x < npose) { if (!PLB_EXP_NOPOSE) pose_adjoint_blocks<T, FG>(D, f, (int)blockIdx.x, npose, sp); return; }
+    const int chunk = xcd_chunk((int)blockIdx.x - npose, (int)gridDim.x - npose);
     const int p = chunk * kBlock + threadIdx.x;
     const bool valid = p < D.N;
     const double* X = frame_x(D, f);

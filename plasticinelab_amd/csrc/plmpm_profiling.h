@@ -53,3 +53,17 @@
         }                                                                                      \
     } while (0)
 
+
+// Experiment (profiles/r04_notes.md): PLB_EXP_NOPOSE=1 drops the pose-adjoint workgroups' code from k_p2g_grad (timing
+// only -- the pose adjoints are then missing): what does the particle path need in registers on its own?
+#ifndef PLB_EXP_NOPOSE
+#define PLB_EXP_NOPOSE 0
+#endif
+// PLB_ABL_NOSORT=1 (timing only): the particle kernels keep the storage order inside a wave (no bitonic network).
+#ifndef PLB_ABL_NOSORT
+#define PLB_ABL_NOSORT 0
+#endif
+// PLB_ABL_PACK=1 (timing only): the scatter's four ds_add_f64 per node replaced by two ds_add_u64 of packed 32-bit pairs.
+#ifndef PLB_ABL_PACK
+#define PLB_ABL_PACK 0
+#endif

@@ -151,3 +151,16 @@ def fk_chopsticks_bwd(pos, rot, v, w, gap, gap_vel, min_gap, lo, hi, pos1_a, rot
                                  *[_p(t) for t in b], C.c_double(gap1_a), _p(pos_a), _p(rot_a), C.byref(gap_a),
                                  _p(v_a), _p(w_a), C.byref(gv_a))
     return pos_a, rot_a, gap_a.value, v_a, w_a, gv_a.value
+
+
+def constitutive(Et, mu, lam, ys, GS, GF, clamp=1e-6, use_float=False, allow_fast=True):
+    """The constitutive block of p2g / p2g.grad for n particles (Et = F_tmp - I): (stress, new_F - I, F_tmp adjoint, fast?)
+    through the Jacobi path or -- allow_fast, per particle -- the elastic fast path of mpm_math.h."""
+    n = len(Et)
+    a = [np.ascontiguousarray(v, dtype=np.float64) for v in (Et, np.broadcast_to(mu, (n,)), np.broadcast_to(lam, (n,)),
+                                                              np.broadcast_to(ys, (n,)), GS, GF)]
+    stress, En, Fta = np.empty((n, 3, 3)), np.empty((n, 3, 3)), np.empty((n, 3, 3))
+    fast = np.zeros(n, np.int32)
+    lib().emul_constitutive(int(use_float), int(allow_fast), n, _p(a[0]), _p(a[1]), _p(a[2]), _p(a[3]), C.c_double(clamp),
+                            _p(a[4]), _p(a[5]), _p(stress), _p(En), _p(Fta), _p(fast))
+    return stress, En, Fta, fast.astype(bool)

@@ -215,3 +215,31 @@ void emul_fk_bwd(const double* pos, const double* rot, const double* v, const do
                  const double* hi, const double* pos1_a, const double* rot1_a, double* pos_a, double* rot_a,
                  double* v_a, double* w_a) { fk_bwd_d(pos, rot, v, w, lo, hi, pos1_a, rot1_a, pos_a, rot_a, v_a, w_a); }
 }
+
+// constitutive block alone: the wave-uniform elastic fast path of mpm_math.h (here: one particle = one "wave") against the
+// Jacobi path on the same inputs.  allow_fast = 0: Jacobi path only; took_fast[p] reports the path taken.
+template <class T> static void constitutive_t(int allow_fast, int n, const double* Et_, const double* mu, const double* lam, const double* ys,
+                                              double clamp, const double* GS_, const double* GF_, double* stress_, double* En_, double* Fta_, int* took_fast) {
+    for (int p = 0; p < n; ++p) {
+        T Et[9], GS[9], GF[9], stress[9], En[9], Fta[9];
+        for (int i = 0; i < 9; ++i) { Et[i] = (T)Et_[9 * p + i]; GS[i] = (T)GS_[9 * p + i]; GF[i] = (T)GF_[9 * p + i]; }
+        Elastic<T> el;
+        const bool fast = allow_fast && elastic_try(Et, (T)mu[p], (T)ys[p], (T)clamp, true, el);
+        if (fast) {
+            for (int i = 0; i < 9; ++i) En[i] = Et[i];
+            elastic_stress(Et, el, (T)mu[p], (T)lam[p], stress);
+            elastic_vjp(Et, el, (T)mu[p], (T)lam[p], GS, GF, Fta);
+        } else {
+            Consti<T> k;
+            constitutive_fwd(Et, (T)mu[p], (T)lam[p], (T)ys[p], k, En, stress, 0);
+            constitutive_vjp(k, (T)mu[p], (T)lam[p], (T)clamp, GS, GF, Fta);
+        }
+        took_fast[p] = fast ? 1 : 0;
+        for (int i = 0; i < 9; ++i) { stress_[9 * p + i] = stress[i]; En_[9 * p + i] = En[i]; Fta_[9 * p + i] = Fta[i]; }
+    }
+}
+extern "C" void emul_constitutive(int use_float, int allow_fast, int n, const double* Et, const double* mu, const double* lam, const double* ys,
+                                  double clamp, const double* GS, const double* GF, double* stress, double* En, double* Fta, int* took_fast) {
+    if (use_float) constitutive_t<float>(allow_fast, n, Et, mu, lam, ys, clamp, GS, GF, stress, En, Fta, took_fast);
+    else constitutive_t<double>(allow_fast, n, Et, mu, lam, ys, clamp, GS, GF, stress, En, Fta, took_fast);
+}

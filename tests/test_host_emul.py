@@ -267,6 +267,68 @@ def test_pack_instantiation_equals_scalar_bit_for_bit(tmp_path):
     import subprocess
     src = os.path.join(os.path.dirname(__file__), "host_emul", "pack_check.cpp")
     exe = str(tmp_path / "pack_check")
-    subprocess.check_call(["g++", "-O1", "-std=c++17", "-ffp-contract=off", src, "-o", exe])
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-ffp-contract=off", "-DPLB_FAST=0", src, "-o", exe])    # the generic (SVD) path: packs never take the scalar-only elastic fast path
     out = subprocess.run([exe], capture_output=True, text=True)
     assert out.returncode == 0 and "mismatches: 0" in out.stdout, out.stdout + out.stderr
+
+
+def _oracle_constitutive(Et, mu, lam, ys, GS, GF):
+    """stress (unscaled) and new_F of p2g + the F_tmp adjoint of <GS, stress> + <GF, new_F> through the oracle's own SVD
+    with the reference's literal backward_svd (oracle/plb_oracle.py::SvdRef, compute_von_mises)."""
+    Ft = (torch.as_tensor(Et) + torch.eye(3, dtype=O.DT)).requires_grad_(True)
+    U, sig, V = O.SvdRef.apply(Ft)
+    mu_t, lam_t = torch.full((len(Et),), mu, dtype=O.DT), torch.full((len(Et),), lam, dtype=O.DT)
+    newF, yields = O.compute_von_mises(Ft, U, sig, V, torch.full((len(Et),), ys, dtype=O.DT), mu_t)
+    J = torch.linalg.det(newF)
+    r = U @ V.transpose(-1, -2)
+    stress = 2 * mu * (newF - r) @ newF.transpose(-1, -2) + torch.eye(3, dtype=O.DT) * (lam_t * J * (J - 1))[:, None, None]
+    (g,) = torch.autograd.grad((stress * torch.as_tensor(GS)).sum() + (newF * torch.as_tensor(GF)).sum(), Ft)
+    return stress.detach().numpy(), newF.detach().numpy(), g.numpy(), yields.numpy()
+
+
+@pytest.mark.parametrize("use_float,tol", [(False, 2e-10), (True, 2e-5)])
+def test_elastic_fast_path_matches_svd_path_and_oracle(use_float, tol):
+    """Round 4: waves in which no particle can yield skip the SVD (polar rotation by Newton steps, closed-form VJP).  One
+    particle = one wave here.  Strains from 1e-7 to ~5 %, with rotations up to ~0.5 rad: the fast path must be TAKEN for
+    the clearly elastic ones, never for a yielding one, and agree with the Jacobi path and with the oracle's literal
+    SVD + backward_svd (clamp 1e-6) in stress, new_F and the F_tmp adjoint."""
+    rng = np.random.default_rng(3)
+    n = 4000
+    mu, lam, ys = 5000 / 2.4, 5000 * 0.2 / (1.2 * 0.6), 200.0
+    scale = 10 ** rng.uniform(-7, -1.3, n)
+    strain = rng.standard_normal((n, 3, 3)) * scale[:, None, None]
+    strain = 0.5 * (strain + strain.transpose(0, 2, 1))
+    w = rng.standard_normal((n, 3)) * rng.uniform(0, 0.5, n)[:, None]
+    Wm = np.zeros((n, 3, 3))
+    Wm[:, 0, 1], Wm[:, 0, 2], Wm[:, 1, 2] = -w[:, 2], w[:, 1], -w[:, 0]
+    Wm -= Wm.transpose(0, 2, 1)
+    R = torch.linalg.matrix_exp(torch.as_tensor(Wm)).numpy()
+    Et = R @ (np.eye(3) + strain) - np.eye(3)
+    Et[:50] = 0.0                                        # the undeformed state: every eigenvalue gap is 0 (clamp regime)
+    Et[50:100] = R[50:100] - np.eye(3)                    # pure rotations
+    GS, GF = rng.standard_normal((n, 3, 3)), rng.standard_normal((n, 3, 3))
+    s_o, F_o, g_o, y_o = _oracle_constitutive(Et, mu, lam, ys, GS, GF)
+    s_f, E_f, g_f, fast = emul.constitutive(Et, mu, lam, ys, GS, GF, use_float=use_float, allow_fast=True)
+    s_s, E_s, g_s, took = emul.constitutive(Et, mu, lam, ys, GS, GF, use_float=use_float, allow_fast=False)
+    assert not took.any()
+    assert not (fast & y_o).any()                        # sufficient condition: never fast when the oracle yields
+    lam3 = np.linalg.eigvalsh(np.einsum("nki,nkj->nij", Et + np.eye(3), Et + np.eye(3)) - np.eye(3))
+    gap = np.minimum(lam3[:, 1] - lam3[:, 0], lam3[:, 2] - lam3[:, 1])
+    clear = (~y_o) & (scale < 0.02) & (gap > (1e-4 if use_float else 3e-6))
+    assert fast[clear].mean() > 0.98 and fast[:50].all() and fast.mean() > 0.5     # (pure rotations: gaps of round-off size, not 0 -- Jacobi path)
+    # relative to each particle's own magnitudes (stress spans seven decades here)
+    def err(a, b):
+        return np.abs(a - b).max(axis=(1, 2)) / np.maximum(np.abs(b).max(axis=(1, 2)), 1e-300)
+    f = fast
+    assert (err(E_f[f] + np.eye(3), F_o[f]) < tol).all()
+    # A = F^T F - I loses eps x angle^2 to cancellation under a rotation whichever path consumes it: the fast path must be
+    # as good as the Jacobi path there, and both within tol of the oracle where that floor is below it
+    e_f, e_s = err(s_f[f], s_o[f]), err(s_s[f], s_o[f])
+    assert (e_f < 20 * tol + 2 * e_s).all(), (e_f - 2 * e_s).max()
+    floor = (6e-8 if use_float else 1e-16) * (w[f] ** 2).sum(1) / scale[f]
+    quiet = floor < tol
+    assert quiet.mean() > 0.3 and (e_f[quiet] < 50 * tol).all()
+    assert (err(g_f[f], g_o[f]) < 50 * tol).all(), err(g_f[f], g_o[f]).max()
+    assert (err(g_s[f], g_o[f]) < 50 * tol).all()
+    # particles the fast path refused: identical to the Jacobi path by construction
+    assert np.array_equal(s_f[~f], s_s[~f]) and np.array_equal(g_f[~f], g_s[~f])
