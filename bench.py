@@ -151,18 +151,13 @@ def build_env(args, device, rank=0, world=1, slabs=False):
     if slabs:
         import torch.distributed as dist
         from plasticinelab_amd.distributed import make_slab_env
+        # the device-side exchange is opt-in (distributed.HaloComm); the bench opts in and CHECKS it against the library
+        # transport before timing anything (transport_check below) -- PLB_PEER_HALOS=0 keeps it off altogether
         env, layout, _ = make_slab_env(cfg, rank, world, compute_dtype=args.dtype, device=device, target_fn=_target,
-                                       xy_margin=XY_MARGIN, migrate_every=1)
+                                       xy_margin=XY_MARGIN, migrate_every=1, peer=True)
         env.loss.set_weights(10, 10, 1, False)
-        backend = dist.get_backend()
-        backend = "RCCL" if backend == "nccl" else backend
-        if env.simulator.engine.native_loops:
-            how = (f"written by a kernel into the neighbours' IPC-mapped receive areas each substep (fwd + adjoint; device-side exchange, native "
-                   f"substep loops, no host-side communication per substep; {backend} for migration and the per-env-step reductions)")
-        else:
-            how = f"summed over {backend} point-to-point each substep (fwd + adjoint)"
         return env, (f"{world} z-slabs {list(layout.bounds)} (reach {layout.halo} layers), grid window = body + {XY_MARGIN} layers, zero-copy halo of "
-                     f"one 4^3 block plane per face side {how}, particle migration every env step")
+                     f"one 4^3 block plane per face side, particle migration every env step")
     if getattr(args, "window", -1) >= 0:
         from plasticinelab_amd.engine.shapes import Shapes
         n = int(128 * args.quality * 0.5)
@@ -242,6 +237,94 @@ def cpu_baseline(args, env):
             "sample": f"one fwd+bwd substep of the {N}-particle / {sim_g.n_grid}^3 workload (seeded perturbed state: v, C, F != 0, I) through "
                       "oracle/mpm_substep_omp.c (C / OpenMP, float64, dense grids and the reference's recompute schedule): median of 3 runs per "
                       f"thread count, best count = {cores} of {avail} available; 1 thread: median of 3; Taichi (the reference's own CPU backend) is not installable here"}
+
+
+def slab_how(env):
+    """How the halos of a slab run travel, in words (config.parallelism)."""
+    import torch.distributed as dist
+    eng = env.simulator.engine
+    backend = dist.get_backend()
+    backend = "RCCL" if backend == "nccl" else backend
+    if eng.native_loops:
+        return (f"halos written by a kernel into the neighbours' IPC-mapped receive areas each substep (fwd + adjoint; device-side exchange, native "
+                f"substep loops, no host-side communication per substep; {backend} for migration and the per-env-step reductions)")
+    return f"halos summed over {backend} point-to-point each substep (fwd + adjoint)"
+
+
+def one_step_loss_and_grad(env, state0, A):
+    """One env step forward + its reverse on the slab engine's current transport: (loss, d loss / d action)."""
+    env.set_state(state0, 666.0, False)
+    loss = rollout(env, seeded_actions(1, A))
+    return float(loss), np.array(env.primitives.get_grad(1), dtype=np.float64)
+
+
+def transport_check(env, state0, A, agree, tol_loss=1e-5, tol_grad=1e-4):
+    """N > 1, device-side exchange set up: run ONE env step fwd + bwd through the peer-write exchange and again through the
+    library's point-to-point transport (RCCL on the GPUs' backend) and compare loss and action gradient.  The first real
+    multi-GPU run of this code happens without anybody watching: a visibility bug of the hand-written exchange across GPUs
+    would give a wrong-but-plausible line, so the line says which transport it trusted and why.  Collective.  Returns the
+    record that goes into the JSON line; the engine is left on the transport to time."""
+    eng = env.simulator.engine
+    rec = {"checked": False, "peer_available": bool(getattr(eng.comm, "peer_mapped", False))}
+    if not rec["peer_available"]:
+        rec["reason"] = getattr(eng.comm, "peer_error", None) or "device-side exchange not set up (PLB_PEER_HALOS=0, or no IPC mapping)"
+        rec["used"] = eng.use_transport("p2p")
+        return rec
+    old_to = os.environ.get("PLMPM_PEER_TIMEOUT")
+    os.environ["PLMPM_PEER_TIMEOUT"] = os.environ.get("PLB_CHECK_PEER_TIMEOUT", "5")      # a dead hand-off costs seconds here, not minutes
+    res, err = {}, {}
+    for kind in ("peer", "p2p"):
+        eng.use_transport(kind)
+        try:
+            res[kind] = one_step_loss_and_grad(env, state0, A)
+            ok = True
+        except Exception as e:                                    # noqa: BLE001
+            ok, err[kind] = False, f"{type(e).__name__}: {str(e)[:160]}"
+        if not agree(ok):
+            res.pop(kind, None)
+            err.setdefault(kind, "failed on another rank")
+    if old_to is None:
+        os.environ.pop("PLMPM_PEER_TIMEOUT", None)
+    else:
+        os.environ["PLMPM_PEER_TIMEOUT"] = old_to
+    rec["checked"] = True
+    rec["errors"] = err or None
+    same = False
+    if "peer" in res and "p2p" in res:
+        (lp, gp), (lq, gq) = res["peer"], res["p2p"]
+        rec["loss_peer"], rec["loss_p2p"] = lp, lq
+        rec["rel_loss"] = abs(lp - lq) / max(abs(lq), 1e-300)
+        rec["rel_grad"] = float(np.abs(gp - gq).max() / max(np.abs(gq).max(), 1e-300))
+        same = rec["rel_loss"] < tol_loss and rec["rel_grad"] < tol_grad
+    same = agree(same)
+    rec["agree"] = same
+    if same:
+        rec["used"] = eng.use_transport("peer")
+    elif "p2p" in res:
+        rec["used"] = eng.use_transport("p2p")
+        rec["reason"] = "device-side exchange disagrees with the library transport (or failed): FALLBACK to point-to-point halos"
+    else:
+        rec["used"] = None
+        rec["reason"] = "neither transport completed one env step"
+    return rec
+
+
+N1_LOSS_FILE = os.path.join(ROOT, "profiles", "n1_final_loss.json")
+
+
+def loss_check(workload, dtype, steps, final_loss, tol=1e-5):
+    """final_loss against the committed single-GPU loss of the same (workload, dtype, steps) -- profiles/n1_final_loss.json,
+    written from N = 1 runs of this very script.  The slab run computes the SAME rollout, so its loss must agree to the
+    engines' round-off; `rel` beyond 1e-5 puts MISMATCH into `metric`."""
+    try:
+        with open(N1_LOSS_FILE) as f:
+            exp = json.load(f).get(f"{workload}|{dtype}|{steps}")
+    except (OSError, ValueError):
+        exp = None
+    if exp is None:
+        return {"n1_expected": None, "rel": None, "ok": None, "source": "profiles/n1_final_loss.json has no entry for this (workload, dtype, steps)"}
+    rel = abs(final_loss - exp) / max(abs(exp), 1e-300)
+    return {"n1_expected": exp, "rel": rel, "ok": bool(rel <= tol), "tol": tol, "source": "profiles/n1_final_loss.json"}
 
 
 def main():
@@ -343,7 +426,7 @@ def main():
         t_phase = now
 
     slabs = world > 1 and not args.replicas
-    env, state0 = None, None
+    env, state0, tcheck = None, None, None
     if slabs:
         note = ""
         watchdog = arm_watchdog()
@@ -355,8 +438,15 @@ def main():
         except Exception as e:                                    # noqa: BLE001
             ok, note = False, f"{type(e).__name__}: {e}"
         if agree(ok):
-            try:                                                  # the warm-up doubles as the feasibility check
+            try:
                 state0 = env.get_state()["state"]
+                tcheck = transport_check(env, state0, env.primitives.action_dim, agree)
+                if tcheck.get("used") is None:
+                    raise RuntimeError(tcheck.get("reason", "no usable halo transport"))
+                parallelism += ", " + slab_how(env)
+                if tcheck.get("checked") and not tcheck.get("agree"):
+                    parallelism += " -- FALLBACK from the device-side exchange: " + str(tcheck.get("errors") or tcheck.get("reason"))
+                # the warm-up doubles as the feasibility check
                 env.set_state(state0, 666.0, False)
                 rollout(env, seeded_actions(max(W, K), env.primitives.action_dim))
                 ok = True
@@ -418,6 +508,24 @@ def main():
                    "parallelism": parallelism},
         "final_loss": float(loss),
     }
+    # self-validation of the line: the loss against the committed single-GPU loss of the same rollout,
+    # which transport carried the halos and whether it was checked, and the size of the RCCL communicator
+    out["loss_check"] = loss_check(out["config"]["workload"], out["dtype"], K, float(loss)) if (slabs or world == 1) else None
+    if out["loss_check"] and out["loss_check"]["ok"] is False:
+        out["metric"] += " -- MISMATCH: final loss differs from the single-GPU run of the same rollout"
+    if slabs:
+        out["halo_transport"] = env.simulator.engine.transport
+        out["transport_check"] = tcheck
+        if tcheck and tcheck.get("checked") and not tcheck.get("agree"):
+            out["metric"] += " -- FALLBACK: device-side halo exchange failed its check, halos over point-to-point"
+    if dist is not None:
+        ranks = None
+        if dist.get_backend() == "nccl":
+            t = torch.ones(1, device=device)
+            dist.all_reduce(t)                                    # what the RCCL communicator itself counts
+            ranks = int(round(t.item()))
+        out["rccl_ranks"] = ranks
+        out["dist_backend"] = dist.get_backend()
 
     workload = out["config"]["workload"]
     if not args.no_roofline:

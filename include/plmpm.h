@@ -282,6 +282,13 @@ int plmpm_peer_open(plmpm_handle h, const void* ipc_handle64, void** dev_ptr);  
 int plmpm_halo_peer_setup(plmpm_handle h, int field, int n_faces, const int* bz_a, const int* bz_b, void* const* local, void* const* remote);
 int plmpm_halo_peer_exchange(plmpm_handle h, int field, int frame);
 int plmpm_peer_status(plmpm_handle h, int* status);
+/* collective re-synchronisation: every rank calls it and then meets the others at a host barrier before the next exchange;
+ * counters, sequence numbers and the status word go back to zero (after a timeout, or an exception between exchanges) */
+int plmpm_halo_peer_reset(plmpm_handle h);
+/* 1: receive areas in uncached device memory (hipDeviceMallocUncached), 0: fine-grained (PLMPM_PEER_MEM=finegrained, or refused) */
+int plmpm_peer_memory_kind(plmpm_handle h, int* uncached);
+/* test hook: scale what this rank sends through face 0 (1 = off) -- a spoiled halo must be noticed by the transport check */
+int plmpm_debug_peer_spoil(plmpm_handle h, double factor);
 int plmpm_slab_step(plmpm_handle h, int first_frame, int n_substeps);         /* fk + n x (p2g | exchange | grid_op + g2p) */
 int plmpm_slab_step_grad(plmpm_handle h, int first_frame, int n_substeps);    /* n x (g2p.grad | exchange | grid_op.grad + p2g.grad), in reverse */
 

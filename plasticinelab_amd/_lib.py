@@ -101,6 +101,9 @@ SYMBOLS = {
     "plmpm_halo_peer_setup": (_I, [_P, _I, _I, _P, _P, _P, _P]),
     "plmpm_halo_peer_exchange": (_I, [_P, _I, _I]),
     "plmpm_peer_status": (_I, [_P, C.POINTER(_I)]),
+    "plmpm_halo_peer_reset": (_I, [_P]),
+    "plmpm_peer_memory_kind": (_I, [_P, C.POINTER(_I)]),
+    "plmpm_debug_peer_spoil": (_I, [_P, _D]),
     "plmpm_slab_step": (_I, [_P, _I, _I]),
     "plmpm_slab_step_grad": (_I, [_P, _I, _I]),
     "plmpm_set_ids": (_I, [_P, _P]),

@@ -153,6 +153,8 @@ struct plmpm_sim {
     unsigned* peer_done = nullptr;        // device: workgroups of the running exchange kernel that have finished their copies
     int* peer_status = nullptr;           // pinned host: 0, or field << 16 | face << 8 | 1 of an arrival that timed out
     std::vector<void*> peer_allocs, peer_mapped;
+    bool peer_uncached = false;           // the receive areas are hipDeviceMallocUncached (else fine-grained)
+    float peer_spoil = 1.0f;              // test hook (plmpm_debug_peer_spoil)
     // optional per-kernel timing with HIP events on the launch stream (plmpm_profile_*)
     bool prof = false;
     std::vector<hipEvent_t> ev_pool;

@@ -240,13 +240,15 @@ template <class T> __device__ __forceinline__ int halo_face_of(const Dev<T>& D, 
     return -1;
 }
 // did the neighbour on face f send block blk (which must lie in face f's planes)?
+// (system-scope loads -- global_load ... sc0 sc1: what a neighbour on another GPU wrote into the receive area must not be
+// served from a stale cache line of this GPU; a few hundred KB per launch, so the cache bypass costs nothing)
 template <class T> __device__ __forceinline__ bool halo_sent(const Dev<T>& D, const HaloIn& H, int f, int blk) {
-    return !H.valid[f] || H.valid[f][blk - H.ba[f] * D.nbx * D.nby] != 0;
+    return !H.valid[f] || __hip_atomic_load(H.valid[f] + (blk - H.ba[f] * D.nbx * D.nby), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0;
 }
 // received value of component c at node (blk, lane); blk must lie in face f's planes
 template <class T> __device__ __forceinline__ T halo_value(const Dev<T>& D, const HaloIn& H, int f, int c, int blk, int lane) {
     const size_t per = (size_t)(H.bb[f] - H.ba[f]) * D.nbx * D.nby * 64;
-    return ((const T*)H.buf[f])[(size_t)c * per + ((size_t)(blk - H.ba[f] * D.nbx * D.nby) << 6) + lane];
+    return __hip_atomic_load((const T*)H.buf[f] + ((size_t)c * per + ((size_t)(blk - H.ba[f] * D.nbx * D.nby) << 6) + lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 // first 64 flags of this workgroup: issued by the grid kernels before they wait for the primitives' poses, so that the
 // two memory latencies overlap

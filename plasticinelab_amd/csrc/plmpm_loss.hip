@@ -150,7 +150,7 @@ __global__ void k_loss_grad(Dev<T> D, int f, int which, const T* gm, const T* td
             } else {                                        // sdf = sdf_local(inv_trans(x, pos, rot))
                 double loc[3], iq[4], na0[3] = {0, 0, 0}, loca[3] = {0, 0, 0};
                 inv_trans(x, pr.pos, pr.rot, loc, iq);
-                shape_local_adj(pr.shape, pr.par, loc, coef, na0, loca, &ga);
+                shape_local_adj(pr.shape, pr.par, loc, coef, na0, loca, &ga, D.P.tie_first);       // minmax_tie applies to the shape SDFs' max / min here as in collide
                 inv_trans_adj(x, pr.pos, pr.rot, iq, loca, pa, ra);
                 for (int d = 0; d < 3; ++d) xa[d] -= pa[d];  // d/dx = -d/dpos
             }

@@ -10,6 +10,14 @@
 //
 // Only the blocks that carry something are sent: a wave per block of the exchange planes looks at the block's activity flag
 // (the flag the scatter kernels set), writes the validity word, and copies the block's 64 nodes per component if it is set.
+//
+// Visibility between DIFFERENT GPUs (round 4; every run before it had all ranks on one GPU, i.e. behind the same L2s): both
+// sides of the hand-off are at system scope.  The writer stores through its caches (sc0 sc1) and drains vmcnt before the
+// counter moves; the receive areas are UNCACHED device memory where the runtime offers it (hipDeviceMallocUncached,
+// fine-grained otherwise), and the readers -- the polling lane here, halo_sent / halo_value in the grid kernels -- use
+// system-scope loads (sc0 sc1: served by memory, never by a stale L1 / L2 line of a half that was read two exchanges ago).
+// MI355X_MICROARCH.md lists "sc0 sc1 stores and loads on both sides" as a valid form of the hand-off on its own; "the
+// next launch is the acquire" is no longer relied upon.
 // The body's cross-section covers about a quarter of the xy window's blocks at config 3, so about a quarter of the plane
 // crosses the link (a 24 x 18-block window: 442 KB per block plane and face dense, ~110 KB as sent).
 //
@@ -37,6 +45,7 @@ struct PeerXchg {
     int* status;
     int code;                    // field << 16 | 1
     long long timeout_ticks;     // of the 100 MHz wall clock
+    float spoil;                 // 1; a test hook (plmpm_debug_peer_spoil) scales what face 0 sends, to prove that a wrong halo is NOTICED
 };
 
 // Stores written THROUGH the L2 (sc0 sc1: system-scope write-through): once the store is acknowledged the data is where the
@@ -75,6 +84,7 @@ __global__ __launch_bounds__(256) void k_halo_xchg(PeerXchg X) {
             for (int c = 0; c < X.ncomp; ++c) {
                 v0[c] = ((const T*)X.src[i][c])[((size_t)(X.blk0[i] + b0) << 6) + lane];
                 v1[c] = ((const T*)X.src[i][c])[((size_t)(X.blk0[i] + b1) << 6) + lane];
+                if (i == 0 && X.spoil != 1.0f) { v0[c] *= (T)X.spoil; v1[c] *= (T)X.spoil; }
             }
             for (int c = 0; c < X.ncomp; ++c) {
                 store_through(data + (size_t)c * count + ((size_t)b0 << 6) + lane, v0[c]);
@@ -93,9 +103,13 @@ __global__ __launch_bounds__(256) void k_halo_xchg(PeerXchg X) {
     if (threadIdx.x == 0) __hip_atomic_store(X.done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // the next launch is stream-ordered behind this one
     if (threadIdx.x < X.n) {
         const int i = threadIdx.x;
+        // an earlier exchange already timed out (a neighbour has stopped): publish -- so that a live neighbour is not kept
+        // waiting by THIS rank -- but do not wait again: the launches still queued behind this one must drain in microseconds,
+        // not in n x PLMPM_PEER_TIMEOUT, before the host gets to look at the status word
+        const bool dead = __hip_atomic_load(X.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0;
         store_through(X.arrive_remote[i], X.seq);
         const long long t0 = wall_clock64();
-        for (;;) {
+        for (; !dead;) {
             const unsigned got = __hip_atomic_load(X.arrive_local[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             if ((int)(got - X.seq) >= 0) break;
             if (wall_clock64() - t0 > X.timeout_ticks) {         // the neighbour is gone: report, do not hang the GPU
@@ -106,7 +120,8 @@ __global__ __launch_bounds__(256) void k_halo_xchg(PeerXchg X) {
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    // the grid kernel that consumes the received planes is a later launch on this stream: its start is the acquire
+    // the grid kernel that consumes the received planes is a later launch on this stream and reads them with system-scope
+    // loads (halo_sent / halo_value, plmpm_kernels.h)
 }
 
 int peer_init(plmpm_sim* s) {
@@ -144,9 +159,18 @@ int plmpm_peer_alloc(plmpm_handle s, size_t bytes, void** dev_ptr, void* ipc_han
     static_assert(sizeof(hipIpcMemHandle_t) == 64, "IPC handles travel as 64 bytes");
     if (peer_init(s)) return -1;
     void* p = nullptr;
-    // fine-grained: coherent at system scope -- a neighbour's stores are visible here once it has released them (k_halo_xchg),
-    // this rank's polling loads see the counter move, and the grid kernels launched behind the exchange read what arrived
-    HIPCHK(hipExtMallocWithFlags(&p, bytes, hipDeviceMallocFinegrained));
+    // uncached device memory: no L2 of this GPU ever holds a line of it, so what a neighbour (another XCD, another process,
+    // another GPU over xGMI) wrote is what the next load returns.  Fine-grained memory -- cached, coherent at system scope
+    // for accesses that ask for it -- where the runtime refuses the flag; the readers use system-scope loads either way.
+    // PLMPM_PEER_MEM=finegrained forces the latter (A/B of the two, profiles/microbench/peer_xchg.hip).
+    const char* pm = getenv("PLMPM_PEER_MEM");
+    hipError_t me = hipErrorUnknown;
+    if (!(pm && !strcmp(pm, "finegrained"))) {
+        me = hipExtMallocWithFlags(&p, bytes, hipDeviceMallocUncached);
+        if (me != hipSuccess) { (void)hipGetLastError(); p = nullptr; }
+    }
+    s->peer_uncached = me == hipSuccess;
+    if (!p) HIPCHK(hipExtMallocWithFlags(&p, bytes, hipDeviceMallocFinegrained));
     s->peer_allocs.push_back(p);
     HIPCHK(hipMemsetAsync(p, 0, bytes, s->stream));
     HIPCHK(hipStreamSynchronize(s->stream));         // zeroed (counter = 0) before anybody learns the handle
@@ -204,6 +228,7 @@ int plmpm_halo_peer_exchange(plmpm_handle s, int field, int frame) {
     memset(&X, 0, sizeof X);
     X.n = F.n; X.ncomp = nc; X.seq = seq; X.done = s->peer_done; X.status = s->peer_status; X.code = (field << 16) | 1;
     X.timeout_ticks = (long long)(peer_timeout_seconds() * 1e8);
+    X.spoil = s->peer_spoil;
     // the substep fields are sparse in the blocks the frame's scatter flagged; the loss mass grid is sent whole
     X.flags = field == PLMPM_HALO_LOSS_MASS ? nullptr : s->fstore + (size_t)frame * s->nflag;
     X.fgl = s->gwg_log2; X.fs = s->fs;
@@ -231,6 +256,37 @@ int plmpm_halo_peer_exchange(plmpm_handle s, int field, int frame) {
     if (s->cfg.dtype == PLMPM_F64) LAUNCHB(s, K_HALO_XCHG, (k_halo_xchg<double>), dim3(nwg), 256, X);
     else LAUNCHB(s, K_HALO_XCHG, (k_halo_xchg<float>), dim3(nwg), 256, X);
     HIPCHK(hipGetLastError());
+    return 0;
+}
+// Collective re-synchronisation (every rank calls it, then a host barrier, before the next exchange): this rank's arrival
+// counters, its sequence numbers, the workgroup counter and the status word go back to zero.  After a timeout -- or an
+// exception between two exchanges on one rank -- the sequence numbers of the two sides of a face no longer agree; without
+// this the engine could never exchange again.
+int plmpm_halo_peer_reset(plmpm_handle s) {
+    NEED_BOUND(s);
+    if (!s->peer_done) return 0;
+    HIPCHK(hipStreamSynchronize(s->stream));
+    for (int f = 0; f < 3; ++f) {
+        plmpm_sim::PeerField& F = s->peer[f];
+        F.seq = 0;
+        for (int i = 0; i < F.n; ++i) HIPCHK(hipMemsetAsync(F.local[i], 0, kPeerHeader, s->stream));
+    }
+    HIPCHK(hipMemsetAsync(s->peer_done, 0, 256, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    *s->peer_status = 0;
+    return 0;
+}
+// test hook: scale what this rank sends through face 0 (1 = off).  A run with a spoiled halo must be NOTICED by whoever
+// compares transports (bench.py's self-check at N > 1, tests/test_gpu_z_bench_contract.py).
+int plmpm_debug_peer_spoil(plmpm_handle s, double factor) {
+    REQUIRE(s, "null handle");
+    s->peer_spoil = (float)factor;
+    return 0;
+}
+// 1: the receive areas are uncached device memory, 0: fine-grained (or none allocated yet)
+int plmpm_peer_memory_kind(plmpm_handle s, int* uncached) {
+    REQUIRE(s && uncached, "null argument");
+    *uncached = s->peer_uncached ? 1 : 0;
     return 0;
 }
 int plmpm_peer_status(plmpm_handle s, int* status) {

@@ -32,8 +32,9 @@ and slabs of ONE plane, whose plane is exchanged with both neighbours (``min_thi
 of the body, at the price of a coarser load balance (8 ranks over ten planes: the largest slab holds 2/10 of the
 particles).
 
-* **Who drives the exchange.**  Two transports, same planes, same kernels consuming them.  *Peer writes* (default when
-  they can be set up, ``PLB_PEER_HALOS=0`` turns them off): every rank allocates its receive areas in fine-grained
+* **Who drives the exchange.**  Two transports, same planes, same kernels consuming them.  *Peer writes* (opt-in:
+  ``peer=True`` / ``PLB_PEER_HALOS=1``; ``bench.py`` opts in at N > 1 and checks them against the library transport on one
+  env step before it times anything): every rank allocates its receive areas in uncached (else fine-grained)
   device memory, the neighbours map them through IPC handles (exchanged once, over ``torch.distributed``), and an
   exchange is ONE kernel on the engine's stream -- copy into the neighbours' areas, publish an arrival counter, wait
   for theirs (``csrc/plmpm_peer.hip``).  The substep loops of an env step are then native (``plmpm_slab_step`` /
@@ -166,9 +167,12 @@ class HaloComm:
 
     def __init__(self, layout: SlabLayout, rank: int, group=None, peer: Optional[bool] = None):
         self.layout, self.rank, self.group = layout, rank, group
-        # peer writes: asked for explicitly, or by default on the GPUs' own backend (PLB_PEER_HALOS=0/1 overrides both)
+        # peer writes are OPT-IN (peer=True, or PLB_PEER_HALOS=1; PLB_PEER_HALOS=0 forbids them): the device-side exchange has
+        # only ever been validated with all ranks on one GPU, and a visibility bug across real GPUs would give wrong halos
+        # silently, not an error.  Callers that can afford the check opt in and compare transports first (bench.py at N > 1:
+        # one env step fwd + bwd through each, same loss and action gradient or the library transport is used).
         env = os.environ.get("PLB_PEER_HALOS", "")
-        self.want_peer = (env == "1") if env in ("0", "1") else (bool(peer) if peer is not None else dist.get_backend(group) == "nccl")
+        self.want_peer = (env == "1") if env in ("0", "1") else bool(peer)
         self.peer_ready = False
         self.stage_host = dist.get_backend(group) == "gloo"      # gloo P2P wants host tensors
         # small host records (loss sums) are reduced on the device when the backend is RCCL
@@ -228,8 +232,16 @@ class HaloComm:
         for field in fields:
             engine.halo_peer_setup(field, [(a, b) for _n, a, b in faces], [local[(field, n)] for n, _a, _b in faces],
                                    [remote[(field, n)] for n, _a, _b in faces])
-        self.peer_ready = True
+        spoil = os.environ.get("PLB_TEST_PEER_SPOIL", "")       # test hook "rank:factor": that rank sends wrong halos through face 0
+        if spoil and int(spoil.split(":")[0]) == self.rank:
+            engine.debug_peer_spoil(float(spoil.split(":")[1]))
+        self.peer_ready = self.peer_mapped = True
         return True
+
+    def use_peer(self, on: bool):
+        """Switch between the two transports of an engine whose peer areas are set up (bench.py's transport check)."""
+        self.peer_ready = bool(on) and bool(getattr(self, "peer_mapped", False))
+        return self.peer_ready
 
     def exchange(self, engine, field, f):
         """Send this rank's copy of the exchanged block planes of ``field`` (frame ``f``) to the neighbours and receive
@@ -370,6 +382,7 @@ class SlabEngine:
         self.comm = comm if comm is not None else HaloComm(layout, rank, group, peer=peer)
         # device-side exchange (peer writes): the substep loops are then the native ones and the host only enqueues
         self.native_loops = bool(getattr(self.comm, "setup_peer", None) and self.comm.setup_peer(engine))
+        self._overlap_asked = self.overlap
         if self.native_loops:
             self.overlap = False                   # the exchange is a kernel in the engine's own stream
         self.soft_contact = False
@@ -381,11 +394,37 @@ class SlabEngine:
     def __getattr__(self, name):                   # everything not overridden goes straight to the engine
         return getattr(self._e, name)
 
+    def use_transport(self, kind: str) -> str:
+        """"peer": device-side exchange + native substep loops (only if the peer areas were set up); "p2p": the
+        torch.distributed point-to-point exchange driven from Python.  Returns the transport now in use.  Collective in
+        effect: every rank must make the same choice before the next step."""
+        on = self.comm.use_peer(kind == "peer") if hasattr(self.comm, "use_peer") else False
+        self.native_loops = on
+        self.overlap = False if on else self._overlap_asked
+        return self.transport
+
+    @property
+    def transport(self) -> str:
+        if self.native_loops:
+            return f"peer-write ({self._e.peer_memory_kind()} IPC-mapped receive areas, device-side exchange kernel)"
+        return {"nccl": "rccl-p2p (batch_isend_irecv)", "gloo": "gloo-p2p staged through host memory"}.get(self.comm.backend, self.comm.backend)
+
+    def reset_exchange(self):
+        """Collective: counters, sequence numbers and status word of the device-side exchange back to zero on every rank,
+        then a barrier -- nobody publishes into an area its owner is about to clear.  Called at every episode reset / segment
+        re-entry, so that an engine recovers from a timed-out or interrupted exchange instead of staying out of step."""
+        if not getattr(self.comm, "peer_mapped", False):
+            return
+        self._e.halo_peer_reset()
+        t = torch.zeros(1, dtype=torch.float64, device=self.comm.scalar_device)
+        self.comm.all_reduce_(t)                   # barrier on either backend
+
     # ---- state
     def set_frame(self, f, x=None, v=None, F=None, C_=None, resort=False):
         self._e.set_frame(f, x=x, v=v, F=F, C_=C_, resort=resort)
         if resort:
             self._since_migration = 0              # a new episode: ownership as assigned by the caller
+            self.reset_exchange()
 
     def get_frame_by_id(self, f, want=("x", "v", "F", "C")):
         """(global ids ascending, rows in that order): the canonical view of a frame whatever its storage epoch."""
@@ -424,6 +463,7 @@ class SlabEngine:
         e.set_frame(0, x=ck["x"], v=ck["v"], F=ck["F"], C_=ck["C"], resort=True)
         e.set_materials(ck["mu"], ck["lam"], ck["ys"])
         self._since_migration = ck["since"]
+        self.reset_exchange()
 
     def adjoint_to_reentry_rows(self, f=0):
         """After the reverse sweep has reached frame ``f`` = the frame a segment re-entered at: undo the migration the
@@ -582,8 +622,8 @@ def make_slab_env(cfg, rank: int, world: int, *, halo: Optional[int] = None, com
     values for the WHOLE cloud (each rank keeps its part).  ``layout`` / ``comm`` override the balanced cut and the
     torch.distributed communicator (measurement tools: profiles/tools/slab_host_cost.py).  ``overlap``: run grid_op /
     grid_op.grad of the blocks outside the exchanged planes while the halos are in flight (``SlabEngine.overlap``).
-    ``peer``: device-side halo exchange by peer writes + native substep loops (None: on for the ``nccl`` backend, off for
-    gloo; the environment variable PLB_PEER_HALOS=0/1 overrides).  Returns (env, layout, owned_index)."""
+    ``peer``: device-side halo exchange by peer writes + native substep loops (opt-in; None / False: off; the environment
+    variable PLB_PEER_HALOS=0/1 overrides).  Returns (env, layout, owned_index)."""
     from .engine import taichi_env as te
     from .engine.losses import Loss
     from .engine.mpm_simulator import MPMSimulator

@@ -384,6 +384,19 @@ class Engine:
         L.check(self.lib.plmpm_peer_status(self.h, C.byref(st)))
         return st.value
 
+    def halo_peer_reset(self):
+        """Counters, sequence numbers and status of the device-side exchange back to zero (collective: every rank, then a
+        host barrier, before the next exchange)."""
+        L.check(self.lib.plmpm_halo_peer_reset(self.h))
+
+    def peer_memory_kind(self):
+        k = C.c_int()
+        L.check(self.lib.plmpm_peer_memory_kind(self.h, C.byref(k)))
+        return "uncached" if k.value else "fine-grained"
+
+    def debug_peer_spoil(self, factor):
+        L.check(self.lib.plmpm_debug_peer_spoil(self.h, C.c_double(factor)))
+
     def slab_step(self, first, n):
         """fk + the forward substeps of one env step of a slab rank, exchanges included: enqueue only."""
         L.check(self.lib.plmpm_slab_step(self.h, first, n))

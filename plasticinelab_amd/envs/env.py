@@ -83,8 +83,20 @@ class PlasticineEnv(_Base):
                 print("nan in r")
             import datetime
             import pickle
-            with open(f"{self.cfg_path}_nan_action_{str(datetime.datetime.now())}", "wb") as f:     # env.py:50-56: the episode's actions, for a replay
-                pickle.dump(self._recorded_actions, f)
+            import tempfile
+            import warnings
+            # env.py:50-56: the episode's actions, for a replay.  The reference always has a real yml path to write next to; here
+            # cfg_path may be a built-in scene name or sit in a read-only package directory -- whatever happens to the dump,
+            # "NaN.." is the exception the caller sees.
+            stamp = datetime.datetime.now().strftime("%Y%m%d_%H%M%S_%f")
+            base = os.path.basename(str(self.cfg_path)) or "scene"
+            for where in (os.path.dirname(os.path.abspath(str(self.cfg_path))), tempfile.gettempdir()):
+                try:
+                    with open(os.path.join(where, f"{base}_nan_action_{stamp}"), "wb") as f:
+                        pickle.dump(self._recorded_actions, f)
+                    break
+                except OSError as e:
+                    warnings.warn(f"could not write the NaN action dump to {where}: {e}")
             raise Exception("NaN..")
         return obs, r, False, loss_info
 

@@ -90,10 +90,22 @@ def _forward_checkpointed_slab(env, init_state, actions, T, H, sub, softness):
 
     def restore(ck):
         eng.reenter(ck)
+        sim.n_particles = env.n_particles = len(ck["ids"])          # Observe / get_state size their arrays by these
         for st, p in zip(ck["prims"], env.primitives):
             p.set_state(0, st)
         sim.cur = 0
 
+    try:
+        return _checkpointed_slab_sweeps(env, actions, T, H, sub, first_ck, restore)
+    finally:
+        # whatever happened (a collective failure raises on every rank together, see below): leave the engine with the
+        # population -- and the row counts the callers read -- it started with
+        restore(first_ck)
+
+
+def _checkpointed_slab_sweeps(env, actions, T, H, sub, first_ck, restore):
+    sim, loss = env.simulator, env.loss
+    eng = sim.engine
     loss.clear_loss()
     checkpoints, total = {0: first_ck}, 0.0
     for i in range(H):
@@ -127,13 +139,16 @@ def _forward_checkpointed_slab(env, init_state, actions, T, H, sub, softness):
                     sim.step(False, actions[s])
                 sim.grad_begin(T * sub)
                 now = eng.get_ids(T * sub)
+                # a face particle that changed sides concerns the two ranks of that face only; the others would walk on into
+                # their next collective and hang.  So the verdict is agreed on first and every rank raises together.
+                err = None
                 if len(now) != len(ids) or not np.array_equal(np.sort(now), np.sort(ids)):
-                    raise RuntimeError("the re-run of a segment ended with another set of rows on this rank than the run it was checkpointed "
+                    err = RuntimeError("the re-run of a segment ended with another set of rows on this rank than the run it was checkpointed "
                                        "from (a particle on a slab face changed sides by round-off): use cfg.SIMULATOR.deterministic")
+                eng._agree(err, "the re-run of a checkpointed segment")
                 order = np.argsort(ids, kind="stable")[np.searchsorted(np.sort(ids), now)]       # row of `ids` holding each id of `now`
                 eng.add_frame_grad(T * sub, xa=ga["x"][order], va=ga["v"][order], Fa=ga["F"][order], Ca=ga["C"][order])
                 for k, g in enumerate(pg):
                     eng.add_primitive_grad(k, T * sub, g)
     loss.loss = total
-    eng.reenter(first_ck)                                           # leave the engine with the population it started with
     return total, np.concatenate(pieces[::-1], axis=0)

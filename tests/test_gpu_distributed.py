@@ -345,6 +345,19 @@ def test_nccl_backend_two_gpus(tmp_path):
         assert relerr(r["grad"], g["grad"]) < 1e-7
 
 
+def test_nccl_backend_two_gpus_device_side_exchange(tmp_path):
+    """... and with the halos written by the exchange kernel into the OTHER GPU's receive areas (xGMI peer writes, uncached
+    areas, system-scope loads on the reading side): the configuration no single-GPU box can exercise."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs")
+    g = np.load(os.path.join(GOLDEN, "rollout_small.npz"))
+    res = launch(tmp_path, 2, "float64", g["actions"], 8, 1, backend="nccl", peer=True)
+    for r in res:
+        assert abs(float(r["loss"]) - float(g["loss"])) / abs(float(g["loss"])) < 1e-10
+        assert relerr(r["grad"], g["grad"]) < 1e-7
+
+
 def test_leaving_the_grid_window_or_the_slab_raises():
     """A stencil outside the allocated grid window, or outside slab + halo in z, sets the error word
     (Engine.check_error raises) and is clamped into the window (no out-of-bounds access); inside both it does not."""

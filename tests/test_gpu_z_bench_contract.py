@@ -46,6 +46,31 @@ def test_bench_lines_single_gpu_and_two_slabs():
         assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
         assert abs(d["value"] - d["steps"] * d["config"]["substeps_per_step"] / (1e-3 * d["ms_per_step"] * d["steps"])) < 1e-6 * d["value"]
     assert "FALLBACK" not in two["metric"] and "z-slabs" in two["config"]["parallelism"] and "IPC-mapped" in two["config"]["parallelism"]
+    # the self-validation keys of the multi-GPU line: which transport carried the halos, that it was checked against the
+    # library transport on one env step (fwd + bwd) before anything was timed, the communicator's size, the loss check
+    tc = two["transport_check"]
+    assert two["halo_transport"].startswith("peer-write") and tc["checked"] and tc["agree"] and tc["rel_loss"] < 1e-5 and tc["rel_grad"] < 1e-4
+    assert two["dist_backend"] == "gloo" and two["rccl_ranks"] is None        # (RCCL reports its own rank count on a multi-GPU node)
+    for d in (one, two):
+        assert set(d["loss_check"]) >= {"n1_expected", "rel", "ok"}            # no committed N = 1 loss for this reduced workload: nulls
     assert "halo_exchange" in two["roofline"]["kernels"] and two["roofline"]["kernel"] != "halo_exchange"
     # the same workload: the two-slab run ends with the single-GPU run's loss (fp32 engines, different summation order)
     assert abs(two["final_loss"] - one["final_loss"]) < 1e-5 * abs(one["final_loss"])
+
+
+def test_a_spoiled_halo_flips_the_line():
+    """The device-side exchange of rank 0 sends wrong values (test hook PLB_TEST_PEER_SPOIL): the transport check sees the
+    loss / gradient of one env step disagree with the library transport, the run falls back to point-to-point halos, says so
+    in `metric`, `halo_transport` and `config.parallelism` -- and still ends with the single-GPU loss."""
+    common = ["--steps", "2", "--warmup", "1", "--particles", "60000", "--no-cpu-baseline", "--no-roofline"]
+    one = run([sys.executable, "bench.py", "--gpus", "1"] + common)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    two = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), "bench.py", "--gpus", "2"] + common,
+              {"PLB_DIST_BACKEND": "gloo", "PLB_PEER_HALOS": "1", "PLB_SLAB_TIMEOUT": "300", "PLB_TEST_PEER_SPOIL": "0:1.5"})
+    tc = two["transport_check"]
+    assert tc["checked"] and not tc["agree"] and (tc["rel_loss"] > 1e-5 or tc["rel_grad"] > 1e-4)
+    assert "FALLBACK" in two["metric"] and "FALLBACK" in two["config"]["parallelism"] and two["halo_transport"].startswith("gloo-p2p")
+    assert two["scaling"] == "strong" and abs(two["final_loss"] - one["final_loss"]) < 1e-5 * abs(one["final_loss"])

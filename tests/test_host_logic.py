@@ -1,6 +1,10 @@
 """CPU tier: host-side mirrors of the reference interface that need no GPU (optimisers, primitive descriptions,
 Tape event bookkeeping with a stub engine)."""
+import json
+import sys
+
 import numpy as np
+from tests.util import ROOT
 import pytest
 
 from plasticinelab_amd.engine.primitives import Primitive, Primitives
@@ -222,3 +226,18 @@ def test_scene_strings_cannot_run_code():
     assert as_value("(0.5, 0.25*2, 1/4)") == (0.5, 0.5, 0.25) and as_value("127<<16") == 127 << 16
     assert as_value("__import__('os').system('true')") == "__import__('os').system('true')"
     assert as_value("box") == "box"
+
+
+def test_loss_check_flags_a_wrong_loss(tmp_path, monkeypatch):
+    """loss_check compares with the committed single-GPU loss of the same (workload, dtype, steps) and a difference beyond 1e-5
+    is a MISMATCH (pure host logic of bench.py, exercised here with a doctored table)."""
+    import importlib
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    table = tmp_path / "n1.json"
+    table.write_text(json.dumps({"config3_cube128|f32|20": 730.97584}))
+    monkeypatch.setattr(bench, "N1_LOSS_FILE", str(table))
+    ok = bench.loss_check("config3_cube128", "f32", 20, 730.97583)
+    bad = bench.loss_check("config3_cube128", "f32", 20, 731.2)
+    none = bench.loss_check("config3_cube128", "f32", 7, 1.0)
+    assert ok["ok"] is True and ok["rel"] < 1e-7 and bad["ok"] is False and bad["rel"] > 1e-4 and none["ok"] is None and none["n1_expected"] is None
