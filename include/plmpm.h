@@ -130,6 +130,10 @@ typedef struct plmpm_sim* plmpm_handle;
 
 const char* plmpm_last_error(void);
 int plmpm_version(void);
+/* what this build of the library was compiled with: bit 0 the EXPERIMENTAL engine variants (two particles per lane, fused-grid
+ * kernels: PLMPM_PK / PLMPM_FUSE_GRID are honoured only then), bit 1 the elastic fast path (-DPLB_FAST=1), bit 2 the XCD-aware
+ * chunk map (-DPLB_XCD_MAP=1) */
+int plmpm_build_flags(void);
 
 /* ---- lifetime ------------------------------------------------------------------------------ */
 /* MPMSimulator.__init__ + Primitives.__init__ (mpm_simulator.py:6-51, primitives.py:263-279) */

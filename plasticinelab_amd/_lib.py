@@ -49,6 +49,7 @@ _P, _I, _D = C.c_void_p, C.c_int, C.c_double
 SYMBOLS = {
     "plmpm_last_error": (C.c_char_p, []),
     "plmpm_version": (_I, []),
+    "plmpm_build_flags": (_I, []),
     "plmpm_create": (_I, [C.POINTER(Config), C.POINTER(Primitive), C.POINTER(_P)]),
     "plmpm_destroy": (_I, [_P]),
     "plmpm_workspace_bytes": (_I, [_P, C.POINTER(Workspace)]),

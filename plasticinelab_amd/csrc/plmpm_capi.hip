@@ -108,13 +108,14 @@ static inline int nblocks_grid(const plmpm_sim* s) { return (s->nblk + (kBlock /
 // persistent grid kernels: a fixed number of workgroups, each striding over its share of the block flags
 static inline int nwg_grid(const plmpm_sim* s) { return s->gwg; }
 
-// clear arguments for the grids of frame `frame` (fused-grid engines)
 #ifndef PLB_PK_DEFAULT
 #define PLB_PK_DEFAULT 0
 #endif
 #ifndef PLB_FUSE_GRID_DEFAULT
 #define PLB_FUSE_GRID_DEFAULT 0      // measured (round 3, profiles/r03_notes.md): not yet faster than the grid kernels at config 3
 #endif
+#if PLB_EXPERIMENTAL
+// clear arguments for the grids of frame `frame` (fused-grid engines)
 template <class T> static ClearArgs<T> clear_args(const plmpm_sim* s, int frame) {
     ClearArgs<T> A;
     memset(&A, 0, sizeof A);
@@ -139,10 +140,14 @@ template <class T> static int fg_flush_t(plmpm_sim* s) {
     return 0;
 }
 #define FG_FLUSH(s) do { if ((s)->fg_pending >= 0) fg_flush_t<T>(s); } while (0)
+#else
+#define FG_FLUSH(s) do {} while (0)
+#endif
 
 template <class T> static int substep_fwd(plmpm_sim* s, int f) {
     FG_FLUSH(s);
     Dev<T> D = make_dev<T>(s, f);
+#if PLB_EXPERIMENTAL
     if (s->fg) {                 // p2g | g2p with grid_op in its tile fill
         if (s->dirty[f]) LAUNCH(s, K_CLEAR, (k_clear_active<T>), dim3(nblocks_grid(s)), D);
         LAUNCH_P2G(s, K_P2G, true, D, f);
@@ -151,6 +156,7 @@ template <class T> static int substep_fwd(plmpm_sim* s, int f) {
         s->vnear[f] = 1;
         return 0;
     }
+#endif
     s->vnear[f] = 0;
     if (s->store) {
         if (s->dirty[f]) LAUNCH(s, K_CLEAR, (k_clear_active<T>), dim3(nblocks_grid(s)), D);   // frame reused without a backward pass
@@ -169,6 +175,7 @@ template <class T> static int substep_bwd(plmpm_sim* s, int f) {
     const int src = (f + 1) & 1, dst = f & 1;
     // frame f+1 re-sorted by the env step that starts there: its v in THIS frame's order was kept aside
     const T* vnext = s->frame_epoch[f + 1] != s->frame_epoch[f] ? (const T*)(s->vend + (size_t)s->frame_epoch[f + 1] * 3 * s->Npad * s->tsz) : nullptr;
+#if PLB_EXPERIMENTAL
     if (s->fg && s->dirty[f]) {
         // g2p.grad (+ grid_op in its tile fill, + the clear of frame f+1's grids) | p2g.grad (+ grid_op.grad in its tile fill)
         const bool chained = s->fg_pending == f + 1;
@@ -190,6 +197,7 @@ template <class T> static int substep_bwd(plmpm_sim* s, int f) {
         s->adj_frame[dst] = f;
         return 0;
     }
+#endif
     FG_FLUSH(s);
     if (!(s->store && s->dirty[f])) {        // this frame's grid is not resident: recompute it (mpm_simulator.py:265-268)
         LAUNCH_P2G(s, K_P2G_RE, false, D, f);
@@ -206,6 +214,7 @@ template <class T> static int substep_bwd(plmpm_sim* s, int f) {
 // Whole env step forward in store mode: p2g(f0) | grid_op(f0) | [g2p(f-1)+p2g(f) fused | grid_op(f)] ... | g2p(last)
 template <class T> static int step_fwd_fused(plmpm_sim* s, int first, int n) {
     FG_FLUSH(s);
+#if PLB_EXPERIMENTAL
     if (s->fg) {                 // p2g(f0) | [g2p(f-1) + p2g(f) with grid_op(f-1) in the tile fill] ... | g2p(last) with grid_op(last)
         for (int f = first; f < first + n; ++f) {
             Dev<T> D = make_dev<T>(s, f);
@@ -229,6 +238,7 @@ template <class T> static int step_fwd_fused(plmpm_sim* s, int first, int n) {
         s->vnear[first + n - 1] = 1;
         return 0;
     }
+#endif
     for (int f = first; f < first + n; ++f) {
         Dev<T> D = make_dev<T>(s, f);
         s->vnear[f] = 0;
@@ -238,6 +248,7 @@ template <class T> static int step_fwd_fused(plmpm_sim* s, int first, int n) {
         } else {
             const Vec4<T>* vprev = (const Vec4<T>*)(s->vstore + (size_t)(f - 1) * s->gstride);
             bool done = false;
+#if PLB_EXPERIMENTAL
             if constexpr (sizeof(T) == 4) {
                 if (s->pk) {
                     PrevGrid<T> pg;
@@ -247,6 +258,7 @@ template <class T> static int step_fwd_fused(plmpm_sim* s, int first, int n) {
                     done = true;
                 }
             }
+#endif
             if (!done) LAUNCH_G2P_P2G(s, D, f, vprev);
         }
         LAUNCH(s, K_GRID_OP, (k_grid_op<T, false>), dim3(nwg_grid(s)), D, f, s->halo_in[PLMPM_HALO_GRID_IN]);
@@ -460,6 +472,7 @@ extern "C" {
 
 const char* plmpm_last_error(void) { return g_err.c_str(); }
 int plmpm_version(void) { return 1; }
+int plmpm_build_flags(void) { return (PLB_EXPERIMENTAL ? 1 : 0) | (PLB_FAST ? 2 : 0) | (PLB_XCD_MAP ? 4 : 0); }
 
 int plmpm_create(const plmpm_config* cfg, const plmpm_primitive* prims, plmpm_handle* out) {
     REQUIRE(cfg && out, "null argument");
@@ -560,13 +573,13 @@ int plmpm_create(const plmpm_config* cfg, const plmpm_primitive* prims, plmpm_ha
     {
         const char* e = getenv("PLMPM_FUSE_GRID");
         const bool want = e ? e[0] != '0' : (PLB_FUSE_GRID_DEFAULT != 0);
-        s->fg = s->store && !s->dist && cfg->deterministic == 0 && want;
+        s->fg = PLB_EXPERIMENTAL && s->store && !s->dist && cfg->deterministic == 0 && want;
     }
     if (s->fg) s->ws.grid_bytes += align_up(s->G * 4 * s->tsz, 256) + align_up((size_t)s->nblk * 4, 256);
     s->ws.grid_bytes += align_up((size_t)(s->F + 1) * kMaxPrim * sizeof(PrimT<double>), 256);
     {
         const char* e = getenv("PLMPM_PK");
-        s->pk = cfg->dtype == PLMPM_F32 && cfg->deterministic == 0 && (e ? e[0] != '0' : (PLB_PK_DEFAULT != 0));
+        s->pk = PLB_EXPERIMENTAL && cfg->dtype == PLMPM_F32 && cfg->deterministic == 0 && (e ? e[0] != '0' : (PLB_PK_DEFAULT != 0));
     }
     s->dirty.assign(s->F + 1, 0);
     s->vnear.assign(s->F + 1, 0);

@@ -15,7 +15,19 @@
 #include <vector>
 
 #include "../../include/plmpm.h"
+// Opt-in engine variants that lost their measurements (round 3: two particles per lane with packed fp32, plmpm_kernels_pk.h;
+// grid_op / grid_op.grad folded into the particle kernels' tile fills) are compiled only into the EXPERIMENTAL build of the
+// library (make experimental -> libplmpm_experimental.so, -DPLB_EXPERIMENTAL=1; tests/test_gpu_fused_grid.py runs against
+// it through PLMPM_LIB).  The default libplmpm.so carries the five hot kernels x {float, double} (+ the deterministic
+// instantiations) and nothing else on the hot path.
+#ifndef PLB_EXPERIMENTAL
+#define PLB_EXPERIMENTAL 0
+#endif
+#if PLB_EXPERIMENTAL
 #include "plmpm_kernels_pk.h"
+#else
+#include "plmpm_kernels.h"
+#endif
 
 // plmpm_sort.hip
 extern "C" size_t plmpm_sort_temp_bytes(int n);

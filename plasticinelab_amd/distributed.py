@@ -193,6 +193,7 @@ class HaloComm:
             bufs.append(torch.zeros(engine.halo_ncomp(field), cnt, dtype=engine.torch_dtype, device=engine.device))
         engine.halo_set_recv(field, [(a, b) for _n, a, b in faces], bufs)
         self._recv[field] = bufs
+        self._engine = engine
 
     def setup_peer(self, engine):
         """Collective, once: receive areas for the three halo fields in fine-grained device memory, IPC handles swapped
@@ -241,6 +242,11 @@ class HaloComm:
     def use_peer(self, on: bool):
         """Switch between the two transports of an engine whose peer areas are set up (bench.py's transport check)."""
         self.peer_ready = bool(on) and bool(getattr(self, "peer_mapped", False))
+        if not self.peer_ready:
+            # every peer exchange pointed the grid kernels' halo input at the peer areas: back to the registered buffers
+            faces = self.layout.faces(self.rank)
+            for field, bufs in self._recv.items():
+                self._engine.halo_set_recv(field, [(a, b) for _n, a, b in faces], bufs)
         return self.peer_ready
 
     def exchange(self, engine, field, f):

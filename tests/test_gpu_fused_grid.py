@@ -17,6 +17,21 @@ from tests.test_gpu_rollout import make_env_sub, run_forward
 pytestmark = pytest.mark.gpu
 
 
+def _experimental_build():
+    from plasticinelab_amd import _lib
+    return bool(_lib.load().plmpm_build_flags() & 1)
+
+
+# The two engine variants tested here lost their measurements in round 3 and are compiled only into the experimental build
+# of the library (`make -C plasticinelab_amd/csrc experimental`; __graft_entry__.build() builds it too).  The default
+# libplmpm.so ignores PLMPM_FUSE_GRID / PLMPM_PK, so against it these tests would compare an engine with itself:
+#     PLMPM_LIB=plasticinelab_amd/libplmpm_experimental.so python -m pytest tests/test_gpu_fused_grid.py -m gpu
+@pytest.fixture(autouse=True)
+def _needs_experimental_build():
+    if not _experimental_build():
+        pytest.skip("opt-in engine variants: run with PLMPM_LIB=plasticinelab_amd/libplmpm_experimental.so")
+
+
 class fuse_grid:
     """engines created inside this block are fused-grid engines (on=True) or keep k_grid_op / k_grid_op_grad (on=False);
     the library reads the variable in plmpm_create"""
