@@ -793,12 +793,20 @@ template <class T> PLB_HD void f_tmp_eform(const T* C, const T* E, typename Lane
     for (int i = 0; i < 9; ++i) Et[i] = E[i] + dt * (C[i] + CE[i]);
 }
 
-// p2g body (mpm_simulator.py:157-184).  Emit(k0,k1,k2, mass, mom[3]) is called for the 27 offsets.
-// Returns new E (F[f+1] - I) in En.
-template <class T, class X, class Emit>
-PLB_HD void p2g_particle(const SimP<typename Lane<T>::scalar>& P, const X* x, const T* v, const T* C, const T* E,
-                         T mu, T lam, T ys, T* En, typename Lane<T>::ivec* base, Emit&& emit) {
-    T fx[3], w[3][3];
+// p2g body (mpm_simulator.py:157-184) in two halves, so that a kernel can put work between them (the scatter kernels reduce a
+// bound of the momentum coefficients over the workgroup before the first contribution leaves a lane):
+//   p2g_prepare: compute_F_tmp, the constitutive model, new E (F[f+1] - I) in En, and the particle's scatter coefficients;
+//   p2g_emit:    Emit(k0,k1,k2, mass, mom[3]) for the 27 offsets.
+// The momentum per unit weight at stencil offset o is affine in o:  q(o) = m v + A (o - fx) dx
+//   = q0 + o_x ax + o_y ay + o_z az,   q0 = m v - A fx dx,  a_d = A[:,d] dx   (3 adds per node instead of a mat-vec)
+template <class T> struct P2GCoef {        // (the weights w[k][d] travel beside it: the rolled stencil loops index them at run time)
+    T q0[3], ax[3], ay[3], az[3];
+    T pm;                   // mass per unit weight (p_mass; the fixed-point scatter folds its scale in)
+};
+template <class T, class X>
+PLB_HD void p2g_prepare(const SimP<typename Lane<T>::scalar>& P, const X* x, const T* v, const T* C, const T* E,
+                        T mu, T lam, T ys, T* En, typename Lane<T>::ivec* base, T (*w)[3], P2GCoef<T>& K) {
+    T fx[3];
     stencil<T, X>(x, P.inv_dx, base, fx, w, nullptr);
     T Et[9], stress[9], A[9];
     f_tmp_eform(C, E, P.dt, Et);
@@ -822,13 +830,16 @@ PLB_HD void p2g_particle(const SimP<typename Lane<T>::scalar>& P, const X* x, co
         constitutive_fwd(Et, mu, lam, ys, k, En, stress, P.tie_first);
     }
     for (int i = 0; i < 9; ++i) A[i] = P.kappa * stress[i] + P.p_mass * C[i];
-    // momentum per unit weight at stencil offset o is affine in o:  q(o) = m v + A (o - fx) dx
-    //   = q0 + o_x ax + o_y ay + o_z az,   q0 = m v - A fx dx,  a_d = A[:,d] dx   (3 adds per node instead of a mat-vec)
-    T ax[3], ay[3], az[3], q0[3];
     for (int a = 0; a < 3; ++a) {
-        ax[a] = A[3 * a] * P.dx; ay[a] = A[3 * a + 1] * P.dx; az[a] = A[3 * a + 2] * P.dx;
-        q0[a] = P.p_mass * v[a] - (ax[a] * fx[0] + ay[a] * fx[1] + az[a] * fx[2]);
+        K.ax[a] = A[3 * a] * P.dx; K.ay[a] = A[3 * a + 1] * P.dx; K.az[a] = A[3 * a + 2] * P.dx;
+        K.q0[a] = P.p_mass * v[a] - (K.ax[a] * fx[0] + K.ay[a] * fx[1] + K.az[a] * fx[2]);
     }
+    K.pm = T(P.p_mass);
+}
+template <class T, class Emit>
+PLB_HD void p2g_emit(const T (*w)[3], const P2GCoef<T>& K, Emit&& emit) {
+    const T q0[3] = {K.q0[0], K.q0[1], K.q0[2]}, ax[3] = {K.ax[0], K.ax[1], K.ax[2]}, ay[3] = {K.ay[0], K.ay[1], K.ay[2]},
+            az[3] = {K.az[0], K.az[1], K.az[2]};
     PLB_ROLL_P2G_I
     for (int i = 0; i < 3; ++i) {
         const T wi = sel3(i, w[0][0], w[1][0], w[2][0]);
@@ -841,10 +852,19 @@ PLB_HD void p2g_particle(const SimP<typename Lane<T>::scalar>& P, const X* x, co
             for (int l = 0; l < 3; ++l) {
                 T wt = wij * w[l][2];
                 T mom[3] = {wt * (qj[0] + T(l) * az[0]), wt * (qj[1] + T(l) * az[1]), wt * (qj[2] + T(l) * az[2])};
-                emit(i, j, l, wt * P.p_mass, mom);
+                emit(i, j, l, wt * K.pm, mom);
             }
         }
     }
+}
+// Returns new E (F[f+1] - I) in En.
+template <class T, class X, class Emit>
+PLB_HD void p2g_particle(const SimP<typename Lane<T>::scalar>& P, const X* x, const T* v, const T* C, const T* E,
+                         T mu, T lam, T ys, T* En, typename Lane<T>::ivec* base, Emit&& emit) {
+    P2GCoef<T> K;
+    T w[3][3];
+    p2g_prepare<T, X>(P, x, v, C, E, mu, lam, ys, En, base, w, K);
+    p2g_emit<T>(w, K, emit);
 }
 
 // g2p body (mpm_simulator.py:223-242).  Fetch(k0,k1,k2, gv[3]) reads grid_v_out.
