@@ -1096,7 +1096,11 @@ __global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_g2p_p2g(Dev<T> D, int
         if (tl.ok) {
             const int ox = base[0] - tl.o[0], oy = base[1] - tl.o[1], oz = base[2] - tl.o[2];
             const int ex = tl.e[0], exy = tl.e[0] * tl.e[1];
-            p2g_particle<T, double>(D.P, x, v, C, E, mu, lam, ys, En, b2, [&](int i, int j, int l, T mass, const T* mom) {
+            P2GCoef<T> K;
+            T w[3][3];
+            p2g_prepare<T, double>(D.P, x, v, C, E, mu, lam, ys, En, b2, w, K);          // (= p2g_particle, with a phase mark in between)
+            PT_MARK(4);
+            p2g_emit<T>(w, K, [&](int i, int j, int l, T mass, const T* mom) {
                 T a0 = mass, a1 = mom[0], a2 = mom[1], a3 = mom[2];
                 PLB_ABLATE_STOP(4, a0 + a1 + a2 + a3, tile);
                 seg_sum4(a0, a1, a2, a3, sg);
@@ -1139,7 +1143,7 @@ __global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_g2p_p2g(Dev<T> D, int
             for (int d = 0; d < 9; ++d) R2[(12 + d) * Np + p] = En[d];
         }
     }
-    PT_MARK(4);
+    PT_MARK(5);
     if (tl.ok && !(PLB_ABLATE & 2)) {
         wg_barrier();
         const int ex = tl.e[0], exy = tl.e[0] * tl.e[1];
@@ -1171,7 +1175,7 @@ __global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_g2p_p2g(Dev<T> D, int
             }
         }
     }
-    PT_MARK(5);
+    PT_MARK(6);
     PT_END(D, 0);
 }
 
@@ -1569,10 +1573,25 @@ __global__ __launch_bounds__(64) void k_pose_adjoint_det(Dev<T> D, int f) {
 // p2g.grad + svd_grad + compute_F_tmp.grad: gather grid_in_adj, finish adjoint frame `dst`
 // FG (fused-grid engines): the pointwise part of grid_op.grad is evaluated in the tile fill (fg_node_gadj) from
 // grid_v_out.grad and the frame's grid_m / grid_v_in; the pose workgroups leave those inputs in place.
+// The particle state this kernel needs AFTER its gather (v, C, E of the frame, F[f+1].grad, the x.grad g2p.grad left, the
+// materials: 36 words per particle) is fetched at the START, straight into LDS (global_load_lds: no VGPR holds it while
+// the gather's 51 accumulators are live -- the kernel sits at 2 waves per SIMD and 233 VGPRs as it is), and read back from
+// LDS behind the gather.  Loading it into registers there costs every wave an HBM round trip in the middle of its life
+// (wave trace, round 4: 8.5k of 17.9k cycles between the end of the gather and the adjoint stores, ~2.5k of them that wait)
+// with one other wave per SIMD to cover it.  fp32 engines (the LDS-DMA moves 4, 12 or 16 bytes per lane).  OPT-IN
+// (-DPLB_P2GG_PREFETCH=1): parity-green and 5 us SLOWER, see below.
+#ifndef PLB_P2GG_PREFETCH
+#define PLB_P2GG_PREFETCH 0         // measured (round 4, replay on identical inputs): 47.1 / 49.0 us with it against 42.7 / 43.3 -- the DMA rows make every
+#endif                              // wait of the prologue a vmcnt(0) over 36 more loads, and the other wave of the SIMD was already covering the stall
+typedef __attribute__((address_space(3))) void plb_lds_void;
+typedef const __attribute__((address_space(1))) void plb_glb_void;
 template <class T, bool FG = false>
 __global__ __launch_bounds__(kBlock, sizeof(T) == 4 ? PLB_P2G_GRAD_WAVES : 1) void k_p2g_grad(Dev<T> D, int f, int src, int dst, int npose) {
+    constexpr bool PRE = PLB_P2GG_PREFETCH && sizeof(T) == 4 && !FG;
+    constexpr int NPRE = 36;
     __shared__ Vec4<T> tile[TileCap<T>::nodes];
     __shared__ PrimT<T> sp[kMaxPrim];
+    __shared__ float stage[PRE ? NPRE * kBlock : 1];
     // the first `npose` workgroups finish grid_op.grad (pose adjoints of the blocks in contact) under cover of the
     // particle workgroups
     if ((int)blockIdx.x < npose) { if (!PLB_EXP_NOPOSE) pose_adjoint_blocks<T, FG>(D, f, (int)blockIdx.x, npose, sp); return; }
@@ -1586,6 +1605,26 @@ __global__ __launch_bounds__(kBlock, sizeof(T) == 4 ? PLB_P2G_GRAD_WAVES : 1) vo
     const Tile tl = load_tile(D, f, TileCap<T>::nodes, chunk);   // stored by the scatter of this frame
     double x[3] = {0.5, 0.5, 0.5};
     if (valid) { x[0] = X[p]; x[1] = X[Np + p]; x[2] = X[2 * Np + p]; }
+    if constexpr (PRE) {
+        if (valid) {
+            // word k of this lane lands at stage[k * 256 + wave * 64 + lane] (the DMA writes wave-uniform base + 4 * lane)
+            float* row = stage + (threadIdx.x & ~63);
+            const float* A1f = reinterpret_cast<const float*>(D.adj[src]);
+            const float* A0f = reinterpret_cast<const float*>(D.adj[dst]);
+            const float* Rf = reinterpret_cast<const float*>(R);
+#define PLB_PRE(k, ptr) __builtin_amdgcn_global_load_lds((plb_glb_void*)(ptr), (plb_lds_void*)(row + (k) * kBlock), 4, 0, 0)
+            PLB_UNROLL
+            for (int d = 0; d < 21; ++d) PLB_PRE(d, Rf + (size_t)d * Np + p);                       // v, C, E
+            PLB_UNROLL
+            for (int d = 0; d < 9; ++d) PLB_PRE(21 + d, A1f + (size_t)(15 + d) * Np + p);           // F[f+1].grad
+            PLB_UNROLL
+            for (int d = 0; d < 3; ++d) PLB_PRE(30 + d, A0f + (size_t)d * Np + p);                  // x.grad so far
+            PLB_PRE(33, reinterpret_cast<const float*>(D.mu) + p);
+            PLB_PRE(34, reinterpret_cast<const float*>(D.lam) + p);
+            PLB_PRE(35, reinterpret_cast<const float*>(D.ys) + p);
+#undef PLB_PRE
+        }
+    }
     const int ex = tl.e[0], exy = tl.e[0] * tl.e[1], tn = exy * tl.e[2];
     if constexpr (FG) {
         // the node adjoints of the whole box: into the LDS tile, or -- a box too large for it -- into grid_in_adj in HBM
@@ -1636,17 +1675,27 @@ __global__ __launch_bounds__(kBlock, sizeof(T) == 4 ? PLB_P2G_GRAD_WAVES : 1) vo
             g[0] = a.w; g[1] = a.x; g[2] = a.y; g[3] = a.z;
         });
     }
+    PT_MARK(2);
     T v[3], C[9], E[9], Ena[9], xa[3], va[3], Ca[9], Ea[9];
     const T* A1 = D.adj[src];
     T* A0 = D.adj[dst];
-    for (int d = 0; d < 3; ++d) { v[d] = R[d * Np + p]; xa[d] = A0[d * Np + p]; }
-    for (int d = 0; d < 9; ++d) { C[d] = R[(3 + d) * Np + p]; E[d] = R[(12 + d) * Np + p]; Ena[d] = A1[(15 + d) * Np + p]; }
-    const T mu = D.mu[p], lam = D.lam[p], ys = D.ys[p];
+    T mu, lam, ys;
+    if constexpr (PRE) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this wave's own DMA rows (nobody else reads them: no barrier)
+        const float* q = stage + threadIdx.x;
+        for (int d = 0; d < 3; ++d) { v[d] = (T)q[d * kBlock]; xa[d] = (T)q[(30 + d) * kBlock]; }
+        for (int d = 0; d < 9; ++d) { C[d] = (T)q[(3 + d) * kBlock]; E[d] = (T)q[(12 + d) * kBlock]; Ena[d] = (T)q[(21 + d) * kBlock]; }
+        mu = (T)q[33 * kBlock]; lam = (T)q[34 * kBlock]; ys = (T)q[35 * kBlock];
+    } else {
+        for (int d = 0; d < 3; ++d) { v[d] = R[d * Np + p]; xa[d] = A0[d * Np + p]; }
+        for (int d = 0; d < 9; ++d) { C[d] = R[(3 + d) * Np + p]; E[d] = R[(12 + d) * Np + p]; Ena[d] = A1[(15 + d) * Np + p]; }
+        mu = D.mu[p]; lam = D.lam[p]; ys = D.ys[p];
+    }
     p2g_finish_grad<T>(D.P, G, v, C, E, mu, lam, ys, Ena, xa, va, Ca, Ea);
-    PT_MARK(2);
+    PT_MARK(3);
     for (int d = 0; d < 3; ++d) { A0[d * Np + p] = xa[d]; A0[(3 + d) * Np + p] = va[d]; }
     for (int d = 0; d < 9; ++d) { A0[(6 + d) * Np + p] = Ca[d]; A0[(15 + d) * Np + p] = Ea[d]; }
-    PT_MARK(3);
+    PT_MARK(4);
     PT_END(D, 20);
 }
 
