@@ -49,11 +49,11 @@ ALG = {
     "gridop+g2p": (15, 14), "gridop+g2p_p2g": (51, 18), "gridop+g2p_grad": (18, 16), "gridop_grad+p2g_grad": (54, 15),
 }
 HBM_PEAK_GBS = 8000.0          # MI355X spec (MI355X_MICROARCH.md); the copy / read rates this box reaches are measured live
-PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r04_pmc.json")
 
 
 def pmc_traffic(kernel, workload, dtype, steps, warmup):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/r03_pmc.json, written by
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/r04_pmc.json, written by
     profiles/tools/pmc_summary.py from separate --pmc FETCH_SIZE / WRITE_SIZE runs of this very command: 2 x
     FETCH_SIZE + WRITE_SIZE, the gfx950 correction of MI355X_MICROARCH.md's HBM section).  None when the file is
     missing or was taken on another workload / dtype / --steps / --warmup -- a stale number is worse than none."""

@@ -363,6 +363,9 @@ int plmpm_profile_read(plmpm_handle h, double* total_ms, int64_t* launches);
  * (kind 0: fused g2p(frame-1)+p2g(frame), 1: g2p.grad(frame), 2: p2g.grad(frame), 3: p2g(frame)).  The rollout is not
  * usable afterwards (the replays accumulate into the grids).  profiles/tools/replay_ab.py */
 int plmpm_replay(plmpm_handle h, int kind, int frame, int reps, double* mean_us);
+/* the same for the substep loop of a whole env step, frames [first, first + n): dir 0 forward, 1 reverse; graph 0: launched
+ * eagerly `reps` times, 1: `reps` replays of one captured hipGraph (what the launch boundaries cost, on identical work) */
+int plmpm_replay_step(plmpm_handle h, int graph, int dir, int first, int n, int reps, double* mean_us);
 /* Measured HBM roof of the device the buffers live on: a 16-byte-per-lane copy src -> dst and a read-only sweep of
  * `bytes` bytes, best of `reps` runs, in GB/s of bytes moved (bench.py reports it next to the 8 TB/s spec). */
 int plmpm_measure_hbm(void* src, void* dst, size_t bytes, int reps, void* hip_stream, double* copy_gbs, double* read_gbs);

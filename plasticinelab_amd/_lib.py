@@ -133,6 +133,7 @@ SYMBOLS = {
     "plmpm_debug_counters": (_I, [_P, _P]),
     "plmpm_profile_enable": (_I, [_P, _I]),
     "plmpm_replay": (_I, [_P, _I, _I, _I, C.POINTER(C.c_double)]),
+    "plmpm_replay_step": (_I, [_P, _I, _I, _I, _I, _I, C.POINTER(C.c_double)]),
     "plmpm_profile_kernel_count": (_I, []),
     "plmpm_profile_kernel_name": (C.c_char_p, [_I]),
     "plmpm_profile_read": (_I, [_P, _P, _P]),

@@ -727,6 +727,7 @@ int plmpm_set_materials(plmpm_handle s, const double* mu, const double* lam, con
     bool uni = true;
     for (int i = 1; i < s->N && uni; ++i) uni = mu[i] == mu[0] && lam[i] == lam[0] && ys[i] == ys[0];
     s->mats_uniform = uni;
+    s->mats_u[0] = mu[0]; s->mats_u[1] = lam[0]; s->mats_u[2] = ys[0];
     s->mats_filled = false;
     HIPCHK(hipMemcpyAsync(s->mats_master, mu, nb, hipMemcpyHostToDevice, s->stream));
     HIPCHK(hipMemcpyAsync(s->mats_master + s->N, lam, nb, hipMemcpyHostToDevice, s->stream));
@@ -1290,7 +1291,58 @@ template <class T> static int replay_t(plmpm_sim* s, int kind, int f, int reps, 
     HIPCHK(hipGetLastError());
     return 0;
 }
+// The same for a whole env step: the forward substep loop (dir 0) or the reverse one (dir 1) of frames [first, first + n)
+// launched `reps` times eagerly (graph 0) or as `reps` replays of ONE captured hipGraph (graph 1) -- what the launch
+// boundaries cost on the stream and inside a graph, on identical work.  Timing only: every repetition re-executes the same
+// frames (the scatters accumulate).
+template <class T> static int replay_step_t(plmpm_sim* s, int graph, int dir, int first, int n, int reps, double* us) {
+    auto body = [&]() {
+        if (dir == 0) {
+            for (int f = first; f < first + n; ++f) s->dirty[f] = 0;          // no clear launches: the same launch list every time
+            step_fwd_fused<T>(s, first, n);
+        } else {
+            for (int f = first + n - 1; f >= first; --f) {
+                s->dirty[f] = 1;                                              // the frame's grids are resident: no forward recompute
+                s->adj_frame[(f + 1) & 1] = f + 1;
+                substep_bwd<T>(s, f);
+            }
+        }
+    };
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0));
+    HIPCHK(hipEventCreate(&e1));
+    hipGraph_t g = nullptr;
+    hipGraphExec_t ge = nullptr;
+    if (graph) {
+        HIPCHK(hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal));
+        body();
+        HIPCHK(hipStreamEndCapture(s->stream, &g));
+        HIPCHK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+    }
+    for (int r = -2; r < reps; ++r) {
+        if (r == 0) HIPCHK(hipEventRecord(e0, s->stream));
+        if (graph) HIPCHK(hipGraphLaunch(ge, s->stream));
+        else body();
+    }
+    HIPCHK(hipEventRecord(e1, s->stream));
+    HIPCHK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+    *us = 1e3 * ms / reps;
+    if (ge) (void)hipGraphExecDestroy(ge);
+    if (g) (void)hipGraphDestroy(g);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
 extern "C" {
+int plmpm_replay_step(plmpm_handle s, int graph, int dir, int first, int n, int reps, double* mean_us) {
+    NEED_BOUND(s);
+    REQUIRE(mean_us && reps > 0 && first >= 0 && n > 1 && first + n <= s->F, "replay_step: bad arguments");
+    REQUIRE(s->store && !s->fg && !s->pk && !s->det && !s->prof, "replay_step: needs the per-frame grid store and the default engine, profiling off");
+    return DISPATCH(s, replay_step_t, s, graph, dir, first, n, reps, mean_us);
+}
 int plmpm_replay(plmpm_handle s, int kind, int frame, int reps, double* mean_us) {
     NEED_BOUND(s);
     REQUIRE(mean_us && reps > 0 && kind >= 0 && kind <= 3, "replay: bad arguments");

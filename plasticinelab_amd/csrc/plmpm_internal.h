@@ -55,6 +55,7 @@ enum { LS_DENSITY = 0, LS_SDF = 1, LS_MAXGM = 2, LS_DOT = 3, LS_SUMGM = 4, LS_MI
 
 struct plmpm_sim {
     bool mats_uniform = false, mats_filled = false;   // set_materials: all particles alike / device arrays written at least once
+    double mats_u[3] = {0, 0, 0};                     // the one (mu, lam, yield stress) of a uniform body: travels in the kernel arguments
     bool det = false;                           // cfg.deterministic: integer-limb accumulation (plmpm_kernels.h: det_add)
     long long* det_grid = nullptr;              //   [8][G] limbs of the grid scatters
     long long* det_small = nullptr;             //   [LS_COUNT + kMaxPrim * 8][2] limbs of the loss scalars / loss pose adjoints
@@ -304,6 +305,13 @@ template <class T> static Dev<T> make_dev(const plmpm_sim* s, int frame = -1, bo
         T* m = (T*)(s->mats_store + (size_t)epoch * 3 * s->Npad * s->tsz);
         D.mu = m; D.lam = m + s->Npad; D.ys = m + 2 * (size_t)s->Npad;
     } else { D.mu = (T*)s->mu; D.lam = (T*)s->lam; D.ys = (T*)s->ys; }
+    // one material for the whole body (the common case): the kernels take it from their arguments instead of loading 12 bytes
+    // per particle -- p2g.grad follows its HBM bytes at ~4.7 TB/s (round 4: 30 MB fewer -> 6.4 us), so 6 MB are 1.3 us
+#ifndef PLB_MATS_UNIFORM
+#define PLB_MATS_UNIFORM 1
+#endif
+    D.mats_uniform = (PLB_MATS_UNIFORM && s->mats_uniform && !s->dist && s->have_mats) ? 1 : 0;
+    for (int i = 0; i < 3; ++i) D.mat_u[i] = (T)s->mats_u[i];
     const bool framed = s->store && frame >= 0;
     char* gin_base = framed ? s->gstore + (size_t)frame * s->gstride : s->grid_in;
     for (int c = 0; c < 4; ++c) D.gin[c] = (T*)gin_base + (size_t)c * s->G;

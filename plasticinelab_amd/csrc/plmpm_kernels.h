@@ -83,6 +83,8 @@ template <class T> struct Dev {
     char* state;                     // particle frames
     T* adj[2];                       // ping-pong adjoint frames
     T *mu, *lam, *ys;
+    int mats_uniform;                // 1: every particle has the material mat_u = (mu, lam, yield stress); the arrays are not read
+    T mat_u[3];
     T* gin[4];                       // grid_m, grid_v_in x/y/z (SoA, accumulated)
     T* goa[3];                       // grid_v_out.grad x/y/z (SoA, accumulated)
     T* goa_prev[3];                  // fused-grid engines: the other of the two grid_v_out.grad buffers (frames alternate)
@@ -105,6 +107,10 @@ template <class T> struct Dev {
     PrimStatic prim[kMaxPrim];
 };
 
+template <class T> __device__ __forceinline__ void load_materials(const Dev<T>& D, int p, T& mu, T& lam, T& ys) {
+    if (D.mats_uniform) { mu = D.mat_u[0]; lam = D.mat_u[1]; ys = D.mat_u[2]; }
+    else { mu = D.mu[p]; lam = D.lam[p]; ys = D.ys[p]; }
+}
 template <class T> __device__ __forceinline__ const double* frame_x(const Dev<T>& D, int f) {
     return reinterpret_cast<const double*>(D.state + (size_t)f * D.frame_bytes);
 }
@@ -786,7 +792,7 @@ __global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_p2g(Dev<T> D, int f) 
         if (valid) {
             for (int d = 0; d < 3; ++d) v[d] = R[d * Np + p];
             for (int d = 0; d < 9; ++d) { C[d] = R[(3 + d) * Np + p]; E[d] = R[(12 + d) * Np + p]; }
-            mu = D.mu[p]; lam = D.lam[p]; ys = D.ys[p];
+            load_materials(D, p, mu, lam, ys);
         }
         const Seg<T> sg = wave_segments<T>(valid ? (base[2] * D.P.n + base[1]) * D.P.n + base[0] : -1);
         const bool emitter = sg.head && valid;
@@ -1025,7 +1031,7 @@ __global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_g2p_p2g(Dev<T> D, int
     if (valid) {
         const T* R = frame_r(D, f);
         for (int d = 0; d < 9; ++d) E[d] = R[(12 + d) * Np + p];
-        mu = D.mu[p]; lam = D.lam[p]; ys = D.ys[p];
+        load_materials(D, p, mu, lam, ys);
     }
     if constexpr (FG) {
         // grid_op of substep f-1 on the box: v_out into the tile, or -- a box too large for it -- into the previous frame's
@@ -1278,8 +1284,9 @@ __global__ __launch_bounds__(kBlock, sizeof(T) == 4 ? PLB_G2PG_WAVES : 1) void k
         T vn[3] = {T(0), T(0), T(0)}, xna[3] = {T(0), T(0), T(0)}, vna[3] = {T(0), T(0), T(0)}, Cna[9], xa[3];
         for (int d = 0; d < 9; ++d) Cna[d] = T(0);
         if (valid) {
-            for (int d = 0; d < 3; ++d) { vn[d] = R1[d * Np + p]; xna[d] = A1[d * Np + p]; vna[d] = A1[(3 + d) * Np + p]; }
-            for (int d = 0; d < 9; ++d) Cna[d] = A1[(6 + d) * Np + p];
+            const int pl = PLB_ABL_FUSEBWD ? (p & 63) : p;          // timing experiment: the adjoint inputs from a 64-particle footprint (L1)
+            for (int d = 0; d < 3; ++d) { vn[d] = R1[d * Np + pl]; xna[d] = A1[d * Np + pl]; vna[d] = A1[(3 + d) * Np + pl]; }
+            for (int d = 0; d < 9; ++d) Cna[d] = A1[(6 + d) * Np + pl];
         }
         if constexpr (EVAL) {
             // grid_op on the box, whatever the tile layout (fixed 8-strides, the box's own extents, or no tile at all: then
@@ -1689,12 +1696,27 @@ __global__ __launch_bounds__(kBlock, sizeof(T) == 4 ? PLB_P2G_GRAD_WAVES : 1) vo
     } else {
         for (int d = 0; d < 3; ++d) { v[d] = R[d * Np + p]; xa[d] = A0[d * Np + p]; }
         for (int d = 0; d < 9; ++d) { C[d] = R[(3 + d) * Np + p]; E[d] = R[(12 + d) * Np + p]; Ena[d] = A1[(15 + d) * Np + p]; }
-        mu = D.mu[p]; lam = D.lam[p]; ys = D.ys[p];
+        load_materials(D, p, mu, lam, ys);
     }
     p2g_finish_grad<T>(D.P, G, v, C, E, mu, lam, ys, Ena, xa, va, Ca, Ea);
     PT_MARK(3);
+    if (PLB_ABL_ST4) {              // timing experiment: the same 24 words as six 16-byte stores (layout [6][Npad] of float4)
+        if constexpr (sizeof(T) == 4) {
+            float4* q = reinterpret_cast<float4*>(A0);
+            q[p] = float4{xa[0], xa[1], xa[2], va[0]};
+            q[Np + p] = float4{va[1], va[2], Ca[0], Ca[1]};
+            q[2 * Np + p] = float4{Ca[2], Ca[3], Ca[4], Ca[5]};
+            q[3 * Np + p] = float4{Ca[6], Ca[7], Ca[8], Ea[0]};
+            q[4 * Np + p] = float4{Ea[1], Ea[2], Ea[3], Ea[4]};
+            q[5 * Np + p] = float4{Ea[5], Ea[6], Ea[7], Ea[8]};
+        }
+    } else if (PLB_ABL_FUSEBWD) {          // timing experiment: what a fused p2g.grad(f) + g2p.grad(f-1) would not write
+        if (xa[0] + va[0] + Ca[0] == T(-1e30)) A0[p] = xa[0];
+        for (int d = 0; d < 9; ++d) A0[(15 + d) * Np + p] = Ea[d];
+    } else {
     for (int d = 0; d < 3; ++d) { A0[d * Np + p] = xa[d]; A0[(3 + d) * Np + p] = va[d]; }
     for (int d = 0; d < 9; ++d) { A0[(6 + d) * Np + p] = Ca[d]; A0[(15 + d) * Np + p] = Ea[d]; }
+    }
     PT_MARK(4);
     PT_END(D, 20);
 }

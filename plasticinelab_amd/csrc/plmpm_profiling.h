@@ -67,3 +67,12 @@
 #ifndef PLB_ABL_PACK
 #define PLB_ABL_PACK 0
 #endif
+// PLB_ABL_FUSEBWD=1 (timing only): p2g.grad does not store the x / v / C adjoints and g2p.grad reads its adjoint inputs and
+// v[f+1] from a 64-particle footprint -- the HBM traffic a fused p2g.grad(f) + g2p.grad(f-1) kernel would not have.
+#ifndef PLB_ABL_FUSEBWD
+#define PLB_ABL_FUSEBWD 0
+#endif
+// PLB_ABL_ST4=1 (timing only): p2g.grad writes its 24 adjoint words as six dwordx4 stores instead of 24 dword stores.
+#ifndef PLB_ABL_ST4
+#define PLB_ABL_ST4 0
+#endif
