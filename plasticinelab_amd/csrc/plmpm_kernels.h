@@ -1003,7 +1003,8 @@ __global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_g2p_p2g(Dev<T> D, int
     // box of frame f-1 (stored by the kernel that scattered it; capacity: the same LDS bytes in Vec4<T> nodes):
     // the tile fill is issued right behind the position loads and overlaps with them and with the sort
     const int wgi = xcd_chunk((int)blockIdx.x, (int)gridDim.x);
-    const Tile ta = load_tile(D, f - 1, (int)(TileCap<T>::nodes * sizeof(Vec4<double>) / sizeof(Vec4<T>)), wgi);
+    Tile ta = load_tile(D, f - 1, (int)(TileCap<T>::nodes * sizeof(Vec4<double>) / sizeof(Vec4<T>)), wgi);
+    if (PLB_EXP_DIRECT & 1) ta.ok = 0;          // experiment: gather v_out straight from the grid (L1 / L2), no LDS tile, no fill
     SortLoad sl = sorted_begin(D, X0, wgi);
     NodeIn<T> fpre;
     int flz = 0, fly = 0, flx = 0;
@@ -1609,7 +1610,8 @@ __global__ __launch_bounds__(kBlock, sizeof(T) == 4 ? PLB_P2G_GRAD_WAVES : 1) vo
     const T* R = frame_r(D, f);
     const int Np = D.Npad;
     PT_BEGIN();
-    const Tile tl = load_tile(D, f, TileCap<T>::nodes, chunk);   // stored by the scatter of this frame
+    Tile tl = load_tile(D, f, TileCap<T>::nodes, chunk);   // stored by the scatter of this frame
+    if (PLB_EXP_DIRECT & 2) tl.ok = 0;          // experiment: gather the node adjoints straight from the grid
     double x[3] = {0.5, 0.5, 0.5};
     if (valid) { x[0] = X[p]; x[1] = X[Np + p]; x[2] = X[2 * Np + p]; }
     if constexpr (PRE) {

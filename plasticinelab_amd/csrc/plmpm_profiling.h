@@ -76,3 +76,8 @@
 #ifndef PLB_ABL_ST4
 #define PLB_ABL_ST4 0
 #endif
+// PLB_EXP_DIRECT bits (experiment): 1 k_g2p_p2g gathers grid_v_out straight from global memory (no LDS tile / fill / barrier),
+// 2 k_p2g_grad gathers grid_in_adj likewise.
+#ifndef PLB_EXP_DIRECT
+#define PLB_EXP_DIRECT 0
+#endif
