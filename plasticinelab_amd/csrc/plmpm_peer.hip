@@ -42,7 +42,8 @@ struct PeerXchg {
     unsigned* arrive_local[2];   // this rank's counters
     unsigned seq;
     unsigned* done;
-    int* status;
+    int* status;                 // pinned host word the host reads
+    int* status_dev;             // device copy of it: what the kernel looks at (a system-scope load of host memory crosses PCIe: +1.4 us per exchange)
     int code;                    // field << 16 | 1
     long long timeout_ticks;     // of the 100 MHz wall clock
     float spoil;                 // 1; a test hook (plmpm_debug_peer_spoil) scales what face 0 sends, to prove that a wrong halo is NOTICED
@@ -106,7 +107,7 @@ __global__ __launch_bounds__(256) void k_halo_xchg(PeerXchg X) {
         // an earlier exchange already timed out (a neighbour has stopped): publish -- so that a live neighbour is not kept
         // waiting by THIS rank -- but do not wait again: the launches still queued behind this one must drain in microseconds,
         // not in n x PLMPM_PEER_TIMEOUT, before the host gets to look at the status word
-        const bool dead = __hip_atomic_load(X.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0;
+        const bool dead = __hip_atomic_load(X.status_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
         store_through(X.arrive_remote[i], X.seq);
         const long long t0 = wall_clock64();
         for (; !dead;) {
@@ -114,6 +115,7 @@ __global__ __launch_bounds__(256) void k_halo_xchg(PeerXchg X) {
             if ((int)(got - X.seq) >= 0) break;
             if (wall_clock64() - t0 > X.timeout_ticks) {         // the neighbour is gone: report, do not hang the GPU
                 __hip_atomic_store(X.status, X.code | (i << 8), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(X.status_dev, X.code | (i << 8), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 break;
             }
             __builtin_amdgcn_s_sleep(2);
@@ -226,7 +228,7 @@ int plmpm_halo_peer_exchange(plmpm_handle s, int field, int frame) {
     const size_t pblk = (size_t)s->nbw[0] * s->nbw[1];              // blocks per plane
     PeerXchg X;
     memset(&X, 0, sizeof X);
-    X.n = F.n; X.ncomp = nc; X.seq = seq; X.done = s->peer_done; X.status = s->peer_status; X.code = (field << 16) | 1;
+    X.n = F.n; X.ncomp = nc; X.seq = seq; X.done = s->peer_done; X.status = s->peer_status; X.status_dev = (int*)(s->peer_done + 16); X.code = (field << 16) | 1;
     X.timeout_ticks = (long long)(peer_timeout_seconds() * 1e8);
     X.spoil = s->peer_spoil;
     // the substep fields are sparse in the blocks the frame's scatter flagged; the loss mass grid is sent whole
