@@ -301,7 +301,22 @@ template <class T> __device__ __forceinline__ bool clamp_to_reach(const Dev<T>& 
 #ifndef PLB_XCD_MAP
 #define PLB_XCD_MAP 0
 #endif
+// Experiment (profiles/r04_notes.md): the 1 024 workgroups a launch starts with all begin at the same instant and stay in step -- every
+// CU's four workgroups load together, gather together, scatter together -- and their lifetimes stretch from 30k to 51k cycles while the
+// workgroups of the second round, which start one by one as slots free up, take 34k.  PLB_STAGGER=D delays the first-round workgroups
+// of slot s (b in [256 s, 256 s + 256)) by s * D shader cycles so that a CU's workgroups are in different phases from the start.
+#ifndef PLB_STAGGER
+#define PLB_STAGGER 0
+#endif
+__device__ __forceinline__ void stagger_start(int b) {
+    if (PLB_STAGGER > 0 && b < 1024) {
+        const long long t0 = (long long)__builtin_readcyclecounter(), wait = (long long)PLB_STAGGER * (b >> 8);
+        while ((long long)__builtin_readcyclecounter() - t0 < wait) __builtin_amdgcn_s_sleep(16);
+    }
+}
 __device__ __forceinline__ int xcd_chunk(int b, int n) {
+    if (PLB_XCD_MAP == 2) return n - 1 - b;            // experiment: does the order in which the chunks are dispatched matter at all?
+    if (PLB_XCD_MAP == 3) { const int h = (n + 1) >> 1; return (b & 1) ? h + (b >> 1) < n ? h + (b >> 1) : b >> 1 : b >> 1; }   // two halves interleaved
     if (!PLB_XCD_MAP) return b;
     const int q = n >> 3, r = n & 7, k = b & 7;
     return k * q + min(k, r) + (b >> 3);
@@ -1002,6 +1017,7 @@ __global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_g2p_p2g(Dev<T> D, int
     PT_BEGIN();
     // box of frame f-1 (stored by the kernel that scattered it; capacity: the same LDS bytes in Vec4<T> nodes):
     // the tile fill is issued right behind the position loads and overlaps with them and with the sort
+    stagger_start((int)blockIdx.x);
     const int wgi = xcd_chunk((int)blockIdx.x, (int)gridDim.x);
     Tile ta = load_tile(D, f - 1, (int)(TileCap<T>::nodes * sizeof(Vec4<double>) / sizeof(Vec4<T>)), wgi);
     if (PLB_EXP_DIRECT & 1) ta.ok = 0;          // experiment: gather v_out straight from the grid (L1 / L2), no LDS tile, no fill
@@ -1215,6 +1231,7 @@ __global__ __launch_bounds__(kBlock, sizeof(T) == 4 ? PLB_G2PG_WAVES : 1) void k
         // (they lead the launch, so they run under cover of the first particle workgroups)
         if ((int)blockIdx.x < CA.nwg_clear) { clear_blocks(D, CA, (int)blockIdx.x, CA.nwg_clear); return; }
     }
+    stagger_start((int)blockIdx.x);
     const int wg = FG ? (int)blockIdx.x - CA.nwg_clear : xcd_chunk((int)blockIdx.x, (int)gridDim.x);
     // 960 nodes x (16 + 24) bytes = 37.5 KiB: four workgroups per CU (128 VGPRs = 4 waves per SIMD, see PLB_G2PG_WAVES)
     constexpr int CAP = sizeof(T) == 4 ? PLB_G2PG_CAP : 480;
@@ -1603,6 +1620,7 @@ __global__ __launch_bounds__(kBlock, sizeof(T) == 4 ? PLB_P2G_GRAD_WAVES : 1) vo
     // the first `npose` workgroups finish grid_op.grad (pose adjoints of the blocks in contact) under cover of the
     // particle workgroups
     if ((int)blockIdx.x < npose) { if (!PLB_EXP_NOPOSE) pose_adjoint_blocks<T, FG>(D, f, (int)blockIdx.x, npose, sp); return; }
+    stagger_start((int)blockIdx.x - npose);
     const int chunk = xcd_chunk((int)blockIdx.x - npose, (int)gridDim.x - npose);
     const int p = chunk * kBlock + threadIdx.x;
     const bool valid = p < D.N;
