@@ -107,3 +107,62 @@ def test_minmax_tie_routing_at_a_clamped_manipulator(tie):
     # the particles are far from the manipulators' path in one env step: only the seeded pose adjoint reaches the actions
     assert np.abs(g - g_ref.numpy()).max() < 1e-12, (g, g_ref)
     assert (g[0] == 0.0) == (tie == "second") and abs(g[1] - 0.02) < 1e-12
+
+
+TIE_SHAPES = {
+    # particles exactly ON the +x face of the box: min(max(q), 0) is the tie min(0, 0) -- "first" lets d sdf/d x = 1 through
+    # (the other branch, length(max(q, 0)), has value 0 there and contributes no gradient), "second" stops it at the constant
+    "Box": (dict(shape="Box", size=(0.125, 0.0625, 0.125)), lambda n: (0.625, np.linspace(0.45, 0.55, n), np.linspace(0.42, 0.58, n))),
+    # on the top cap of the cylinder (axis y; the reference's h is its radius, r its half height): same min(0, 0), seen in d / d y
+    "Cylinder": (dict(shape="Cylinder", h=0.125, r=0.0625), lambda n: (np.linspace(0.45, 0.55, n), 0.5625, 0.5)),
+    # on the mid-plane between the two sticks: min(sdf_a, sdf_b) of two bitwise-equal distances -- the adjoint goes to stick
+    # a ("first") or to stick b ("second"): d sdf/d x changes sign, and so does the adjoint of the gap
+    "Chopsticks": (dict(shape="Chopsticks", h=0.25, r=0.03125, init_gap=0.125, minimal_gap=0.0625),
+                   lambda n: (0.5, np.linspace(0.30, 0.45, n), np.linspace(0.45, 0.55, n))),
+}
+
+
+@pytest.mark.parametrize("shape", list(TIE_SHAPES))
+def test_minmax_tie_in_the_contact_loss_through_shape_sdfs(shape, oracle_c):
+    """minmax_tie applies to every max / min on the differentiated path (include/plmpm.h), the shape SDFs under the contact
+    loss included (k_loss_grad -> shape_local_adj): particles placed EXACTLY on a tie of the shape's SDF (coordinates that
+    are exact in binary), soft contact loss alone, engine against the oracle's autograd under both settings -- and the two
+    settings really give different gradients there."""
+    cfg, sim, prims, x0 = oracle_scene("Move", 1, n_particles=600)
+    kw, place = TIE_SHAPES[shape]
+    adim = 7 if shape == "Chopsticks" else 6
+    prims = [O.PrimCfg(init_pos=(0.5, 0.5, 0.5), init_rot=(1.0, 0.0, 0.0, 0.0), action_dim=adim, action_scale=(0.01,) * adim, **kw)]
+    n_tie = 40
+    x0 = x0.copy()
+    px, py, pz = place(n_tie)
+    x0[:n_tie, 0], x0[:n_tie, 1], x0[:n_tie, 2] = px, py, pz
+    state, mats, poses = O.init_state(x0), O.materials(sim), O.init_poses(prims)
+    tgt = sparse_target("Move3D-v1")
+    ref_sdf = c_sdf(oracle_c, tgt, sim.dx)
+    got = {}
+    for tie in ("second", "first"):
+        eng = engine_for(sim, prims, dtype="float64", minmax_tie=tie)
+        load_state(eng, 0, state, mats, poses)
+        eng.loss_set_target(tgt)
+        eng.loss_set_weights(0, 0, 1, True)                       # the soft contact term alone
+        out = eng.loss_forward(0)
+        x = state[0].clone().requires_grad_(True)
+        pin = [tuple(t.clone().requires_grad_(True) for t in po) for po in poses]
+        with semantics(minmax_tie=tie):
+            L, parts = O.compute_loss(sim, O.LossCfg(soft_contact=True), prims, x, pin,
+                                      torch.as_tensor(tgt.reshape(-1)), torch.as_tensor(ref_sdf.reshape(-1)))
+            Lc = parts["contact_loss"]
+            gs = torch.autograd.grad(Lc, [x] + [t for po in pin for t in po], allow_unused=True)
+        assert abs(out["contact_loss"] - float(Lc)) <= 1e-10 * abs(float(Lc))
+        eng.grad_begin(0)
+        eng.loss_backward(0)
+        gx = eng.get_frame_grad(0)["x"]
+        assert relerr(gx, gs[0].numpy()) < 1e-9, tie
+        ref_pose = np.concatenate([np.zeros(t.numel()) if g is None else g.numpy().reshape(-1) for g, t in zip(gs[1:], pin[0])])
+        pg = eng.get_primitive_grad(0, 0)[:len(ref_pose)]
+        assert np.abs(pg - ref_pose).max() <= 1e-9 * max(np.abs(ref_pose).max(), 1e-300), (tie, pg, ref_pose)
+        got[tie] = gx[:n_tie].copy()
+        eng.close()
+    # on the tie the two routings differ: in d loss / d x of the particles that sit on it
+    c = 1 if shape == "Cylinder" else 0
+    assert np.abs(got["first"][:, c] - got["second"][:, c]).max() > 1e-3 * max(np.abs(got["first"]).max(), np.abs(got["second"]).max())
