@@ -436,9 +436,6 @@ template <class T> PLB_HD void svd_eform(const T* Et, Svd3<T>& r) {
 #ifndef PLB_FAST
 #define PLB_FAST 0          // measured (round 4, profiles/r04_notes.md): parity-green and not faster -- the kernels do not follow their
 #endif                      // constitutive instruction count (the whole block is 3.3 us of the forward kernel's 48.5); opt-in: -DPLB_FAST=1
-#ifndef PLB_ABL_CONST
-#define PLB_ABL_CONST 0
-#endif
 template <class T> struct TolFast;
 template <> struct TolFast<float> {
     static constexpr int it_small = 3, it_big = 5;          // Newton steps for ||A|| <= 0.1 / < 0.9: error e -> e^2 / 2
@@ -811,11 +808,7 @@ PLB_HD void p2g_prepare(const SimP<typename Lane<T>::scalar>& P, const X* x, con
     T Et[9], stress[9], A[9];
     f_tmp_eform(C, E, P.dt, Et);
     bool fast = false;
-#if PLB_ABL_CONST        /* timing experiment only (wrong results): no constitutive model at all */
-    fast = true;
-    for (int i = 0; i < 9; ++i) { En[i] = Et[i]; stress[i] = mu * Et[i]; }
-#endif
-    if constexpr (PLB_FAST && !PLB_ABL_CONST && std::is_floating_point<T>::value) {
+    if constexpr (PLB_FAST && std::is_floating_point<T>::value) {
         // a wave without a lane that can yield: polar rotation instead of the SVD (elastic fast path above); the forward
         // pass has no use for the eigenvalue gaps
         Elastic<T> el;
@@ -1084,14 +1077,10 @@ PLB_HD void p2g_finish_grad(const SimP<typename Lane<T>::scalar>& P, const P2GGa
     bool fast = false;
     Elastic<T> el;
     Consti<T> k;
-#if PLB_ABL_CONST        /* timing experiment only (wrong results): no constitutive model at all */
-    for (int i = 0; i < 9; ++i) stress[i] = mu * Et[i];
-#else
     if constexpr (PLB_FAST && std::is_floating_point<T>::value)
         fast = elastic_try(Et, mu, ys, T(P.svd_clamp), true, el);         // wave-uniform (elastic fast path above)
     if (fast) elastic_stress(Et, el, mu, lam, stress);
     else constitutive_fwd(Et, mu, lam, ys, k, En, stress, P.tie_first);
-#endif
     for (int i = 0; i < 9; ++i) A[i] = P.kappa * stress[i] + P.p_mass * C[i];
     const T* M = G.M;
     const T* Aa = G.Aa;
@@ -1109,14 +1098,10 @@ PLB_HD void p2g_finish_grad(const SimP<typename Lane<T>::scalar>& P, const P2GGa
     for (int d = 0; d < 3; ++d) xa_io[d] += P.inv_dx * fxa[d];
     T GS[9], Fta[9];
     for (int i = 0; i < 9; ++i) { Ca[i] = P.p_mass * Aa[i]; GS[i] = P.kappa * Aa[i]; }
-#if PLB_ABL_CONST
-    for (int i = 0; i < 9; ++i) Fta[i] = mu * GS[i] + En_a[i];
-#else
     if constexpr (PLB_FAST && std::is_floating_point<T>::value) {
         if (fast) elastic_vjp(Et, el, mu, lam, GS, En_a, Fta);
         else constitutive_vjp(k, mu, lam, P.svd_clamp, GS, En_a, Fta);
     } else constitutive_vjp(k, mu, lam, P.svd_clamp, GS, En_a, Fta);
-#endif
     // F_tmp = (I + dt C) F :  C.grad += dt Fta F^T ;  F.grad = (I + dt C)^T Fta
     T Fm[9];
     for (int i = 0; i < 9; ++i) Fm[i] = E[i];

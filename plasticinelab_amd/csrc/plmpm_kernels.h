@@ -299,24 +299,9 @@ template <class T> __device__ __forceinline__ bool clamp_to_reach(const Dev<T>& 
 // stencil boxes; with the identity map those neighbours sit on eight different L2s.  Here XCD k takes the k-th
 // CONTIGUOUS eighth of the chunks: the tile fills of neighbouring workgroups hit the same L2.
 #ifndef PLB_XCD_MAP
-#define PLB_XCD_MAP 0
+#define PLB_XCD_MAP 0            // measured (round 4): no effect either way (48.9 / 31.2 / 43.9 us with it against 48.6 / 30.9 / 43.9): the identity stays
 #endif
-// Experiment (profiles/r04_notes.md): the 1 024 workgroups a launch starts with all begin at the same instant and stay in step -- every
-// CU's four workgroups load together, gather together, scatter together -- and their lifetimes stretch from 30k to 51k cycles while the
-// workgroups of the second round, which start one by one as slots free up, take 34k.  PLB_STAGGER=D delays the first-round workgroups
-// of slot s (b in [256 s, 256 s + 256)) by s * D shader cycles so that a CU's workgroups are in different phases from the start.
-#ifndef PLB_STAGGER
-#define PLB_STAGGER 0
-#endif
-__device__ __forceinline__ void stagger_start(int b) {
-    if (PLB_STAGGER > 0 && b < 1024) {
-        const long long t0 = (long long)__builtin_readcyclecounter(), wait = (long long)PLB_STAGGER * (b >> 8);
-        while ((long long)__builtin_readcyclecounter() - t0 < wait) __builtin_amdgcn_s_sleep(16);
-    }
-}
 __device__ __forceinline__ int xcd_chunk(int b, int n) {
-    if (PLB_XCD_MAP == 2) return n - 1 - b;            // experiment: does the order in which the chunks are dispatched matter at all?
-    if (PLB_XCD_MAP == 3) { const int h = (n + 1) >> 1; return (b & 1) ? h + (b >> 1) < n ? h + (b >> 1) : b >> 1 : b >> 1; }   // two halves interleaved
     if (!PLB_XCD_MAP) return b;
     const int q = n >> 3, r = n & 7, k = b & 7;
     return k * q + min(k, r) + (b >> 3);
@@ -744,7 +729,7 @@ __device__ __forceinline__ bool sorted_finish(const Dev<T>& D, SortLoad& s, int&
     // padding lanes carry the largest key either way; the 32-bit network needs (cells << 6) to fit
     // (skipping the sort when the lanes already come in few runs of equal keys was measured in round 2: the extra LDS
     // atomics of the shorter runs cost more than the sort, profiles/r02_notes.md)
-    const int src = PLB_ABL_NOSORT ? (int)(threadIdx.x & 63) : (D.P.n <= 256 ? wave_sort_lanes32(p0 < D.N ? (unsigned)s.key : 0x3ffffffu) : wave_sort_lanes(s.key));
+    const int src = (D.P.n <= 256 ? wave_sort_lanes32(p0 < D.N ? (unsigned)s.key : 0x3ffffffu) : wave_sort_lanes(s.key));
     p = (p0 & ~63) + src;
     for (int d = 0; d < 3; ++d) x[d] = __shfl(s.x0[d], src);       // the position travels with the sort
     for (int d = 0; d < 3; ++d) base[d] = (int)(x[d] * (double)D.P.inv_dx - 0.5);
@@ -826,13 +811,7 @@ __global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_p2g(Dev<T> D, int f) 
                         det_add(q, q + 4, (double)a0); det_add(q + 1, q + 5, (double)a1); det_add(q + 2, q + 6, (double)a2); det_add(q + 3, q + 7, (double)a3);
                     } else {
                         double* q = reinterpret_cast<double*>(&tile[(oz + l) * exy + (oy + j) * ex + (ox + i)]);
-                        if (PLB_ABL_PACK) {          // timing experiment (wrong sums): two 64-bit integer atomics per node instead of four f64
-                            unsigned long long* qi = reinterpret_cast<unsigned long long*>(q);
-                            atomicAdd(qi, ((unsigned long long)(unsigned)(int)(a0 * 1e6f) << 32) | (unsigned)(int)(a1 * 1e6f));
-                            atomicAdd(qi + 1, ((unsigned long long)(unsigned)(int)(a2 * 1e6f) << 32) | (unsigned)(int)(a3 * 1e6f));
-                        } else {
                         atomicAdd(q, (double)a0); atomicAdd(q + 1, (double)a1); atomicAdd(q + 2, (double)a2); atomicAdd(q + 3, (double)a3);
-                        }
                     }
                 }
             });
@@ -1017,10 +996,8 @@ __global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_g2p_p2g(Dev<T> D, int
     PT_BEGIN();
     // box of frame f-1 (stored by the kernel that scattered it; capacity: the same LDS bytes in Vec4<T> nodes):
     // the tile fill is issued right behind the position loads and overlaps with them and with the sort
-    stagger_start((int)blockIdx.x);
     const int wgi = xcd_chunk((int)blockIdx.x, (int)gridDim.x);
     Tile ta = load_tile(D, f - 1, (int)(TileCap<T>::nodes * sizeof(Vec4<double>) / sizeof(Vec4<T>)), wgi);
-    if (PLB_EXP_DIRECT & 1) ta.ok = 0;          // experiment: gather v_out straight from the grid (L1 / L2), no LDS tile, no fill
     SortLoad sl = sorted_begin(D, X0, wgi);
     NodeIn<T> fpre;
     int flz = 0, fly = 0, flx = 0;
@@ -1134,13 +1111,7 @@ __global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_g2p_p2g(Dev<T> D, int
                         det_add(q, q + 4, (double)a0); det_add(q + 1, q + 5, (double)a1); det_add(q + 2, q + 6, (double)a2); det_add(q + 3, q + 7, (double)a3);
                     } else {
                         double* q = reinterpret_cast<double*>(&tile[(oz + l) * exy + (oy + j) * ex + (ox + i)]);
-                        if (PLB_ABL_PACK) {          // timing experiment (wrong sums): two 64-bit integer atomics per node instead of four f64
-                            unsigned long long* qi = reinterpret_cast<unsigned long long*>(q);
-                            atomicAdd(qi, ((unsigned long long)(unsigned)(int)(a0 * 1e6f) << 32) | (unsigned)(int)(a1 * 1e6f));
-                            atomicAdd(qi + 1, ((unsigned long long)(unsigned)(int)(a2 * 1e6f) << 32) | (unsigned)(int)(a3 * 1e6f));
-                        } else {
                         atomicAdd(q, (double)a0); atomicAdd(q + 1, (double)a1); atomicAdd(q + 2, (double)a2); atomicAdd(q + 3, (double)a3);
-                        }
                     }
                 }
             });
@@ -1231,7 +1202,6 @@ __global__ __launch_bounds__(kBlock, sizeof(T) == 4 ? PLB_G2PG_WAVES : 1) void k
         // (they lead the launch, so they run under cover of the first particle workgroups)
         if ((int)blockIdx.x < CA.nwg_clear) { clear_blocks(D, CA, (int)blockIdx.x, CA.nwg_clear); return; }
     }
-    stagger_start((int)blockIdx.x);
     const int wg = FG ? (int)blockIdx.x - CA.nwg_clear : xcd_chunk((int)blockIdx.x, (int)gridDim.x);
     // 960 nodes x (16 + 24) bytes = 37.5 KiB: four workgroups per CU (128 VGPRs = 4 waves per SIMD, see PLB_G2PG_WAVES)
     constexpr int CAP = sizeof(T) == 4 ? PLB_G2PG_CAP : 480;
@@ -1302,9 +1272,8 @@ __global__ __launch_bounds__(kBlock, sizeof(T) == 4 ? PLB_G2PG_WAVES : 1) void k
         T vn[3] = {T(0), T(0), T(0)}, xna[3] = {T(0), T(0), T(0)}, vna[3] = {T(0), T(0), T(0)}, Cna[9], xa[3];
         for (int d = 0; d < 9; ++d) Cna[d] = T(0);
         if (valid) {
-            const int pl = PLB_ABL_FUSEBWD ? (p & 63) : p;          // timing experiment: the adjoint inputs from a 64-particle footprint (L1)
-            for (int d = 0; d < 3; ++d) { vn[d] = R1[d * Np + pl]; xna[d] = A1[d * Np + pl]; vna[d] = A1[(3 + d) * Np + pl]; }
-            for (int d = 0; d < 9; ++d) Cna[d] = A1[(6 + d) * Np + pl];
+            for (int d = 0; d < 3; ++d) { vn[d] = R1[d * Np + p]; xna[d] = A1[d * Np + p]; vna[d] = A1[(3 + d) * Np + p]; }
+            for (int d = 0; d < 9; ++d) Cna[d] = A1[(6 + d) * Np + p];
         }
         if constexpr (EVAL) {
             // grid_op on the box, whatever the tile layout (fixed 8-strides, the box's own extents, or no tile at all: then
@@ -1598,29 +1567,15 @@ __global__ __launch_bounds__(64) void k_pose_adjoint_det(Dev<T> D, int f) {
 // p2g.grad + svd_grad + compute_F_tmp.grad: gather grid_in_adj, finish adjoint frame `dst`
 // FG (fused-grid engines): the pointwise part of grid_op.grad is evaluated in the tile fill (fg_node_gadj) from
 // grid_v_out.grad and the frame's grid_m / grid_v_in; the pose workgroups leave those inputs in place.
-// The particle state this kernel needs AFTER its gather (v, C, E of the frame, F[f+1].grad, the x.grad g2p.grad left, the
-// materials: 36 words per particle) is fetched at the START, straight into LDS (global_load_lds: no VGPR holds it while
-// the gather's 51 accumulators are live -- the kernel sits at 2 waves per SIMD and 233 VGPRs as it is), and read back from
-// LDS behind the gather.  Loading it into registers there costs every wave an HBM round trip in the middle of its life
-// (wave trace, round 4: 8.5k of 17.9k cycles between the end of the gather and the adjoint stores, ~2.5k of them that wait)
-// with one other wave per SIMD to cover it.  fp32 engines (the LDS-DMA moves 4, 12 or 16 bytes per lane).  OPT-IN
-// (-DPLB_P2GG_PREFETCH=1): parity-green and 5 us SLOWER, see below.
-#ifndef PLB_P2GG_PREFETCH
-#define PLB_P2GG_PREFETCH 0         // measured (round 4, replay on identical inputs): 47.1 / 49.0 us with it against 42.7 / 43.3 -- the DMA rows make every
-#endif                              // wait of the prologue a vmcnt(0) over 36 more loads, and the other wave of the SIMD was already covering the stall
-typedef __attribute__((address_space(3))) void plb_lds_void;
-typedef const __attribute__((address_space(1))) void plb_glb_void;
+// (Fetching the particle state this kernel needs behind its gather at the START by LDS-DMA -- global_load_lds, 36 words per
+// particle -- was built and measured in round 4: parity-green, 47.1 / 49.0 us against 42.7 / 43.3; profiles/r04_ablation_hooks.patch.)
 template <class T, bool FG = false>
 __global__ __launch_bounds__(kBlock, sizeof(T) == 4 ? PLB_P2G_GRAD_WAVES : 1) void k_p2g_grad(Dev<T> D, int f, int src, int dst, int npose) {
-    constexpr bool PRE = PLB_P2GG_PREFETCH && sizeof(T) == 4 && !FG;
-    constexpr int NPRE = 36;
     __shared__ Vec4<T> tile[TileCap<T>::nodes];
     __shared__ PrimT<T> sp[kMaxPrim];
-    __shared__ float stage[PRE ? NPRE * kBlock : 1];
     // the first `npose` workgroups finish grid_op.grad (pose adjoints of the blocks in contact) under cover of the
     // particle workgroups
-    if ((int)blockIdx.x < npose) { if (!PLB_EXP_NOPOSE) pose_adjoint_blocks<T, FG>(D, f, (int)blockIdx.x, npose, sp); return; }
-    stagger_start((int)blockIdx.x - npose);
+    if ((int)blockIdx.x < npose) { pose_adjoint_blocks<T, FG>(D, f, (int)blockIdx.x, npose, sp); return; }
     const int chunk = xcd_chunk((int)blockIdx.x - npose, (int)gridDim.x - npose);
     const int p = chunk * kBlock + threadIdx.x;
     const bool valid = p < D.N;
@@ -1629,29 +1584,8 @@ __global__ __launch_bounds__(kBlock, sizeof(T) == 4 ? PLB_P2G_GRAD_WAVES : 1) vo
     const int Np = D.Npad;
     PT_BEGIN();
     Tile tl = load_tile(D, f, TileCap<T>::nodes, chunk);   // stored by the scatter of this frame
-    if (PLB_EXP_DIRECT & 2) tl.ok = 0;          // experiment: gather the node adjoints straight from the grid
     double x[3] = {0.5, 0.5, 0.5};
     if (valid) { x[0] = X[p]; x[1] = X[Np + p]; x[2] = X[2 * Np + p]; }
-    if constexpr (PRE) {
-        if (valid) {
-            // word k of this lane lands at stage[k * 256 + wave * 64 + lane] (the DMA writes wave-uniform base + 4 * lane)
-            float* row = stage + (threadIdx.x & ~63);
-            const float* A1f = reinterpret_cast<const float*>(D.adj[src]);
-            const float* A0f = reinterpret_cast<const float*>(D.adj[dst]);
-            const float* Rf = reinterpret_cast<const float*>(R);
-#define PLB_PRE(k, ptr) __builtin_amdgcn_global_load_lds((plb_glb_void*)(ptr), (plb_lds_void*)(row + (k) * kBlock), 4, 0, 0)
-            PLB_UNROLL
-            for (int d = 0; d < 21; ++d) PLB_PRE(d, Rf + (size_t)d * Np + p);                       // v, C, E
-            PLB_UNROLL
-            for (int d = 0; d < 9; ++d) PLB_PRE(21 + d, A1f + (size_t)(15 + d) * Np + p);           // F[f+1].grad
-            PLB_UNROLL
-            for (int d = 0; d < 3; ++d) PLB_PRE(30 + d, A0f + (size_t)d * Np + p);                  // x.grad so far
-            PLB_PRE(33, reinterpret_cast<const float*>(D.mu) + p);
-            PLB_PRE(34, reinterpret_cast<const float*>(D.lam) + p);
-            PLB_PRE(35, reinterpret_cast<const float*>(D.ys) + p);
-#undef PLB_PRE
-        }
-    }
     const int ex = tl.e[0], exy = tl.e[0] * tl.e[1], tn = exy * tl.e[2];
     if constexpr (FG) {
         // the node adjoints of the whole box: into the LDS tile, or -- a box too large for it -- into grid_in_adj in HBM
@@ -1707,36 +1641,13 @@ __global__ __launch_bounds__(kBlock, sizeof(T) == 4 ? PLB_P2G_GRAD_WAVES : 1) vo
     const T* A1 = D.adj[src];
     T* A0 = D.adj[dst];
     T mu, lam, ys;
-    if constexpr (PRE) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this wave's own DMA rows (nobody else reads them: no barrier)
-        const float* q = stage + threadIdx.x;
-        for (int d = 0; d < 3; ++d) { v[d] = (T)q[d * kBlock]; xa[d] = (T)q[(30 + d) * kBlock]; }
-        for (int d = 0; d < 9; ++d) { C[d] = (T)q[(3 + d) * kBlock]; E[d] = (T)q[(12 + d) * kBlock]; Ena[d] = (T)q[(21 + d) * kBlock]; }
-        mu = (T)q[33 * kBlock]; lam = (T)q[34 * kBlock]; ys = (T)q[35 * kBlock];
-    } else {
-        for (int d = 0; d < 3; ++d) { v[d] = R[d * Np + p]; xa[d] = A0[d * Np + p]; }
-        for (int d = 0; d < 9; ++d) { C[d] = R[(3 + d) * Np + p]; E[d] = R[(12 + d) * Np + p]; Ena[d] = A1[(15 + d) * Np + p]; }
-        load_materials(D, p, mu, lam, ys);
-    }
+    for (int d = 0; d < 3; ++d) { v[d] = R[d * Np + p]; xa[d] = A0[d * Np + p]; }
+    for (int d = 0; d < 9; ++d) { C[d] = R[(3 + d) * Np + p]; E[d] = R[(12 + d) * Np + p]; Ena[d] = A1[(15 + d) * Np + p]; }
+    load_materials(D, p, mu, lam, ys);
     p2g_finish_grad<T>(D.P, G, v, C, E, mu, lam, ys, Ena, xa, va, Ca, Ea);
     PT_MARK(3);
-    if (PLB_ABL_ST4) {              // timing experiment: the same 24 words as six 16-byte stores (layout [6][Npad] of float4)
-        if constexpr (sizeof(T) == 4) {
-            float4* q = reinterpret_cast<float4*>(A0);
-            q[p] = float4{xa[0], xa[1], xa[2], va[0]};
-            q[Np + p] = float4{va[1], va[2], Ca[0], Ca[1]};
-            q[2 * Np + p] = float4{Ca[2], Ca[3], Ca[4], Ca[5]};
-            q[3 * Np + p] = float4{Ca[6], Ca[7], Ca[8], Ea[0]};
-            q[4 * Np + p] = float4{Ea[1], Ea[2], Ea[3], Ea[4]};
-            q[5 * Np + p] = float4{Ea[5], Ea[6], Ea[7], Ea[8]};
-        }
-    } else if (PLB_ABL_FUSEBWD) {          // timing experiment: what a fused p2g.grad(f) + g2p.grad(f-1) would not write
-        if (xa[0] + va[0] + Ca[0] == T(-1e30)) A0[p] = xa[0];
-        for (int d = 0; d < 9; ++d) A0[(15 + d) * Np + p] = Ea[d];
-    } else {
     for (int d = 0; d < 3; ++d) { A0[d * Np + p] = xa[d]; A0[(3 + d) * Np + p] = va[d]; }
     for (int d = 0; d < 9; ++d) { A0[(6 + d) * Np + p] = Ca[d]; A0[(15 + d) * Np + p] = Ea[d]; }
-    }
     PT_MARK(4);
     PT_END(D, 20);
 }

@@ -54,30 +54,6 @@
     } while (0)
 
 
-// Experiment (profiles/r04_notes.md): PLB_EXP_NOPOSE=1 drops the pose-adjoint workgroups' code from k_p2g_grad (timing
-// only -- the pose adjoints are then missing): what does the particle path need in registers on its own?
-#ifndef PLB_EXP_NOPOSE
-#define PLB_EXP_NOPOSE 0
-#endif
-// PLB_ABL_NOSORT=1 (timing only): the particle kernels keep the storage order inside a wave (no bitonic network).
-#ifndef PLB_ABL_NOSORT
-#define PLB_ABL_NOSORT 0
-#endif
-// PLB_ABL_PACK=1 (timing only): the scatter's four ds_add_f64 per node replaced by two ds_add_u64 of packed 32-bit pairs.
-#ifndef PLB_ABL_PACK
-#define PLB_ABL_PACK 0
-#endif
-// PLB_ABL_FUSEBWD=1 (timing only): p2g.grad does not store the x / v / C adjoints and g2p.grad reads its adjoint inputs and
-// v[f+1] from a 64-particle footprint -- the HBM traffic a fused p2g.grad(f) + g2p.grad(f-1) kernel would not have.
-#ifndef PLB_ABL_FUSEBWD
-#define PLB_ABL_FUSEBWD 0
-#endif
-// PLB_ABL_ST4=1 (timing only): p2g.grad writes its 24 adjoint words as six dwordx4 stores instead of 24 dword stores.
-#ifndef PLB_ABL_ST4
-#define PLB_ABL_ST4 0
-#endif
-// PLB_EXP_DIRECT bits (experiment): 1 k_g2p_p2g gathers grid_v_out straight from global memory (no LDS tile / fill / barrier),
-// 2 k_p2g_grad gathers grid_in_adj likewise.
-#ifndef PLB_EXP_DIRECT
-#define PLB_EXP_DIRECT 0
-#endif
+// The timing-only hooks of round 4's replay ablations (PLB_ABL_PACK / NOSORT / FUSEBWD / ST4 / CONST, PLB_EXP_DIRECT / NOPOSE, PLB_STAGGER,
+// the reversed / interleaved dispatch orders and the LDS-DMA prefetch of k_p2g_grad) are not in the product source: apply
+// profiles/r04_ablation_hooks.patch to get them back (profiles/r04_notes.md says which number came from which).
