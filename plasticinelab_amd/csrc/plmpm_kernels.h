@@ -1212,8 +1212,10 @@ __global__ __launch_bounds__(kBlock, sizeof(T) == 4 ? PLB_G2PG_WAVES : 1) void k
     int p, base[3];
     double x[3];
     PT_BEGIN();
-    if (wg == 0 && threadIdx.x == 0) (FG ? D.contact_next : D.contact)[0] = 0;     // the list k_grid_op_grad(f) (FG: this kernel for frame f-1) is about to fill
+    // (in front of the kernel's first store: behind one, hipcc no longer proves the descriptor unclobbered and fetches it with a vector
+    // load + readfirstlane instead of s_load)
     const Tile tl = load_tile(D, f, DET ? CAP / 2 : CAP, wg);       // stored by the scatter of this frame (DET: 6 limbs per node in tile_a)
+    if (wg == 0 && threadIdx.x == 0) (FG ? D.contact_next : D.contact)[0] = 0;     // the list k_grid_op_grad(f) (FG: this kernel for frame f-1) is about to fill
     SortLoad sl = sorted_begin(D, X, wg);
 
     const int ex = tl.e[0], exy = tl.e[0] * tl.e[1], tn = exy * tl.e[2];
