@@ -7,7 +7,8 @@ import plasticinelab_amd._lib as L
 L.LIB_PATH = os.environ.get('EXP_LIB', L.LIB_PATH)      # a -DPLB_PHASE_TIMING build of libplmpm.so
 import bench
 class A: pass
-args = A(); args.particles = 500_000; args.quality = 2; args.steps = 2; args.warmup = 1; args.dtype = 'float32'
+args = A(); args.particles = int(os.environ.get('TRACE_PARTICLES', 500_000)); args.quality = 2; args.steps = 2; args.warmup = 1; args.dtype = 'float32'
+args.side = float(os.environ.get('TRACE_SIDE', 0.31))        # 62 500 particles at the headline's density: TRACE_PARTICLES=62500 TRACE_SIDE=0.155
 dev = torch.device('cuda:0')
 env, _ = bench.build_env(args, dev)
 sim = env.simulator
