@@ -22,7 +22,8 @@
 
 namespace plb {
 
-constexpr int kBlock = 256;          // threads per workgroup in particle kernels
+constexpr int kBlock = 256;          // threads per workgroup in particle kernels: 256 particles per box.  Measured optimum (round 4: 512 -> -11 %,
+                                     // 128 -> -18 % substeps/s); NOT a tunable -- the 128 build also ends with another loss: something relies on it
 // minimum waves per SIMD the register allocator must leave room for (second __launch_bounds__ argument)
 #ifndef PLB_P2G_WAVES
 #define PLB_P2G_WAVES 4
