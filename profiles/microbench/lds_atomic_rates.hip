@@ -9,7 +9,7 @@
 #include <cstdio>
 
 constexpr int ITER = 4096;
-enum { F32 = 0, F64 = 1, U32 = 2, U64 = 3, RMW64 = 4, F32x2 = 5 };
+enum { F32 = 0, F64 = 1, U32 = 2, U64 = 3, RMW64 = 4, F32x2 = 5, RMW128 = 6, RMW128PRE = 7 };
 
 // lane -> node: active lanes take distinct nodes, 32 B apart (Vec4<double> tile) or 16 B apart (Vec4<float> tile)
 template <int MODE, int ACT>
@@ -25,6 +25,22 @@ __global__ __launch_bounds__(256) void k(float* out, int waves_active) {
         for (int it = 0; it < ITER; it += 4) {
             // 4 components of one node, then the next node of the stencil: the access shape of the scatter loop
             const int node = (slot * 3 + (it >> 2) * 7 + wave * 64) & 255;
+            if (MODE == RMW128 || MODE == RMW128PRE) {
+                // the 4 components of a node as ONE float4 read-modify-write (a per-wave private tile needs no atomics: in one step of
+                // the scatter loop the head lanes of a wave address different nodes).  PRE: the read is issued 16 dependent VALU
+                // instructions (the DPP reduction's length) before its value is needed
+                typedef float f4 __attribute__((ext_vector_type(4)));
+                volatile f4* q = reinterpret_cast<volatile f4*>(buf) + node;
+                f4 v = *q;
+                float a = 1.0f + it;
+                if (MODE == RMW128PRE) {
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) asm volatile("v_fmac_f32 %0, %0, %0" : "+v"(a));
+                }
+                v.x += a; v.y += a; v.z += a; v.w += a;
+                *q = v;
+                continue;
+            }
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 if (MODE == F32) atomicAdd(reinterpret_cast<float*>(buf) + node * 4 + c, 1.0f);
@@ -54,6 +70,6 @@ template <int MODE, int ACT> void run(const char* name, float* out) {
 int main() {
     float* out; hipMalloc(&out, 1 << 20);
 #define ROW(M, name) run<M, 1>(name, out); run<M, 8>(name, out); run<M, 16>(name, out); run<M, 32>(name, out); run<M, 64>(name, out);
-    ROW(F64, "ds_add_f64") ROW(F32, "ds_add_f32") ROW(U32, "ds_add_u32") ROW(U64, "ds_add_u64") ROW(RMW64, "rd+wr b64")
+    ROW(F64, "ds_add_f64") ROW(F32, "ds_add_f32") ROW(U32, "ds_add_u32") ROW(U64, "ds_add_u64") ROW(RMW64, "rd+wr b64") ROW(RMW128, "rmw b128/4") ROW(RMW128PRE, "rmw128+16v")
     return 0;
 }
