@@ -25,9 +25,11 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--step", type=int, default=10)
     ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--particles", type=int, default=500_000)
+    ap.add_argument("--side", type=float, default=0.31, help="62 500 particles at the headline's density: --particles 62500 --side 0.155")
     a = ap.parse_args()
-    args = argparse.Namespace(steps=a.step + 2, warmup=0, quality=2, particles=500_000, dtype="float32", workload="config3_cube128",
-                              yield_stress=200.0, side=0.31, window=-1, deterministic=False)
+    args = argparse.Namespace(steps=a.step + 2, warmup=0, quality=2, particles=a.particles, dtype="float32", workload="config3_cube128",
+                              yield_stress=200.0, side=a.side, window=-1, deterministic=False)
     env, _ = bench.build_env(args, torch.device("cuda", 0))
     sim = env.simulator
     eng = sim.engine
