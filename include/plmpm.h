@@ -130,10 +130,6 @@ typedef struct plmpm_sim* plmpm_handle;
 
 const char* plmpm_last_error(void);
 int plmpm_version(void);
-/* what this build of the library was compiled with: bit 0 the EXPERIMENTAL engine variants (two particles per lane, fused-grid
- * kernels: PLMPM_PK / PLMPM_FUSE_GRID are honoured only then), bit 1 the elastic fast path (-DPLB_FAST=1), bit 2 the XCD-aware
- * chunk map (-DPLB_XCD_MAP=1) */
-int plmpm_build_flags(void);
 
 /* ---- lifetime ------------------------------------------------------------------------------ */
 /* MPMSimulator.__init__ + Primitives.__init__ (mpm_simulator.py:6-51, primitives.py:263-279) */
@@ -286,13 +282,12 @@ int plmpm_peer_open(plmpm_handle h, const void* ipc_handle64, void** dev_ptr);  
 int plmpm_halo_peer_setup(plmpm_handle h, int field, int n_faces, const int* bz_a, const int* bz_b, void* const* local, void* const* remote);
 int plmpm_halo_peer_exchange(plmpm_handle h, int field, int frame);
 int plmpm_peer_status(plmpm_handle h, int* status);
-/* collective re-synchronisation: every rank calls it and then meets the others at a host barrier before the next exchange;
- * counters, sequence numbers and the status word go back to zero (after a timeout, or an exception between exchanges) */
-int plmpm_halo_peer_reset(plmpm_handle h);
+/* collective re-synchronisation in two phases, every rank calling each and meeting the others at a host barrier behind it:
+ * phase 0 drains this rank's enqueued exchange kernels (nobody can publish an old sequence number any more), phase 1 sets
+ * counters, sequence numbers and the status word back to zero (after a timeout, or an exception between exchanges) */
+int plmpm_halo_peer_reset(plmpm_handle h, int phase);
 /* 1: receive areas in uncached device memory (hipDeviceMallocUncached), 0: fine-grained (PLMPM_PEER_MEM=finegrained, or refused) */
 int plmpm_peer_memory_kind(plmpm_handle h, int* uncached);
-/* test hook: scale what this rank sends through face 0 (1 = off) -- a spoiled halo must be noticed by the transport check */
-int plmpm_debug_peer_spoil(plmpm_handle h, double factor);
 int plmpm_slab_step(plmpm_handle h, int first_frame, int n_substeps);         /* fk + n x (p2g | exchange | grid_op + g2p) */
 int plmpm_slab_step_grad(plmpm_handle h, int first_frame, int n_substeps);    /* n x (g2p.grad | exchange | grid_op.grad + p2g.grad), in reverse */
 
@@ -341,36 +336,6 @@ int plmpm_loss_set_globals(plmpm_handle h, const double* in32);
 int plmpm_loss_finish(plmpm_handle h, const double* global32, double* out6);   /* host arithmetic of loss.py:137-162,252-254 */
 int plmpm_loss_backward_local(plmpm_handle h, int frame);
 int plmpm_check_error(plmpm_handle h, int* flags);
-/* tuning aid: {error word, workgroups of the fused forward kernel that fell back to global atomics, workgroups on
- * the LDS-tile path, sum of their tile sizes in nodes} since the last call */
-int plmpm_debug_counters(plmpm_handle h, int* out4);
-
-/* ---- introspection ------------------------------------------------------------------------- */
-/* number of grid nodes with mass > 0 and number of active 4^3 blocks after the last forward substep */
-int plmpm_grid_stats(plmpm_handle h, int frame, int64_t* active_nodes, int64_t* active_blocks);
-/* diagnostics: the stencil bounding box (origin node x,y,z, extent x,y,z) of every 256-particle workgroup of a frame
- * that has been scattered, as the kernels stage it in LDS; out = int32[n_workgroups][6] (out may be NULL to query
- * n_workgroups).  A box of more than 1024 (fp32) / 512 (fp64) nodes takes the slow global-memory path. */
-int plmpm_tile_boxes(plmpm_handle h, int frame, int32_t* out, int max_workgroups, int* n_workgroups);
-/* per-kernel timing with HIP events recorded on the launch stream, around every hot-path kernel.
- * enable(1) starts collecting; read() synchronises, returns summed milliseconds and launch counts for
- * the plmpm_profile_kernel_count() kernel classes and resets the collection. */
-int plmpm_profile_enable(plmpm_handle h, int on);
-int plmpm_profile_kernel_count(void);
-const char* plmpm_profile_kernel_name(int id);
-int plmpm_profile_read(plmpm_handle h, double* total_ms, int64_t* launches);
-/* profiling aid: launch one hot-path kernel `reps` times on the engine's current state, mean duration in microseconds
- * (kind 0: fused g2p(frame-1)+p2g(frame), 1: g2p.grad(frame), 2: p2g.grad(frame), 3: p2g(frame)).  The rollout is not
- * usable afterwards (the replays accumulate into the grids).  profiles/tools/replay_ab.py */
-int plmpm_replay(plmpm_handle h, int kind, int frame, int reps, double* mean_us);
-/* the same for the substep loop of a whole env step, frames [first, first + n): dir 0 forward, 1 reverse; graph 0: launched
- * eagerly `reps` times, 1: `reps` replays of one captured hipGraph (what the launch boundaries cost, on identical work) */
-int plmpm_replay_step(plmpm_handle h, int graph, int dir, int first, int n, int reps, double* mean_us);
-/* Measured HBM roof of the device the buffers live on: a 16-byte-per-lane copy src -> dst and a read-only sweep of
- * `bytes` bytes, best of `reps` runs, in GB/s of bytes moved (bench.py reports it next to the 8 TB/s spec). */
-int plmpm_measure_hbm(void* src, void* dst, size_t bytes, int reps, void* hip_stream, double* copy_gbs, double* read_gbs);
-/* storage order: perm[i] = original particle index stored at sorted slot i */
-int plmpm_get_order(plmpm_handle h, int32_t* perm);
 
 #ifdef __cplusplus
 }

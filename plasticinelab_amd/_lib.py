@@ -1,4 +1,4 @@
-"""ctypes binding of libplmpm.so (include/plmpm.h).
+"""ctypes binding of libplmpm.so (include/plmpm.h; the tools of include/plmpm_tools.h for bench.py / profiles / tests).
 
 There is no fallback: if the HIP library is missing or fails to load, importing
 the engine raises.  Build it with ``python -c "import __graft_entry__ as g; g.build()"``
@@ -44,7 +44,8 @@ class Workspace(C.Structure):
                 ("grid_bytes", C.c_size_t), ("misc_bytes", C.c_size_t)]
 
 
-# every symbol include/plmpm.h declares: name -> (restype, argtypes)
+# every symbol include/plmpm.h (the boundary) and include/plmpm_tools.h (measurement, diagnostics, test hooks) declare:
+# name -> (restype, argtypes)
 _P, _I, _D = C.c_void_p, C.c_int, C.c_double
 SYMBOLS = {
     "plmpm_last_error": (C.c_char_p, []),
@@ -102,7 +103,7 @@ SYMBOLS = {
     "plmpm_halo_peer_setup": (_I, [_P, _I, _I, _P, _P, _P, _P]),
     "plmpm_halo_peer_exchange": (_I, [_P, _I, _I]),
     "plmpm_peer_status": (_I, [_P, C.POINTER(_I)]),
-    "plmpm_halo_peer_reset": (_I, [_P]),
+    "plmpm_halo_peer_reset": (_I, [_P, _I]),
     "plmpm_peer_memory_kind": (_I, [_P, C.POINTER(_I)]),
     "plmpm_debug_peer_spoil": (_I, [_P, _D]),
     "plmpm_slab_step": (_I, [_P, _I, _I]),

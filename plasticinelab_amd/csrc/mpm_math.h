@@ -66,107 +66,22 @@
 
 namespace plb {
 
-// ---------------------------------------------------------------- lane packs
-// Everything below is written for a "lane value" T: a scalar (float, double) or a pack of TWO particles' values per
-// GPU lane (P2 = two floats; positions D2 = two doubles, stencil bases I2 = two ints, conditions M2 = two bools).  A
-// wave64 fp32 instruction takes 4 cycles on a 16-lane SIMD of this part and only the packed forms (v_pk_fma_f32,
-// v_pk_mul_f32, v_pk_add_f32: two fp32 operations per lane in ~5 cycles) reach the vector peak; with two particles
-// per lane every add / multiply / fma of the per-particle arithmetic pairs up for free (the operands of the two
-// particles sit in the two halves of one 64-bit register pair by construction).  Conditions are therefore never
-// branched on per value: `sel(cond, a, b)` picks per component, `any(cond)` guards work that is rare.
-#if defined(__HIPCC__)
-typedef float plb_f2 __attribute__((ext_vector_type(2)));
-#endif
-struct M2 { bool x, y; };
-struct I2 {
-    int x, y;
-    PLB_HD I2() {}
-    PLB_HD I2(int a) : x(a), y(a) {}
-    PLB_HD I2(int a, int b) : x(a), y(b) {}
-};
-struct D2 {
-    double x, y;
-    PLB_HD D2() {}
-    PLB_HD D2(double a) : x(a), y(a) {}
-    PLB_HD D2(double a, double b) : x(a), y(b) {}
-    PLB_HD double lo() const { return x; }
-    PLB_HD double hi() const { return y; }
-};
-struct P2 {
-#if defined(__HIPCC__)
-    plb_f2 v;
-    PLB_HD P2() {}
-    PLB_HD P2(float a) : v{a, a} {}
-    PLB_HD P2(float a, float b) : v{a, b} {}
-    PLB_HD explicit P2(plb_f2 a) : v(a) {}
-    PLB_HD float lo() const { return v.x; }
-    PLB_HD float hi() const { return v.y; }
-#else
-    float a_, b_;
-    PLB_HD P2() {}
-    PLB_HD P2(float a) : a_(a), b_(a) {}
-    PLB_HD P2(float a, float b) : a_(a), b_(b) {}
-    PLB_HD float lo() const { return a_; }
-    PLB_HD float hi() const { return b_; }
-#endif
-};
-#if defined(__HIPCC__)
-PLB_HD P2 operator+(P2 a, P2 b) { return P2(a.v + b.v); }
-PLB_HD P2 operator-(P2 a, P2 b) { return P2(a.v - b.v); }
-PLB_HD P2 operator*(P2 a, P2 b) { return P2(a.v * b.v); }
-PLB_HD P2 operator-(P2 a) { return P2(-a.v); }
-#else
-PLB_HD P2 operator+(P2 a, P2 b) { return P2(a.lo() + b.lo(), a.hi() + b.hi()); }
-PLB_HD P2 operator-(P2 a, P2 b) { return P2(a.lo() - b.lo(), a.hi() - b.hi()); }
-PLB_HD P2 operator*(P2 a, P2 b) { return P2(a.lo() * b.lo(), a.hi() * b.hi()); }
-PLB_HD P2 operator-(P2 a) { return P2(-a.lo(), -a.hi()); }
-#endif
-PLB_HD P2 operator/(P2 a, P2 b) { return P2(a.lo() / b.lo(), a.hi() / b.hi()); }
-PLB_HD P2& operator+=(P2& a, P2 b) { a = a + b; return a; }
-PLB_HD P2& operator-=(P2& a, P2 b) { a = a - b; return a; }
-PLB_HD P2& operator*=(P2& a, P2 b) { a = a * b; return a; }
-PLB_HD M2 operator<(P2 a, P2 b) { return M2{a.lo() < b.lo(), a.hi() < b.hi()}; }
-PLB_HD M2 operator>(P2 a, P2 b) { return M2{a.lo() > b.lo(), a.hi() > b.hi()}; }
-PLB_HD M2 operator<=(P2 a, P2 b) { return M2{a.lo() <= b.lo(), a.hi() <= b.hi()}; }
-PLB_HD M2 operator>=(P2 a, P2 b) { return M2{a.lo() >= b.lo(), a.hi() >= b.hi()}; }
-PLB_HD M2 operator==(P2 a, P2 b) { return M2{a.lo() == b.lo(), a.hi() == b.hi()}; }
-PLB_HD M2 operator!=(P2 a, P2 b) { return M2{a.lo() != b.lo(), a.hi() != b.hi()}; }
-PLB_HD D2 operator+(D2 a, D2 b) { return D2(a.x + b.x, a.y + b.y); }
-PLB_HD D2 operator-(D2 a, D2 b) { return D2(a.x - b.x, a.y - b.y); }
-PLB_HD D2 operator*(D2 a, D2 b) { return D2(a.x * b.x, a.y * b.y); }
-PLB_HD D2 operator/(D2 a, D2 b) { return D2(a.x / b.x, a.y / b.y); }
-PLB_HD M2 operator<(D2 a, D2 b) { return M2{a.x < b.x, a.y < b.y}; }
-PLB_HD M2 operator>(D2 a, D2 b) { return M2{a.x > b.x, a.y > b.y}; }
-PLB_HD M2 operator&&(M2 a, M2 b) { return M2{a.x && b.x, a.y && b.y}; }
-PLB_HD M2 operator||(M2 a, M2 b) { return M2{a.x || b.x, a.y || b.y}; }
-PLB_HD M2 operator!(M2 a) { return M2{!a.x, !a.y}; }
-PLB_HD I2 operator+(I2 a, I2 b) { return I2(a.x + b.x, a.y + b.y); }
-PLB_HD I2 operator-(I2 a, I2 b) { return I2(a.x - b.x, a.y - b.y); }
-
+// ---------------------------------------------------------------- lane values
+// The arithmetic below is written for a "lane value" T (float or double) without data-dependent branches on values:
+// `sel(cond, a, b)` picks, `any(cond)` guards work that is rare.  (Round 3 also instantiated it for packs of two
+// particles per lane -- v_pk_*_f32 -- which needed 25 % fewer vector instructions and ran 25 % slower at half the
+// occupancy; that variant left the tree in round 5, see profiles/r03_notes.md and git history.)
 // what belongs to a lane value T: its scalar, its condition type, the integer pack of its stencil base
 template <class T> struct Lane { typedef T scalar; typedef bool mask; typedef int ivec; };
-template <> struct Lane<P2> { typedef float scalar; typedef M2 mask; typedef I2 ivec; };
-template <> struct Lane<D2> { typedef double scalar; typedef M2 mask; typedef I2 ivec; };
 
 PLB_HD float sel(bool c, float a, float b) { return c ? a : b; }
 PLB_HD double sel(bool c, double a, double b) { return c ? a : b; }
 PLB_HD int sel(bool c, int a, int b) { return c ? a : b; }
-PLB_HD P2 sel(M2 c, P2 a, P2 b) { return P2(c.x ? a.lo() : b.lo(), c.y ? a.hi() : b.hi()); }
-PLB_HD D2 sel(M2 c, D2 a, D2 b) { return D2(c.x ? a.x : b.x, c.y ? a.y : b.y); }
-PLB_HD I2 sel(M2 c, I2 a, I2 b) { return I2(c.x ? a.x : b.x, c.y ? a.y : b.y); }
 PLB_HD bool any(bool c) { return c; }
-PLB_HD bool any(M2 c) { return c.x || c.y; }
 // conversions between the value kinds of one lane layout
 template <class To, class From> PLB_HD To cvt(From v) { return (To)v; }
-template <> PLB_HD D2 cvt<D2, P2>(P2 v) { return D2((double)v.lo(), (double)v.hi()); }
-template <> PLB_HD P2 cvt<P2, D2>(D2 v) { return P2((float)v.x, (float)v.y); }
-template <> PLB_HD D2 cvt<D2, I2>(I2 v) { return D2((double)v.x, (double)v.y); }
-template <> PLB_HD D2 cvt<D2, float>(float v) { return D2((double)v); }
-template <> PLB_HD D2 cvt<D2, double>(double v) { return D2(v); }
-template <> PLB_HD D2 cvt<D2, int>(int v) { return D2((double)v); }
 PLB_HD int to_int(double v) { return (int)v; }
 PLB_HD int to_int(float v) { return (int)v; }
-PLB_HD I2 to_int(D2 v) { return I2((int)v.x, (int)v.y); }
 
 // ---------------------------------------------------------------- scalar helpers
 template <class T> PLB_HD T t_sqrt(T x);
@@ -227,12 +142,6 @@ template <> PLB_HD float t_expm1_fast<float>(float e) {
     return __expf(e) - 1.0f;
 }
 #endif
-// the same helpers for a pack: component by component (the hardware has no packed transcendentals)
-#define PLB_P2_MAP1(fn) template <> PLB_HD P2 fn<P2>(P2 x) { return P2(fn<float>(x.lo()), fn<float>(x.hi())); }
-PLB_P2_MAP1(t_sqrt) PLB_P2_MAP1(t_exp) PLB_P2_MAP1(t_log) PLB_P2_MAP1(t_log1p) PLB_P2_MAP1(t_expm1)
-PLB_P2_MAP1(t_rcp) PLB_P2_MAP1(t_rsqrt) PLB_P2_MAP1(t_fsqrt) PLB_P2_MAP1(t_log1p_fast) PLB_P2_MAP1(t_expm1_fast)
-#undef PLB_P2_MAP1
-template <> PLB_HD D2 t_sqrt<D2>(D2 x) { return D2(sqrt(x.x), sqrt(x.y)); }
 template <class T> PLB_HD T t_abs(T x) { return sel(x < T(0), -x, x); }
 template <class T> PLB_HD T t_max(T a, T b) { return sel(a > b, a, b); }
 template <class T> PLB_HD T t_min(T a, T b) { return sel(a < b, a, b); }
@@ -250,7 +159,6 @@ template <> struct Tol<double> {
     static PLB_HD double dd() { return 1e-4; }
     static PLB_HD double small_angle() { return 1e-12; }
 };
-template <> struct Tol<P2> : Tol<float> {};
 
 // ---------------------------------------------------------------- 3x3 helpers (row major)
 template <class T> PLB_HD void mat_mul(const T* a, const T* b, T* c) {          // c = a b
@@ -697,8 +605,6 @@ template <class T> PLB_HD T dd_log(T a, T b) {       // (log a - log b)/(a - b),
     return t_log1p_fast(t) * t_rcp(t * b);
 }
 
-template <> PLB_HD P2 dd_exp<P2>(P2 a, P2 b) { return P2(dd_exp<float>(a.lo(), b.lo()), dd_exp<float>(a.hi(), b.hi())); }
-template <> PLB_HD P2 dd_log<P2>(P2 a, P2 b) { return P2(dd_log<float>(a.lo(), b.lo()), dd_log<float>(a.hi(), b.hi())); }
 
 // VJP of (new_F, stress) w.r.t. F_tmp: returns Ft_adj = d<GF,new_F>/dFt + d<GS,stress>/dFt.
 // Replaces p2g.grad's U/sig/V adjoints + svd_grad    (mpm_simulator.py:92-115, :276-277)

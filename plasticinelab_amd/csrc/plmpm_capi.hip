@@ -85,9 +85,11 @@ __global__ void k_copy_frame(char* state, size_t frame_bytes, int src, int dst) 
 
 // global += local; local = 0   (pose adjoints after the cross-rank sum)
 // dst += src (the neighbour's copy of exchanged block planes, fields that no grid kernel adds on first touch)
+// (src may be a receive area of the device-side exchange, written by a neighbour GPU: system-scope load, as every other reader
+// of those areas -- plmpm_peer.hip -- so that the fine-grained fallback allocation cannot serve a stale cache line either)
 template <class T> __global__ void k_add_region(T* dst, const T* src, size_t n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) dst[i] += src[i];
+    if (i < n) dst[i] += __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 template <class T> __global__ void k_grid_stats(Dev<T> D, unsigned long long* out) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -103,61 +105,12 @@ static const HaloIn kNoHalo = {0, {0, 0}, {0, 0}, {nullptr, nullptr}, 0};
 // workgroups at the head of every k_p2g_grad launch that finish grid_op.grad's pose adjoints (64 waves: the blocks in
 // contact with a manipulator number a few dozen)
 constexpr int kPoseWG = PLB_POSE_WG;
-constexpr int kClearWG = 64;
 static inline int nblocks_grid(const plmpm_sim* s) { return (s->nblk + (kBlock / 64) - 1) / (kBlock / 64); }
 // persistent grid kernels: a fixed number of workgroups, each striding over its share of the block flags
 static inline int nwg_grid(const plmpm_sim* s) { return s->gwg; }
 
-#ifndef PLB_PK_DEFAULT
-#define PLB_PK_DEFAULT 0
-#endif
-#ifndef PLB_FUSE_GRID_DEFAULT
-#define PLB_FUSE_GRID_DEFAULT 0      // measured (round 3, profiles/r03_notes.md): not yet faster than the grid kernels at config 3
-#endif
-#if PLB_EXPERIMENTAL
-// clear arguments for the grids of frame `frame` (fused-grid engines)
-template <class T> static ClearArgs<T> clear_args(const plmpm_sim* s, int frame) {
-    ClearArgs<T> A;
-    memset(&A, 0, sizeof A);
-    A.frame = frame;
-    if (frame < 0) return A;
-    const Dev<T> Df = make_dev<T>(s, frame, true);
-    A.nwg = nblocks_particles(s, frame);
-    A.nwg_clear = 0;
-    for (int c = 0; c < 4; ++c) A.gin[c] = Df.gin[c];
-    for (int c = 0; c < 3; ++c) A.goa[c] = Df.goa[c];
-    A.flags = Df.flags;
-    return A;
-}
-// the frame a fused-grid reverse substep left behind, when no g2p.grad of the frame before it follows
-template <class T> static int fg_flush_t(plmpm_sim* s) {
-    if (s->fg_pending < 0) return 0;
-    const int f = s->fg_pending;
-    Dev<T> D = make_dev<T>(s, f, true);
-    hipLaunchKernelGGL((k_clear_boxes<T>), dim3(nblocks_particles(s, f)), dim3(kBlock), 0, s->stream, D, clear_args<T>(s, f));
-    s->dirty[f] = 0;
-    s->fg_pending = -1;
-    return 0;
-}
-#define FG_FLUSH(s) do { if ((s)->fg_pending >= 0) fg_flush_t<T>(s); } while (0)
-#else
-#define FG_FLUSH(s) do {} while (0)
-#endif
-
 template <class T> static int substep_fwd(plmpm_sim* s, int f) {
-    FG_FLUSH(s);
     Dev<T> D = make_dev<T>(s, f);
-#if PLB_EXPERIMENTAL
-    if (s->fg) {                 // p2g | g2p with grid_op in its tile fill
-        if (s->dirty[f]) LAUNCH(s, K_CLEAR, (k_clear_active<T>), dim3(nblocks_grid(s)), D);
-        LAUNCH_P2G(s, K_P2G, true, D, f);
-        s->dirty[f] = 1;
-        LAUNCH(s, K_FG_G2P, (k_g2p<T, true>), dim3(nblocks_particles(s, f)), D, f);
-        s->vnear[f] = 1;
-        return 0;
-    }
-#endif
-    s->vnear[f] = 0;
     if (s->store) {
         if (s->dirty[f]) LAUNCH(s, K_CLEAR, (k_clear_active<T>), dim3(nblocks_grid(s)), D);   // frame reused without a backward pass
         LAUNCH_P2G(s, K_P2G, true, D, f);
@@ -175,30 +128,6 @@ template <class T> static int substep_bwd(plmpm_sim* s, int f) {
     const int src = (f + 1) & 1, dst = f & 1;
     // frame f+1 re-sorted by the env step that starts there: its v in THIS frame's order was kept aside
     const T* vnext = s->frame_epoch[f + 1] != s->frame_epoch[f] ? (const T*)(s->vend + (size_t)s->frame_epoch[f + 1] * 3 * s->Npad * s->tsz) : nullptr;
-#if PLB_EXPERIMENTAL
-    if (s->fg && s->dirty[f]) {
-        // g2p.grad (+ grid_op in its tile fill, + the clear of frame f+1's grids) | p2g.grad (+ grid_op.grad in its tile fill)
-        const bool chained = s->fg_pending == f + 1;
-        if (!chained) {
-            FG_FLUSH(s);
-            hipMemsetAsync(s->contact, 0, 4, s->stream);                          // both contact counters: no g2p.grad reset them
-            hipMemsetAsync(s->contact + s->nblk + 1, 0, 4, s->stream);
-        }
-        ++s->contact_stamp;                  // (the marks start at 0 and the first stamp is 1)
-        Dev<T> Dg = make_dev<T>(s, f, true);
-        ClearArgs<T> ca = clear_args<T>(s, chained ? f + 1 : -1);
-        ca.nwg_clear = chained ? kClearWG : 0;                            // workgroups at the head of the launch do the clear
-        const int nwg = nblocks_particles(s, f) + ca.nwg_clear;
-        if (s->vnear[f]) LAUNCH(s, K_FG_G2P_GRAD, (k_g2p_grad<T, false, 1 + NEAR_LOAD>), dim3(nwg), Dg, f, src, dst, vnext, ca);
-        else LAUNCH(s, K_FG_G2P_GRAD, (k_g2p_grad<T, false, 1 + NEAR_EVAL>), dim3(nwg), Dg, f, src, dst, vnext, ca);
-        if (chained) s->dirty[f + 1] = 0;
-        LAUNCH(s, K_FG_P2G_GRAD, (k_p2g_grad<T, true>), dim3(nblocks_particles(s, f) + kPoseWG), Dg, f, src, dst, kPoseWG);
-        s->fg_pending = f;                   // dirty[f] stays set until the frame's grids are cleared
-        s->adj_frame[dst] = f;
-        return 0;
-    }
-#endif
-    FG_FLUSH(s);
     if (!(s->store && s->dirty[f])) {        // this frame's grid is not resident: recompute it (mpm_simulator.py:265-268)
         LAUNCH_P2G(s, K_P2G_RE, false, D, f);
         LAUNCH(s, K_GRID_OP_RE, (k_grid_op<T, false>), dim3(nwg_grid(s)), D, f, kNoHalo);
@@ -213,53 +142,14 @@ template <class T> static int substep_bwd(plmpm_sim* s, int f) {
 
 // Whole env step forward in store mode: p2g(f0) | grid_op(f0) | [g2p(f-1)+p2g(f) fused | grid_op(f)] ... | g2p(last)
 template <class T> static int step_fwd_fused(plmpm_sim* s, int first, int n) {
-    FG_FLUSH(s);
-#if PLB_EXPERIMENTAL
-    if (s->fg) {                 // p2g(f0) | [g2p(f-1) + p2g(f) with grid_op(f-1) in the tile fill] ... | g2p(last) with grid_op(last)
-        for (int f = first; f < first + n; ++f) {
-            Dev<T> D = make_dev<T>(s, f);
-            if (s->dirty[f]) LAUNCHG_CLEAR(s, D);
-            if (f == first) LAUNCH_P2G(s, K_P2G, true, D, f);
-            else {
-                PrevGrid<T> pg;
-                memset(&pg, 0, sizeof pg);
-                for (int c = 0; c < 4; ++c) pg.gin[c] = (const T*)(s->gstore + (size_t)(f - 1) * s->gstride) + (size_t)c * s->G;
-                pg.vout = (const Vec4<T>*)(s->vstore + (size_t)(f - 1) * s->gstride);      // nodes near a primitive; all nodes of boxes that exceed the LDS tile
-                s->vnear[f - 1] = 1;
-                if constexpr (sizeof(T) == 4) {
-                    if (s->pk) { LAUNCHB(s, K_FG_G2P_P2G, (k_g2p_p2g_pk<true>), dim3(nblocks_particles(s, f)), kBlockPk, D, f, pg); }
-                    else LAUNCH(s, K_FG_G2P_P2G, (k_g2p_p2g<T, false, true>), dim3(nblocks_particles(s, f)), D, f, pg);
-                } else LAUNCH(s, K_FG_G2P_P2G, (k_g2p_p2g<T, false, true>), dim3(nblocks_particles(s, f)), D, f, pg);
-            }
-            s->dirty[f] = 1;
-        }
-        Dev<T> D = make_dev<T>(s, first + n - 1);
-        LAUNCH(s, K_FG_G2P, (k_g2p<T, true>), dim3(nblocks_particles(s, first + n - 1)), D, first + n - 1);
-        s->vnear[first + n - 1] = 1;
-        return 0;
-    }
-#endif
     for (int f = first; f < first + n; ++f) {
         Dev<T> D = make_dev<T>(s, f);
-        s->vnear[f] = 0;
         if (s->dirty[f]) LAUNCHG_CLEAR(s, D);
         if (f == first) {
             LAUNCH_P2G(s, K_P2G, true, D, f);
         } else {
             const Vec4<T>* vprev = (const Vec4<T>*)(s->vstore + (size_t)(f - 1) * s->gstride);
-            bool done = false;
-#if PLB_EXPERIMENTAL
-            if constexpr (sizeof(T) == 4) {
-                if (s->pk) {
-                    PrevGrid<T> pg;
-                    memset(&pg, 0, sizeof pg);
-                    pg.vout = vprev;
-                    LAUNCHB(s, K_G2P_P2G, (k_g2p_p2g_pk<false>), dim3(nblocks_particles(s, f)), kBlockPk, D, f, pg);
-                    done = true;
-                }
-            }
-#endif
-            if (!done) LAUNCH_G2P_P2G(s, D, f, vprev);
+            LAUNCH_G2P_P2G(s, D, f, vprev);
         }
         LAUNCH(s, K_GRID_OP, (k_grid_op<T, false>), dim3(nwg_grid(s)), D, f, s->halo_in[PLMPM_HALO_GRID_IN]);
         s->dirty[f] = 1;
@@ -271,7 +161,6 @@ template <class T> static int step_fwd_fused(plmpm_sim* s, int first, int n) {
 
 // phase-split variants used by the multi-GPU driver (store_grid mode only)
 template <class T> static int phase_p2g(plmpm_sim* s, int f) {
-    FG_FLUSH(s);
     Dev<T> D = make_dev<T>(s, f);
     if (s->dirty[f]) LAUNCH(s, K_CLEAR, (k_clear_active<T>), dim3(nblocks_grid(s)), D);
     LAUNCH_P2G(s, K_P2G, true, D, f);
@@ -285,7 +174,6 @@ template <class T> static int phase_grid_g2p(plmpm_sim* s, int f, bool defer_g2p
     s->frame_epoch[f + 1] = s->frame_epoch[f];                 // g2p (now or fused into the next p2g) writes frame f + 1 in this order
     HaloIn H = s->halo_in[PLMPM_HALO_GRID_IN];
     H.part = part;
-    s->vnear[f] = 0;
     LAUNCH(s, K_GRID_OP, (k_grid_op<T, false>), dim3(nwg_grid(s)), D, f, H);
     if (part == 1) return 0;
     if (!defer_g2p) LAUNCH(s, K_G2P, (k_g2p<T>), dim3(nblocks_particles(s, f)), D, f);
@@ -293,7 +181,6 @@ template <class T> static int phase_grid_g2p(plmpm_sim* s, int f, bool defer_g2p
 }
 // g2p(f-1), deferred by the previous phase_grid_g2p, fused with p2g(f) exactly as in step_fwd_fused
 template <class T> static int phase_g2p_p2g(plmpm_sim* s, int f) {
-    FG_FLUSH(s);
     Dev<T> D = make_dev<T>(s, f);
     if (s->dirty[f]) LAUNCHG_CLEAR(s, D);
     const Vec4<T>* vprev = (const Vec4<T>*)(s->vstore + (size_t)(f - 1) * s->gstride);
@@ -302,7 +189,6 @@ template <class T> static int phase_g2p_p2g(plmpm_sim* s, int f) {
     return 0;
 }
 template <class T> static int phase_grad_scatter(plmpm_sim* s, int f) {
-    FG_FLUSH(s);
     Dev<T> D = make_dev<T>(s, f);
     const T* vnext = s->frame_epoch[f + 1] != s->frame_epoch[f] ? (const T*)(s->vend + (size_t)s->frame_epoch[f + 1] * 3 * s->Npad * s->tsz) : nullptr;
     LAUNCH_G2P_GRAD(s, D, f, (f + 1) & 1, f & 1, vnext);
@@ -472,7 +358,7 @@ extern "C" {
 
 const char* plmpm_last_error(void) { return g_err.c_str(); }
 int plmpm_version(void) { return 1; }
-int plmpm_build_flags(void) { return (PLB_EXPERIMENTAL ? 1 : 0) | (PLB_FAST ? 2 : 0) | (PLB_XCD_MAP ? 4 : 0); }
+int plmpm_build_flags(void) { return (PLB_FAST ? 2 : 0) | (PLB_XCD_MAP ? 4 : 0); }
 
 int plmpm_create(const plmpm_config* cfg, const plmpm_primitive* prims, plmpm_handle* out) {
     REQUIRE(cfg && out, "null argument");
@@ -507,7 +393,7 @@ int plmpm_create(const plmpm_config* cfg, const plmpm_primitive* prims, plmpm_ha
     s->act_total = s->act_ofs[s->P];
     s->N = cfg->n_particles;
     const int cap = std::max(cfg->particle_capacity, cfg->n_particles);
-    s->Npad = (int)align_up(cap, kBlock);
+    s->Npad = (int)align_up(cap, kRowPad);
     s->n = cfg->n_grid; s->Gfull = (size_t)s->n * s->n * s->n;
     // grid window: the box of 4^3 blocks that is allocated and swept (all-zero grid_lo / grid_hi = the whole grid)
     for (int d = 0; d < 3; ++d) {
@@ -567,22 +453,9 @@ int plmpm_create(const plmpm_config* cfg, const plmpm_primitive* prims, plmpm_ha
     s->store = cfg->store_grid != 0;
     s->gstride = align_up(s->G * 4 * s->tsz, 256);
     if (s->store) s->ws.grid_bytes += 2 * (size_t)s->F * s->gstride + align_up((size_t)s->F * s->nflag * 4, 256);
-    s->ws.grid_bytes += align_up((size_t)(s->F + 1) * (s->Npad / kBlock) * 8 * 4, 256) + align_up((size_t)2 * (s->nblk + 1) * 4, 256);
-    // fused-grid path (grid_op inside the particle kernels' tile fills): one GPU, grid store, floating-point atomics.
-    // PLMPM_FUSE_GRID=0 keeps the grid kernels (A/B measurements, and the reference for the parity test of the fused path)
-    {
-        const char* e = getenv("PLMPM_FUSE_GRID");
-        const bool want = e ? e[0] != '0' : (PLB_FUSE_GRID_DEFAULT != 0);
-        s->fg = PLB_EXPERIMENTAL && s->store && !s->dist && cfg->deterministic == 0 && want;
-    }
-    if (s->fg) s->ws.grid_bytes += align_up(s->G * 4 * s->tsz, 256) + align_up((size_t)s->nblk * 4, 256);
+    s->ws.grid_bytes += align_up((size_t)(s->F + 1) * (s->Npad / kBlock) * 8 * 4, 256) + align_up((size_t)(s->nblk + 1) * 4, 256);
     s->ws.grid_bytes += align_up((size_t)(s->F + 1) * kMaxPrim * sizeof(PrimT<double>), 256);
-    {
-        const char* e = getenv("PLMPM_PK");
-        s->pk = PLB_EXPERIMENTAL && cfg->dtype == PLMPM_F32 && cfg->deterministic == 0 && (e ? e[0] != '0' : (PLB_PK_DEFAULT != 0));
-    }
     s->dirty.assign(s->F + 1, 0);
-    s->vnear.assign(s->F + 1, 0);
     s->ws.misc_bytes = 2 * align_up((size_t)(s->F + 1) * P1 * 7 * 8, 256) + 2 * align_up((size_t)(s->F + 1) * P1 * 8 * 8, 256)  // poses(+adj), padded
                        + 4 * align_up((size_t)(s->F + 1) * P1 * 3 * 8, 256)                       // v,w (+adj)
                        + 4 * align_up((size_t)(s->F + 1) * P1 * 8, 256)                           // gap, gap_vel (+adj)
@@ -661,11 +534,7 @@ int plmpm_bind_workspace(plmpm_handle s, void* state, void* adjoint, void* grid,
         s->fstore = (int*)take((size_t)s->F * s->nflag * 4);
     }
     s->tiles = (int*)take((size_t)(s->F + 1) * (s->Npad / kBlock) * 8 * 4);
-    s->contact = (int*)take((size_t)2 * (s->nblk + 1) * 4);
-    if (s->fg) {
-        s->grid_out_adj2 = take(s->G * 4 * s->tsz);
-        s->contact_mark = (int*)take((size_t)s->nblk * 4);
-    }
+    s->contact = (int*)take((size_t)(s->nblk + 1) * 4);
     s->ptab = take((size_t)(s->F + 1) * kMaxPrim * sizeof(PrimT<double>));
     s->det_grid = s->det ? (long long*)take(s->G * 8 * 8) : nullptr;
     REQUIRE((size_t)(p - s->gridw) <= s->ws.grid_bytes, "internal: grid workspace overflow");
@@ -727,7 +596,7 @@ int plmpm_set_materials(plmpm_handle s, const double* mu, const double* lam, con
     bool uni = true;
     for (int i = 1; i < s->N && uni; ++i) uni = mu[i] == mu[0] && lam[i] == lam[0] && ys[i] == ys[0];
     s->mats_uniform = uni;
-    s->mats_u[0] = mu[0]; s->mats_u[1] = lam[0]; s->mats_u[2] = ys[0];
+    if (s->N > 0) { s->mats_u[0] = mu[0]; s->mats_u[1] = lam[0]; s->mats_u[2] = ys[0]; }      // (a slab rank may hold no rows)
     s->mats_filled = false;
     HIPCHK(hipMemcpyAsync(s->mats_master, mu, nb, hipMemcpyHostToDevice, s->stream));
     HIPCHK(hipMemcpyAsync(s->mats_master + s->N, lam, nb, hipMemcpyHostToDevice, s->stream));
@@ -1340,14 +1209,14 @@ extern "C" {
 int plmpm_replay_step(plmpm_handle s, int graph, int dir, int first, int n, int reps, double* mean_us) {
     NEED_BOUND(s);
     REQUIRE(mean_us && reps > 0 && first >= 0 && n > 1 && first + n <= s->F, "replay_step: bad arguments");
-    REQUIRE(s->store && !s->fg && !s->pk && !s->det && !s->prof, "replay_step: needs the per-frame grid store and the default engine, profiling off");
+    REQUIRE(s->store && !s->det && !s->prof, "replay_step: needs the per-frame grid store and the default engine, profiling off");
     return DISPATCH(s, replay_step_t, s, graph, dir, first, n, reps, mean_us);
 }
 int plmpm_replay(plmpm_handle s, int kind, int frame, int reps, double* mean_us) {
     NEED_BOUND(s);
     REQUIRE(mean_us && reps > 0 && kind >= 0 && kind <= 3, "replay: bad arguments");
     REQUIRE(frame >= (kind == 0 ? 1 : 0) && frame < s->F, "replay: frame %d out of range", frame);
-    REQUIRE(s->store && !s->fg && !s->pk, "replay: needs the per-frame grid store and the default engine");
+    REQUIRE(s->store, "replay: needs the per-frame grid store and the default engine");
     return DISPATCH(s, replay_t, s, kind, frame, reps, mean_us);
 }
 

@@ -15,19 +15,8 @@
 #include <vector>
 
 #include "../../include/plmpm.h"
-// Opt-in engine variants that lost their measurements (round 3: two particles per lane with packed fp32, plmpm_kernels_pk.h;
-// grid_op / grid_op.grad folded into the particle kernels' tile fills) are compiled only into the EXPERIMENTAL build of the
-// library (make experimental -> libplmpm_experimental.so, -DPLB_EXPERIMENTAL=1; tests/test_gpu_fused_grid.py runs against
-// it through PLMPM_LIB).  The default libplmpm.so carries the five hot kernels x {float, double} (+ the deterministic
-// instantiations) and nothing else on the hot path.
-#ifndef PLB_EXPERIMENTAL
-#define PLB_EXPERIMENTAL 0
-#endif
-#if PLB_EXPERIMENTAL
-#include "plmpm_kernels_pk.h"
-#else
+#include "../../include/plmpm_tools.h"       // measurement / diagnostics / test hooks: same library, not the boundary
 #include "plmpm_kernels.h"
-#endif
 
 // plmpm_sort.hip
 extern "C" size_t plmpm_sort_temp_bytes(int n);
@@ -114,20 +103,7 @@ struct plmpm_sim {
     char* vstore = nullptr;      // grid_v_out per frame (AoS T4)
     int* fstore = nullptr;
     int* contact = nullptr;      // [0] = n, [1..n]: blocks whose pose adjoints k_grid_op_grad left to the k_p2g_grad launch
-                                 // (two lists of nblk + 1: fused-grid engines alternate between them, frame by frame)
-    // Fused-grid engines (one GPU, grid store, not deterministic): grid_op / grid_op.grad are evaluated inside the tile
-    // fills of the particle kernels (plmpm_kernels.h: fg_node_vout / fg_node_gadj) -- 1 launch per forward substep and 2
-    // per reverse substep instead of 2 and 3.  The grids of the frame the last reverse substep finished with
-    // (fg_pending) are cleared by the next g2p.grad, or by k_clear_boxes when something else comes first.
-    bool fg = false;
-    int fg_pending = -1;
-    std::vector<char> vnear;         // frame f: grid_v_out / contact bit of the nodes near a primitive are in the frame's grid_v_out store
-    // two particles per lane with packed fp32 arithmetic (plmpm_kernels_pk.h): fp32 engines, floating-point atomics
-    bool pk = false;
-    char* grid_out_adj2 = nullptr;   // second grid_v_out.grad buffer (frames alternate)
-    char* ptab = nullptr;            // [(F+1)][kMaxPrim] PrimT<T>: the primitives per substep, for the fills (k_build_prims)
-    int* contact_mark = nullptr;     // [nblk] stamp of the g2p.grad launch that last listed the block as in contact
-    int contact_stamp = 0;
+    char* ptab = nullptr;            // [(F+1)][kMaxPrim] PrimT<T>: the primitives per substep, for the grid kernels (k_build_prims)
     int* tiles = nullptr;        // per-frame stencil boxes of the particle workgroups: [(F+1)][Npad/256][8]
     // Per-env-step storage order ("epochs").  Epoch 0 is the order chosen at reset (perm_d).  With cfg.resort_steps,
     // plmpm_step re-sorts the step's first frame along the Hilbert curve before it starts (epoch = step index); the
@@ -176,11 +152,10 @@ struct plmpm_sim {
 };
 
 enum KernelId { K_P2G = 0, K_GRID_OP, K_G2P, K_P2G_RE, K_GRID_OP_RE, K_G2P_GRAD, K_GRID_OP_GRAD, K_P2G_GRAD, K_CLEAR, K_G2P_P2G,
-                // fused-grid engines: the same particle kernels with grid_op / grid_op.grad evaluated in their tile fills
-                K_FG_G2P, K_FG_G2P_P2G, K_FG_G2P_GRAD, K_FG_P2G_GRAD, K_HALO_XCHG, K_COUNT };
+                K_HALO_XCHG, K_COUNT };
 static const char* kKernelNames[K_COUNT] = {"p2g", "grid_op", "g2p", "p2g_recompute", "grid_op_recompute",
                                             "g2p_grad", "grid_op_grad", "p2g_grad", "clear_active", "g2p_p2g",
-                                            "gridop+g2p", "gridop+g2p_p2g", "gridop+g2p_grad", "gridop_grad+p2g_grad", "halo_exchange"};
+                                            "halo_exchange"};
 
 static void prof_begin(plmpm_sim* s, int id) {
     if (!s->prof) return;
@@ -197,8 +172,13 @@ static void prof_end(plmpm_sim* s) {
     if (!s->prof) return;
     (void)hipEventRecord(s->ev_pool[s->ev_used.back().second + 1], s->stream);
 }
-// Experiment hook (profiles/r04_notes.md): PLB_DYNLDS="kernel:bytes,..." adds dynamic LDS to a kernel's launches, which
-// lowers the workgroups a CU can hold -- how much does each kernel's time depend on its occupancy?  Read once; 0 otherwise.
+// Experiment hook (profiles/r04_notes.md), compiled only with -DPLB_DYNLDS_HOOK=1: the environment variable
+// PLB_DYNLDS="kernel:bytes,..." adds dynamic LDS to a kernel's launches, which lowers the workgroups a CU can hold -- how much
+// does each kernel's time depend on its occupancy?  The product build launches with 0 bytes and never reads the environment.
+#ifndef PLB_DYNLDS_HOOK
+#define PLB_DYNLDS_HOOK 0
+#endif
+#if PLB_DYNLDS_HOOK
 static inline unsigned dyn_lds(int id) {
     static unsigned tab[K_COUNT];
     static bool init = false;
@@ -221,6 +201,9 @@ static inline unsigned dyn_lds(int id) {
     }
     return tab[id];
 }
+#else
+static inline unsigned dyn_lds(int) { return 0; }
+#endif
 #define LAUNCHG_CLEAR(s, D) LAUNCH(s, K_CLEAR, (k_clear_active<T>), dim3(nblocks_grid(s)), D)
 #define LAUNCHB(s, id, kern, grid, block, ...)                                             \
     do {                                                                                   \
@@ -244,23 +227,17 @@ static inline unsigned dyn_lds(int id) {
     } while (0)
 #define LAUNCH_G2P_P2G(s, D, f, vprev)                                                                           \
     do {                                                                                                         \
-        PrevGrid<T> pg_;                                                                                         \
-        memset(&pg_, 0, sizeof pg_);                                                                             \
-        pg_.vout = vprev;                                                                                        \
         if ((s)->det) {                                                                                          \
-            LAUNCH(s, K_G2P_P2G, (k_g2p_p2g<T, true>), dim3(nblocks_particles(s, f)), D, f, pg_);                \
+            LAUNCH(s, K_G2P_P2G, (k_g2p_p2g<T, true>), dim3(nblocks_particles(s, f)), D, f, vprev);                \
             DET_RESOLVE(s, D.gin[0], D.gin[1], D.gin[2], D.gin[3]);                                              \
-        } else LAUNCH(s, K_G2P_P2G, (k_g2p_p2g<T>), dim3(nblocks_particles(s, f)), D, f, pg_);                   \
+        } else LAUNCH(s, K_G2P_P2G, (k_g2p_p2g<T>), dim3(nblocks_particles(s, f)), D, f, vprev);                   \
     } while (0)
 #define LAUNCH_G2P_GRAD(s, D, f, src, dst, vnext)                                                                \
     do {                                                                                                         \
-        ClearArgs<T> ca_;                                                                                        \
-        memset(&ca_, 0, sizeof ca_);                                                                             \
-        ca_.frame = -1;                                                                                          \
         if ((s)->det) {                                                                                          \
-            LAUNCH(s, K_G2P_GRAD, (k_g2p_grad<T, true>), dim3(nblocks_particles(s, f)), D, f, src, dst, vnext, ca_);  \
+            LAUNCH(s, K_G2P_GRAD, (k_g2p_grad<T, true>), dim3(nblocks_particles(s, f)), D, f, src, dst, vnext);  \
             DET_RESOLVE(s, D.goa[0], D.goa[1], D.goa[2], (T*)nullptr);                                           \
-        } else LAUNCH(s, K_G2P_GRAD, (k_g2p_grad<T>), dim3(nblocks_particles(s, f)), D, f, src, dst, vnext, ca_);     \
+        } else LAUNCH(s, K_G2P_GRAD, (k_g2p_grad<T>), dim3(nblocks_particles(s, f)), D, f, src, dst, vnext);     \
     } while (0)
 // p2g.grad with the pose adjoints of the blocks in contact: spare workgroups of the same launch, or -- deterministic
 // engines -- one wave walking the contact list in block order first
@@ -274,8 +251,7 @@ static inline unsigned dyn_lds(int id) {
 
 // ---------------------------------------------------------------------------------------------
 // frame >= 0 with the grid store on: that frame's own grid_in / flags; otherwise the shared scratch grid
-// fg: a launch of the fused-grid path -- the frame's parity picks the grid_v_out.grad buffer and the contact list
-template <class T> static Dev<T> make_dev(const plmpm_sim* s, int frame = -1, bool fg = false) {
+template <class T> static Dev<T> make_dev(const plmpm_sim* s, int frame = -1) {
     Dev<T> D;
     const plmpm_config& c = s->cfg;
     double dx = 1.0 / c.n_grid;
@@ -315,19 +291,12 @@ template <class T> static Dev<T> make_dev(const plmpm_sim* s, int frame = -1, bo
     const bool framed = s->store && frame >= 0;
     char* gin_base = framed ? s->gstore + (size_t)frame * s->gstride : s->grid_in;
     for (int c = 0; c < 4; ++c) D.gin[c] = (T*)gin_base + (size_t)c * s->G;
-    {
-        char* ga = s->grid_out_adj;
-        char* gb = s->grid_out_adj2 ? s->grid_out_adj2 : s->grid_out_adj;
-        if (fg && (frame & 1)) std::swap(ga, gb);
-        for (int c = 0; c < 3; ++c) { D.goa[c] = (T*)ga + (size_t)c * s->G; D.goa_prev[c] = (T*)gb + (size_t)c * s->G; }
-    }
+    for (int c = 0; c < 3; ++c) D.goa[c] = (T*)s->grid_out_adj + (size_t)c * s->G;
     D.grid_out = (Vec4<T>*)(framed ? s->vstore + (size_t)frame * s->gstride : s->grid_out);
     D.grid_in_adj = (Vec4<T>*)s->grid_in_adj;
     D.flags = framed ? s->fstore + (size_t)frame * s->nflag : s->flags;
     D.tiles = s->tiles;
-    D.contact = s->contact + ((fg && (frame & 1)) ? s->nblk + 1 : 0);
-    D.contact_next = s->contact + ((fg && (frame & 1)) ? 0 : s->nblk + 1);
-    D.contact_mark = s->contact_mark; D.stamp = s->contact_stamp;
+    D.contact = s->contact;
     D.ptab = (const PrimT<T>*)s->ptab;
     D.det = s->det_grid; D.det_stride = s->G;
     D.trace = (unsigned long long*)s->staging;      // profiling builds only (needs N * 24 * 8 >= 3 * 16384 * 128 bytes)

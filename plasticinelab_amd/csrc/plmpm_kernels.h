@@ -22,8 +22,18 @@
 
 namespace plb {
 
-constexpr int kBlock = 256;          // threads per workgroup in particle kernels: 256 particles per box.  Measured optimum (round 4: 512 -> -11 %,
-                                     // 128 -> -18 % substeps/s); NOT a tunable -- the 128 build also ends with another loss: something relies on it
+#ifndef PLB_KBLOCK
+#define PLB_KBLOCK 256
+#endif
+constexpr int kBlock = PLB_KBLOCK;   // threads per workgroup in particle kernels: 256 particles per box.  Measured optimum (round 4: 512 -> -11 %,
+                                     // 128 -> -18 % substeps/s).  What depends on it: the wave round-robin of the grid kernels (a power of two
+                                     // of waves), the per-wave box slots (kSred), and the row padding Npad -- the helper kernels of the library
+                                     // (re-sort, loss adjoint, frame I/O) run 256-thread workgroups over Npad / 256 chunks, so Npad is padded to
+                                     // a multiple of BOTH (round 4's -DPLB_KBLOCK=128 build padded to 128 only: the last 128 rows never
+                                     // reached those kernels, which is the "other loss" its notes report)
+static_assert(kBlock >= 64 && kBlock <= 1024 && (kBlock & (kBlock - 1)) == 0, "kBlock: a power of two of 64-lane waves");
+constexpr int kRowPad = kBlock > 256 ? kBlock : 256;       // frames are padded to whole workgroups of either size
+constexpr int kSred = (kBlock / 64) * 6 + 8;               // LDS ints of block_tile_publish / _collect: one box per wave
 // minimum waves per SIMD the register allocator must leave room for (second __launch_bounds__ argument)
 #ifndef PLB_P2G_WAVES
 #define PLB_P2G_WAVES 4
@@ -88,17 +98,13 @@ template <class T> struct Dev {
     T mat_u[3];
     T* gin[4];                       // grid_m, grid_v_in x/y/z (SoA, accumulated)
     T* goa[3];                       // grid_v_out.grad x/y/z (SoA, accumulated)
-    T* goa_prev[3];                  // fused-grid engines: the other of the two grid_v_out.grad buffers (frames alternate)
     Vec4<T>*grid_out, *grid_in_adj;  // AoS
     int* flags;
     int* tiles;                      // [(F+1)][workgroups][8]: stencil box of each 256-particle workgroup, per frame
     int* contact;                    // [0] = n, [1..n] = blocks whose pose adjoints are still due (grid_op.grad -> p2g.grad)
-    int* contact_next;               // fused-grid engines: the list of the frame before this one (its counter is reset here)
     const PrimT<T>* ptab;            // [(F+1)][kMaxPrim] the primitives as a grid node sees them during substep f (k_build_prims, once
-                                     // per env step behind the kinematics chain): the grid kernels and the fused-grid fills read them
-                                     // straight from here -- uniform addresses, no LDS copy, no per-workgroup set-up
-    int* contact_mark;               // fused-grid engines: [n_blocks] stamp of the launch that last put the block on a contact list
-    int stamp;                       //   this launch's stamp
+                                     // per env step behind the kinematics chain): the grid kernels read them straight from here --
+                                     // uniform addresses, no LDS copy, no per-workgroup set-up
     unsigned long long* trace;       // profiling builds only
     long long* det;                  // deterministic mode only (else null): two-limb fixed-point accumulators, [8][det_stride]
     size_t det_stride;               //   component c of a node: hi limb det[c * stride + idx], lo limb det[(4 + c) * stride + idx]
@@ -503,7 +509,7 @@ template <> __device__ __forceinline__ void seg_sum3<float>(float& a, float& b, 
 }
 #undef PLB_DPP_STEP
 
-// all threads call; valid == false for padding lanes.  sred: LDS int[6*4+8], written once per kernel.
+// all threads call; valid == false for padding lanes.  sred: LDS int[kSred], written once per kernel.
 // In two halves so that a kernel can put its own barrier between them: every wave publishes its box ...
 __device__ __forceinline__ void block_tile_publish(const int* base, bool valid, int* sred) {
     int lo[3], hi[3];
@@ -554,159 +560,6 @@ template <class T> __device__ __forceinline__ Tile load_tile(const Dev<T>& D, in
     return t;
 }
 
-
-// ---- grid_op folded into the particle kernels (fused-grid engines: one GPU, per-frame grid store) ----------------------
-// grid_op (mpm_simulator.py:189-221) is pointwise per node: v_out = f(grid_m, grid_v_in, poses).  Instead of a kernel
-// of its own between the scatter and the gather (a launch boundary + one latency-bound pass for 2 % of the bytes),
-// the kernels that gather v_out evaluate it while they fill their LDS tile from grid_m / grid_v_in -- redundantly for
-// nodes that lie in several workgroups' boxes (a node is in ~4.5 boxes at config 3), which costs ~1-2 % of their
-// vector work.  Likewise grid_op.grad: the tile fill of p2g.grad evaluates the pointwise adjoint from grid_v_out.grad
-// and the frame's own grid_m / grid_v_in.  Nothing is written back, so nothing can be cleared by the kernel that
-// reads it (other workgroups read the same nodes): frame f's grids are cleared by g2p.grad of frame f - 1, over the
-// stencil boxes of frame f's workgroups (clear_boxes), and the two grid_v_out.grad buffers alternate between frames.
-template <class T> struct PrevGrid {
-    const Vec4<T>* vout;             // grid_v_out of the previous substep (engines with grid kernels)
-    const T* gin[4];                 // grid_m / grid_v_in of the previous substep (fused-grid engines)
-};
-// v_out of node (ix, iy, iz) from grid_m / grid_v_in; .w = 1: the node is in contact with a movable primitive (its
-// pose adjoints are due in the reverse pass).  The expensive part -- collide, double-precision rigid-body geometry -- only
-// concerns the nodes within reach of a primitive (prim_within_reach), and is evaluated in the FORWARD pass only:
-//   NEAR_STORE (forward fills): every box node's {v_out, contact bit} also goes to the frame's grid_v_out store `vnear`
-//                               (every workgroup whose box holds the node writes the same four words: 16 B x ~4.5 per
-//                               node -- cheaper than evaluating v_out a second time in g2p.grad, measured round 3);
-//   NEAR_LOAD  (g2p.grad's fill): reads them back, exactly as an engine with grid kernels reads grid_v_out -- no
-//                               primitives, no grid_m / grid_v_in there -- and takes the contact bit from .w;
-//   NEAR_EVAL: evaluate, touch nothing (a frame whose forward substep did not run through a fused-grid kernel).
-// In two halves so that a kernel can put independent work (its in-wave sort, its particle loads) between the issue of
-// the grid loads and their first use: fg_node_load issues them, fg_node_eval computes.
-enum { NEAR_EVAL = 0, NEAR_STORE = 1, NEAR_LOAD = 2 };
-// Number of primitives a workgroup's fill has to look at: 0 when its whole stencil box lies outside every primitive's
-// reach (prim_within_reach, the same bound, taken for the box's nearest point) -- workgroup-uniform, so the ~95 % of the
-// workgroups that are nowhere near a manipulator skip the per-node culls altogether.
-template <class T> __device__ __forceinline__ int fg_box_prims(const Dev<T>& D, const PrimT<T>* sp, const Tile& t) {
-    if (PLB_FG_ABL & 1) return 0;
-    const float inv_n = 1.0f / (float)D.P.n;
-    bool near = false;
-    for (int p = 0; p < D.nprim; ++p) {
-        float d2 = 0.f;
-        for (int d = 0; d < 3; ++d) {
-            const float c = (float)sp[p].pos[d], lo = (float)t.o[d] * inv_n, hi = (float)(t.o[d] + t.e[d] - 1) * inv_n;
-            const float q = c < lo ? lo - c : (c > hi ? c - hi : 0.f);
-            d2 += q * q;
-        }
-        const float reach = sp[p].rb + (D.P.softness > T(0) ? 2.302585093f / (float)D.P.softness : 0.0f) + 2e-3f;     // node test: + 1e-3
-        near |= !(d2 > reach * reach);
-    }
-    return near ? D.nprim : 0;
-}
-template <class T> struct NodeIn { int idx; T m, mv[3]; };
-template <class T> __device__ __forceinline__ NodeIn<T> fg_node_load(const Dev<T>& D, const T* const* gin, int ix, int iy, int iz) {
-    NodeIn<T> n;
-    n.idx = node_index(D, ix, iy, iz);
-    n.m = gin[0][n.idx]; n.mv[0] = gin[1][n.idx]; n.mv[1] = gin[2][n.idx]; n.mv[2] = gin[3][n.idx];
-    return n;
-}
-template <int MODE, class T> __device__ __forceinline__ Vec4<T> fg_node_eval(const Dev<T>& D, const PrimT<T>* sp, int ix, int iy, int iz,
-                                                                              const NodeIn<T>& n, Vec4<T>* vnear, int np) {
-    const int idx = n.idx;
-    const T m = n.m;
-    const T mv[3] = {n.mv[0], n.mv[1], n.mv[2]};
-    T vo[3];
-    const int I[3] = {ix, iy, iz};
-    bool touch = false;
-    if (MODE == NEAR_EVAL) {
-        grid_node_fwd<T>(D.P, I, m, mv, np, sp, vo, &touch);
-        return Vec4<T>{vo[0], vo[1], vo[2], touch ? T(1) : T(0)};
-    }
-    const bool near = np > 0 && m > T(1e-12) && node_near_any(D.P, I, np, sp);
-    if (MODE == NEAR_LOAD && near) return vnear[idx];
-    grid_node_fwd<T>(D.P, I, m, mv, near ? np : 0, sp, vo, &touch);       // far nodes: no primitive passes its cull anyway
-    const Vec4<T> a{vo[0], vo[1], vo[2], touch ? T(1) : T(0)};
-    if (MODE == NEAR_STORE) vnear[idx] = a;            // every box node (see above: g2p.grad gathers from the store)
-    return a;
-}
-template <int MODE, class T> __device__ __forceinline__ Vec4<T> fg_node_vout(const Dev<T>& D, const T* const* gin, const PrimT<T>* sp, int ix, int iy, int iz,
-                                                                              Vec4<T>* vnear, int np, int* index = nullptr) {
-    const NodeIn<T> n = fg_node_load(D, gin, ix, iy, iz);
-    if (index) *index = n.idx;
-    return fg_node_eval<MODE>(D, sp, ix, iy, iz, n, vnear, np);
-}
-// {grid_v_in.grad, grid_m.grad} of node (ix, iy, iz) from grid_v_out.grad and the frame's grid_m / grid_v_in (the
-// pose adjoints of the nodes in contact are computed once per node elsewhere: pose_adjoint_blocks)
-template <class T> struct NodeAdjIn { int idx; T gm, mv[3], va[3]; };
-template <class T> __device__ __forceinline__ NodeAdjIn<T> fg_node_gadj_load(const Dev<T>& D, int ix, int iy, int iz) {
-    NodeAdjIn<T> n;
-    n.idx = node_index(D, ix, iy, iz);
-    n.gm = D.gin[0][n.idx];
-    for (int c = 0; c < 3; ++c) { n.mv[c] = D.gin[1 + c][n.idx]; n.va[c] = D.goa[c][n.idx]; }
-    return n;
-}
-template <class T> __device__ __forceinline__ Vec4<T> fg_node_gadj_eval(const Dev<T>& D, const PrimT<T>* sp, int ix, int iy, int iz, int np, const NodeAdjIn<T>& n) {
-    T ma, mva[3];
-    const int I[3] = {ix, iy, iz};
-    grid_node_bwd<T, false>(D.P, I, n.gm, n.mv, np, sp, n.va, &ma, mva, [](int, const PoseAdj<T>&, bool) {});
-    return Vec4<T>{mva[0], mva[1], mva[2], ma};
-}
-template <class T> __device__ __forceinline__ Vec4<T> fg_node_gadj(const Dev<T>& D, const PrimT<T>* sp, int ix, int iy, int iz, int np, int* index = nullptr) {
-    const NodeAdjIn<T> n = fg_node_gadj_load(D, ix, iy, iz);
-    if (index) *index = n.idx;
-    return fg_node_gadj_eval(D, sp, ix, iy, iz, np, n);
-}
-// a node in contact with a movable primitive: its block goes on the frame's contact list, once (the block's mark takes
-// this launch's stamp; stamps are never reused, so the marks are never cleared)
-// (a plain load first: a block in contact is marked by thousands of box nodes -- ~64 nodes x ~4.5 boxes -- and that many
-// same-address atomics serialise in the L2; only the first few arrivals still see the bit clear)
-template <class T> __device__ __forceinline__ void fg_mark_contact(const Dev<T>& D, int idx) {
-    const int blk = idx >> 6;
-    int* mk = &D.contact_mark[blk];
-    if (__hip_atomic_load(mk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == D.stamp) return;      // read at the L2, where the atomics land
-    if (atomicExch(mk, D.stamp) != D.stamp) D.contact[1 + atomicAdd(&D.contact[0], 1)] = blk;
-}
-// The grids of a frame whose reverse substep is complete, cleared over the stencil boxes of its particle workgroups
-// (every scatter of the frame -- through a tile or direct -- stays inside its workgroup's box): grid_m / grid_v_in,
-// the block flags and the grid_v_out.grad buffer the frame used.
-template <class T> struct ClearArgs {
-    int frame;                       // < 0: nothing to clear
-    int nwg;                         // particle workgroups of that frame
-    int nwg_clear;                   // workgroups at the head of the k_g2p_grad launch that do the clear (clear_blocks)
-    T* gin[4];
-    T* goa[3];
-    int* flags;
-};
-template <class T> __device__ __forceinline__ void clear_boxes(const Dev<T>& D, const ClearArgs<T>& A) {
-    for (int wg = blockIdx.x; wg < A.nwg; wg += gridDim.x) {
-        const int* q = D.tiles + ((size_t)A.frame * D.twg + wg) * 8;
-        const int o0 = q[0], o1 = q[1], o2 = q[2], ex = q[3], exy = q[3] * q[4], tn = exy * q[5];
-        for (int i = threadIdx.x; i < tn; i += kBlock) {
-            int lz, ly, lx;
-            tile_coords(i, ex, exy, lz, ly, lx);
-            const int idx = node_index(D, o0 + lx, o1 + ly, o2 + lz);
-            A.gin[0][idx] = T(0); A.gin[1][idx] = T(0); A.gin[2][idx] = T(0); A.gin[3][idx] = T(0);
-            A.goa[0][idx] = T(0); A.goa[1][idx] = T(0); A.goa[2][idx] = T(0);
-            A.flags[flag_slot(D, idx >> 6)] = 0;
-        }
-    }
-}
-template <class T> __global__ __launch_bounds__(kBlock) void k_clear_boxes(Dev<T> D, ClearArgs<T> A) { clear_boxes(D, A); }
-// The same clear through the block flags (the scatters set them for every block they touch): wave `w` of `nw` takes the
-// flag rows of grid workgroups w, w + nw, ... (flags are stored per grid workgroup: flag_slot) and zeroes the 64 nodes of
-// each flagged block with one store per component.
-template <class T> __device__ __forceinline__ void clear_blocks(const Dev<T>& D, const ClearArgs<T>& A, int wg, int nwg) {
-    if (A.frame < 0 || (PLB_FG_ABL & 2)) return;
-    const int lane = threadIdx.x & 63, nblk = D.nbx * D.nby * D.nbz;
-    for (int g = wg * (kBlock / 64) + (threadIdx.x >> 6); g < (1 << D.fgl); g += nwg * (kBlock / 64))
-        for (int k0 = 0; k0 < D.fs; k0 += 64) {
-            const int k = k0 + lane, b = g + (k << D.fgl);
-            const bool in = k < D.fs && b < nblk;
-            const int fl = in ? A.flags[g * D.fs + k] : 0;
-            for (unsigned long long r = __ballot(fl != 0); r; r &= r - 1) {
-                const int kk = k0 + __ffsll((long long)r) - 1, blk = g + (kk << D.fgl), idx = (blk << 6) | lane;
-                A.gin[0][idx] = T(0); A.gin[1][idx] = T(0); A.gin[2][idx] = T(0); A.gin[3][idx] = T(0);
-                A.goa[0][idx] = T(0); A.goa[1][idx] = T(0); A.goa[2][idx] = T(0);
-                if (lane == 0) A.flags[g * D.fs + kk] = 0;
-            }
-        }
-}
 
 // Sorted particle load in two halves so that independent memory traffic can be issued in between.
 struct SortLoad { double x0[3]; long long key; };
@@ -767,7 +620,7 @@ __device__ __forceinline__ bool load_sorted_particle(const Dev<T>& D, const doub
 // doubles: half the tile capacity), see det_add.
 template <class T, bool WRITE_F, bool DET = false>
 __global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_p2g(Dev<T> D, int f) {
-    __shared__ int sred[32];
+    __shared__ int sred[kSred];
     // accumulate in double: on gfx950 ds_add_f64 is ~5x cheaper per instruction than ds_add_f32
     // (profiles/microbench/lds_atomics.hip), and the node sums lose no precision
     __shared__ Vec4<double> tile[TileCap<T>::nodes];
@@ -917,11 +770,9 @@ __global__ __launch_bounds__(kBlock) void k_grid_op(Dev<T> D, int f, HaloIn H) {
 
 // ------------------------------------------------------------------------------------------------
 // g2p (mpm_simulator.py:223-242): gather v_out through an LDS tile, write x,v,C of frame f+1
-// FG: fused-grid engines -- v_out is evaluated from grid_m / grid_v_in while the tile is filled (fg_node_vout)
-template <class T, bool FG = false>
+template <class T>
 __global__ __launch_bounds__(kBlock) void k_g2p(Dev<T> D, int f) {
     __shared__ Vec4<T> tile[TileCap<T>::nodes];
-    const PrimT<T>* sp = D.ptab + (size_t)f * kMaxPrim;
     const int wgi = xcd_chunk((int)blockIdx.x, (int)gridDim.x);
     const int p = wgi * kBlock + threadIdx.x;
     const bool valid = p < D.N;
@@ -931,18 +782,7 @@ __global__ __launch_bounds__(kBlock) void k_g2p(Dev<T> D, int f) {
     double x[3] = {0.5, 0.5, 0.5};
     if (valid) { x[0] = X[p]; x[1] = X[Np + p]; x[2] = X[2 * Np + p]; }
     const int ex = tl.e[0], exy = tl.e[0] * tl.e[1], tn = exy * tl.e[2];
-    if constexpr (FG) {
-        // v_out of every node of the box: into the LDS tile, or -- a box too large for it -- into the frame's grid_v_out
-        // in HBM, which the gather below then reads (workgroups with overlapping boxes write the same values)
-        const int np = fg_box_prims(D, sp, tl);
-        for (int i = threadIdx.x; i < tn; i += kBlock) {
-            int lz, ly, lx, idx;
-            tile_coords(i, ex, exy, lz, ly, lx);
-            const Vec4<T> a = fg_node_vout<NEAR_STORE>(D, D.gin, sp, tl.o[0] + lx, tl.o[1] + ly, tl.o[2] + lz, D.grid_out, np, &idx);
-            if (tl.ok) tile[i] = a; else D.grid_out[idx] = a;
-        }
-        __syncthreads();
-    } else if (tl.ok) {
+    if (tl.ok) {
         for (int i = threadIdx.x; i < tn; i += kBlock) {
             int lz, ly, lx;
                 tile_coords(i, ex, exy, lz, ly, lx);
@@ -979,13 +819,10 @@ __global__ __launch_bounds__(kBlock) void k_g2p(Dev<T> D, int f) {
 // are written once and go straight on (in registers) into the scatter; the LDS region first holds the
 // grid_v_out(f-1) tile, then -- after the gather -- is reused for the f64 accumulation tile of grid_in(f).
 // D is built for frame f (grid_in / flags of f); vout_prev is grid_v_out of substep f-1.
-// FG (fused-grid engines): grid_op of substep f-1 is evaluated in the tile fill, from grid_m / grid_v_in of frame f-1.
-template <class T, bool DET = false, bool FG = false>
-__global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_g2p_p2g(Dev<T> D, int f, PrevGrid<T> G0) {
-    __shared__ int sred[32];
+template <class T, bool DET = false>
+__global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_g2p_p2g(Dev<T> D, int f, const Vec4<T>* vout_prev) {
+    __shared__ int sred[kSred];
     __shared__ Vec4<double> tile[TileCap<T>::nodes];
-    const PrimT<T>* sp = D.ptab + (size_t)(f - 1) * kMaxPrim;      // FG: the primitives during substep f-1
-    const Vec4<T>* vout_prev = G0.vout;          // FG: the previous frame's grid_v_out store, written here for boxes too large for the tile
     Vec4<T>* tile_v = reinterpret_cast<Vec4<T>*>(tile);          // first use of the same LDS
     const int Np = D.Npad;
     // ---------------- g2p(f-1): gather
@@ -1000,17 +837,9 @@ __global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_g2p_p2g(Dev<T> D, int
     const int wgi = xcd_chunk((int)blockIdx.x, (int)gridDim.x);
     Tile ta = load_tile(D, f - 1, (int)(TileCap<T>::nodes * sizeof(Vec4<double>) / sizeof(Vec4<T>)), wgi);
     SortLoad sl = sorted_begin(D, X0, wgi);
-    NodeIn<T> fpre;
-    int flz = 0, fly = 0, flx = 0;
     {
         const int ex = ta.e[0], exy = ta.e[0] * ta.e[1], tn = exy * ta.e[2];
-        if constexpr (FG) {
-            // first pass of the fill (most boxes have <= 256 nodes): only the loads, their values are used behind the sort
-            if ((int)threadIdx.x < tn) {
-                tile_coords((int)threadIdx.x, ex, exy, flz, fly, flx);
-                fpre = fg_node_load(D, G0.gin, ta.o[0] + flx, ta.o[1] + fly, ta.o[2] + flz);
-            }
-        } else if (ta.ok)
+        if (ta.ok)
             for (int i = threadIdx.x; i < tn; i += kBlock) {
                 int lz, ly, lx;
                 tile_coords(i, ex, exy, lz, ly, lx);
@@ -1028,25 +857,7 @@ __global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_g2p_p2g(Dev<T> D, int
         for (int d = 0; d < 9; ++d) E[d] = R[(12 + d) * Np + p];
         load_materials(D, p, mu, lam, ys);
     }
-    if constexpr (FG) {
-        // grid_op of substep f-1 on the box: v_out into the tile, or -- a box too large for it -- into the previous frame's
-        // grid_v_out store, from where the gather below reads it
-        const int ex = ta.e[0], exy = ta.e[0] * ta.e[1], tn = exy * ta.e[2];
-        Vec4<T>* vst = const_cast<Vec4<T>*>(vout_prev);
-        const int np = fg_box_prims(D, sp, ta);
-        if ((int)threadIdx.x < tn) {
-            const Vec4<T> a = fg_node_eval<NEAR_STORE>(D, sp, ta.o[0] + flx, ta.o[1] + fly, ta.o[2] + flz, fpre, vst, np);
-            if (ta.ok) tile_v[threadIdx.x] = a; else vst[fpre.idx] = a;
-        }
-        for (int i = threadIdx.x + kBlock; i < tn; i += kBlock) {
-            int lz, ly, lx, idx;
-            tile_coords(i, ex, exy, lz, ly, lx);
-            const Vec4<T> a = fg_node_vout<NEAR_STORE>(D, G0.gin, sp, ta.o[0] + lx, ta.o[1] + ly, ta.o[2] + lz, vst, np, &idx);
-            if (ta.ok) tile_v[i] = a; else vst[idx] = a;
-        }
-    }
-    if (FG && !ta.ok) __syncthreads();                               // v_out went through HBM
-    else wg_barrier();                                               // tile_v complete
+    wg_barrier();                                               // tile_v complete
     PT_MARK(1);
     double x[3] = {0.5, 0.5, 0.5};
     T v[3] = {T(0), T(0), T(0)}, C[9];
@@ -1188,22 +999,9 @@ __global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_g2p_p2g(Dev<T> D, int
 #ifndef PLB_G2PG_FIX8
 #define PLB_G2PG_FIX8 1
 #endif
-// FG (fused-grid engines; never DET): v_out comes from grid_m / grid_v_in in the tile fill, which also finds the blocks
-// in contact with a movable primitive (D.contact, consumed by the pose workgroups of the k_p2g_grad launch behind this
-// one); the grids of the frame the previous reverse substep finished with are cleared at the end (CA).
-// FGMODE: 0 grid kernels | 1 + NEAR_LOAD (the frame's forward substep ran through a fused-grid kernel) | 1 + NEAR_EVAL
-template <class T, bool DET = false, int FGMODE = 0>
-__global__ __launch_bounds__(kBlock, sizeof(T) == 4 ? PLB_G2PG_WAVES : 1) void k_g2p_grad(Dev<T> D, int f, int src, int dst, const T* vnext, ClearArgs<T> CA) {
-    constexpr bool FG = FGMODE != 0;
-    constexpr bool EVAL = FGMODE == 1 + NEAR_EVAL;     // v_out evaluated here (a frame whose forward ran through the grid kernels' engine path)
-    const PrimT<T>* sp = D.ptab + (size_t)f * kMaxPrim;
-    if constexpr (FG) {
-        // spare workgroups behind the particle workgroups: clear the grids of the frame the previous reverse substep
-        // finished with (one coalesced 256-byte row per block and component, found through the block flags)
-        // (they lead the launch, so they run under cover of the first particle workgroups)
-        if ((int)blockIdx.x < CA.nwg_clear) { clear_blocks(D, CA, (int)blockIdx.x, CA.nwg_clear); return; }
-    }
-    const int wg = FG ? (int)blockIdx.x - CA.nwg_clear : xcd_chunk((int)blockIdx.x, (int)gridDim.x);
+template <class T, bool DET = false>
+__global__ __launch_bounds__(kBlock, sizeof(T) == 4 ? PLB_G2PG_WAVES : 1) void k_g2p_grad(Dev<T> D, int f, int src, int dst, const T* vnext) {
+    const int wg = xcd_chunk((int)blockIdx.x, (int)gridDim.x);
     // 960 nodes x (16 + 24) bytes = 37.5 KiB: four workgroups per CU (128 VGPRs = 4 waves per SIMD, see PLB_G2PG_WAVES)
     constexpr int CAP = sizeof(T) == 4 ? PLB_G2PG_CAP : 480;
     __shared__ Vec4<T> tile[CAP];                    // v_out values
@@ -1216,7 +1014,7 @@ __global__ __launch_bounds__(kBlock, sizeof(T) == 4 ? PLB_G2PG_WAVES : 1) void k
     // (in front of the kernel's first store: behind one, hipcc no longer proves the descriptor unclobbered and fetches it with a vector
     // load + readfirstlane instead of s_load)
     const Tile tl = load_tile(D, f, DET ? CAP / 2 : CAP, wg);       // stored by the scatter of this frame (DET: 6 limbs per node in tile_a)
-    if (wg == 0 && threadIdx.x == 0) (FG ? D.contact_next : D.contact)[0] = 0;     // the list k_grid_op_grad(f) (FG: this kernel for frame f-1) is about to fill
+    if (wg == 0 && threadIdx.x == 0) D.contact[0] = 0;     // the list k_grid_op_grad(f) is about to fill
     SortLoad sl = sorted_begin(D, X, wg);
 
     const int ex = tl.e[0], exy = tl.e[0] * tl.e[1], tn = exy * tl.e[2];
@@ -1228,42 +1026,20 @@ __global__ __launch_bounds__(kBlock, sizeof(T) == 4 ? PLB_G2PG_WAVES : 1) void k
     // cost 2 us (512 instead of ~230 tile slots to zero and flush), so only this kernel has it.
     const bool fix8 = PLB_G2PG_FIX8 && !DET && sizeof(T) == 4 && CAP >= 512 && tl.ok && tl.e[0] <= 8 && tl.e[1] <= 8 && tl.e[2] <= 8;
     const int n8 = tl.e[2] << 6;                                    // slots of the z planes in use
-    NodeIn<T> fpre;
-    int flz = 0, fly = 0, flx = 0;
-    // a stored v_out whose .w is set: the node touches a movable primitive -- its block goes on the contact list
-    auto stored = [&](int idx) -> Vec4<T> {
-        const Vec4<T> a = D.grid_out[idx];
-        if constexpr (FG) { if (a.w != T(0)) fg_mark_contact(D, idx); }
-        return a;
-    };
-    if constexpr (EVAL) {
-        // first pass of the v_out fill: only the grid loads; they fly during the sort (fill_finish below)
-        if ((int)threadIdx.x < tn) {
-            tile_coords((int)threadIdx.x, ex, exy, flz, fly, flx);
-            fpre = fg_node_load(D, D.gin, tl.o[0] + flx, tl.o[1] + fly, tl.o[2] + flz);
-        }
-        if (tl.ok)
-            for (int i = threadIdx.x; i < (fix8 ? n8 : tn); i += kBlock) { tile_a[3 * i] = 0.0; tile_a[3 * i + 1] = 0.0; tile_a[3 * i + 2] = 0.0; }
-    } else if (fix8) {
+    if (fix8) {
         for (int i = threadIdx.x; i < n8; i += kBlock) {
             const int lx = i & 7, ly = (i >> 3) & 7, lz = i >> 6;
             if (lx < tl.e[0] && ly < tl.e[1] && lz < tl.e[2])
-                tile[i] = stored(node_index(D, tl.o[0] + lx, tl.o[1] + ly, tl.o[2] + lz));
+                tile[i] = D.grid_out[node_index(D, tl.o[0] + lx, tl.o[1] + ly, tl.o[2] + lz)];
             tile_a[3 * i] = 0.0; tile_a[3 * i + 1] = 0.0; tile_a[3 * i + 2] = 0.0;
         }
     } else if (tl.ok)
         for (int i = threadIdx.x; i < tn; i += kBlock) {
             int lz, ly, lx;
                 tile_coords(i, ex, exy, lz, ly, lx);
-            tile[i] = stored(node_index(D, tl.o[0] + lx, tl.o[1] + ly, tl.o[2] + lz));
+            tile[i] = D.grid_out[node_index(D, tl.o[0] + lx, tl.o[1] + ly, tl.o[2] + lz)];
             tile_a[3 * i] = 0.0; tile_a[3 * i + 1] = 0.0; tile_a[3 * i + 2] = 0.0;
             if (DET) { tile_a[3 * (tn + i)] = 0.0; tile_a[3 * (tn + i) + 1] = 0.0; tile_a[3 * (tn + i) + 2] = 0.0; }   // lo limbs
-        }
-    else if (FG)                                    // no tile: the gather reads the store itself; the box still reports its contacts
-        for (int i = threadIdx.x; i < tn; i += kBlock) {
-            int lz, ly, lx;
-            tile_coords(i, ex, exy, lz, ly, lx);
-            (void)stored(node_index(D, tl.o[0] + lx, tl.o[1] + ly, tl.o[2] + lz));
         }
     PT_MARK(0);
     const bool valid = sorted_finish(D, sl, p, x, base, false, wg);
@@ -1277,25 +1053,6 @@ __global__ __launch_bounds__(kBlock, sizeof(T) == 4 ? PLB_G2PG_WAVES : 1) void k
         if (valid) {
             for (int d = 0; d < 3; ++d) { vn[d] = R1[d * Np + p]; xna[d] = A1[d * Np + p]; vna[d] = A1[(3 + d) * Np + p]; }
             for (int d = 0; d < 9; ++d) Cna[d] = A1[(6 + d) * Np + p];
-        }
-        if constexpr (EVAL) {
-            // grid_op on the box, whatever the tile layout (fixed 8-strides, the box's own extents, or no tile at all: then
-            // v_out goes to the frame's grid_v_out in HBM and the gather reads it from there); nodes in contact with a
-            // movable primitive put their block on the contact list
-            auto put = [&](int i, int lx, int ly, int lz, int idx, const Vec4<T>& a) {
-                if (a.w != T(0)) fg_mark_contact(D, idx);
-                if (fix8) tile[(lz << 6) + (ly << 3) + lx] = a;
-                else if (tl.ok) tile[i] = a;
-                else D.grid_out[idx] = a;
-            };
-            if ((int)threadIdx.x < tn)
-                put((int)threadIdx.x, flx, fly, flz, fpre.idx, fg_node_eval<NEAR_EVAL>(D, sp, tl.o[0] + flx, tl.o[1] + fly, tl.o[2] + flz, fpre, D.grid_out, D.nprim));
-            for (int i = threadIdx.x + kBlock; i < tn; i += kBlock) {
-                int lz, ly, lx, idx;
-                tile_coords(i, ex, exy, lz, ly, lx);
-                const Vec4<T> a = fg_node_vout<NEAR_EVAL>(D, D.gin, sp, tl.o[0] + lx, tl.o[1] + ly, tl.o[2] + lz, D.grid_out, D.nprim, &idx);
-                put(i, lx, ly, lz, idx, a);
-            }
         }
         __syncthreads();                             // tile / tile_a complete (the loads above are in flight)
         PT_MARK(2);
@@ -1377,7 +1134,6 @@ __global__ __launch_bounds__(kBlock, sizeof(T) == 4 ? PLB_G2PG_WAVES : 1) void k
                     if (emitter) {
                         int idx = node_index(D, base[0] + i, base[1] + j, base[2] + l);
                         atomicAdd(&D.goa[0][idx], a0); atomicAdd(&D.goa[1][idx], a1); atomicAdd(&D.goa[2][idx], a2);
-                        if constexpr (FG) D.flags[flag_slot(D, idx >> 6)] = 1;
                     }
                 });
         }
@@ -1394,7 +1150,6 @@ __global__ __launch_bounds__(kBlock, sizeof(T) == 4 ? PLB_G2PG_WAVES : 1) void k
             if (ax != 0.0 || ay != 0.0 || az != 0.0) {
                 int idx = node_index(D, tl.o[0] + (i & 7), tl.o[1] + ((i >> 3) & 7), tl.o[2] + (i >> 6));
                 atomicAdd(&D.goa[0][idx], (T)ax); atomicAdd(&D.goa[1][idx], (T)ay); atomicAdd(&D.goa[2][idx], (T)az);
-                if constexpr (FG) D.flags[flag_slot(D, idx >> 6)] = 1;      // the clear goes by the flags
             }
         }
     } else if (tl.ok) {
@@ -1417,7 +1172,6 @@ __global__ __launch_bounds__(kBlock, sizeof(T) == 4 ? PLB_G2PG_WAVES : 1) void k
                 tile_coords(i, ex, exy, lz, ly, lx);
                 int idx = node_index(D, tl.o[0] + lx, tl.o[1] + ly, tl.o[2] + lz);
                 atomicAdd(&D.goa[0][idx], (T)ax); atomicAdd(&D.goa[1][idx], (T)ay); atomicAdd(&D.goa[2][idx], (T)az);
-                if constexpr (FG) D.flags[flag_slot(D, idx >> 6)] = 1;
             }
         }
     }
@@ -1430,8 +1184,7 @@ __global__ __launch_bounds__(kBlock, sizeof(T) == 4 ? PLB_G2PG_WAVES : 1) void k
 // One wave, one 4^3 block.  POSE = false computes the velocity adjoint only and returns true when an owned node of
 // the block touches a movable primitive: its pose adjoints are then still due and the block's inputs are left in
 // place for the POSE = true pass, which clears them.
-// KEEP (fused-grid engines, POSE pass): leave the block's inputs alone -- particle workgroups of the same launch read them.
-template <class T, bool POSE, bool KEEP = false>
+template <class T, bool POSE>
 __device__ __forceinline__ bool grid_block_bwd(const Dev<T>& D, const HaloIn& H, int blk, int lane, const PrimT<T>* sp, double* sacc, int* shit) {
     const int idx = (blk << 6) | lane;
     int I[3];
@@ -1475,7 +1228,7 @@ __device__ __forceinline__ bool grid_block_bwd(const Dev<T>& D, const HaloIn& H,
     const bool defer = !POSE && __any(due);
     if (!POSE) D.grid_in_adj[idx] = Vec4<T>{mva[0], mva[1], mva[2], ma};      // vector part first: (x, y) is an aligned register pair for the packed gather
     if (defer && hf >= 0) { D.goa[0][idx] = va[0]; D.goa[1][idx] = va[1]; D.goa[2][idx] = va[2]; }
-    if (!defer && !KEEP) {
+    if (!defer) {
         D.goa[0][idx] = T(0); D.goa[1][idx] = T(0); D.goa[2][idx] = T(0);
         // this frame's grid is consumed: leave grid_in / flags clean for the next scatter into them.  grid_in_adj
         // is never cleared -- p2g.grad only reads nodes of active blocks, which are all rewritten every substep.
@@ -1505,7 +1258,7 @@ __global__ __launch_bounds__(kBlock, sizeof(T) == 4 ? PLB_GOG_WAVES : 1) void k_
 }
 
 // the pose-adjoint workgroups of the p2g.grad launch: blocks listed in D.contact, one wave each
-template <class T, bool KEEP = false>
+template <class T>
 __device__ __forceinline__ void pose_adjoint_blocks(const Dev<T>& D, int f, int wg, int nwg, PrimT<T>* sp) {
     __shared__ double sacc[kMaxPrim * 15];
     __shared__ int shit;
@@ -1515,7 +1268,7 @@ __device__ __forceinline__ void pose_adjoint_blocks(const Dev<T>& D, int f, int 
     __syncthreads();
     const int lane = threadIdx.x & 63, count = D.contact[0];
     for (int i = wg * (kBlock / 64) + (threadIdx.x >> 6); i < count; i += nwg * (kBlock / 64))
-        grid_block_bwd<T, true, KEEP>(D, HaloIn{}, D.contact[1 + i], lane, sp, sacc, &shit);
+        grid_block_bwd<T, true>(D, HaloIn{}, D.contact[1 + i], lane, sp, sacc, &shit);
     __syncthreads();
     if (shit && threadIdx.x < D.nprim * 15) {
         int q = threadIdx.x / 15, c = threadIdx.x % 15;
@@ -1568,17 +1321,15 @@ __global__ __launch_bounds__(64) void k_pose_adjoint_det(Dev<T> D, int f) {
 
 // ------------------------------------------------------------------------------------------------
 // p2g.grad + svd_grad + compute_F_tmp.grad: gather grid_in_adj, finish adjoint frame `dst`
-// FG (fused-grid engines): the pointwise part of grid_op.grad is evaluated in the tile fill (fg_node_gadj) from
-// grid_v_out.grad and the frame's grid_m / grid_v_in; the pose workgroups leave those inputs in place.
 // (Fetching the particle state this kernel needs behind its gather at the START by LDS-DMA -- global_load_lds, 36 words per
 // particle -- was built and measured in round 4: parity-green, 47.1 / 49.0 us against 42.7 / 43.3; profiles/r04_ablation_hooks.patch.)
-template <class T, bool FG = false>
+template <class T>
 __global__ __launch_bounds__(kBlock, sizeof(T) == 4 ? PLB_P2G_GRAD_WAVES : 1) void k_p2g_grad(Dev<T> D, int f, int src, int dst, int npose) {
     __shared__ Vec4<T> tile[TileCap<T>::nodes];
     __shared__ PrimT<T> sp[kMaxPrim];
     // the first `npose` workgroups finish grid_op.grad (pose adjoints of the blocks in contact) under cover of the
     // particle workgroups
-    if ((int)blockIdx.x < npose) { pose_adjoint_blocks<T, FG>(D, f, (int)blockIdx.x, npose, sp); return; }
+    if ((int)blockIdx.x < npose) { pose_adjoint_blocks<T>(D, f, (int)blockIdx.x, npose, sp); return; }
     const int chunk = xcd_chunk((int)blockIdx.x - npose, (int)gridDim.x - npose);
     const int p = chunk * kBlock + threadIdx.x;
     const bool valid = p < D.N;
@@ -1590,28 +1341,7 @@ __global__ __launch_bounds__(kBlock, sizeof(T) == 4 ? PLB_P2G_GRAD_WAVES : 1) vo
     double x[3] = {0.5, 0.5, 0.5};
     if (valid) { x[0] = X[p]; x[1] = X[Np + p]; x[2] = X[2 * Np + p]; }
     const int ex = tl.e[0], exy = tl.e[0] * tl.e[1], tn = exy * tl.e[2];
-    if constexpr (FG) {
-        // the node adjoints of the whole box: into the LDS tile, or -- a box too large for it -- into grid_in_adj in HBM
-        NodeAdjIn<T> pre;
-        int plz = 0, ply = 0, plx = 0;
-        if ((int)threadIdx.x < tn) {
-            tile_coords((int)threadIdx.x, ex, exy, plz, ply, plx);
-            pre = fg_node_gadj_load(D, tl.o[0] + plx, tl.o[1] + ply, tl.o[2] + plz);
-        }
-        const PrimT<T>* gp = D.ptab + (size_t)f * kMaxPrim;
-        const int np = fg_box_prims(D, gp, tl);
-        if ((int)threadIdx.x < tn) {
-            const Vec4<T> a = fg_node_gadj_eval(D, gp, tl.o[0] + plx, tl.o[1] + ply, tl.o[2] + plz, np, pre);
-            if (tl.ok) tile[threadIdx.x] = a; else D.grid_in_adj[pre.idx] = a;
-        }
-        for (int i = threadIdx.x + kBlock; i < tn; i += kBlock) {
-            int lz, ly, lx, idx;
-            tile_coords(i, ex, exy, lz, ly, lx);
-            const Vec4<T> a = fg_node_gadj(D, gp, tl.o[0] + lx, tl.o[1] + ly, tl.o[2] + lz, np, &idx);
-            if (tl.ok) tile[i] = a; else D.grid_in_adj[idx] = a;
-        }
-        __syncthreads();
-    } else if (tl.ok) {
+    if (tl.ok) {
         for (int i = threadIdx.x; i < tn; i += kBlock) {
             int lz, ly, lx;
                 tile_coords(i, ex, exy, lz, ly, lx);
@@ -1659,7 +1389,7 @@ __global__ __launch_bounds__(kBlock, sizeof(T) == 4 ? PLB_P2G_GRAD_WAVES : 1) vo
 // wave pre-reduction scheme as k_p2g.  gm is a dense blocked T grid (zeroed by the caller).
 template <class T, bool DET = false>
 __global__ __launch_bounds__(kBlock) void k_grid_mass(Dev<T> D, int f, T* gm) {
-    __shared__ int sred[32];
+    __shared__ int sred[kSred];
     __shared__ double tile[TileCap<T>::nodes * 4];
     const double* X = frame_x(D, f);
     int p, base[3];

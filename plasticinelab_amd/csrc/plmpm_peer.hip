@@ -260,14 +260,22 @@ int plmpm_halo_peer_exchange(plmpm_handle s, int field, int frame) {
     HIPCHK(hipGetLastError());
     return 0;
 }
-// Collective re-synchronisation (every rank calls it, then a host barrier, before the next exchange): this rank's arrival
-// counters, its sequence numbers, the workgroup counter and the status word go back to zero.  After a timeout -- or an
-// exception between two exchanges on one rank -- the sequence numbers of the two sides of a face no longer agree; without
-// this the engine could never exchange again.
-int plmpm_halo_peer_reset(plmpm_handle s) {
+// Collective re-synchronisation in two phases, with a host barrier over the ranks behind EACH (SlabEngine.reset_exchange):
+//   phase 0 (drain): wait until every exchange kernel this rank has enqueued is finished -- after the barrier no rank has a
+//                    kernel left that could still publish an (old, large) sequence number into a neighbour's arrival counter;
+//   phase 1 (clear): this rank's arrival counters, its sequence numbers, the workgroup counter and the status word go back to
+//                    zero -- after the second barrier every rank starts again at sequence number 1.
+// (One phase -- clear, then a barrier -- is not enough: a neighbour whose exchange kernels were still draining could store its
+// old sequence number into the counter just cleared, and the first exchange after the reset would pass its arrival test
+// `(int)(got - seq) >= 0` on that stale value and read a half the neighbour had not written yet.)
+// After a timeout -- or an exception between two exchanges on one rank -- the sequence numbers of the two sides of a face no
+// longer agree; without this the engine could never exchange again.
+int plmpm_halo_peer_reset(plmpm_handle s, int phase) {
     NEED_BOUND(s);
+    REQUIRE(phase == 0 || phase == 1, "halo_peer_reset: phase must be 0 (drain) or 1 (clear)");
     if (!s->peer_done) return 0;
     HIPCHK(hipStreamSynchronize(s->stream));
+    if (phase == 0) return 0;
     for (int f = 0; f < 3; ++f) {
         plmpm_sim::PeerField& F = s->peer[f];
         F.seq = 0;

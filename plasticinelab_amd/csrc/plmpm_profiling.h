@@ -1,6 +1,6 @@
 // Profiling-only hooks of the particle kernels.  Nothing here emits code in a normal build: the macros expand to
-// nothing (or to a constant-false test) unless libplmpm.so is compiled with -DPLB_PHASE_TIMING / -DPLB_ABLATE=... /
-// -DPLB_FG_ABL=... (profiles/r0N_notes.md name the builds that were measured this way; the Makefile's EXTRA carries the flags).
+// nothing (or to a constant-false test) unless libplmpm.so is compiled with -DPLB_PHASE_TIMING / -DPLB_ABLATE=...
+// (profiles/r0N_notes.md name the builds that were measured this way; the Makefile's EXTRA carries the flags).
 #pragma once
 
 // profiling builds only (-DPLB_PHASE_TIMING): PT_MARK(k) stamps s_memtime at the end of phase k; for the launch of
@@ -24,13 +24,9 @@
 #define PT_END(D, slot0) do {} while (0)
 #endif
 
-// Ablations (timing only -- results are wrong): PLB_ABLATE bits 1 no LDS atomics, 2 no tile flush, 4 no scatter at all;
-// PLB_FG_ABL bits 1 the fused-grid tile fills ignore the primitives, 2 no clear of the previous frame's grids.
+// Ablations (timing only -- results are wrong): PLB_ABLATE bits 1 no LDS atomics, 2 no tile flush, 4 no scatter at all.
 #ifndef PLB_ABLATE
 #define PLB_ABLATE 0
-#endif
-#ifndef PLB_FG_ABL
-#define PLB_FG_ABL 0
 #endif
 // inside a scatter lambda: stop here when ablation bit `bit` is set, keeping `sum` alive so the arithmetic before it is not
 // optimised away

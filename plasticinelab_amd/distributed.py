@@ -374,6 +374,13 @@ class HaloComm:
         return out.cpu().numpy()
 
 
+def _collective(exc):
+    """Mark an exception that every rank raises together (the ranks agreed on it through a reduction first): whoever catches
+    it may run collectives in its clean-up, which is NOT true of an exception one rank raises on its own."""
+    exc.collective = True
+    return exc
+
+
 class SlabEngine:
     """Proxy around one rank's ``Engine`` that turns ``step`` / ``step_grad`` / ``loss_*`` into the phase-split,
     halo-exchanging, migrating versions.  ``MPMSimulator``, ``Loss`` and ``Tape`` work on it unchanged."""
@@ -416,14 +423,17 @@ class SlabEngine:
         return {"nccl": "rccl-p2p (batch_isend_irecv)", "gloo": "gloo-p2p staged through host memory"}.get(self.comm.backend, self.comm.backend)
 
     def reset_exchange(self):
-        """Collective: counters, sequence numbers and status word of the device-side exchange back to zero on every rank,
-        then a barrier -- nobody publishes into an area its owner is about to clear.  Called at every episode reset / segment
-        re-entry, so that an engine recovers from a timed-out or interrupted exchange instead of staying out of step."""
+        """Collective, two phases with a barrier behind each: (0) every rank waits for the exchange kernels it has enqueued --
+        behind the barrier nobody can still publish an old sequence number into a neighbour's arrival counter; (1) every rank
+        clears its counters, sequence numbers and status word -- behind the second barrier all sides start again at sequence
+        number 1.  Called at every episode reset / segment re-entry, so that an engine recovers from a timed-out or interrupted
+        exchange instead of staying out of step (a single clear + barrier could be overwritten by a neighbour still draining)."""
         if not getattr(self.comm, "peer_mapped", False):
             return
-        self._e.halo_peer_reset()
-        t = torch.zeros(1, dtype=torch.float64, device=self.comm.scalar_device)
-        self.comm.all_reduce_(t)                   # barrier on either backend
+        for phase in (0, 1):
+            self._e.halo_peer_reset(phase)
+            t = torch.zeros(1, dtype=torch.float64, device=self.comm.scalar_device)
+            self.comm.all_reduce_(t)               # barrier on either backend
 
     # ---- state
     def set_frame(self, f, x=None, v=None, F=None, C_=None, resort=False):
@@ -444,11 +454,16 @@ class SlabEngine:
         flags = torch.tensor([float(self._e.error_flags()), float(self._e.peer_status() if self.native_loops else 0)],
                              dtype=torch.float64, device=self.comm.scalar_device)
         self.comm.all_reduce_(flags, op=dist.ReduceOp.MAX)
+        # (what is raised from here is raised on EVERY rank -- the flags were combined first: marked `collective`, so that a
+        # caller's clean-up knows it may run collectives of its own, optimizer/checkpoint.py)
         if flags[1].item():
             st = int(flags[1].item())
-            raise RuntimeError(f"halo exchange: an arrival timed out on some rank (status 0x{st:x}: field {st >> 16}, face {(st >> 8) & 255}) "
-                               "-- a neighbouring rank stopped enqueueing; results of this env step are not valid")
-        self._e.check_error(int(flags[0].item()))
+            raise _collective(RuntimeError(f"halo exchange: an arrival timed out on some rank (status 0x{st:x}: field {st >> 16}, face {(st >> 8) & 255}) "
+                                           "-- a neighbouring rank stopped enqueueing; results of this env step are not valid"))
+        try:
+            self._e.check_error(int(flags[0].item()))
+        except Exception as exc:
+            raise _collective(exc)
 
     # ---- segment checkpoints (optimizer/checkpoint.py): this rank's population at a frame, and re-entry with it
     def checkpoint(self, f):
@@ -460,16 +475,19 @@ class SlabEngine:
         return dict(ids=e.get_ids(f).copy(), x=fr["x"], v=fr["v"], F=fr["F"], C=fr["C"], mu=mu, lam=lam, ys=ys,
                     since=self._since_migration)
 
-    def reenter(self, ck):
+    def reenter(self, ck, collective=True):
         """Make frame 0 the checkpointed population (a new episode for the engine: epoch 0 again, rows in the checkpoint's
-        order, Hilbert-sorted storage); the next ``step`` migrates exactly as the run the checkpoint was taken from did."""
+        order, Hilbert-sorted storage); the next ``step`` migrates exactly as the run the checkpoint was taken from did.
+        ``collective=False``: this rank alone (clean-up after a failure the other ranks do not know of) -- the exchange is NOT
+        re-synchronised; the next ``set_state`` / ``reenter`` all ranks take part in does that."""
         e = self._e
         e.set_population(len(ck["ids"]))
         e.set_ids(ck["ids"])
         e.set_frame(0, x=ck["x"], v=ck["v"], F=ck["F"], C_=ck["C"], resort=True)
         e.set_materials(ck["mu"], ck["lam"], ck["ys"])
         self._since_migration = ck["since"]
-        self.reset_exchange()
+        if collective:
+            self.reset_exchange()
 
     def adjoint_to_reentry_rows(self, f=0):
         """After the reverse sweep has reached frame ``f`` = the frame a segment re-entered at: undo the migration the
@@ -482,9 +500,9 @@ class SlabEngine:
         bad = torch.tensor([0.0 if err is None else 1.0], dtype=torch.float64, device=self.comm.scalar_device)
         self.comm.all_reduce_(bad, op=dist.ReduceOp.MAX)
         if err is not None:
-            raise err
+            raise _collective(err)
         if bad.item() > 0:
-            raise RuntimeError(f"rank {self.rank}: another rank failed in {where}")
+            raise _collective(RuntimeError(f"rank {self.rank}: another rank failed in {where}"))
 
     # ---- migration
     def migrate(self, f):

@@ -384,10 +384,10 @@ class Engine:
         L.check(self.lib.plmpm_peer_status(self.h, C.byref(st)))
         return st.value
 
-    def halo_peer_reset(self):
-        """Counters, sequence numbers and status of the device-side exchange back to zero (collective: every rank, then a
-        host barrier, before the next exchange)."""
-        L.check(self.lib.plmpm_halo_peer_reset(self.h))
+    def halo_peer_reset(self, phase):
+        """Collective re-synchronisation of the device-side exchange in two phases, a host barrier over the ranks behind each:
+        0 = drain (this rank's enqueued exchange kernels are finished), 1 = clear (counters, sequence numbers, status word)."""
+        L.check(self.lib.plmpm_halo_peer_reset(self.h, int(phase)))
 
     def peer_memory_kind(self):
         k = C.c_int()

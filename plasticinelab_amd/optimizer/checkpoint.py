@@ -88,19 +88,25 @@ def _forward_checkpointed_slab(env, init_state, actions, T, H, sub, softness):
     env.set_state(init_state, softness, False)
     first_ck = dict(eng.checkpoint(0), prims=[p.get_state(0) for p in env.primitives])
 
-    def restore(ck):
-        eng.reenter(ck)
+    def restore(ck, collective=True):
+        eng.reenter(ck, collective=collective)
         sim.n_particles = env.n_particles = len(ck["ids"])          # Observe / get_state size their arrays by these
         for st, p in zip(ck["prims"], env.primitives):
             p.set_state(0, st)
         sim.cur = 0
 
+    # Whatever happens, leave the engine with the population -- and the row counts the callers read -- it started with.  The
+    # full restore re-synchronises the device-side exchange, which is a collective: it may only run where EVERY rank runs it,
+    # i.e. after a normal return or after a failure the ranks agreed on (SlabEngine._agree / _check mark those exceptions
+    # `collective`).  A failure of this rank alone (NaN guard, engine error, out of memory) restores local state only: a
+    # collective here would pair with whatever collective the other ranks are in and hang them or corrupt their reduction.
     try:
-        return _checkpointed_slab_sweeps(env, actions, T, H, sub, first_ck, restore)
-    finally:
-        # whatever happened (a collective failure raises on every rank together, see below): leave the engine with the
-        # population -- and the row counts the callers read -- it started with
-        restore(first_ck)
+        out = _checkpointed_slab_sweeps(env, actions, T, H, sub, first_ck, restore)
+    except BaseException as exc:
+        restore(first_ck, collective=bool(getattr(exc, "collective", False)))
+        raise
+    restore(first_ck)
+    return out
 
 
 def _checkpointed_slab_sweeps(env, actions, T, H, sub, first_ck, restore):

@@ -1,5 +1,5 @@
-"""CPU tier: the C-ABI library loads, exports every symbol include/plmpm.h declares, and refuses to run
-without a GPU (no compute calls here)."""
+"""CPU tier: the C-ABI library loads, exports every symbol include/plmpm.h (the drop-in boundary) and
+include/plmpm_tools.h (measurement, diagnostics, test hooks) declare, and refuses to run without a GPU (no compute calls here)."""
 import ctypes
 import os
 import re
@@ -11,10 +11,31 @@ from plasticinelab_amd import _lib
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def declared_symbols():
-    text = open(os.path.join(ROOT, "include", "plmpm.h")).read()
+def declared_in(header):
+    text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(plmpm_[a-z_0-9]+)\s*\(", text)))
+    return set(re.findall(r"\b(plmpm_[a-z_0-9]+)\s*\(", text))
+
+
+def declared_symbols():
+    return sorted(declared_in("plmpm.h") | declared_in("plmpm_tools.h"))
+
+
+def test_boundary_header_carries_no_scaffolding():
+    """include/plmpm.h is what INTEGRATION.md tells a maintainer to bind: nothing that only serves bench.py, profiles/tools or
+    the tests may be declared there, and the two headers do not overlap."""
+    boundary, tools = declared_in("plmpm.h"), declared_in("plmpm_tools.h")
+    assert not (boundary & tools)
+    for name in boundary:
+        assert not re.match(r"plmpm_(debug_|replay|profile_|tile_boxes|measure_hbm|build_flags|grid_stats|get_order)", name), name
+    assert {"plmpm_create", "plmpm_step", "plmpm_step_grad", "plmpm_set_action", "plmpm_get_action_grad", "plmpm_get_frame",
+            "plmpm_set_frame", "plmpm_loss_forward", "plmpm_loss_backward", "plmpm_destroy"} <= boundary
+    # the product's Python layer (engine/, envs/, optimizer/, autograd, distributed) works through the boundary alone, except
+    # for the two introspection calls the engine object forwards to its callers
+    allowed = {"plmpm_grid_stats", "plmpm_get_order", "plmpm_build_flags", "plmpm_profile_enable", "plmpm_profile_read",
+               "plmpm_profile_kernel_count", "plmpm_profile_kernel_name", "plmpm_tile_boxes", "plmpm_debug_counters",
+               "plmpm_debug_peer_spoil", "plmpm_replay", "plmpm_replay_step", "plmpm_measure_hbm"}
+    assert tools == allowed
 
 
 def test_header_and_binding_agree():

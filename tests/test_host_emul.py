@@ -261,17 +261,6 @@ def test_node_between_two_manipulators():
         assert np.abs(ref[:3]).max() > 0 and relerr(pose[k][:14], ref) < 1e-10
 
 
-def test_pack_instantiation_equals_scalar_bit_for_bit(tmp_path):
-    """mpm_math.h instantiated for two particles per lane (P2 / D2 / I2: what k_g2p_p2g_pk runs) against the scalar
-    float instantiation on 20 000 random particle pairs (elastic, yielding, nearly singular): identical bits."""
-    import subprocess
-    src = os.path.join(os.path.dirname(__file__), "host_emul", "pack_check.cpp")
-    exe = str(tmp_path / "pack_check")
-    subprocess.check_call(["g++", "-O1", "-std=c++17", "-ffp-contract=off", "-DPLB_FAST=0", src, "-o", exe])    # the generic (SVD) path: packs never take the scalar-only elastic fast path
-    out = subprocess.run([exe], capture_output=True, text=True)
-    assert out.returncode == 0 and "mismatches: 0" in out.stdout, out.stdout + out.stderr
-
-
 def _oracle_constitutive(Et, mu, lam, ys, GS, GF):
     """stress (unscaled) and new_F of p2g + the F_tmp adjoint of <GS, stress> + <GF, new_F> through the oracle's own SVD
     with the reference's literal backward_svd (oracle/plb_oracle.py::SvdRef, compute_von_mises)."""
