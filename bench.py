@@ -1,12 +1,15 @@
 #!/usr/bin/env python
 """Benchmark: MPM substeps/sec (forward + backward) on the BASELINE.json workload.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--dtype float32] [--no-cpu-baseline]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--repeats R] [--dtype float32] [--no-cpu-baseline]
 
 One "step" = one env step of the hot path: `substeps` x substep forward, the loss, and -- after the K
 forward steps -- the K reverse steps (loss adjoint + `substeps` x substep_grad + primitive-chain adjoint),
 exactly the call sequence of Solver.forward (plb/optimizer/solver.py:31-44).  The timed region starts with
-the particle state already resident in HBM and covers K steps forward + K steps backward.
+the particle state already resident in HBM and covers K steps forward + K steps backward.  The K-step rollout is timed
+R = 5 times (--repeats; the state is put back outside the timed spans, barrier + synchronize on both sides of each), `value`
+and `ms_per_step` are the MEDIAN repetition, `value_min` / `value_max` / `repeat_ms_per_step` show the spread -- one 0.12 s
+rollout on a fresh box varies by more than most kernel changes are worth.
 
 Workload (config.workload "config3_cube128"): BASELINE.json configs[2] as synthesised in SURVEY.md 8(d):
 128^3 grid (quality 2, 39 substeps / env step), one elastoplastic cube of side 0.31 at (0.5, 0.2, 0.5)
@@ -20,6 +23,16 @@ two or more per rank while the body allows it (config 3's cube spans ten planes:
 (N = 8: slabs of one or two planes, the plane of a one-plane slab exchanged with both neighbours).  If the slab path
 cannot run at all (a particle leaving the grid window, an RCCL error, a hang caught by the watchdog) the bench falls
 back to N independent replicas of the workload ("scaling": "weak") and says so in `metric` and in config.parallelism.
+
+Extra points in the same line, measured AFTER the headline's timed region (they never touch it):
+  N = 1  `secondary`      BASELINE configs[3]'s size on one GPU (256^3 / 2M elastic particles, 2 env steps), child process;
+         `secondary_f64`  the float64 engine -- the reference's own precision (mpm_simulator.py:8) -- on the headline workload,
+                          4 env steps, child process;
+  N >= 2 `secondary`      a list, run inside the same world: configs[3] (256^3 / 2M, sigma_y = 1e9, 2 env steps) cut into N
+                          z-slabs at N = 2, 4, 8, and configs[4] (512^3 / 16M, half sigma_y = 50 / half 1e9, ONE env step of 159
+                          substeps with the per-frame grid store) at N = 8 -- the sizes SURVEY 8(e) says can scale -- each with
+                          value, job_frac, loss_check against the committed single-GPU loss, halo_transport and
+                          strong_scaling_eff against the committed single-GPU rate (profiles/n1_reference_points.json).
 """
 from __future__ import annotations
 
@@ -43,17 +56,13 @@ ALG = {
     "p2g_recompute": (27, 8), "grid_op_recompute": (0, 7), "g2p_grad": (18, 9),
     "grid_op_grad": (0, 11), "p2g_grad": (54, 4), "clear_active": (0, 0),
     "g2p_p2g": (51, 7),        # g2p(f-1) + p2g(f) fused
-    # fused-grid engine (the default on one GPU): grid_op / grid_op.grad evaluated inside the particle kernels' tile
-    # fills, so their rows are added to the kernel that absorbs them (grid_op: 0 N + 11 A, its recompute in the reverse
-    # pass 0 N + 7 A, grid_op.grad 0 N + 11 A)
-    "gridop+g2p": (15, 14), "gridop+g2p_p2g": (51, 18), "gridop+g2p_grad": (18, 16), "gridop_grad+p2g_grad": (54, 15),
 }
 HBM_PEAK_GBS = 8000.0          # MI355X spec (MI355X_MICROARCH.md); the copy / read rates this box reaches are measured live
-PMC_FILE = os.path.join(ROOT, "profiles", "r04_pmc.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r05_pmc.json")
 
 
 def pmc_traffic(kernel, workload, dtype, steps, warmup):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/r04_pmc.json, written by
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/r05_pmc.json, written by
     profiles/tools/pmc_summary.py from separate --pmc FETCH_SIZE / WRITE_SIZE runs of this very command: 2 x
     FETCH_SIZE + WRITE_SIZE, the gfx950 correction of MI355X_MICROARCH.md's HBM section).  None when the file is
     missing or was taken on another workload / dtype / --steps / --warmup -- a stale number is worse than none."""
@@ -66,6 +75,11 @@ def pmc_traffic(kernel, workload, dtype, steps, warmup):
         return (None, None) if k is None else (float(k["hbm_bytes_per_launch"]), d.get("source"))
     except (OSError, ValueError, KeyError):
         return None, None
+
+
+def mixed_yield(n):
+    """BASELINE configs[4]: half the particles plastic (sigma_y = 50), half elastic (1e9), alternating in caller order."""
+    return np.where(np.arange(n) % 2 == 0, 50.0, 1e9)
 
 
 def workload_cfg(n_particles=500_000, quality=2, max_steps=1024, yield_stress=200.0, side=0.31):
@@ -108,18 +122,24 @@ WORKLOADS = {"config3_cube128": None, "triplemove128": "TripleMove", "rope128": 
 
 
 def mass_grid(x, n, p_mass):
-    """host copy of compute_grid_m_kernel (only used to synthesise the benchmark's own target grid)."""
+    """host copy of compute_grid_m_kernel (only used to synthesise the benchmark's own target grid): 27 weighted histograms
+    over the bounding box of the stencils (np.bincount; the 16M-particle / 512^3 point would spend minutes in np.add.at)."""
     xs = x * n
     base = (xs - 0.5).astype(np.int64)
     fx = xs - base
     w = [0.5 * (1.5 - fx) ** 2, 0.75 - (fx - 1) ** 2, 0.5 * (fx - 0.5) ** 2]
-    g = np.zeros(n * n * n)
+    lo = base.min(0)
+    ext = base.max(0) - lo + 3
+    b = base - lo
+    box = np.zeros(int(ext[0]) * int(ext[1]) * int(ext[2]))
     for i in range(3):
         for j in range(3):
             for k in range(3):
-                idx = ((base[:, 0] + i) * n + base[:, 1] + j) * n + base[:, 2] + k
-                np.add.at(g, idx, w[i][:, 0] * w[j][:, 1] * w[k][:, 2] * p_mass)
-    return g.reshape(n, n, n)
+                idx = ((b[:, 0] + i) * ext[1] + b[:, 1] + j) * ext[2] + b[:, 2] + k
+                box += np.bincount(idx, weights=w[i][:, 0] * w[j][:, 1] * w[k][:, 2] * p_mass, minlength=len(box))
+    g = np.zeros((n, n, n))
+    g[lo[0]:lo[0] + ext[0], lo[1]:lo[1] + ext[1], lo[2]:lo[2] + ext[2]] = box.reshape(ext)
+    return g
 
 
 def seeded_actions(K, A):
@@ -154,7 +174,8 @@ def build_env(args, device, rank=0, world=1, slabs=False):
         # the device-side exchange is opt-in (distributed.HaloComm); the bench opts in and CHECKS it against the library
         # transport before timing anything (transport_check below) -- PLB_PEER_HALOS=0 keeps it off altogether
         env, layout, _ = make_slab_env(cfg, rank, world, compute_dtype=args.dtype, device=device, target_fn=_target,
-                                       xy_margin=XY_MARGIN, migrate_every=1, peer=True)
+                                       xy_margin=XY_MARGIN, migrate_every=1, peer=True,
+                                       yield_stress=mixed_yield(args.particles) if getattr(args, "mixed_yield", False) else None)
         env.loss.set_weights(10, 10, 1, False)
         return env, (f"{world} z-slabs {list(layout.bounds)} (reach {layout.halo} layers), grid window = body + {XY_MARGIN} layers, zero-copy halo of "
                      f"one 4^3 block plane per face side, particle migration every env step")
@@ -165,12 +186,16 @@ def build_env(args, device, rank=0, world=1, slabs=False):
         cfg.SIMULATOR["grid_window"] = ([int(v) for v in np.maximum(b.min(0) - args.window, 0)],
                                         [int(v) for v in np.minimum(b.max(0) + 3 + args.window, n)])
     env = TaichiEnv(cfg, compute_dtype=args.dtype, device=device)
+    if getattr(args, "mixed_yield", False):
+        env.simulator._yield_stress = mixed_yield(env.simulator.n_particles)
     env.initialize()
     env.loss.load_target_density(grids=_target(env.init_particles, env.simulator))
     env.loss.set_weights(10, 10, 1, False)
     note = "" if getattr(args, "window", -1) < 0 else f", grid window = body + {args.window} layers"
     if getattr(args, "deterministic", False):
         note += ", deterministic accumulation"
+    if getattr(args, "mixed_yield", False):
+        note += ", sigma_y = 50 / 1e9 alternating"
     return env, (("single GPU" if world == 1 else f"{world} independent replicas (no collective)") + note)
 
 
@@ -309,49 +334,251 @@ def transport_check(env, state0, A, agree, tol_loss=1e-5, tol_grad=1e-4):
     return rec
 
 
-def secondary_point(args):
-    """The config-4-size single-GPU point, so that it is the DRIVER that observes it: BASELINE configs[3]'s workload (256^3 grid,
-    2M elastic particles: sigma_y = 1e9, 79 substeps per env step) on one GPU, 2 env steps fwd + bwd, grid window = body + 24
-    layers, in a child process of its own (its 30 GB of frames do not meet the headline's) after the headline's timed region and
-    roofline pass.  Four times the particles amortise the workgroups' latency chains and the grid kernels: the whole substep
-    reaches a higher fraction of the roofline than at 128^3 / 500k."""
-    import subprocess
-    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--particles", "2000000", "--quality", "4", "--window", "24", "--steps", "2",
-           "--warmup", "1", "--yield-stress", "1e9", "--dtype", args.dtype, "--no-cpu-baseline", "--no-secondary"]
+N1_LOSS_FILE = os.path.join(ROOT, "profiles", "n1_final_loss.json")
+N1_POINTS_FILE = os.path.join(ROOT, "profiles", "n1_reference_points.json")
+
+
+def n1_reference(workload, dtype, steps):
+    """The committed single-GPU record of a (workload, dtype, steps) rollout -- {"value", "final_loss", "source"} from
+    profiles/n1_reference_points.json (written from N = 1 runs of this script / profiles/tools/config5_n1_reference.py), or the
+    older loss-only file profiles/n1_final_loss.json -- or None."""
+    key = f"{workload}|{dtype}|{steps}"
     try:
-        p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+        with open(N1_POINTS_FILE) as f:
+            rec = json.load(f).get(key)
+        if rec is not None:
+            return dict(rec, file="profiles/n1_reference_points.json")
+    except (OSError, ValueError):
+        pass
+    try:
+        with open(N1_LOSS_FILE) as f:
+            v = json.load(f).get(key)
+        if v is not None:
+            return {"final_loss": v, "value": None, "file": "profiles/n1_final_loss.json"}
+    except (OSError, ValueError):
+        pass
+    return None
+
+
+def loss_check(workload, dtype, steps, final_loss, tol=1e-5):
+    """final_loss against the committed single-GPU loss of the same (workload, dtype, steps).  The slab run computes the SAME
+    rollout, so its loss must agree to the engines' round-off; `rel` beyond 1e-5 puts MISMATCH into `metric`."""
+    ref = n1_reference(workload, dtype, steps)
+    if ref is None or ref.get("final_loss") is None:
+        return {"n1_expected": None, "rel": None, "ok": None, "source": "no committed single-GPU loss for this (workload, dtype, steps)"}
+    exp = ref["final_loss"]
+    rel = abs(final_loss - exp) / max(abs(exp), 1e-300)
+    return {"n1_expected": exp, "rel": rel, "ok": bool(rel <= tol), "tol": tol, "source": ref["file"]}
+
+
+def workload_name(args, n_grid):
+    if getattr(args, "mixed_yield", False):
+        return f"mixed{n_grid}_{args.particles}p"
+    if args.workload != "config3_cube128":
+        return args.workload if (args.particles, args.quality) == (500_000, 2) else f"{args.workload.rstrip('0123456789')}{n_grid}_{args.particles}p"
+    return "config3_cube128" if (args.particles, args.quality, args.side) == (500_000, 2, 0.31) else f"cube{n_grid}_{args.particles}p"
+
+
+def child_point(extra, timeout=600):
+    """One more single-GPU point in a child process of its own (its frames do not meet the headline's): the bench line it
+    prints, reduced to the keys a secondary point carries."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1"] + extra + ["--no-cpu-baseline", "--no-secondary"]
+    try:
+        p = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, cwd=ROOT)
         line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
         if p.returncode != 0 or not line:
             return {"error": f"rc {p.returncode}: {p.stderr[-300:]}"}
         d = json.loads(line[-1])
         r = d["roofline"]
         return {"workload": d["config"]["workload"], "n_grid": d["config"]["n_grid"], "n_particles": d["config"]["n_particles"],
-                "substeps_per_step": d["config"]["substeps_per_step"], "steps": d["steps"], "warmup": d["warmup"], "dtype": d["dtype"],
-                "value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"],
+                "substeps_per_step": d["config"]["substeps_per_step"], "steps": d["steps"], "warmup": d["warmup"], "repeats": d["repeats"],
+                "dtype": d["dtype"], "value": d["value"], "value_min": d["value_min"], "value_max": d["value_max"], "unit": d["unit"],
+                "ms_per_step": d["ms_per_step"],
                 "substep_kernel_sum_us": r["substep_kernel_sum_us"], "substep_alg_MB": r["substep_alg_MB"], "substep_frac": r["substep_frac"],
                 "job_frac": r["job_frac"], "dominant_kernel": r["kernel"], "dominant_frac": r["frac"], "active_nodes": r["active_nodes"],
                 "final_loss": d["final_loss"], "parallelism": d["config"]["parallelism"],
                 "command": "python bench.py " + " ".join(cmd[2:])}
-    except Exception as e:                                        # noqa: BLE001 -- the secondary point never takes the headline down
+    except Exception as e:                                        # noqa: BLE001 -- a secondary point never takes the headline down
         return {"error": f"{type(e).__name__}: {e}"}
 
 
-N1_LOSS_FILE = os.path.join(ROOT, "profiles", "n1_final_loss.json")
+def secondary_scale():
+    """Test knob: PLB_SECONDARY_SCALE = s runs the secondary points with s x the particles in a cube of s^(1/3) x the side (the
+    same particles per cell); the contract tests use it, the driver's runs do not (1)."""
+    return float(os.environ.get("PLB_SECONDARY_SCALE", "1"))
 
 
-def loss_check(workload, dtype, steps, final_loss, tol=1e-5):
-    """final_loss against the committed single-GPU loss of the same (workload, dtype, steps) -- profiles/n1_final_loss.json,
-    written from N = 1 runs of this very script.  The slab run computes the SAME rollout, so its loss must agree to the
-    engines' round-off; `rel` beyond 1e-5 puts MISMATCH into `metric`."""
+# the secondary points: BASELINE configs[3] and configs[4] as SURVEY 8(d) synthesises them (~8 particles per cell: cube side
+# 0.25 of the domain at either grid)
+def point_config4(scale=1.0):
+    return dict(label="configs[3]: 256^3 / 2M elastic", particles=int(round(2_000_000 * scale)), quality=4.0, steps=2, warmup=1,
+                yield_stress=1e9, side=0.25 * scale ** (1 / 3), mixed_yield=False)
+
+
+def point_config5(scale=1.0):
+    return dict(label="configs[4]: 512^3 / 16M, half sigma_y = 50 / half 1e9, one env step of 159 substeps", particles=int(round(16_000_000 * scale)),
+                quality=8.0, steps=1, warmup=1, yield_stress=200.0, side=0.25 * scale ** (1 / 3), mixed_yield=True)
+
+
+def secondary_point(args):
+    """The config-4-size single-GPU point, so that it is the DRIVER that observes it: BASELINE configs[3]'s workload (256^3 grid,
+    2M elastic particles: sigma_y = 1e9, cube side 0.25 = ~8 particles per cell, 79 substeps per env step) on one GPU, 2 env steps
+    fwd + bwd, grid window = body + 24 layers.  Four times the particles amortise the workgroups' latency chains and the grid
+    kernels: the whole substep reaches a higher fraction of the roofline than at 128^3 / 500k."""
+    pt = point_config4(secondary_scale())
+    return child_point(["--particles", str(pt["particles"]), "--quality", "4", "--side", repr(pt["side"]), "--window", "24", "--steps", "2", "--warmup", "1",
+                        "--repeats", "3", "--yield-stress", "1e9", "--dtype", args.dtype])
+
+
+def secondary_f64_point(args):
+    """The float64 engine on the headline workload, 4 env steps fwd + bwd: the reference computes in float64 only
+    (mpm_simulator.py:8), so this is its own precision stated beside the fp32 number (same kernels, T = double)."""
+    d = child_point(["--steps", "4", "--warmup", "1", "--repeats", "3", "--dtype", "float64", "--particles", str(args.particles),
+                     "--quality", repr(args.quality), "--side", repr(args.side), "--yield-stress", repr(args.yield_stress)])
+    ref = n1_reference(d.get("workload"), "f32", 4) if "error" not in d else None
+    if ref and ref.get("final_loss"):
+        d["f32_loss_same_rollout"] = ref["final_loss"]
+        d["rel_to_f32_loss"] = abs(d["final_loss"] - ref["final_loss"]) / abs(ref["final_loss"])
+    return d
+
+
+class World:
+    """rank / world / device and the control-plane collectives of a run (a gloo group of its own when the data plane is RCCL)."""
+
+    def __init__(self):
+        self.rank = int(os.environ.get("RANK", 0))
+        self.world = int(os.environ.get("WORLD_SIZE", 1))
+        local = int(os.environ.get("LOCAL_RANK", 0)) % max(torch.cuda.device_count(), 1)
+        torch.cuda.set_device(local)
+        self.device = torch.device("cuda", local)
+        self.dist, self.ctl = None, None
+        if self.world > 1:
+            import datetime
+            import torch.distributed as dist
+            self.dist = dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            backend = os.environ.get("PLB_DIST_BACKEND", "nccl")     # "gloo" lets several ranks share one GPU (testing only)
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=self.device)
+                # control plane (agreement, barriers, the max over ranks) on its own gloo group: it keeps working when the
+                # data plane -- RCCL point-to-point between slabs -- does not
+                self.ctl = dist.new_group(backend="gloo", timeout=datetime.timedelta(seconds=1800))
+            else:
+                dist.init_process_group(backend)
+
+    def barrier(self):
+        torch.cuda.synchronize()
+        if self.dist is not None:
+            self.dist.barrier(group=self.ctl)
+        torch.cuda.synchronize()
+
+    def agree(self, ok):
+        """True only if every rank succeeded."""
+        if self.dist is None:
+            return ok
+        t = torch.tensor([1.0 if ok else 0.0])
+        if self.ctl is None and self.dist.get_backend() == "nccl":
+            t = t.to(self.device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN, group=self.ctl)
+        return bool(t.item() > 0.5)
+
+    def max_over_ranks(self, x):
+        if self.dist is None:
+            return x
+        t = torch.tensor([x], dtype=torch.float64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.ctl)
+        return float(t.item())
+
+    def sum_over_ranks(self, values):
+        t = torch.tensor([float(v) for v in values], dtype=torch.float64)
+        if self.dist is not None:
+            if self.ctl is None and self.dist.get_backend() == "nccl":
+                t = t.to(self.device)
+            self.dist.all_reduce(t, group=self.ctl)
+            t = t.cpu()
+        return [float(v) for v in t]
+
+
+def timed_rollouts(Wd, env, state0, acts, repeats):
+    """`repeats` x the K-step rollout, each bracketed by barrier + synchronize, the state put back outside the timed spans
+    (inputs resident in HBM when a span starts): -> (seconds per repetition, max over ranks; loss of the last one)."""
+    times, loss = [], None
+    for _ in range(repeats):
+        env.set_state(state0, 666.0, False)
+        Wd.barrier()
+        t0 = time.perf_counter()
+        loss = rollout(env, acts)
+        Wd.barrier()
+        times.append(Wd.max_over_ranks(time.perf_counter() - t0))
+    return times, loss
+
+
+def slab_point(Wd, base_args, pt, transport):
+    """One secondary point at N >= 2, inside the running world: build the point's slab engines, warm up (= feasibility), time
+    `repeats` rollouts, check the loss against the committed single-GPU loss.  Every failure is agreed on by all ranks before
+    anyone moves on (a rank that bailed out alone would leave the others in their next exchange)."""
+    import copy
+    a = copy.copy(base_args)
+    a.particles, a.quality, a.steps, a.warmup = pt["particles"], pt["quality"], pt["steps"], pt["warmup"]
+    a.yield_stress, a.side, a.mixed_yield, a.workload, a.window, a.deterministic = pt["yield_stress"], pt["side"], pt["mixed_yield"], "config3_cube128", -1, False
+    rec = {"label": pt["label"], "n_gpus": Wd.world, "steps": a.steps, "warmup": a.warmup, "dtype": "f32" if a.dtype == "float32" else "f64"}
+    env, err = None, None
+    t_build = time.perf_counter()
     try:
-        with open(N1_LOSS_FILE) as f:
-            exp = json.load(f).get(f"{workload}|{dtype}|{steps}")
-    except (OSError, ValueError):
-        exp = None
-    if exp is None:
-        return {"n1_expected": None, "rel": None, "ok": None, "source": "profiles/n1_final_loss.json has no entry for this (workload, dtype, steps)"}
-    rel = abs(final_loss - exp) / max(abs(exp), 1e-300)
-    return {"n1_expected": exp, "rel": rel, "ok": bool(rel <= tol), "tol": tol, "source": "profiles/n1_final_loss.json"}
+        env, parallelism = build_env(a, Wd.device, Wd.rank, Wd.world, slabs=True)
+        eng = env.simulator.engine
+        used = eng.use_transport(transport)               # what the headline's transport check settled on
+        state0 = env.get_state()["state"]
+        A = env.primitives.action_dim
+        if a.warmup > 0:
+            env.set_state(state0, 666.0, False)
+            rollout(env, seeded_actions(a.warmup, A))
+        ok = True
+    except Exception as e:                                        # noqa: BLE001
+        ok, err = False, f"{type(e).__name__}: {str(e)[:200]}"
+    if not Wd.agree(ok):
+        rec["error"] = err or "failed on another rank"
+        return rec, env
+    rec["build_and_warmup_s"] = round(time.perf_counter() - t_build, 2)
+    sim = env.simulator
+    sub = sim.substeps
+    try:
+        times, loss = timed_rollouts(Wd, env, state0, seeded_actions(a.steps, A), max(1, min(3, base_args.repeats)))
+        nodes, _ = sim.engine.grid_stats(0)
+        ok = True
+    except Exception as e:                                        # noqa: BLE001
+        ok, err, times, loss, nodes = False, f"{type(e).__name__}: {str(e)[:200]}", [], None, 0
+    if not Wd.agree(ok):
+        rec["error"] = err or "failed on another rank"
+        return rec, env
+    n_all, a_all = Wd.sum_over_ranks([sim.n_particles, nodes])     # halo nodes are active on both neighbours: swept twice, counted twice
+    med = sorted(times)[len(times) // 2]
+    total = a.steps * sub
+    name = workload_name(a, sim.n_grid)
+    alg = 4.0 * (150 * n_all + 57 * a_all)
+    rec.update({"workload": name, "n_grid": sim.n_grid, "n_particles": a.particles, "substeps_per_step": sub, "repeats": len(times),
+                "value": total / med, "value_min": total / max(times), "value_max": total / min(times), "unit": "substeps/s",
+                "ms_per_step": 1e3 * med / a.steps, "scaling": "strong", "final_loss": float(loss),
+                "job_alg_MB_per_substep": alg * 1e-6, "job_frac": alg * (total / med) / (Wd.world * HBM_PEAK_GBS * 1e9),
+                "active_nodes_all_ranks": int(a_all), "halo_transport": sim.engine.transport, "parallelism": parallelism + ", " + slab_how(env)})
+    rec["loss_check"] = loss_check(name, rec["dtype"], a.steps, float(loss))
+    ref = n1_reference(name, rec["dtype"], a.steps)
+    if ref and ref.get("value"):
+        rec["n1_value"] = ref["value"]
+        rec["n1_source"] = ref.get("source")
+        rec["strong_scaling_eff"] = rec["value"] / (Wd.world * ref["value"])
+    else:
+        rec["n1_value"], rec["strong_scaling_eff"] = None, None
+    return rec, env
+
+
+def close_env(env):
+    """Give an engine's HBM back (the secondary points are built after the headline's engine is gone)."""
+    try:
+        env.simulator.engine.close()
+    except Exception:                                             # noqa: BLE001
+        pass
 
 
 def main():
@@ -359,6 +586,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--repeats", type=int, default=5, help="the K-step rollout is timed this many times (state re-uploaded outside the timed "
+                    "spans); value / ms_per_step are the median repetition")
     ap.add_argument("--dtype", default="float32")
     ap.add_argument("--particles", type=int, default=500_000)
     ap.add_argument("--workload", default="config3_cube128", choices=sorted(WORKLOADS),
@@ -366,61 +595,24 @@ def main():
                          "TripleMove-v1 / Rope-v1 geometry (6 spheres / 2 spheres + static cylinder + ground friction) at 128^3 with ~500k "
                          "particles -- BASELINE configs[2] as it names the scenes")
     ap.add_argument("--quality", type=float, default=2)
+    ap.add_argument("--side", type=float, default=0.31, help="side of the synthetic cube (0.31 at 128^3 / 500k = ~8 particles per cell)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--replicas", action="store_true", help="N > 1: independent replicas instead of z-slabs")
     ap.add_argument("--yield-stress", type=float, default=200.0, help="von Mises yield stress of the cube (200 = the workload; 1e9 = elastic: an "
                     "experiment knob, not the headline)")
+    ap.add_argument("--mixed-yield", action="store_true", help="BASELINE configs[4]'s material: sigma_y = 50 / 1e9 alternating over the particles")
     ap.add_argument("--deterministic", action="store_true", help="single GPU: the bit-reproducible engine (integer-limb accumulation); "
                     "a cost measurement, not the headline")
-    ap.add_argument("--no-secondary", action="store_true", help="N = 1, headline workload: skip the second, larger single-GPU point (BASELINE "
-                    "configs[3]'s size: 256^3 grid, 2M elastic particles, 2 env steps) that is run in a child process AFTER the headline's "
-                    "timed region and reported under `secondary`")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary points (module docstring) that are measured AFTER the "
+                    "headline's timed region and reported under `secondary` / `secondary_f64`")
     ap.add_argument("--window", type=int, default=-1, help="single GPU: allocate / sweep only the body's bounding box + this many node "
                     "layers of the grid (plmpm_config.grid_lo / grid_hi); -1 = the whole grid, as the reference lays it out")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", 0))
-    world = int(os.environ.get("WORLD_SIZE", 1))
-    local = int(os.environ.get("LOCAL_RANK", 0)) % max(torch.cuda.device_count(), 1)
-    torch.cuda.set_device(local)
-    device = torch.device("cuda", local)
-    dist, ctl = None, None
-    if world > 1:
-        import datetime
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = os.environ.get("PLB_DIST_BACKEND", "nccl")     # "gloo" lets two ranks share one GPU (testing only)
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=device)
-            # control plane (agreement, barriers, the max over ranks) on its own gloo group: it keeps working when the
-            # data plane -- RCCL point-to-point between slabs -- does not
-            ctl = dist.new_group(backend="gloo", timeout=datetime.timedelta(seconds=1800))
-        else:
-            dist.init_process_group(backend)
-
-    def barrier():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier(group=ctl)
-        torch.cuda.synchronize()
-
-    def agree(ok):
-        """True only if every rank succeeded."""
-        if dist is None:
-            return ok
-        t = torch.tensor([1.0 if ok else 0.0])
-        if ctl is None and dist.get_backend() == "nccl":
-            t = t.to(device)
-        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=ctl)
-        return bool(t.item() > 0.5)
-
-    def max_over_ranks(x):
-        if dist is None:
-            return x
-        t = torch.tensor([x], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=ctl)
-        return float(t.item())
+    Wd = World()
+    rank, world, device, dist = Wd.rank, Wd.world, Wd.device, Wd.dist
+    barrier, agree, max_over_ranks = Wd.barrier, Wd.agree, Wd.max_over_ranks
 
     # A slab run that HANGS (a rank stuck in an RCCL call has no exception to catch) must not take the whole job with
     # it: if the slab build + warm-up has not been agreed on within PLB_SLAB_TIMEOUT seconds, every rank replaces its
@@ -444,7 +636,7 @@ def main():
         t.start()
         return t
 
-    K, W = args.steps, args.warmup
+    K, W, R = args.steps, args.warmup, max(1, args.repeats)
     phases = {}                                   # where this process' wall clock goes (seconds), reported as `phases_s`
     t_phase = time.perf_counter()
 
@@ -489,6 +681,8 @@ def main():
         if not ok:
             if rank == 0:
                 print(f"[bench] slab path unavailable ({note or 'another rank failed'}); falling back to replicas", file=sys.stderr)
+            if env is not None:
+                close_env(env)
             env, slabs, state0 = None, False, None
             os.environ["PLB_BENCH_NOTE"] = "slab path unavailable" + (f": {note[:120]}" if note else "")
             torch.cuda.empty_cache()
@@ -510,16 +704,11 @@ def main():
         env.set_state(state0, 666.0, False)
         rollout(env, seeded_actions(W, A))
     phase_done("warmup")
-    env.set_state(state0, 666.0, False)          # inputs resident in HBM before the timed region
     acts = seeded_actions(K, A)
-    barrier()
-    phase_done("upload")
-    t0 = time.perf_counter()
-    loss = rollout(env, acts)
-    barrier()
-    elapsed = time.perf_counter() - t0
+    # EXACTLY K steps per repetition, R repetitions, each bracketed by barrier + synchronize; inputs resident in HBM before each
+    times, loss = timed_rollouts(Wd, env, state0, acts, R)
     phase_done("timed")
-    elapsed = max_over_ranks(elapsed)
+    elapsed = sorted(times)[len(times) // 2]                   # the median repetition (max over ranks each)
     total_substeps = K * sub * (1 if slabs else world)         # slabs: one shared workload; replicas: one each
     value = total_substeps / elapsed
 
@@ -529,13 +718,14 @@ def main():
         "value": value, "unit": "substeps/s", "n_gpus": world,
         "steps": K, "warmup": W, "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True, "scaling": "strong" if (slabs or world == 1) else "weak",
         "vs_baseline": None, "dtype": "f32" if args.dtype == "float32" else "f64", "data": "synthetic",
-        "config": {"workload": ((args.workload if (args.particles, args.quality) == (500_000, 2) else f"{args.workload.rstrip('0123456789')}{sim.n_grid}_{args.particles}p")
-                                if args.workload != "config3_cube128" else
-                                ("config3_cube128" if (args.particles, args.quality) == (500_000, 2) else f"cube{sim.n_grid}_{args.particles}p")),
+        "config": {"workload": workload_name(args, sim.n_grid),
                    "n_grid": sim.n_grid,
                    "n_particles": args.particles if slabs else sim.n_particles,
                    "substeps_per_step": sub, "primitives": len(env.primitives), "positions": "f64", "loss": "sdf+density+hard contact",
                    "parallelism": parallelism},
+        # the K-step rollout was timed `repeats` times; value / ms_per_step are the median repetition
+        "repeats": R, "value_min": total_substeps / max(times), "value_max": total_substeps / min(times),
+        "repeat_ms_per_step": [round(1e3 * t / K, 5) for t in times], "timed_region_s": round(sum(times), 5),
         "final_loss": float(loss),
     }
     # self-validation of the line: the loss against the committed single-GPU loss of the same rollout,
@@ -548,6 +738,9 @@ def main():
         out["transport_check"] = tcheck
         if tcheck and tcheck.get("checked") and not tcheck.get("agree"):
             out["metric"] += " -- FALLBACK: device-side halo exchange failed its check, halos over point-to-point"
+        ref = n1_reference(out["config"]["workload"], out["dtype"], K)
+        out["n1_value"] = ref.get("value") if ref else None
+        out["strong_scaling_eff"] = value / (world * ref["value"]) if ref and ref.get("value") else None
     if dist is not None:
         ranks = None
         if dist.get_backend() == "nccl":
@@ -571,14 +764,9 @@ def main():
         sim.engine.profile_enable(False)
         phase_done("roofline_pass")
         N = sim.n_particles                                   # this rank's particles (at reset)
-        tot = torch.tensor([float(N), float(nodes)], dtype=torch.float64)
-        if dist is not None:
-            if ctl is None and dist.get_backend() == "nccl":
-                tot = tot.to(device)
-            dist.all_reduce(tot, group=ctl)                   # halo nodes are active on both neighbours: counted twice, as they are swept twice
-            tot = tot.cpu()
+        tot = Wd.sum_over_ranks([N, nodes])                   # halo nodes are active on both neighbours: counted twice, as they are swept twice
         if slabs is False and world > 1:
-            tot /= world                                      # replicas: every rank holds the whole workload
+            tot = [v / world for v in tot]                    # replicas: every rank holds the whole workload
     if rank == 0 and not args.no_roofline:
         kernels = {}
         for name, (ms, cnt) in prof.items():
@@ -617,11 +805,52 @@ def main():
                            "job_alg_MB_per_substep": alg_unit * 1e-6,
                            "job_frac": alg_unit * value / (world * HBM_PEAK_GBS * 1e9),
                            "kernels": kernels}
-    headline = (args.workload, args.particles, args.quality, args.window, args.yield_stress) == ("config3_cube128", 500_000, 2, -1, 200.0)
-    if rank == 0 and world == 1 and headline and not args.no_secondary and not args.no_roofline and not getattr(args, "deterministic", False):
+    headline = (args.workload, args.particles, args.quality, args.window, args.yield_stress, args.side, args.mixed_yield) == \
+               ("config3_cube128", 500_000, 2, -1, 200.0, 0.31, False)
+    # (PLB_FORCE_SECONDARY=1: the contract tests run the secondary points behind a reduced headline, with PLB_SECONDARY_SCALE)
+    want_secondary = (headline or os.environ.get("PLB_FORCE_SECONDARY") == "1") and not args.no_secondary and not args.no_roofline and not args.deterministic and args.dtype == "float32"
+    if world == 1 and want_secondary and rank == 0:
         out["secondary"] = secondary_point(args)
         phase_done("secondary")
-    if rank == 0 and not args.no_cpu_baseline and args.workload == "config3_cube128":      # the C / OpenMP restatement knows Sphere manipulators only
+        out["secondary_f64"] = secondary_f64_point(args)
+        phase_done("secondary_f64")
+    if world > 1 and want_secondary and slabs:
+        # the sizes that can scale, inside the same world, after the headline's engine has given its HBM back.  A point
+        # that hangs must not cost the headline: after PLB_SECONDARY_TIMEOUT seconds rank 0 prints the line as it stands and
+        # every rank leaves.
+        import threading
+        transport = "peer" if (tcheck and tcheck.get("agree")) else "p2p"
+        close_env(env)
+        del env, sim
+        torch.cuda.empty_cache()
+        points = [point_config4(secondary_scale())] if world in (2, 4, 8) else []
+        if world == 8:
+            points.append(point_config5(secondary_scale()))
+        out["secondary"] = []
+        limit = float(os.environ.get("PLB_SECONDARY_TIMEOUT", 900))
+
+        def give_up():
+            if rank == 0:
+                out["secondary"].append({"error": f"secondary points not finished after {limit:.0f} s: abandoned"})
+                out["phases_s"] = {k: round(v, 4) for k, v in phases.items()}
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+
+        timer = threading.Timer(limit, give_up)
+        timer.daemon = True
+        timer.start()
+        for pt in points:
+            rec, penv = slab_point(Wd, args, pt, transport)
+            out["secondary"].append(rec)
+            if penv is not None:
+                close_env(penv)
+            del penv
+            torch.cuda.empty_cache()
+            phase_done("secondary")
+        timer.cancel()
+        env = None
+    # (rank 0 at N = 1 only; the C / OpenMP restatement knows Sphere manipulators only)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload == "config3_cube128" and env is not None:
         out["cpu_baseline"] = cpu_baseline(args, env)
         phase_done("cpu_baseline")
     if rank == 0:

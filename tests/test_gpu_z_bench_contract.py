@@ -16,7 +16,12 @@ from tests.util import ROOT
 pytestmark = pytest.mark.gpu
 
 KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
-        "data", "config", "roofline", "phases_s")
+        "data", "config", "roofline", "phases_s", "repeats", "value_min", "value_max", "repeat_ms_per_step", "secondary")
+# a secondary point of the N >= 2 line: BASELINE configs[3] / configs[4] sizes cut into the same world's slabs
+POINT_KEYS = ("label", "workload", "n_gpus", "n_grid", "n_particles", "steps", "value", "value_min", "value_max", "unit", "ms_per_step",
+              "job_frac", "loss_check", "halo_transport", "strong_scaling_eff", "n1_value", "final_loss")
+# the secondary points run at 3 % of their size here (PLB_SECONDARY_SCALE: same particles per cell) behind the reduced headline
+SECONDARY = {"PLB_FORCE_SECONDARY": "1", "PLB_SECONDARY_SCALE": "0.03"}
 
 
 def run(cmd, extra_env=None):
@@ -30,15 +35,18 @@ def run(cmd, extra_env=None):
 
 def test_bench_lines_single_gpu_and_two_slabs():
     common = ["--steps", "2", "--warmup", "1", "--particles", "60000", "--no-cpu-baseline"]
-    one = run([sys.executable, "bench.py", "--gpus", "1"] + common)
+    one = run([sys.executable, "bench.py", "--gpus", "1"] + common, SECONDARY)
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     two = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                "--master-port", str(port), "bench.py", "--gpus", "2"] + common,
-              {"PLB_DIST_BACKEND": "gloo", "PLB_PEER_HALOS": "1", "PLB_SLAB_TIMEOUT": "300"})
+              dict(SECONDARY, PLB_DIST_BACKEND="gloo", PLB_PEER_HALOS="1", PLB_SLAB_TIMEOUT="300"))
     for d, n in ((one, 1), (two, 2)):
         assert all(k in d for k in KEYS), [k for k in KEYS if k not in d]
+        # the K-step rollout is timed `repeats` times; value / ms_per_step are the median repetition
+        assert d["repeats"] == 5 and len(d["repeat_ms_per_step"]) == 5 and d["value_min"] <= d["value"] <= d["value_max"]
+        assert abs(sorted(d["repeat_ms_per_step"])[2] - d["ms_per_step"]) < 1e-4
         assert d["n_gpus"] == n and d["steps"] == 2 and d["warmup"] == 1 and d["unit"] == "substeps/s" and d["higher_is_better"] is True
         assert d["scaling"] == "strong" and d["dtype"] == "f32" and d["data"] == "synthetic" and d["vs_baseline"] is None
         assert "model" not in d["config"] and d["config"]["n_particles"] == 60000
@@ -56,6 +64,19 @@ def test_bench_lines_single_gpu_and_two_slabs():
     assert "halo_exchange" in two["roofline"]["kernels"] and two["roofline"]["kernel"] != "halo_exchange"
     # the same workload: the two-slab run ends with the single-GPU run's loss (fp32 engines, different summation order)
     assert abs(two["final_loss"] - one["final_loss"]) < 1e-5 * abs(one["final_loss"])
+    # N = 1: the config-4-size point and the float64 engine on the headline workload, in child processes behind the timed region
+    s1, s64 = one["secondary"], one["secondary_f64"]
+    assert "error" not in s1 and s1["n_grid"] == 256 and s1["steps"] == 2 and s1["value"] > 0 and 0 < s1["job_frac"] < 1, s1
+    assert "error" not in s64 and s64["dtype"] == "f64" and s64["steps"] == 4 and s64["n_particles"] == 60000 and s64["value"] > 0, s64
+    # N = 2: the SAME config-4-size workload cut into the world's two slabs, inside the same run, with its own self-checks
+    assert isinstance(two["secondary"], list) and len(two["secondary"]) == 1
+    p = two["secondary"][0]
+    assert "error" not in p and all(k in p for k in POINT_KEYS), (p, [k for k in POINT_KEYS if k not in p])
+    assert p["n_gpus"] == 2 and p["n_grid"] == 256 and p["workload"] == s1["workload"] and p["n_particles"] == s1["n_particles"]
+    assert p["halo_transport"].startswith("peer-write") and p["value"] > 0 and 0 < p["job_frac"] < 1
+    assert set(p["loss_check"]) >= {"n1_expected", "rel", "ok"}               # (no committed N = 1 record at this reduced size: nulls)
+    # ... and it IS the same rollout as the single-GPU child process ran: same loss
+    assert abs(p["final_loss"] - s1["final_loss"]) < 1e-5 * abs(s1["final_loss"]), (p["final_loss"], s1["final_loss"])
 
 
 def test_a_spoiled_halo_flips_the_line():

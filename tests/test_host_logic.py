@@ -241,3 +241,41 @@ def test_loss_check_flags_a_wrong_loss(tmp_path, monkeypatch):
     bad = bench.loss_check("config3_cube128", "f32", 20, 731.2)
     none = bench.loss_check("config3_cube128", "f32", 7, 1.0)
     assert ok["ok"] is True and ok["rel"] < 1e-7 and bad["ok"] is False and bad["rel"] > 1e-4 and none["ok"] is None and none["n1_expected"] is None
+
+
+def test_bench_secondary_points_and_reference_records(tmp_path, monkeypatch):
+    """Host logic of bench.py's secondary points: the configs[3] / configs[4] recipes keep ~8 particles per cell at any test scale,
+    the workload names they are filed under, and the committed single-GPU record (value + loss) a slab point is checked against."""
+    import importlib
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    for pt, n in ((bench.point_config4(), 256), (bench.point_config5(), 512), (bench.point_config4(0.03), 256), (bench.point_config5(0.01), 512)):
+        assert int(128 * pt["quality"] * 0.5) == n
+        ppc = pt["particles"] / (pt["side"] * n) ** 3
+        assert 7.0 < ppc < 8.5, ppc                                              # SURVEY 8(d): the ~8 ppc cube recipe
+    assert bench.point_config5()["mixed_yield"] and bench.point_config5()["steps"] == 1 and bench.point_config4()["yield_stress"] == 1e9
+    ys = bench.mixed_yield(6)
+    assert list(ys) == [50.0, 1e9, 50.0, 1e9, 50.0, 1e9]
+
+    class A:
+        workload, particles, quality, side, mixed_yield = "config3_cube128", 500_000, 2, 0.31, False
+    assert bench.workload_name(A, 128) == "config3_cube128"
+    A.particles, A.quality, A.side = 2_000_000, 4.0, 0.25
+    assert bench.workload_name(A, 256) == "cube256_2000000p"
+    A.particles, A.quality, A.mixed_yield = 16_000_000, 8.0, True
+    assert bench.workload_name(A, 512) == "mixed512_16000000p"
+    # the reference records: value + loss from n1_reference_points.json, loss-only entries from the older table
+    pts, old = tmp_path / "pts.json", tmp_path / "old.json"
+    pts.write_text(json.dumps({"cube256_2000000p|f32|2": {"value": 2000.0, "final_loss": 5.0, "source": "test"}}))
+    old.write_text(json.dumps({"config3_cube128|f32|20": 730.97584}))
+    monkeypatch.setattr(bench, "N1_POINTS_FILE", str(pts))
+    monkeypatch.setattr(bench, "N1_LOSS_FILE", str(old))
+    r = bench.n1_reference("cube256_2000000p", "f32", 2)
+    assert r["value"] == 2000.0 and r["final_loss"] == 5.0
+    assert bench.n1_reference("config3_cube128", "f32", 20) == {"final_loss": 730.97584, "value": None, "file": "profiles/n1_final_loss.json"}
+    assert bench.n1_reference("cube256_2000000p", "f32", 3) is None
+    assert bench.loss_check("cube256_2000000p", "f32", 2, 5.00001)["ok"] is True and bench.loss_check("cube256_2000000p", "f32", 2, 5.1)["ok"] is False
+    # the target grid synthesised on the host: sums to N p_mass whatever the cloud
+    x = np.random.default_rng(0).random((5000, 3)) * 0.3 + 0.3
+    g = bench.mass_grid(x, 32, 1e-3)
+    assert g.shape == (32, 32, 32) and abs(g.sum() - 5.0) < 1e-12 and (g >= 0).all()
