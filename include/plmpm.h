@@ -102,6 +102,11 @@ typedef struct plmpm_config {
      *                           (primive_base.py:100-103), the influence clamp, shape SDFs, the contact loss's max(sdf, 0). */
     int32_t contact_min_adjoint;
     int32_t minmax_tie;
+    /* persistent workgroups of the grid kernels (grid_op, grid_op.grad; rounded down to a power of two, at most 512 and at most
+     * blocks / 4); 0 = 512.  Only ranks that SHARE a GPU need it: the fused exchange + grid kernels of the device-side halo
+     * exchange wait inside the launch for the neighbours, so every workgroup of every rank on a GPU must be resident at once
+     * (plmpm_peer_fused): at most 512 / ranks-per-GPU there. */
+    int32_t grid_workgroups;
 } plmpm_config;
 
 /* One rigid manipulator; mirrors Primitive.default_config + per-shape params
@@ -288,6 +293,10 @@ int plmpm_peer_status(plmpm_handle h, int* status);
 int plmpm_halo_peer_reset(plmpm_handle h, int phase);
 /* 1: receive areas in uncached device memory (hipDeviceMallocUncached), 0: fine-grained (PLMPM_PEER_MEM=finegrained, or refused) */
 int plmpm_peer_memory_kind(plmpm_handle h, int* uncached);
+/* 1: plmpm_slab_step / plmpm_slab_step_grad fold each exchange into the grid kernel that consumes it (send the owned blocks of
+ * the exchanged planes | interior blocks | wait | blocks of the exchanged planes: one launch, the interior hides the arrival);
+ * 0: exchange kernel + grid kernel (PLMPM_PEER_FUSED=0, or a build with -DPLB_PEER_FUSED_DEFAULT=0) */
+int plmpm_peer_fused(plmpm_handle h, int* fused);
 int plmpm_slab_step(plmpm_handle h, int first_frame, int n_substeps);         /* fk + n x (p2g | exchange | grid_op + g2p) */
 int plmpm_slab_step_grad(plmpm_handle h, int first_frame, int n_substeps);    /* n x (g2p.grad | exchange | grid_op.grad + p2g.grad), in reverse */
 

@@ -29,7 +29,8 @@ class Config(C.Structure):
                 ("svd_grad_clamp", C.c_double), ("slab_z0", C.c_int32), ("slab_z1", C.c_int32),
                 ("store_grid", C.c_int32), ("slab_halo", C.c_int32), ("resort_steps", C.c_int32),
                 ("grid_lo", C.c_int32 * 3), ("grid_hi", C.c_int32 * 3), ("particle_capacity", C.c_int32),
-                ("deterministic", C.c_int32), ("contact_min_adjoint", C.c_int32), ("minmax_tie", C.c_int32)]
+                ("deterministic", C.c_int32), ("contact_min_adjoint", C.c_int32), ("minmax_tie", C.c_int32),
+                ("grid_workgroups", C.c_int32)]
 
 
 class Primitive(C.Structure):
@@ -104,6 +105,7 @@ SYMBOLS = {
     "plmpm_halo_peer_exchange": (_I, [_P, _I, _I]),
     "plmpm_peer_status": (_I, [_P, C.POINTER(_I)]),
     "plmpm_halo_peer_reset": (_I, [_P, _I]),
+    "plmpm_peer_fused": (_I, [_P, C.POINTER(_I)]),
     "plmpm_peer_memory_kind": (_I, [_P, C.POINTER(_I)]),
     "plmpm_debug_peer_spoil": (_I, [_P, _D]),
     "plmpm_slab_step": (_I, [_P, _I, _I]),

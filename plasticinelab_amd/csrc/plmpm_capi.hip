@@ -169,12 +169,14 @@ template <class T> static int phase_p2g(plmpm_sim* s, int f) {
 }
 // part: 0 every active block | 1 only the blocks outside the exchanged planes (nothing else: the halos may still be in
 // flight) | 2 the blocks of the exchanged planes, then g2p
-template <class T> static int phase_grid_g2p(plmpm_sim* s, int f, bool defer_g2p = false, int part = 0) {
+// X (device-side exchange of grid_m / grid_v_in folded into the launch, part = 0 only): k_grid_op_x
+template <class T> static int phase_grid_g2p(plmpm_sim* s, int f, bool defer_g2p = false, int part = 0, const PeerXchg* X = nullptr) {
     Dev<T> D = make_dev<T>(s, f);
     s->frame_epoch[f + 1] = s->frame_epoch[f];                 // g2p (now or fused into the next p2g) writes frame f + 1 in this order
     HaloIn H = s->halo_in[PLMPM_HALO_GRID_IN];
     H.part = part;
-    LAUNCH(s, K_GRID_OP, (k_grid_op<T, false>), dim3(nwg_grid(s)), D, f, H);
+    if (X && X->n > 0) LAUNCH(s, K_GRID_OP_X, (k_grid_op_x<T>), dim3(nwg_grid(s)), D, f, H, *X);
+    else LAUNCH(s, K_GRID_OP, (k_grid_op<T, false>), dim3(nwg_grid(s)), D, f, H);
     if (part == 1) return 0;
     if (!defer_g2p) LAUNCH(s, K_G2P, (k_g2p<T>), dim3(nblocks_particles(s, f)), D, f);
     return 0;
@@ -194,11 +196,12 @@ template <class T> static int phase_grad_scatter(plmpm_sim* s, int f) {
     LAUNCH_G2P_GRAD(s, D, f, (f + 1) & 1, f & 1, vnext);
     return 0;
 }
-template <class T> static int phase_grad_gather(plmpm_sim* s, int f, int part = 0) {
+template <class T> static int phase_grad_gather(plmpm_sim* s, int f, int part = 0, const PeerXchg* X = nullptr) {
     Dev<T> D = make_dev<T>(s, f);
     HaloIn H = s->halo_in[PLMPM_HALO_GRID_OUT_ADJ];
     H.part = part;
-    LAUNCH(s, K_GRID_OP_GRAD, (k_grid_op_grad<T>), dim3(nwg_grid(s)), D, f, H);
+    if (X && X->n > 0) LAUNCH(s, K_GRID_OP_GRAD_X, (k_grid_op_grad_x<T>), dim3(nwg_grid(s)), D, f, H, *X);
+    else LAUNCH(s, K_GRID_OP_GRAD, (k_grid_op_grad<T>), dim3(nwg_grid(s)), D, f, H);
     if (part == 1) return 0;
     LAUNCH_P2G_GRAD(s, D, f, (f + 1) & 1, f & 1);
     s->dirty[f] = 0;
@@ -408,7 +411,8 @@ int plmpm_create(const plmpm_config* cfg, const plmpm_primitive* prims, plmpm_ha
     // persistent grid kernels: a power-of-two number of workgroups (<= kGridWG, about one wave per 1-4 blocks), each
     // with its blocks' flags side by side
     s->gwg = 1; s->gwg_log2 = 0;
-    while (s->gwg * 2 <= kGridWG && s->gwg * 2 * (kBlock / 64) <= s->nblk) { s->gwg *= 2; ++s->gwg_log2; }
+    const int gwg_max = cfg->grid_workgroups > 0 ? std::min(cfg->grid_workgroups, kGridWG) : kGridWG;
+    while (s->gwg * 2 <= gwg_max && s->gwg * 2 * (kBlock / 64) <= s->nblk) { s->gwg *= 2; ++s->gwg_log2; }
     s->fs = (s->nblk + s->gwg - 1) / s->gwg;
     s->nflag = s->gwg * s->fs;
     s->F = cfg->max_frames;
@@ -1011,6 +1015,24 @@ int plmpm_grad_gather(plmpm_handle s, int frame) {
 }
 // ---- halos: zero-copy exchange of whole block planes ---------------------------------------------------------------
 }  // extern "C"
+int plmpm_grid_g2p_xchg(plmpm_sim* s, int frame, int chain, const PeerXchg* X) {
+    NEED_BOUND(s);
+    REQUIRE(s->store && frame >= 0 && frame < s->F, "grid_g2p: bad call");
+    REQUIRE(!chain || frame + 1 < s->F, "grid_g2p: only a substep with a successor chains");
+    REQUIRE(s->interior_fwd != frame, "grid_g2p with the exchange folded in: the interior blocks were already done by plmpm_grid_interior");
+    DISPATCH(s, phase_grid_g2p, s, frame, chain != 0, 0, X);
+    HIPCHK(hipGetLastError());
+    if (chain) s->g2p_deferred = frame;
+    return 0;
+}
+int plmpm_grad_gather_xchg(plmpm_sim* s, int frame, const PeerXchg* X) {
+    NEED_BOUND(s);
+    REQUIRE(s->store && frame >= 0 && frame < s->F, "grad_gather: bad call");
+    REQUIRE(s->interior_bwd != frame, "grad_gather with the exchange folded in: the interior blocks were already done by plmpm_grad_gather_interior");
+    DISPATCH(s, phase_grad_gather, s, frame, 0, X);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
 int plmpm_halo_field(plmpm_sim* s, int field, int frame, char** base, int* ncomp) {
     if (field == PLMPM_HALO_GRID_IN) {
         REQUIRE(s->store && frame >= 0 && frame < s->F, "halo: grid_in needs store_grid and a valid frame");

@@ -139,7 +139,9 @@ struct plmpm_sim {
         unsigned seq = 0;
     };
     PeerField peer[3];
-    unsigned* peer_done = nullptr;        // device: workgroups of the running exchange kernel that have finished their copies
+    unsigned* peer_done = nullptr;        // device: [0] workgroups of the running exchange that have finished their copies, [8] tag of the
+                                          //   last exchange whose arrivals the poller saw, [16] device copy of the status word
+    unsigned peer_tag = 0;                // tags of the exchanges of this engine (all fields): unique, never 0
     int* peer_status = nullptr;           // pinned host: 0, or field << 16 | face << 8 | 1 of an arrival that timed out
     std::vector<void*> peer_allocs, peer_mapped;
     bool peer_uncached = false;           // the receive areas are hipDeviceMallocUncached (else fine-grained)
@@ -152,10 +154,10 @@ struct plmpm_sim {
 };
 
 enum KernelId { K_P2G = 0, K_GRID_OP, K_G2P, K_P2G_RE, K_GRID_OP_RE, K_G2P_GRAD, K_GRID_OP_GRAD, K_P2G_GRAD, K_CLEAR, K_G2P_P2G,
-                K_HALO_XCHG, K_COUNT };
+                K_HALO_XCHG, K_GRID_OP_X, K_GRID_OP_GRAD_X, K_COUNT };
 static const char* kKernelNames[K_COUNT] = {"p2g", "grid_op", "g2p", "p2g_recompute", "grid_op_recompute",
                                             "g2p_grad", "grid_op_grad", "p2g_grad", "clear_active", "g2p_p2g",
-                                            "halo_exchange"};
+                                            "halo_exchange", "xchg+grid_op", "xchg+grid_op_grad"};
 
 static void prof_begin(plmpm_sim* s, int id) {
     if (!s->prof) return;
@@ -369,4 +371,11 @@ extern "C" int plmpm_launch_fk(plmpm_sim* s, int first, int n);                 
 extern "C" void plmpm_launch_fk_grad(plmpm_sim* s, int first, int n, int step);
 int plmpm_halo_field(plmpm_sim* s, int field, int frame, char** base, int* ncomp);   // plmpm_capi.hip: base of a halo field's SoA components
 int plmpm_convert_adjoint(plmpm_sim* s, int which, int from, int to);                 // plmpm_capi.hip: adjoint frame `which` into another storage epoch
+// plmpm_capi.hip: plmpm_grid_g2p / plmpm_grad_gather with the field's device-side exchange folded into the grid kernel (X built
+// by plmpm_peer.hip: peer_prepare); X->n == 0 (no neighbour) falls back to the plain launch
+int plmpm_grid_g2p_xchg(plmpm_sim* s, int frame, int chain, const PeerXchg* X);
+int plmpm_grad_gather_xchg(plmpm_sim* s, int frame, const PeerXchg* X);
+#ifndef PLB_PEER_FUSED_DEFAULT
+#define PLB_PEER_FUSED_DEFAULT 1
+#endif
 

@@ -270,7 +270,8 @@ template <class T> __device__ __forceinline__ int first_flags(const Dev<T>& D) {
     return lane < D.fs ? D.flags[blockIdx.x * D.fs + lane] : 0;
 }
 // CAND: blocks of the exchanged planes are candidates whatever their flag
-template <bool CAND, class T, class Body> __device__ __forceinline__ void for_each_active_block(const Dev<T>& D, const HaloIn& H, int flags0, Body&& body) {
+// part: H.part, or -- the fused exchange + grid kernels make two passes over the same (kernel-argument) HaloIn -- the pass's own
+template <bool CAND, class T, class Body> __device__ __forceinline__ void for_each_active_block(const Dev<T>& D, const HaloIn& H, int part, int flags0, Body&& body) {
     const int nblk = D.nbx * D.nby * D.nbz, g = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int k0 = 0; k0 < D.fs; k0 += 64) {
         const int k = k0 + lane, b = g + (k << D.fgl);
@@ -279,12 +280,137 @@ template <bool CAND, class T, class Body> __device__ __forceinline__ void for_ea
         // blocks in the exchanged planes are candidates whatever their flag: the neighbour's particles may reach
         // nodes that none of ours do (the body skips a candidate whose summed mass is zero everywhere)
         const bool face = H.n > 0 && halo_face_of(D, H, b) >= 0;
-        const unsigned long long m = __ballot(in && (fl != 0 || (CAND && face)) && (H.part == 0 || (H.part == 2) == face));
+        const unsigned long long m = __ballot(in && (fl != 0 || (CAND && face)) && (part == 0 || (part == 2) == face));
         __syncthreads();             // bodies may clear flags: every wave must have taken the same snapshot first
         int rank = 0;
         for (unsigned long long r = m; r; r &= r - 1, ++rank)
             if ((rank & (kBlock / 64 - 1)) == wave) body(g + ((k0 + __ffsll((long long)r) - 1) << D.fgl));
     }
+}
+
+// ---- device-side halo exchange (plmpm_peer.hip), as a kernel of its own or folded into the grid kernel that consumes it ----
+// One exchange of a halo field: this rank's copy of the exchanged block planes goes straight into the neighbours' receive
+// areas (IPC-mapped, uncached), an arrival counter is published behind the data, and the neighbours' counters are waited for.
+//   receive area of a face:  [256 B: arrival counter][half 0][half 1],  half = [one validity word per 4^3 block, padded to
+//                            256 B][ncomp x count scalars];  exchange k of a field writes half k & 1 (plmpm_peer.hip: why two)
+struct PeerXchg {
+    int n, ncomp;                // faces with a neighbour (0: no exchange), components of the field
+    const void* src[4];          // component c of this rank's grid array (block 0 of the window)
+    char* dst[2];                // the half of the neighbour's receive area this exchange writes: validity words, then data
+    size_t data_ofs[2];          // bytes from dst to the data
+    int blk0[2], nblk[2];        // first block and number of blocks of the face's planes
+    const int* flags;            // activity flags of the frame's blocks (flag_slot layout); nullptr: every block is sent
+    int fgl, fs;
+    unsigned* arrive_remote[2];  // the neighbour's counter for this rank's planes
+    unsigned* arrive_local[2];   // this rank's counters
+    unsigned seq;
+    unsigned* done;              // [0]: workgroups of the running launch that have finished their sends; [8]: tag of the last exchange whose
+                                 // neighbours have all arrived (fused kernels: what the workgroups other than the poller wait on)
+    unsigned tag;                // this exchange's tag (unique per engine, never 0)
+    int* status;                 // pinned host word the host reads
+    int* status_dev;             // device copy of it: what the kernels look at (a system-scope load of host memory crosses PCIe: +1.4 us per exchange)
+    int code;                    // field << 16 | 1
+    long long timeout_ticks;     // of the 100 MHz wall clock
+    float spoil;                 // 1; a test hook (plmpm_debug_peer_spoil) scales what face 0 sends, to prove that a wrong halo is NOTICED
+};
+// Stores written THROUGH the L2 (sc0 sc1: system-scope write-through): once the store is acknowledged the data is where the
+// neighbour -- another XCD, another process, another GPU -- reads it, and no L2 write-back is needed before the arrival
+// counter moves.  (A release fence at system scope writes back everything the PREVIOUS kernels left dirty in this XCD's L2
+// -- megabytes of particle state after a particle kernel: 11 us per exchange instead of 6; a system fence per thread: 25.)
+__device__ __forceinline__ void store_through(float* p, float v) { asm volatile("global_store_dword %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ void store_through(double* p, double v) { asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ void store_through(int* p, int v) { asm volatile("global_store_dword %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ void store_through(unsigned* p, unsigned v) { asm volatile("global_store_dword %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory"); }
+
+// the block `bl` of face i's planes (wave-uniform): validity word (lane 0), and -- if the block carries something -- its 64 nodes
+// per component, read from this rank's grid and stored through to the neighbour
+template <class T> __device__ __forceinline__ void xchg_send_block(const PeerXchg& X, int i, int bl, int lane) {
+    const int blk = X.blk0[i] + bl;
+    const bool on = X.flags ? (X.flags[(blk & ((1 << X.fgl) - 1)) * X.fs + (blk >> X.fgl)] != 0) : true;      // flag_slot
+    if (lane == 0) store_through((int*)X.dst[i] + bl, on ? 1 : 0);
+    if (!on) return;
+    T* data = (T*)(X.dst[i] + X.data_ofs[i]);
+    const size_t count = (size_t)X.nblk[i] << 6;
+    T v[4];
+    for (int c = 0; c < X.ncomp; ++c) {
+        v[c] = ((const T*)X.src[c])[((size_t)blk << 6) + lane];
+        if (i == 0 && X.spoil != 1.0f) v[c] *= (T)X.spoil;
+    }
+    for (int c = 0; c < X.ncomp; ++c) store_through(data + (size_t)c * count + ((size_t)bl << 6) + lane, v[c]);
+}
+// all threads of a workgroup call, behind their sends: every wave waits for the acknowledgements of its own stores, the
+// workgroup counts itself done, and the LAST workgroup of the launch -- every copy has landed -- publishes the arrival
+// counters.  Returns true in that workgroup (all threads).
+__device__ __forceinline__ bool xchg_publish(const PeerXchg& X) {
+    __shared__ int s_last;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const bool last = __hip_atomic_fetch_add(X.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+        if (last) {
+            __hip_atomic_store(X.done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // the next launch is stream-ordered behind this one
+            // (published even when an earlier exchange timed out: a live neighbour is not kept waiting by THIS rank)
+            if (X.n > 0) store_through(X.arrive_remote[0], X.seq);          // (constant indices: kernel-argument fields read with
+            if (X.n > 1) store_through(X.arrive_remote[1], X.seq);          //  run-time indices become dependent loads inside the kernel)
+        }
+        s_last = last;
+    }
+    __syncthreads();
+    return s_last != 0;
+}
+// threads 0 .. n-1 of the calling wave(s) wait for the neighbours' counters (one lane per face).  A neighbour that has stopped
+// is reported after timeout_ticks -- and never waited for again: an earlier timeout (status_dev != 0) makes the launches still
+// queued behind it drain in microseconds, not in n x PLMPM_PEER_TIMEOUT, before the host gets to look at the status word.
+__device__ __forceinline__ void xchg_wait_lanes(const PeerXchg& X) {
+    if ((int)threadIdx.x < X.n) {
+        const int i = threadIdx.x;
+        unsigned* const mine = i == 0 ? X.arrive_local[0] : X.arrive_local[1];
+        const bool dead = __hip_atomic_load(X.status_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+        const long long t0 = wall_clock64();
+        for (; !dead;) {
+            const unsigned got = __hip_atomic_load(mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if ((int)(got - X.seq) >= 0) break;
+            if (wall_clock64() - t0 > X.timeout_ticks) {         // the neighbour is gone: report, do not hang the GPU
+                __hip_atomic_store(X.status, X.code | (i << 8), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(X.status_dev, X.code | (i << 8), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(2);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+}
+// Folded into a persistent grid kernel (k_grid_op_x / k_grid_op_grad_x): workgroup g sends the blocks of the exchanged planes
+// that it OWNS (g, g + G, ...: the blocks it will itself sum and process once the neighbour's copy is there -- program order
+// inside the workgroup keeps a block's send ahead of the write-back of its complete sums, no other workgroup touches it), one
+// wave per block; then the launch's last workgroup publishes.  Every workgroup of the launch must be resident for the wait
+// that follows to end (the launch is sized for that: plmpm_peer.hip).
+// The wait is hierarchical: the publishing workgroup alone polls the neighbours' counters (uncached memory: hundreds of
+// workgroups polling one uncached word queue up at its memory channel -- measured: 40 us per launch instead of 10) and then
+// raises a tag in ordinary device memory, which the other workgroups poll in the L2 (xchg_wait_arrived).
+template <class T> __device__ __forceinline__ void xchg_push_owned(const Dev<T>& D, const PeerXchg& X) {
+    const int g = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        if (i >= X.n) break;
+        const int lo = X.blk0[i], hi = X.blk0[i] + X.nblk[i];
+        int k = lo > g ? (lo - g + (1 << D.fgl) - 1) >> D.fgl : 0;
+        for (int r = 0, b = g + (k << D.fgl); b < hi; ++r, ++k, b = g + (k << D.fgl))
+            if ((r & (kBlock / 64 - 1)) == wave) xchg_send_block<T>(X, i, b - lo, lane);
+    }
+    if (xchg_publish(X)) {           // the launch's poller: neighbours' arrivals (or a timeout), then the tag for everybody else
+        xchg_wait_lanes(X);
+        __syncthreads();
+        // (relaxed: the tag carries no data -- what arrived is read from uncached memory with system-scope loads; a release
+        // here would write back everything the previous kernels left dirty in this XCD's L2)
+        if (threadIdx.x == 0) __hip_atomic_store(X.done + 8, X.tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+// all threads of every workgroup call, in front of the blocks of the exchanged planes
+__device__ __forceinline__ void xchg_wait_arrived(const PeerXchg& X) {
+    if (threadIdx.x == 0)
+        while (__hip_atomic_load(X.done + 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != X.tag) __builtin_amdgcn_s_sleep(1);
+    __syncthreads();
 }
 
 // The 3-wide stencil at `base` must stay inside the reach box: the allocated grid window, and in z also this rank's
@@ -727,15 +853,24 @@ __global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_p2g(Dev<T> D, int f) 
 // ------------------------------------------------------------------------------------------------
 // grid_op (mpm_simulator.py:189-221) over active 4^3 blocks; one wave per block.
 // CLEAR: forward pass -- consume grid_in (zero it and the flag for the next substep).
-template <class T, bool CLEAR>
-__global__ __launch_bounds__(kBlock) void k_grid_op(Dev<T> D, int f, HaloIn H) {
+// XCHG: the device-side exchange of grid_m / grid_v_in is part of this launch -- send the owned blocks of the exchanged planes |
+// grid_op on the blocks outside them, while the neighbours' copies are in flight | wait for the arrival | the blocks of the
+// exchanged planes.  One launch instead of an exchange kernel + a grid kernel, and the interior hides the arrival.  Measured
+// (round 5, a middle rank of 8 at config 3, one block plane thick = no interior at all, profiles/r05_slab_host_cost.txt): 19.5 us
+// against 10.4 + 8.5 forward, 17.0 against 10.4 + 10.1 in reverse -- the launch saved is paid back by the hand-shake's own
+// latency chain (store acknowledgements -> counter -> publish -> poll -> tag -> system-scope loads of the received planes: 6 us
+// with nothing to hide it behind).  Two things these kernels must NOT do, both measured at +20 us per launch: keep a mutable
+// copy of HaloIn (dynamic indexing sends it to LDS / scratch: the pass number is an argument of for_each_active_block instead),
+// and index kernel-argument arrays with run-time indices (dependent scalar loads inside the kernel: the faces are unrolled).
+template <class T, bool CLEAR, bool XCHG>
+__device__ __forceinline__ void grid_op_body(const Dev<T>& D, int f, const HaloIn& H, const PeerXchg& X) {
     // the primitives of this substep: ready-made records in HBM (k_build_prims), read through uniform addresses -- no
     // assembly from the pose arrays, no LDS copy and no barrier in front of the first block (this kernel is one chain of
     // latencies: flags -> grid loads -> node arithmetic -> stores)
     const PrimT<T>* sp = D.ptab + (size_t)f * kMaxPrim;
     const int fl0 = first_flags(D);
     const int lane = threadIdx.x & 63;
-    for_each_active_block<true>(D, H, fl0, [&](int blk) {
+    auto body = [&](int blk) {
         const int idx = (blk << 6) | lane;
         int I[3];
         block_nodes(D, blk, lane, I);
@@ -765,8 +900,18 @@ __global__ __launch_bounds__(kBlock) void k_grid_op(Dev<T> D, int f, HaloIn H) {
             D.gin[0][idx] = T(0); D.gin[1][idx] = T(0); D.gin[2][idx] = T(0); D.gin[3][idx] = T(0);
             if (lane == 0) D.flags[flag_slot(D, blk)] = 0;
         }
-    });
+    };
+    if constexpr (XCHG) {
+        xchg_push_owned<T>(D, X);
+        for_each_active_block<true>(D, H, 1, fl0, body);
+        xchg_wait_arrived(X);
+        for_each_active_block<true>(D, H, 2, fl0, body);
+    } else for_each_active_block<true>(D, H, H.part, fl0, body);
 }
+template <class T, bool CLEAR>
+__global__ __launch_bounds__(kBlock) void k_grid_op(Dev<T> D, int f, HaloIn H) { grid_op_body<T, CLEAR, false>(D, f, H, PeerXchg{}); }
+template <class T>
+__global__ __launch_bounds__(kBlock) void k_grid_op_x(Dev<T> D, int f, HaloIn H, PeerXchg X) { grid_op_body<T, false, true>(D, f, H, X); }
 
 // ------------------------------------------------------------------------------------------------
 // g2p (mpm_simulator.py:223-242): gather v_out through an LDS tile, write x,v,C of frame f+1
@@ -1244,17 +1389,31 @@ __device__ __forceinline__ bool grid_block_bwd(const Dev<T>& D, const HaloIn& H,
 #ifndef PLB_GOG_WAVES
 #define PLB_GOG_WAVES 1          // 4 (128 VGPRs + 60 B scratch) measured: 14.1 -> 17.8 us
 #endif
-template <class T>
-__global__ __launch_bounds__(kBlock, sizeof(T) == 4 ? PLB_GOG_WAVES : 1) void k_grid_op_grad(Dev<T> D, int f, HaloIn H) {
+template <class T, bool XCHG>
+__device__ __forceinline__ void grid_op_grad_body(const Dev<T>& D, int f, const HaloIn& H, const PeerXchg& X) {
     const PrimT<T>* sp = D.ptab + (size_t)f * kMaxPrim;          // see k_grid_op
     const int fl0 = first_flags(D);
     const int lane = threadIdx.x & 63;
     // the forward grid_op marked every block of the exchanged planes that carries mass, so the flags alone are
     // complete here: no halo candidates
-    for_each_active_block<false>(D, H, fl0, [&](int blk) {
+    auto body = [&](int blk) {
         if (grid_block_bwd<T, false>(D, H, blk, lane, sp, nullptr, nullptr) && lane == 0)
             D.contact[1 + atomicAdd(&D.contact[0], 1)] = blk;
-    });
+    };
+    if constexpr (XCHG) {              // the exchange of grid_v_out.grad folded in, exactly as in k_grid_op_x
+        xchg_push_owned<T>(D, X);
+        for_each_active_block<false>(D, H, 1, fl0, body);
+        xchg_wait_arrived(X);
+        for_each_active_block<false>(D, H, 2, fl0, body);
+    } else for_each_active_block<false>(D, H, H.part, fl0, body);
+}
+template <class T>
+__global__ __launch_bounds__(kBlock, sizeof(T) == 4 ? PLB_GOG_WAVES : 1) void k_grid_op_grad(Dev<T> D, int f, HaloIn H) {
+    grid_op_grad_body<T, false>(D, f, H, PeerXchg{});
+}
+template <class T>
+__global__ __launch_bounds__(kBlock, sizeof(T) == 4 ? PLB_GOG_WAVES : 1) void k_grid_op_grad_x(Dev<T> D, int f, HaloIn H, PeerXchg X) {
+    grid_op_grad_body<T, true>(D, f, H, X);
 }
 
 // the pose-adjoint workgroups of the p2g.grad launch: blocks listed in D.contact, one wave each

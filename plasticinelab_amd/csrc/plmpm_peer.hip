@@ -30,33 +30,7 @@ namespace {
 
 constexpr size_t kPeerHeader = 256;
 
-struct PeerXchg {
-    int n, ncomp;
-    const void* src[2][4];       // component c of this rank's grid array (block 0 of the window)
-    char* dst[2];                // the half of the neighbour's receive area this exchange writes: validity words, then data
-    size_t data_ofs[2];          // bytes from dst to the data
-    int blk0[2], nblk[2];        // first block and number of blocks of the face's planes
-    const int* flags;            // activity flags of the frame's blocks (flag_slot layout); nullptr: every block is sent
-    int fgl, fs;
-    unsigned* arrive_remote[2];  // the neighbour's counter for this rank's planes
-    unsigned* arrive_local[2];   // this rank's counters
-    unsigned seq;
-    unsigned* done;
-    int* status;                 // pinned host word the host reads
-    int* status_dev;             // device copy of it: what the kernel looks at (a system-scope load of host memory crosses PCIe: +1.4 us per exchange)
-    int code;                    // field << 16 | 1
-    long long timeout_ticks;     // of the 100 MHz wall clock
-    float spoil;                 // 1; a test hook (plmpm_debug_peer_spoil) scales what face 0 sends, to prove that a wrong halo is NOTICED
-};
-
-// Stores written THROUGH the L2 (sc0 sc1: system-scope write-through): once the store is acknowledged the data is where the
-// neighbour -- another XCD, another process, another GPU -- reads it, and no L2 write-back is needed before the arrival
-// counter moves.  (A release fence at system scope writes back everything the PREVIOUS kernels left dirty in this XCD's L2
-// -- megabytes of particle state after a particle kernel: 11 us per exchange instead of 6; a system fence per thread: 25.)
-__device__ __forceinline__ void store_through(float* p, float v) { asm volatile("global_store_dword %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory"); }
-__device__ __forceinline__ void store_through(double* p, double v) { asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory"); }
-__device__ __forceinline__ void store_through(int* p, int v) { asm volatile("global_store_dword %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory"); }
-__device__ __forceinline__ void store_through(unsigned* p, unsigned v) { asm volatile("global_store_dword %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory"); }
+// (PeerXchg, store_through and the publish / wait halves live in plmpm_kernels.h: the grid kernels use them too)
 
 template <class T>
 __global__ __launch_bounds__(256) void k_halo_xchg(PeerXchg X) {
@@ -83,8 +57,8 @@ __global__ __launch_bounds__(256) void k_halo_xchg(PeerXchg X) {
             const int b0 = wave + k0 * nwave, b1 = k1 >= 0 ? wave + k1 * nwave : b0;
             T v0[4], v1[4];
             for (int c = 0; c < X.ncomp; ++c) {
-                v0[c] = ((const T*)X.src[i][c])[((size_t)(X.blk0[i] + b0) << 6) + lane];
-                v1[c] = ((const T*)X.src[i][c])[((size_t)(X.blk0[i] + b1) << 6) + lane];
+                v0[c] = ((const T*)X.src[c])[((size_t)(X.blk0[i] + b0) << 6) + lane];
+                v1[c] = ((const T*)X.src[c])[((size_t)(X.blk0[i] + b1) << 6) + lane];
                 if (i == 0 && X.spoil != 1.0f) { v0[c] *= (T)X.spoil; v1[c] *= (T)X.spoil; }
             }
             for (int c = 0; c < X.ncomp; ++c) {
@@ -100,28 +74,12 @@ __global__ __launch_bounds__(256) void k_halo_xchg(PeerXchg X) {
     if (threadIdx.x == 0) last = __hip_atomic_fetch_add(X.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
     __syncthreads();
     if (!last) return;
-    // the last workgroup: every copy of this launch has landed.  Publish, then wait for the neighbours.
-    if (threadIdx.x == 0) __hip_atomic_store(X.done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // the next launch is stream-ordered behind this one
-    if (threadIdx.x < X.n) {
-        const int i = threadIdx.x;
-        // an earlier exchange already timed out (a neighbour has stopped): publish -- so that a live neighbour is not kept
-        // waiting by THIS rank -- but do not wait again: the launches still queued behind this one must drain in microseconds,
-        // not in n x PLMPM_PEER_TIMEOUT, before the host gets to look at the status word
-        const bool dead = __hip_atomic_load(X.status_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
-        store_through(X.arrive_remote[i], X.seq);
-        const long long t0 = wall_clock64();
-        for (; !dead;) {
-            const unsigned got = __hip_atomic_load(X.arrive_local[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            if ((int)(got - X.seq) >= 0) break;
-            if (wall_clock64() - t0 > X.timeout_ticks) {         // the neighbour is gone: report, do not hang the GPU
-                __hip_atomic_store(X.status, X.code | (i << 8), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                __hip_atomic_store(X.status_dev, X.code | (i << 8), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                break;
-            }
-            __builtin_amdgcn_s_sleep(2);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // the last workgroup: every copy of this launch has landed.  Publish, then wait for the neighbours (one lane per face).
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(X.done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // the next launch is stream-ordered behind this one
+        for (int i = 0; i < X.n; ++i) store_through(X.arrive_remote[i], X.seq);
     }
+    xchg_wait_lanes(X);
     // the grid kernel that consumes the received planes is a later launch on this stream and reads them with system-scope
     // loads (halo_sent / halo_value, plmpm_kernels.h)
 }
@@ -212,31 +170,28 @@ int plmpm_halo_peer_setup(plmpm_handle s, int field, int n_faces, const int* bz_
     return 0;
 }
 
-// One exchange of `field` (frame: which frame's grid_m / grid_v_in for PLMPM_HALO_GRID_IN): push, publish, wait -- one
-// launch on the engine's stream -- and point the grid kernels' halo input at the half that is being filled.
-int plmpm_halo_peer_exchange(plmpm_handle s, int field, int frame) {
-    NEED_BOUND(s);
-    REQUIRE(field >= 0 && field < 3, "halo_peer_exchange: unknown field %d", field);
+// The arguments of exchange number ++seq of `field` (frame: which frame's grid_m / grid_v_in for PLMPM_HALO_GRID_IN) and the
+// halo input of the grid kernels pointed at the half that exchange fills.  X.n = 0: this rank has no neighbour.
+static int peer_prepare(plmpm_sim* s, int field, int frame, PeerXchg& X, size_t* blocks_out = nullptr, size_t* most_out = nullptr) {
     plmpm_sim::PeerField& F = s->peer[field];
     HaloIn& H = s->halo_in[field];
-    if (F.n == 0) { memset(&H, 0, sizeof H); return 0; }
+    memset(&X, 0, sizeof X);
+    memset(&H, 0, sizeof H);
+    if (F.n == 0) return 0;
     REQUIRE(*s->peer_status == 0, "halo exchange: an earlier arrival timed out (status 0x%x: field %d, face %d) -- a neighbouring rank has stopped",
             *s->peer_status, *s->peer_status >> 16, (*s->peer_status >> 8) & 255);
     char* base; int nc;
     if (plmpm_halo_field(s, field, frame, &base, &nc)) return -1;
     const unsigned seq = ++F.seq;
     const size_t pblk = (size_t)s->nbw[0] * s->nbw[1];              // blocks per plane
-    PeerXchg X;
-    memset(&X, 0, sizeof X);
-    X.n = F.n; X.ncomp = nc; X.seq = seq; X.done = s->peer_done; X.status = s->peer_status; X.status_dev = (int*)(s->peer_done + 16); X.code = (field << 16) | 1;
+    X.n = F.n; X.ncomp = nc; X.seq = seq; X.done = s->peer_done; X.tag = ++s->peer_tag ? s->peer_tag : ++s->peer_tag; X.status = s->peer_status; X.status_dev = (int*)(s->peer_done + 16); X.code = (field << 16) | 1;
     X.timeout_ticks = (long long)(peer_timeout_seconds() * 1e8);
     X.spoil = s->peer_spoil;
     // the substep fields are sparse in the blocks the frame's scatter flagged; the loss mass grid is sent whole
     X.flags = field == PLMPM_HALO_LOSS_MASS ? nullptr : s->fstore + (size_t)frame * s->nflag;
     X.fgl = s->gwg_log2; X.fs = s->fs;
-    size_t blocks = 0;
-    memset(&H, 0, sizeof H);
-    for (int c = 0; c < nc; ++c) X.src[0][c] = X.src[1][c] = base + (size_t)c * s->G * s->tsz;
+    size_t blocks = 0, most = 0;
+    for (int c = 0; c < nc; ++c) X.src[c] = base + (size_t)c * s->G * s->tsz;
     for (int i = 0; i < F.n; ++i) {
         const size_t nblk = (size_t)(F.bb[i] - F.ba[i]) * pblk, vbytes = align_up(nblk * 4, 256);
         const size_t half = vbytes + (size_t)nc * F.count[i] * s->tsz;
@@ -246,18 +201,46 @@ int plmpm_halo_peer_exchange(plmpm_handle s, int field, int frame) {
         X.arrive_remote[i] = (unsigned*)F.remote[i];
         X.arrive_local[i] = (unsigned*)F.local[i];
         blocks += nblk;
+        most = std::max(most, nblk);
         H.ba[i] = F.ba[i]; H.bb[i] = F.bb[i];
         H.valid[i] = (const int*)(F.local[i] + kPeerHeader + (seq & 1) * half);
         H.buf[i] = F.local[i] + kPeerHeader + (seq & 1) * half + vbytes;
     }
     H.n = F.n;
-    size_t most = 0;
-    for (int i = 0; i < F.n; ++i) most = std::max<size_t>(most, (size_t)(F.bb[i] - F.ba[i]) * pblk);
+    if (blocks_out) *blocks_out = blocks;
+    if (most_out) *most_out = most;
+    return 0;
+}
+
+// One exchange of `field` as a launch of its own: push, publish, wait -- on the engine's stream.
+int plmpm_halo_peer_exchange(plmpm_handle s, int field, int frame) {
+    NEED_BOUND(s);
+    REQUIRE(field >= 0 && field < 3, "halo_peer_exchange: unknown field %d", field);
+    PeerXchg X;
+    size_t blocks = 0, most = 0;
+    if (peer_prepare(s, field, frame, X, &blocks, &most)) return -1;
+    if (X.n == 0) return 0;
     // 64 workgroups (the kernel is three memory latencies long whatever its size), more when a face has more than 64 blocks per wave
     const unsigned nwg = (unsigned)std::max<size_t>(std::min<size_t>(64, std::max<size_t>(1, (blocks + 3) / 4)), (most + 255) / 256);
     if (s->cfg.dtype == PLMPM_F64) LAUNCHB(s, K_HALO_XCHG, (k_halo_xchg<double>), dim3(nwg), 256, X);
     else LAUNCHB(s, K_HALO_XCHG, (k_halo_xchg<float>), dim3(nwg), 256, X);
     HIPCHK(hipGetLastError());
+    return 0;
+}
+// The exchanges of the two substep fields FOLDED INTO the grid kernels that consume them (k_grid_op_x / k_grid_op_grad_x:
+// send the owned blocks of the exchanged planes | the interior blocks | wait | the blocks of the exchanged planes): one launch
+// per exchange + grid phase instead of two, and the interior hides the arrival.  Every workgroup of such a launch spins until
+// the neighbours have published, so all of them must be resident at once -- on the neighbours' GPUs too: with one rank per GPU
+// the 512 persistent grid workgroups are (k_grid_op_grad: 2 per CU x 256 CUs); ranks that SHARE a GPU (the tests) must be
+// built with plmpm_config.grid_workgroups <= 512 / ranks-per-GPU, and say so with PLMPM_PEER_FUSED=1 -- or keep the exchange
+// kernels (default there: distributed.make_slab_env decides).  PLMPM_PEER_FUSED=0 keeps the separate kernels everywhere.
+static bool peer_fused(const plmpm_sim* s) {
+    const char* e = getenv("PLMPM_PEER_FUSED");
+    return e ? e[0] != '0' : (PLB_PEER_FUSED_DEFAULT != 0);
+}
+int plmpm_peer_fused(plmpm_handle s, int* fused) {
+    REQUIRE(s && fused, "null argument");
+    *fused = peer_fused(s) ? 1 : 0;
     return 0;
 }
 // Collective re-synchronisation in two phases, with a host barrier over the ranks behind EACH (SlabEngine.reset_exchange):
@@ -312,12 +295,19 @@ int plmpm_slab_step(plmpm_handle s, int first, int n) {
     NEED_BOUND(s);
     REQUIRE(n >= 1 && first >= 0 && first + n < s->F + 1, "slab_step: frames [%d, %d] out of range", first, first + n);
     if (plmpm_fk(s, first, n)) return -1;
+    const bool fused = peer_fused(s) && s->peer[PLMPM_HALO_GRID_IN].n > 0;
     int pending = 0;
     for (int f = first; f < first + n; ++f) {
         if (plmpm_p2g(s, f, pending)) return -1;
-        if (plmpm_halo_peer_exchange(s, PLMPM_HALO_GRID_IN, f)) return -1;
         pending = f + 1 < first + n;
-        if (plmpm_grid_g2p(s, f, pending)) return -1;
+        if (fused) {
+            PeerXchg X;
+            if (peer_prepare(s, PLMPM_HALO_GRID_IN, f, X)) return -1;
+            if (plmpm_grid_g2p_xchg(s, f, pending, &X)) return -1;
+        } else {
+            if (plmpm_halo_peer_exchange(s, PLMPM_HALO_GRID_IN, f)) return -1;
+            if (plmpm_grid_g2p(s, f, pending)) return -1;
+        }
     }
     return 0;
 }
@@ -326,10 +316,17 @@ int plmpm_slab_step(plmpm_handle s, int first, int n) {
 int plmpm_slab_step_grad(plmpm_handle s, int first, int n) {
     NEED_BOUND(s);
     REQUIRE(n >= 1 && first >= 0 && first + n < s->F + 1, "slab_step_grad: frames [%d, %d] out of range", first, first + n);
+    const bool fused = peer_fused(s) && s->peer[PLMPM_HALO_GRID_OUT_ADJ].n > 0;
     for (int f = first + n - 1; f >= first; --f) {
         if (plmpm_grad_scatter(s, f)) return -1;
-        if (plmpm_halo_peer_exchange(s, PLMPM_HALO_GRID_OUT_ADJ, f)) return -1;
-        if (plmpm_grad_gather(s, f)) return -1;
+        if (fused) {
+            PeerXchg X;
+            if (peer_prepare(s, PLMPM_HALO_GRID_OUT_ADJ, f, X)) return -1;
+            if (plmpm_grad_gather_xchg(s, f, &X)) return -1;
+        } else {
+            if (plmpm_halo_peer_exchange(s, PLMPM_HALO_GRID_OUT_ADJ, f)) return -1;
+            if (plmpm_grad_gather(s, f)) return -1;
+        }
     }
     return 0;
 }

@@ -419,7 +419,8 @@ class SlabEngine:
     @property
     def transport(self) -> str:
         if self.native_loops:
-            return f"peer-write ({self._e.peer_memory_kind()} IPC-mapped receive areas, device-side exchange kernel)"
+            how = "exchange folded into the grid kernels" if self._e.peer_fused() else "device-side exchange kernel"
+            return f"peer-write ({self._e.peer_memory_kind()} IPC-mapped receive areas, {how})"
         return {"nccl": "rccl-p2p (batch_isend_irecv)", "gloo": "gloo-p2p staged through host memory"}.get(self.comm.backend, self.comm.backend)
 
     def reset_exchange(self):
@@ -676,6 +677,22 @@ def make_slab_env(cfg, rank: int, world: int, *, halo: Optional[int] = None, com
     env.all_particles = x_all
     cfg.SIMULATOR.n_particles = len(mine)
     cfg.SIMULATOR["store_grid"] = True
+    # Ranks that SHARE a GPU (tests, emulations: more ranks than devices): the fused exchange + grid kernels of the device-side
+    # exchange wait inside the launch for the neighbours, so the grid workgroups of ALL ranks on a GPU must be resident at once --
+    # 512 of them fit (k_grid_op_grad: two 256-thread workgroups per CU); take half of a rank's share, as a power of two.
+    # (processes of a torch.distributed world only: a one-process emulation of a rank -- profiles/tools/slab_host_cost.py -- has
+    # the GPU to itself)
+    procs = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+    per_gpu = -(-procs // max(torch.cuda.device_count(), 1)) if torch.cuda.is_available() else 1
+    if per_gpu > 1:
+        cap = 8
+        while cap * 2 <= 256 // per_gpu:
+            cap *= 2
+        cfg.SIMULATOR["grid_workgroups"] = cap
+    elif world > 1:
+        # one rank per GPU: 256 of the 512 workgroups that fit -- no margin at all would mean that one CU reserved or masked by
+        # anybody turns the wait inside the fused kernels into a timeout
+        cfg.SIMULATOR["grid_workgroups"] = 256
     env.n_particles = len(mine)
     z0, z1 = layout.slab(rank)
     window = None

@@ -35,7 +35,8 @@ class Engine:
                  dtype: str = "float32", svd_grad_clamp: float = 1e-6, device: Optional[torch.device] = None,
                  slab: Optional[Sequence[int]] = None, store_grid="auto", slab_halo: int = 0, resort_steps: int = 2,
                  grid_window: Optional[Sequence[Sequence[int]]] = None, particle_capacity: Optional[int] = None,
-                 allocate: bool = True, deterministic: bool = False, contact_min_adjoint: str = "add", minmax_tie: str = "second"):
+                 allocate: bool = True, deterministic: bool = False, contact_min_adjoint: str = "add", minmax_tie: str = "second",
+                 grid_workgroups: int = 0):
         self.lib = L.load()
         if not torch.cuda.is_available():
             raise L.EngineError("no ROCm device visible: the MPM engine has no CPU path")
@@ -75,6 +76,7 @@ class Engine:
         # unverified Taichi autodiff semantics as switches (include/plmpm.h)
         cfg.contact_min_adjoint = {"add": 0, "argmin": 1}[contact_min_adjoint]
         cfg.minmax_tie = {"second": 0, "first": 1}[minmax_tie]
+        cfg.grid_workgroups = int(grid_workgroups)          # 0: 512; ranks that share a GPU pass 512 / ranks-per-GPU or less (include/plmpm.h)
         self.deterministic = bool(deterministic)
         parr = (L.Primitive * max(len(primitives), 1))()
         self.action_dims = []
@@ -388,6 +390,12 @@ class Engine:
         """Collective re-synchronisation of the device-side exchange in two phases, a host barrier over the ranks behind each:
         0 = drain (this rank's enqueued exchange kernels are finished), 1 = clear (counters, sequence numbers, status word)."""
         L.check(self.lib.plmpm_halo_peer_reset(self.h, int(phase)))
+
+    def peer_fused(self):
+        """True: the native slab loops fold each exchange into the grid kernel that consumes it (plmpm_peer_fused)."""
+        k = C.c_int()
+        L.check(self.lib.plmpm_peer_fused(self.h, C.byref(k)))
+        return bool(k.value)
 
     def peer_memory_kind(self):
         k = C.c_int()

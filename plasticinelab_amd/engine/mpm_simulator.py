@@ -75,7 +75,8 @@ class MPMSimulator:
                              store_grid=cfg.get("store_grid", "auto"),
                              grid_window=grid_window if grid_window is not None else cfg.get("grid_window", None),
                              particle_capacity=particle_capacity, deterministic=bool(cfg.get("deterministic", False)),
-                             contact_min_adjoint=str(cfg.get("contact_min_adjoint", "add")), minmax_tie=str(cfg.get("minmax_tie", "second")))
+                             contact_min_adjoint=str(cfg.get("contact_min_adjoint", "add")), minmax_tie=str(cfg.get("minmax_tie", "second")),
+                             grid_workgroups=int(cfg.get("grid_workgroups", 0)))
         if hasattr(primitives, "_bind"):
             primitives._bind(self.engine)
         self._mats = None

@@ -84,7 +84,8 @@ def main():
     np.savez(f"{out_path}.{rank}.npz", loss=loss, grad=grad, mine=mine, ids=ids, x=fr["x"], v=fr["v"], bounds=np.array(layout.bounds),
              migrations=eng.migrations, rows_moved=eng.rows_moved, window=np.concatenate(eng.grid_window()),
              grid_bytes=ws["grid_bytes"], total_bytes=sum(ws.values()), count=eng.frame_info(sim.cur)[0],
-             native_loops=int(getattr(eng, "native_loops", False)))
+             native_loops=int(getattr(eng, "native_loops", False)),
+             fused=int(bool(getattr(eng, "native_loops", False)) and eng.peer_fused()))
     dist.barrier()
     dist.destroy_process_group()
 

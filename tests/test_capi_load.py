@@ -52,7 +52,7 @@ def test_library_exports_every_declared_symbol():
 
 
 def test_struct_layout_matches_header():
-    assert ctypes.sizeof(_lib.Config) == 6 * 4 + 8 * 8 + 15 * 4 + 4      # 6 int32, 8 doubles, 15 int32 (+pad)
+    assert ctypes.sizeof(_lib.Config) == 6 * 4 + 8 * 8 + 16 * 4          # 6 int32, 8 doubles, 16 int32
     assert ctypes.sizeof(_lib.Primitive) == 2 * 4 + (3 + 1 + 7 + 3 + 3) * 8 + 2 * 4
     assert ctypes.sizeof(_lib.Workspace) == 4 * ctypes.sizeof(ctypes.c_size_t)
 

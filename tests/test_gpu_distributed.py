@@ -25,7 +25,7 @@ def free_port():
 
 
 def launch(tmp_path, world, dtype, actions, xy_margin, migrate_every, backend="gloo", scene=None, overlap=False, deterministic=False, halo=None,
-           segment=0, peer=False):
+           segment=0, peer=False, fused=True):
     out = str(tmp_path / "r")
     act = str(tmp_path / "actions.npy")
     np.save(act, actions)
@@ -34,7 +34,8 @@ def launch(tmp_path, world, dtype, actions, xy_margin, migrate_every, backend="g
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    HSA_ENABLE_IPC_MODE_LEGACY="0", PLB_DIST_BACKEND=backend, PLB_TEST_OVERLAP="1" if overlap else "0", PLB_TEST_DETERMINISTIC="1" if deterministic else "0",
-                   PLB_TEST_HALO="" if halo is None else str(halo), PLB_TEST_SEGMENT=str(segment) if segment else "", PLB_TEST_PEER="1" if peer else "0", PLMPM_PEER_TIMEOUT="60")
+                   PLB_TEST_HALO="" if halo is None else str(halo), PLB_TEST_SEGMENT=str(segment) if segment else "", PLB_TEST_PEER="1" if peer else "0", PLMPM_PEER_TIMEOUT="60",
+                   PLMPM_PEER_FUSED="1" if fused else "0")
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_gpu_worker.py"), out, dtype, act,
                                        "none" if xy_margin is None else str(xy_margin), str(migrate_every)]
                                       + ([json.dumps(scene)] if scene else []),
@@ -193,15 +194,18 @@ def test_config4_full_size_split_over_two_ranks(tmp_path):
     print(f"\n[256^3 / 2M particles in 2 slabs] loss {loss:.9g}, particles per rank {[int(r['count']) for r in res]}, rows moved {[int(r['rows_moved']) for r in res]}")
 
 
-@pytest.mark.parametrize("dtype,world", [("float64", 2), ("float64", 3), ("float32", 3)])
-def test_peer_write_halos_match_golden_rollout(tmp_path, dtype, world):
-    """Device-side halo exchange (csrc/plmpm_peer.hip): receive areas in fine-grained device memory mapped by the
-    neighbours through IPC handles, one kernel per exchange (copy into the neighbours' areas, publish the arrival counter,
-    wait for theirs), the substep loops native (plmpm_slab_step / plmpm_slab_step_grad) -- no host-side communication per
-    substep.  Same planes and same consuming kernels as the torch.distributed transport, so the same results: the golden
-    rollout with migration every env step, a middle rank with two faces included."""
+@pytest.mark.parametrize("dtype,world,fused", [("float64", 2, True), ("float64", 3, True), ("float32", 3, True), ("float64", 3, False), ("float32", 2, False)])
+def test_peer_write_halos_match_golden_rollout(tmp_path, dtype, world, fused):
+    """Device-side halo exchange (csrc/plmpm_peer.hip): receive areas in uncached device memory mapped by the
+    neighbours through IPC handles, the substep loops native (plmpm_slab_step / plmpm_slab_step_grad) -- no host-side
+    communication per substep.  fused (the default): each exchange is part of the grid kernel that consumes it (send the owned
+    blocks of the exchanged planes | interior blocks | wait for the neighbours | blocks of the exchanged planes); not fused
+    (PLMPM_PEER_FUSED=0): one kernel per exchange (copy, publish, wait) in front of the grid kernel.  Same planes and same
+    node arithmetic as the torch.distributed transport, so the same results: the golden rollout with migration every env step,
+    a middle rank with two faces included."""
     g = np.load(os.path.join(GOLDEN, "rollout_small.npz"))
-    res = launch(tmp_path, world, dtype, g["actions"], 6, migrate_every=1, peer=True)
+    res = launch(tmp_path, world, dtype, g["actions"], 6, migrate_every=1, peer=True, fused=fused)
+    assert all(int(r["fused"]) == int(fused) for r in res)
     ltol, gtol, xtol = (1e-10, 1e-7, 1e-10) if dtype == "float64" else (1e-5, 1e-4, 2e-5)
     assert all(int(r["native_loops"]) == 1 for r in res)
     for r in res:
