@@ -376,6 +376,6 @@ int plmpm_convert_adjoint(plmpm_sim* s, int which, int from, int to);           
 int plmpm_grid_g2p_xchg(plmpm_sim* s, int frame, int chain, const PeerXchg* X);
 int plmpm_grad_gather_xchg(plmpm_sim* s, int frame, const PeerXchg* X);
 #ifndef PLB_PEER_FUSED_DEFAULT
-#define PLB_PEER_FUSED_DEFAULT 1
+#define PLB_PEER_FUSED_DEFAULT 0       // measured (round 5): no wall-clock gain for a thin rank of 8 at config 3 (91.0 against 89.3 us per substep)
 #endif
 

@@ -227,13 +227,15 @@ int plmpm_halo_peer_exchange(plmpm_handle s, int field, int frame) {
     HIPCHK(hipGetLastError());
     return 0;
 }
-// The exchanges of the two substep fields FOLDED INTO the grid kernels that consume them (k_grid_op_x / k_grid_op_grad_x:
-// send the owned blocks of the exchanged planes | the interior blocks | wait | the blocks of the exchanged planes): one launch
-// per exchange + grid phase instead of two, and the interior hides the arrival.  Every workgroup of such a launch spins until
-// the neighbours have published, so all of them must be resident at once -- on the neighbours' GPUs too: with one rank per GPU
-// the 512 persistent grid workgroups are (k_grid_op_grad: 2 per CU x 256 CUs); ranks that SHARE a GPU (the tests) must be
-// built with plmpm_config.grid_workgroups <= 512 / ranks-per-GPU, and say so with PLMPM_PEER_FUSED=1 -- or keep the exchange
-// kernels (default there: distributed.make_slab_env decides).  PLMPM_PEER_FUSED=0 keeps the separate kernels everywhere.
+// Opt-in (PLMPM_PEER_FUSED=1): the exchanges of the two substep fields FOLDED INTO the grid kernels that consume them
+// (k_grid_op_x / k_grid_op_grad_x: send the owned blocks of the exchanged planes | the interior blocks | wait | the blocks of
+// the exchanged planes): one launch per exchange + grid phase instead of two, and the interior blocks' grid work hides the
+// arrival -- the overlap the point-to-point transport gets from SlabEngine(overlap=True), here inside one launch.  Every
+// workgroup of such a launch waits for the neighbours, so all of them must be resident at once -- on the neighbours' GPUs too:
+// 512 grid workgroups fit a GPU exactly (k_grid_op_grad: 2 per CU x 256 CUs), so distributed.make_slab_env builds fused engines
+// with plmpm_config.grid_workgroups = 256 (one rank per GPU) or 256 / ranks-per-GPU (ranks sharing a GPU: the tests).
+// Off by default: measured on a middle rank of 8 at config 3 (one block plane thick: no interior to hide anything behind) the
+// kernels sum to 86.7 us per fwd+bwd substep against 89.1 but the wall clock is 91.0 against 89.3 (profiles/r05_slab_host_cost.txt).
 static bool peer_fused(const plmpm_sim* s) {
     const char* e = getenv("PLMPM_PEER_FUSED");
     return e ? e[0] != '0' : (PLB_PEER_FUSED_DEFAULT != 0);

@@ -677,14 +677,16 @@ def make_slab_env(cfg, rank: int, world: int, *, halo: Optional[int] = None, com
     env.all_particles = x_all
     cfg.SIMULATOR.n_particles = len(mine)
     cfg.SIMULATOR["store_grid"] = True
-    # Ranks that SHARE a GPU (tests, emulations: more ranks than devices): the fused exchange + grid kernels of the device-side
-    # exchange wait inside the launch for the neighbours, so the grid workgroups of ALL ranks on a GPU must be resident at once --
-    # 512 of them fit (k_grid_op_grad: two 256-thread workgroups per CU); take half of a rank's share, as a power of two.
+    # PLMPM_PEER_FUSED=1 (opt-in): the fused exchange + grid kernels of the device-side exchange wait inside the launch for the
+    # neighbours, so the grid workgroups of ALL ranks on a GPU must be resident at once -- 512 of them fit (k_grid_op_grad: two
+    # 256-thread workgroups per CU); ranks that share a GPU (tests, emulations) take half of a rank's share, as a power of two.
     # (processes of a torch.distributed world only: a one-process emulation of a rank -- profiles/tools/slab_host_cost.py -- has
     # the GPU to itself)
     procs = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
     per_gpu = -(-procs // max(torch.cuda.device_count(), 1)) if torch.cuda.is_available() else 1
-    if per_gpu > 1:
+    if os.environ.get("PLMPM_PEER_FUSED", "0") in ("", "0"):
+        pass                                       # exchange kernels (the default): nothing waits inside a grid kernel
+    elif per_gpu > 1:
         cap = 8
         while cap * 2 <= 256 // per_gpu:
             cap *= 2

@@ -25,7 +25,7 @@ def free_port():
 
 
 def launch(tmp_path, world, dtype, actions, xy_margin, migrate_every, backend="gloo", scene=None, overlap=False, deterministic=False, halo=None,
-           segment=0, peer=False, fused=True):
+           segment=0, peer=False, fused=False):
     out = str(tmp_path / "r")
     act = str(tmp_path / "actions.npy")
     np.save(act, actions)
@@ -198,9 +198,9 @@ def test_config4_full_size_split_over_two_ranks(tmp_path):
 def test_peer_write_halos_match_golden_rollout(tmp_path, dtype, world, fused):
     """Device-side halo exchange (csrc/plmpm_peer.hip): receive areas in uncached device memory mapped by the
     neighbours through IPC handles, the substep loops native (plmpm_slab_step / plmpm_slab_step_grad) -- no host-side
-    communication per substep.  fused (the default): each exchange is part of the grid kernel that consumes it (send the owned
-    blocks of the exchanged planes | interior blocks | wait for the neighbours | blocks of the exchanged planes); not fused
-    (PLMPM_PEER_FUSED=0): one kernel per exchange (copy, publish, wait) in front of the grid kernel.  Same planes and same
+    communication per substep.  Not fused (the default): one kernel per exchange (copy, publish, wait) in front of the grid
+    kernel; fused (PLMPM_PEER_FUSED=1): each exchange is part of the grid kernel that consumes it (send the owned blocks of the
+    exchanged planes | interior blocks | wait for the neighbours | blocks of the exchanged planes).  Same planes and same
     node arithmetic as the torch.distributed transport, so the same results: the golden rollout with migration every env step,
     a middle rank with two faces included."""
     g = np.load(os.path.join(GOLDEN, "rollout_small.npz"))
@@ -237,8 +237,8 @@ def test_segment_checkpointed_backward_on_slab_ranks(tmp_path, world, segment, p
         assert relerr(r["grad"], grad) < 1e-7
 
 
-@pytest.mark.parametrize("peer", [False, True])
-def test_thin_slabs_one_block_plane_per_rank(tmp_path, peer):
+@pytest.mark.parametrize("peer,fused", [(False, False), (True, False), (True, True)])
+def test_thin_slabs_one_block_plane_per_rank(tmp_path, peer, fused):
     """The layout `bench.py --gpus 8` uses on config 3: a reach of 2 node layers (one of stencil, one of drift) lets a slab
     be ONE block plane, which then lies in the exchange range of both its faces -- it goes to both neighbours, and
     k_grid_op / k_grid_op_grad add both received copies.  Here: the benchmark's cube on a 64^3 grid (20 layers = 5-6 block
@@ -259,8 +259,8 @@ def test_thin_slabs_one_block_plane_per_rank(tmp_path, peer):
     env.simulator.engine.close()
     del env
     torch.cuda.empty_cache()
-    res = launch(tmp_path, 5, "float64", acts, 10, 1, scene=scene, halo=2, peer=peer)
-    assert all(int(r["native_loops"]) == int(peer) for r in res)
+    res = launch(tmp_path, 5, "float64", acts, 10, 1, scene=scene, halo=2, peer=peer, fused=fused)
+    assert all(int(r["native_loops"]) == int(peer) and int(r["fused"]) == int(fused) for r in res)
     b = [int(v) for v in res[0]["bounds"]]
     assert min(hi - lo for lo, hi in zip(b[1:-2], b[2:-1])) == 4, b          # the middle slabs are single block planes
     for r in res:
