@@ -279,3 +279,52 @@ def test_bench_secondary_points_and_reference_records(tmp_path, monkeypatch):
     x = np.random.default_rng(0).random((5000, 3)) * 0.3 + 0.3
     g = bench.mass_grid(x, 32, 1e-3)
     assert g.shape == (32, 32, 32) and abs(g.sum() - 5.0) < 1e-12 and (g >= 0).all()
+
+
+def test_checkpointed_slab_cleanup_runs_collectives_only_after_agreed_failures(monkeypatch):
+    """optimizer/checkpoint.py on slab ranks: the engine is always left with the population it started with, but the full
+    restore re-synchronises the device-side exchange -- a collective -- and may only run where every rank runs it: after a normal
+    return or a failure the ranks agreed on (SlabEngine._agree / _check mark those exceptions).  A failure of one rank alone
+    restores local state only."""
+    from plasticinelab_amd import distributed as D
+    from plasticinelab_amd.optimizer import checkpoint as ck
+
+    calls = []
+
+    class Eng:
+        def checkpoint(self, f):
+            return {"ids": np.arange(5)}
+
+        def reenter(self, c, collective=True):
+            calls.append(collective)
+
+    class Prim:
+        def get_state(self, f):
+            return np.zeros(7)
+
+        def set_state(self, f, s):
+            pass
+
+    class Sim:
+        engine, n_particles, cur, substeps = Eng(), 5, 0, 3
+
+    class Env:
+        simulator, loss, primitives, n_particles = Sim(), None, [Prim()], 5
+
+        def set_state(self, *a):
+            pass
+
+    for exc, want in ((RuntimeError("NaN on this rank"), [False]), (D._collective(RuntimeError("agreed")), [True]), (None, [True])):
+        calls.clear()
+
+        def sweeps(*a, _exc=exc, **k):
+            if _exc is not None:
+                raise _exc
+            return 1.5, np.zeros((2, 6))
+        monkeypatch.setattr(ck, "_checkpointed_slab_sweeps", sweeps)
+        if exc is None:
+            assert ck._forward_checkpointed_slab(Env(), None, np.zeros((2, 6)), 1, 2, 3, 666.0)[0] == 1.5
+        else:
+            with pytest.raises(RuntimeError, match=str(exc)):
+                ck._forward_checkpointed_slab(Env(), None, np.zeros((2, 6)), 1, 2, 3, 666.0)
+        assert calls == want, (exc, calls)
