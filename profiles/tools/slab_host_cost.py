@@ -87,11 +87,14 @@ def main():
     ap.add_argument("--profile", action="store_true", help="cProfile one rollout (top functions by own time)")
     ap.add_argument("--kernels", action="store_true", help="per-kernel HIP-event durations of one more rollout")
     ap.add_argument("--peer", action="store_true", help="device-side exchange (one kernel per exchange) + native substep loops")
+    ap.add_argument("--grid-wg", type=int, default=0, help="persistent workgroups of the grid kernels (plmpm_config.grid_workgroups; 0 = the default)")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(0)
     sub = int(2e-3 // (0.5e-4 / (args.quality * 0.5)))
     cfg = bench.workload_cfg(args.particles, args.quality, max_steps=max(args.steps, 1) * sub + 1)
+    if args.grid_wg:
+        cfg.SIMULATOR["grid_workgroups"] = args.grid_wg
     n = int(128 * args.quality * 0.5)
     # interior-rank geometry: rank 1 of 3 owns the whole body and has two faces just outside it
     layout = D.SlabLayout(n, (0, int(0.31 * n) // 4 * 4, (int(0.70 * n) + 3) // 4 * 4, n))
