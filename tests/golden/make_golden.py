@@ -1,12 +1,16 @@
 """Regenerates the fixtures under tests/golden/.  Run in the BUILD container only
 (it reads /root/reference, which does not exist on the GPU box):
 
-    python tests/golden/make_golden.py shapes targets rollout_small rollout_move rollout_shapes
+    python tests/golden/make_golden.py shapes scenes targets rollout_small rollout_move rollout_shapes
 
 What each fixture pins
   shapes.npz           the reference's own particle sampler (plb/engine/shapes/shape_maker.py, the one
                        reference file that runs here -- loaded by file path) for Move/TripleMove/Rope v1:
                        sha256 of the full float64 array + its first 64 rows.  REAL reference output.
+  scenes.json          all 50 tasks (ten families x five versions, plb/envs/*.yml + VARIANTS): digest of the merged config tree as the
+                       REAL YAML files give it, and sha256 / row count of the particle cloud the REAL reference sampler draws
+                       for it.  Pins the built-in scene tables (plasticinelab_amd/envs/scenes.py) and "identical initial
+                       conditions" for every task.  REAL reference data / output.
   target_<name>.npz    sparse copy (index + value of the non-zero nodes) of reference target mass grids
                        plb/envs/assets/<name>.npy, used as loss targets.  REAL reference data.
   target_sums.npz      sum / p_mass and non-zero count of all 50 reference target grids (KAT: every one
@@ -53,6 +57,27 @@ def make_shapes():
         out[f"{name}_shape"] = np.array(x.shape)
         print(name, x.shape, out[f"{name}_sha256"])
     np.savez_compressed(os.path.join(HERE, "shapes.npz"), **out)
+
+
+def make_scenes():
+    """Every task of the reference (plb/envs/__init__.py:6-14): the scene as its YAML + variant give it (merged the way
+    PlasticineEnv.load_varaints does, env.py:63-86) and the reference sampler's output for it."""
+    import contextlib, io, json
+    from plasticinelab_amd.envs.scenes import ENV_NAMES, load_variant_file
+    from tests.util import canon_tree, scene_digest
+    Shapes = ref_shapes()
+    out = {}
+    for name in ENV_NAMES:
+        for version in range(1, 6):
+            cfg = load_variant_file(f"{REF}/plb/envs/{name.lower()}.yml", version)
+            shapes = [{k: (v if not isinstance(v, str) else v) for k, v in dict(s).items()} for s in cfg.SHAPES]
+            with contextlib.redirect_stdout(io.StringIO()):
+                x, _ = Shapes(shapes).get()
+            x = np.ascontiguousarray(x, np.float64)
+            out[f"{name}-v{version}"] = {"cfg_sha256": scene_digest(cfg), "x_sha256": hashlib.sha256(x.tobytes()).hexdigest(), "n": int(len(x))}
+            print(f"{name}-v{version}", len(x), out[f"{name}-v{version}"]["x_sha256"][:12])
+    with open(os.path.join(HERE, "scenes.json"), "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
 
 
 def make_targets():

@@ -57,3 +57,37 @@ def test_cfg_tree_semantics():
     with pytest.raises(ValueError):
         merge_lists([{"a": 1}], [{"zz": 1}])
     assert isinstance(CfgNode({"x": {"y": 1}}).x, CfgNode)
+
+
+def _scene_fixture():
+    import json
+    with open(os.path.join(GOLDEN, "scenes.json")) as f:
+        return json.load(f)
+
+
+@pytest.mark.parametrize("name", ["Move", "TripleMove", "Rope", "Writer", "Torus", "Rollingpin", "Chopsticks", "Pinch", "Table", "Assembly"])
+def test_every_task_matches_the_reference_scene_files(name):
+    """All 50 tasks (ten families x versions 1-5): the built-in scene tables give the config tree the reference's YAML + VARIANTS
+    give (digest of the canonical tree, taken from the REAL files: tests/golden/scenes.json), and the sampler draws the particle
+    cloud the REAL reference sampler draws for it, bit for bit -- "identical initial conditions" for every task, not only Move."""
+    from tests.util import scene_digest
+    fx = _scene_fixture()
+    for version in range(1, 6):
+        cfg = load_scene(name, version)
+        want = fx[f"{name}-v{version}"]
+        assert scene_digest(cfg) == want["cfg_sha256"], f"{name}-v{version}: scene table differs from plb/envs/{name.lower()}.yml"
+        x = np.ascontiguousarray(Shapes(cfg.SHAPES).get()[0], np.float64)
+        assert len(x) == want["n"] and hashlib.sha256(x.tobytes()).hexdigest() == want["x_sha256"], f"{name}-v{version}: particle cloud"
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/plb/envs"), reason="the reference checkout is only present in the build container")
+def test_scene_fixture_is_what_the_reference_files_say_today():
+    """Build container: the committed digests are those of the reference's YAML files as they lie under /root/reference (merged by
+    load_variant_file, the counterpart of PlasticineEnv.load_varaints, env.py:63-86)."""
+    from tests.util import scene_digest
+    from plasticinelab_amd.envs.scenes import ENV_NAMES, load_variant_file
+    fx = _scene_fixture()
+    assert len(fx) == 50
+    for name in ENV_NAMES:
+        for version in range(1, 6):
+            assert scene_digest(load_variant_file(f"/root/reference/plb/envs/{name.lower()}.yml", version)) == fx[f"{name}-v{version}"]["cfg_sha256"]

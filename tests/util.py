@@ -69,3 +69,29 @@ def sparse_target(name="Move3D-v1"):
 def seeded_actions(horizon, action_dim, seed=0, scale=0.01):
     """default_rng(seed).uniform(-1,1,(H,A))*0.01."""
     return np.random.default_rng(seed).uniform(-1, 1, (horizon, action_dim)) * scale
+
+
+def canon_tree(x):
+    """A config (sub)tree as plain JSON-able data with ONE spelling per value: mappings sorted by key, sequences as lists, numbers as
+    float hex, strings that spell a Python literal ("(127<<16)", "0.2049/2", "(0.7, 0.7, 0.7)" -- the reference's YAML style)
+    evaluated first.  Two scene descriptions are the same scene iff their canon_tree is equal."""
+    from plasticinelab_amd.config import CfgNode
+    if isinstance(x, str):
+        y = as_value(x)
+        return x if isinstance(y, str) else canon_tree(y)
+    if isinstance(x, (CfgNode, dict)):
+        return {str(k): canon_tree(v) for k, v in sorted(dict(x).items())}
+    if isinstance(x, (list, tuple)):
+        return [canon_tree(v) for v in x]
+    if isinstance(x, bool) or x is None:
+        return x
+    if isinstance(x, (int, float, np.integer, np.floating)):
+        return float(x).hex()
+    raise TypeError(type(x))
+
+
+def scene_digest(cfg):
+    """sha256 of the canonical form of what defines a task: SIMULATOR, SHAPES, PRIMITIVES, ENV."""
+    import hashlib
+    import json
+    return hashlib.sha256(json.dumps(canon_tree({k: cfg[k] for k in ("SIMULATOR", "SHAPES", "PRIMITIVES", "ENV")}), sort_keys=True).encode()).hexdigest()
