@@ -32,7 +32,9 @@ Extra points in the same line, measured AFTER the headline's timed region (they 
                           z-slabs at N = 2, 4, 8, and configs[4] (512^3 / 16M, half sigma_y = 50 / half 1e9, ONE env step of 159
                           substeps with the per-frame grid store) at N = 8 -- the sizes SURVEY 8(e) says can scale -- each with
                           value, job_frac, loss_check against the committed single-GPU loss, halo_transport and
-                          strong_scaling_eff against the committed single-GPU rate (profiles/n1_reference_points.json).
+                          strong_scaling_eff against the committed single-GPU rate (profiles/n1_reference_points.json), and
+                          `halo_overlapped`: the same engine with the exchange folded into the grid kernels (configs[4]'s
+                          "halo-overlapped substeps"), timed and loss-checked the same way.
 """
 from __future__ import annotations
 
@@ -534,8 +536,13 @@ def slab_point(Wd, base_args, pt, transport):
     rec = {"label": pt["label"], "n_gpus": Wd.world, "steps": a.steps, "warmup": a.warmup, "dtype": "f32" if a.dtype == "float32" else "f64"}
     env, err = None, None
     t_build = time.perf_counter()
+    fused_before = os.environ.get("PLMPM_PEER_FUSED")
     try:
+        # built so that BOTH forms of the device-side exchange can run on it (the fused grid kernels need every grid workgroup
+        # resident: make_slab_env caps plmpm_config.grid_workgroups when it sees PLMPM_PEER_FUSED=1); timed with the default form
+        os.environ["PLMPM_PEER_FUSED"] = "1"
         env, parallelism = build_env(a, Wd.device, Wd.rank, Wd.world, slabs=True)
+        os.environ["PLMPM_PEER_FUSED"] = "0"
         eng = env.simulator.engine
         used = eng.use_transport(transport)               # what the headline's transport check settled on
         state0 = env.get_state()["state"]
@@ -548,6 +555,7 @@ def slab_point(Wd, base_args, pt, transport):
         ok, err = False, f"{type(e).__name__}: {str(e)[:200]}"
     if not Wd.agree(ok):
         rec["error"] = err or "failed on another rank"
+        os.environ["PLMPM_PEER_FUSED"] = fused_before or "0"
         return rec, env
     rec["build_and_warmup_s"] = round(time.perf_counter() - t_build, 2)
     sim = env.simulator
@@ -579,6 +587,32 @@ def slab_point(Wd, base_args, pt, transport):
         rec["strong_scaling_eff"] = rec["value"] / (Wd.world * ref["value"])
     else:
         rec["n1_value"], rec["strong_scaling_eff"] = None, None
+    # BASELINE configs[4] asks for "halo-overlapped substeps": the same engine once more with the exchange FOLDED INTO the grid
+    # kernels (PLMPM_PEER_FUSED=1: send | interior blocks | wait | blocks of the exchanged planes in one launch -- the interior hides
+    # the arrival), timed and loss-checked like the default form.  Only on the device-side transport; its failure costs nothing else.
+    if sim.engine.native_loops:
+        try:
+            os.environ["PLMPM_PEER_FUSED"] = "1"
+            env.set_state(state0, 666.0, False)
+            rollout(env, seeded_actions(1, A))                     # warm-up of the fused kernels (first use: code load)
+            t2, l2 = timed_rollouts(Wd, env, state0, seeded_actions(a.steps, A), len(times))
+            ok = True
+        except Exception as e:                                    # noqa: BLE001
+            ok, err = False, f"{type(e).__name__}: {str(e)[:200]}"
+        finally:
+            os.environ["PLMPM_PEER_FUSED"] = "0"
+        if Wd.agree(ok):
+            m2 = sorted(t2)[len(t2) // 2]
+            rec["halo_overlapped"] = {"value": total / m2, "value_min": total / max(t2), "value_max": total / min(t2), "final_loss": float(l2),
+                                      "loss_check": loss_check(name, rec["dtype"], a.steps, float(l2)),
+                                      "halo_transport": "peer-write, exchange folded into the grid kernels (PLMPM_PEER_FUSED=1)",
+                                      "speedup_vs_default": med / m2}
+        else:
+            rec["halo_overlapped"] = {"error": err or "failed on another rank"}
+    if fused_before is None:
+        os.environ.pop("PLMPM_PEER_FUSED", None)
+    else:
+        os.environ["PLMPM_PEER_FUSED"] = fused_before
     return rec, env
 
 

@@ -77,6 +77,11 @@ def test_bench_lines_single_gpu_and_two_slabs():
     assert set(p["loss_check"]) >= {"n1_expected", "rel", "ok"}               # (no committed N = 1 record at this reduced size: nulls)
     # ... and it IS the same rollout as the single-GPU child process ran: same loss
     assert abs(p["final_loss"] - s1["final_loss"]) < 1e-5 * abs(s1["final_loss"]), (p["final_loss"], s1["final_loss"])
+    # "halo-overlapped substeps" (BASELINE configs[4]): the same engine timed once more with the exchange folded into the grid
+    # kernels -- the interior blocks' grid work hides the arrival -- and loss-checked like the default form
+    ho = p["halo_overlapped"]
+    assert "error" not in ho and ho["value"] > 0 and "folded into the grid kernels" in ho["halo_transport"], ho
+    assert abs(ho["final_loss"] - s1["final_loss"]) < 1e-5 * abs(s1["final_loss"]) and set(ho["loss_check"]) >= {"n1_expected", "rel", "ok"}
 
 
 def test_a_spoiled_halo_flips_the_line():
