@@ -328,3 +328,30 @@ def test_checkpointed_slab_cleanup_runs_collectives_only_after_agreed_failures(m
             with pytest.raises(RuntimeError, match=str(exc)):
                 ck._forward_checkpointed_slab(Env(), None, np.zeros((2, 6)), 1, 2, 3, 666.0)
         assert calls == want, (exc, calls)
+
+
+def test_exchange_reset_is_two_phases_with_a_barrier_behind_each():
+    """SlabEngine.reset_exchange: drain on every rank, barrier, clear on every rank, barrier -- a single clear +
+    barrier could be overwritten by a neighbour whose exchange kernels were still draining.  Host logic only: the order of calls."""
+    from plasticinelab_amd import distributed as D
+    log = []
+
+    class Eng:
+        def halo_peer_reset(self, phase):
+            log.append(("reset", phase))
+
+    class Comm:
+        peer_mapped = True
+        scalar_device = "cpu"
+
+        def all_reduce_(self, t, op=None):
+            log.append(("barrier",))
+
+    se = D.SlabEngine.__new__(D.SlabEngine)
+    se._e, se.comm = Eng(), Comm()
+    se.reset_exchange()
+    assert log == [("reset", 0), ("barrier",), ("reset", 1), ("barrier",)]
+    log.clear()
+    se.comm.peer_mapped = False                     # point-to-point transport: nothing to re-synchronise
+    se.reset_exchange()
+    assert log == []
