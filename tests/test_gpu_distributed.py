@@ -312,6 +312,49 @@ def test_peer_exchange_wait_is_bounded(monkeypatch):
         eng.halo_peer_exchange(eng.HALO_GRID_IN, 0)
 
 
+def test_fused_exchange_wait_is_bounded_too(monkeypatch):
+    """The same for the exchange FOLDED INTO the grid kernels (PLMPM_PEER_FUSED=1), where every workgroup of the launch waits: the
+    loss-mass exchange is answered (loop-back), the substep fields' neighbours are silent -- the first forward substep's grid kernel
+    gives up after PLMPM_PEER_TIMEOUT, every workgroup is released by the poller's tag, the rest of the env step drains without
+    waiting again, and the step raises."""
+    import sys
+    import time
+    import torch
+    import bench
+    sys.path.insert(0, os.path.join(ROOT, "profiles", "tools"))
+    import slab_host_cost as shc
+    from plasticinelab_amd import distributed as D
+
+    class HalfSilent(shc.LoopbackComm):
+        def setup_peer(self, engine):
+            faces = self.layout.faces(self.rank)
+            for field in (engine.HALO_GRID_IN, engine.HALO_GRID_OUT_ADJ, engine.HALO_LOSS_MASS):
+                local = [engine.peer_alloc(field, a, b)[0] for _n, a, b in faces]
+                remote = local if field == engine.HALO_LOSS_MASS else [engine.peer_alloc(field, a, b)[0] for _n, a, b in faces]
+                engine.halo_peer_setup(field, [(a, b) for _n, a, b in faces], local, remote)
+            self.peer_ready = True
+            return True
+
+    monkeypatch.setenv("PLMPM_PEER_TIMEOUT", "0.3")
+    monkeypatch.setenv("PLMPM_PEER_FUSED", "1")
+    cfg = bench.workload_cfg(20_000, 1, max_steps=40)
+    layout = D.SlabLayout(64, (0, 16, 36, 64))
+    env, _, _ = D.make_slab_env(cfg, 1, 3, compute_dtype="float32", target_fn=bench._target, layout=layout,
+                                comm=HalfSilent(layout, 1, True), xy_margin=8, migrate_every=0)
+    eng = env.simulator.engine
+    assert eng.native_loops and eng.peer_fused() and eng.peer_status() == 0
+    env.set_state(env.get_state()["state"], 666.0, False)            # the loss-mass exchange of the initial loss is answered
+    assert eng.peer_status() == 0
+    t0 = time.time()
+    with pytest.raises(RuntimeError, match="timed out.*field 0"):
+        env.step(bench.seeded_actions(1, 6)[0])
+        eng._check()
+    assert 0.25 < time.time() - t0 < 30                              # one timeout, not one per substep
+    torch.cuda.synchronize()                                          # the GPU is still there
+    st = eng.peer_status()
+    assert st & 1 and (st >> 16) == eng.HALO_GRID_IN
+
+
 def test_config5_rank_fits_in_hbm():
     """BASELINE configs[4]: 512^3 grid, 16M particles in a cube of side 0.25, 8 z-slabs.  What one rank has to allocate
     for a whole env step (159 substeps) in store mode, as plmpm_workspace_bytes reports it -- nothing is allocated
