@@ -406,10 +406,21 @@ template <class T> __device__ __forceinline__ void xchg_push_owned(const Dev<T>&
         if (threadIdx.x == 0) __hip_atomic_store(X.done + 8, X.tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
-// all threads of every workgroup call, in front of the blocks of the exchanged planes
+// all threads of every workgroup call, in front of the blocks of the exchanged planes.  Bounded like the poller's wait (twice its
+// limit: the poller raises the tag after ITS timeout at the latest): a launch whose workgroups are not all resident -- more grid
+// workgroups than the GPU holds at once, so that the publishing workgroup never gets to run -- reports face 0xff instead of hanging.
 __device__ __forceinline__ void xchg_wait_arrived(const PeerXchg& X) {
-    if (threadIdx.x == 0)
-        while (__hip_atomic_load(X.done + 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != X.tag) __builtin_amdgcn_s_sleep(1);
+    if (threadIdx.x == 0) {
+        const long long t0 = wall_clock64();
+        while (__hip_atomic_load(X.done + 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != X.tag) {
+            if (wall_clock64() - t0 > 2 * X.timeout_ticks) {
+                __hip_atomic_store(X.status, X.code | (0xff << 8), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(X.status_dev, X.code | (0xff << 8), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+    }
     __syncthreads();
 }
 
