@@ -355,6 +355,49 @@ def test_fused_exchange_wait_is_bounded_too(monkeypatch):
     assert st & 1 and (st >> 16) == eng.HALO_GRID_IN
 
 
+@pytest.mark.parametrize("peer", [False, True])
+def test_a_rank_without_particles_steps_and_differentiates(peer):
+    """Migration can leave a rank without a single row (the body moved out of its slab): every particle launch is then of size zero
+    and must be skipped, the grid kernels still run over the exchanged planes, state / gradient I/O returns empty arrays, and a
+    whole env step forward + backward goes through.  One process, middle rank of three, loop-back exchange; re-entered with an
+    EMPTY population (plmpm_set_population(0)), host-driven and native substep loops."""
+    import sys
+    import bench
+    sys.path.insert(0, os.path.join(ROOT, "profiles", "tools"))
+    import slab_host_cost as shc
+    from plasticinelab_amd import distributed as D
+    from plasticinelab_amd.engine.taichi_env import Tape
+    cfg = bench.workload_cfg(20_000, 1, max_steps=40)
+    layout = D.SlabLayout(64, (0, 16, 36, 64))
+    env, _, _ = D.make_slab_env(cfg, 1, 3, compute_dtype="float32", target_fn=bench._target, layout=layout,
+                                comm=shc.LoopbackComm(layout, 1, peer), xy_margin=8, migrate_every=0)
+    eng = env.simulator.engine
+    assert eng.native_loops == peer
+    empty = dict(ids=np.zeros(0, np.int32), x=np.zeros((0, 3)), v=np.zeros((0, 3)), F=np.zeros((0, 3, 3)), C=np.zeros((0, 3, 3)),
+                 mu=np.zeros(0), lam=np.zeros(0), ys=np.zeros(0), since=0)
+    eng.reenter(empty)
+    env.simulator.n_particles = env.n_particles = 0
+    env.simulator.cur = 0
+    env._is_copy = False                                               # tape mode (what set_state(..., is_copy=False) sets)
+    env.loss.reset(); env.loss.clear()
+    assert eng.frame_info(0)[0] == 0
+    with Tape(env):
+        env.step(bench.seeded_actions(1, 6)[0])
+        env.compute_loss()
+    eng._check()
+    f = env.simulator.cur
+    assert f == env.simulator.substeps and eng.frame_info(f)[0] == 0
+    fr = eng.get_frame(f)
+    assert fr["x"].shape == (0, 3) and fr["F"].shape == (0, 3, 3)
+    assert eng.get_frame_grad(0)["x"].shape == (0, 3)
+    assert eng.grid_stats(0)[0] == 0                                   # nothing was scattered
+    g = np.asarray(env.primitives.get_grad(1))
+    assert g.shape == (1, 6) and np.isfinite(g).all() and np.isfinite(env.loss.loss)
+    # no mass anywhere: this rank's density term is the target's own mass on the nodes it owns (z in [16, 36))
+    want = float(np.abs(env.loss.target_density[:, :, 16:36]).sum())
+    assert want > 0 and abs(env.loss.density_loss - want) < 1e-5 * want
+
+
 def test_config5_rank_fits_in_hbm():
     """BASELINE configs[4]: 512^3 grid, 16M particles in a cube of side 0.25, 8 z-slabs.  What one rank has to allocate
     for a whole env step (159 substeps) in store mode, as plmpm_workspace_bytes reports it -- nothing is allocated
