@@ -99,3 +99,28 @@ def test_integration_doc_structs_match_the_library_binding():
         a, b = ns[name], getattr(_lib, name)
         assert ctypes.sizeof(a) == ctypes.sizeof(b), name
         assert [(f[0], getattr(a, f[0]).offset) for f in a._fields_] == [(f[0], getattr(b, f[0]).offset) for f in b._fields_], name
+
+
+def test_create_rejects_bad_configurations_with_a_message():
+    """Error behaviour of the boundary, no GPU needed: plmpm_create validates its configuration before it looks for a device, returns
+    non-zero, never throws across the ABI, and plmpm_last_error says what was wrong (the reference asserts in
+    MPMSimulator.__init__, mpm_simulator.py:8; Primitives, primitives.py:263-279)."""
+    lib = _lib.load()
+
+    def create(**kw):
+        cfg = _lib.Config()
+        cfg.dtype, cfg.n_grid, cfg.n_particles, cfg.max_frames, cfg.substeps = 0, 64, 10, 4, 19
+        for k, v in kw.items():
+            setattr(cfg, k, v)
+        h = ctypes.c_void_p()
+        rc = lib.plmpm_create(ctypes.byref(cfg), None, ctypes.byref(h))
+        return rc, lib.plmpm_last_error().decode()
+
+    for kw, needle in (({"dtype": 7}, "dtype"), ({"n_grid": 62}, "multiple of 4"), ({"n_grid": 4}, "multiple of 4"), ({"n_particles": 0}, "positive"),
+                       ({"n_primitives": 9}, "at most 8"), ({"max_frames": 0}, "max_frames"), ({"n_primitives": 2}, "prims is null")):
+        rc, msg = create(**kw)
+        assert rc != 0 and needle in msg, (kw, msg)
+    assert lib.plmpm_create(None, None, None) != 0 and "null" in lib.plmpm_last_error().decode()
+    # entry points on a null handle fail the same way instead of crashing
+    assert lib.plmpm_substep(None, 0) != 0 and lib.plmpm_step(None, 0, 19) != 0
+    assert lib.plmpm_set_softness(None, ctypes.c_double(1.0)) != 0
