@@ -634,6 +634,22 @@ def slab_window(x_all: np.ndarray, n_grid: int, layout: SlabLayout, rank: int, x
     return [int(v) for v in lo], [int(v) for v in hi]
 
 
+def fused_grid_workgroups(fused: bool, world: int, ranks_per_gpu: int) -> int:
+    """plmpm_config.grid_workgroups of a slab engine (0 = the library's default of 512).  Exchange kernels (the default): nothing
+    waits inside a grid kernel, no cap.  Fused exchange + grid kernels: every grid workgroup of every rank on a GPU must be resident
+    at once and 512 fit (k_grid_op_grad: two 256-thread workgroups per CU x 256 CUs) -- one rank per GPU runs 256 of them (no margin
+    at all would mean that one CU reserved or masked by anybody turns the wait into a timeout), ranks that share a GPU (tests,
+    emulations) half of their share of 512, as a power of two, at least 8."""
+    if not fused or world <= 1:
+        return 0
+    if ranks_per_gpu <= 1:
+        return 256
+    cap = 8
+    while cap * 2 <= 256 // ranks_per_gpu:
+        cap *= 2
+    return cap
+
+
 def make_slab_env(cfg, rank: int, world: int, *, halo: Optional[int] = None, compute_dtype=None, device=None, group=None,
                   target_fn: Optional[Callable] = None, particles: Optional[np.ndarray] = None,
                   layout: Optional[SlabLayout] = None, comm: Optional[HaloComm] = None,
@@ -684,17 +700,9 @@ def make_slab_env(cfg, rank: int, world: int, *, halo: Optional[int] = None, com
     # the GPU to itself)
     procs = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
     per_gpu = -(-procs // max(torch.cuda.device_count(), 1)) if torch.cuda.is_available() else 1
-    if os.environ.get("PLMPM_PEER_FUSED", "0") in ("", "0"):
-        pass                                       # exchange kernels (the default): nothing waits inside a grid kernel
-    elif per_gpu > 1:
-        cap = 8
-        while cap * 2 <= 256 // per_gpu:
-            cap *= 2
+    cap = fused_grid_workgroups(os.environ.get("PLMPM_PEER_FUSED", "0") not in ("", "0"), world, per_gpu)
+    if cap:
         cfg.SIMULATOR["grid_workgroups"] = cap
-    elif world > 1:
-        # one rank per GPU: 256 of the 512 workgroups that fit -- no margin at all would mean that one CU reserved or masked by
-        # anybody turns the wait inside the fused kernels into a timeout
-        cfg.SIMULATOR["grid_workgroups"] = 256
     env.n_particles = len(mine)
     z0, z1 = layout.slab(rank)
     window = None

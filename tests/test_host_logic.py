@@ -355,3 +355,15 @@ def test_exchange_reset_is_two_phases_with_a_barrier_behind_each():
     se.comm.peer_mapped = False                     # point-to-point transport: nothing to re-synchronise
     se.reset_exchange()
     assert log == []
+
+
+def test_grid_workgroups_of_engines_built_for_the_fused_exchange():
+    """Every grid workgroup of every rank on a GPU must be resident while the fused exchange + grid kernels wait for the neighbours:
+    512 fit a GPU; the cap leaves a margin and is a power of two (the flag layout of the grid kernels needs one)."""
+    from plasticinelab_amd.distributed import fused_grid_workgroups as cap
+    assert cap(False, 8, 1) == 0 and cap(False, 8, 8) == 0 and cap(True, 1, 1) == 0          # exchange kernels / one rank: the default
+    assert cap(True, 8, 1) == 256 and cap(True, 2, 1) == 256                                 # one rank per GPU
+    assert [cap(True, n, n) for n in (2, 3, 4, 5, 8, 16, 64)] == [128, 64, 64, 32, 32, 16, 8]
+    for n in (2, 3, 4, 5, 8, 16):
+        c = cap(True, n, n)
+        assert c & (c - 1) == 0 and n * c <= 256
