@@ -294,7 +294,7 @@ def one_step_loss_and_grad(env, state0, A):
     return float(loss), np.array(env.primitives.get_grad(1), dtype=np.float64)
 
 
-def transport_check(env, state0, A, agree, tol_loss=1e-5, tol_grad=1e-4):
+def transport_check(env, state0, A, agree, tol_loss=1e-5, tol_grad=1e-4, gather=None):
     """N > 1, device-side exchange set up: run ONE env step fwd + bwd through the peer-write exchange and again through the
     library's point-to-point transport (RCCL on the GPUs' backend) and compare loss and action gradient.  The first real
     multi-GPU run of this code happens without anybody watching: a visibility bug of the hand-written exchange across GPUs
@@ -302,6 +302,9 @@ def transport_check(env, state0, A, agree, tol_loss=1e-5, tol_grad=1e-4):
     record that goes into the JSON line; the engine is left on the transport to time."""
     eng = env.simulator.engine
     rec = {"checked": False, "peer_available": bool(getattr(eng.comm, "peer_mapped", False))}
+    # first-contact record of every rank (distributed.HaloComm.setup_peer): device, hipDeviceCanAccessPeer towards both neighbours,
+    # kind of memory the receive areas got, whether the IPC handles opened, one hand-off of the exchange's pattern across each face
+    rec["preflight"] = gather(getattr(eng.comm, "preflight", None)) if gather else None
     if not rec["peer_available"]:
         rec["reason"] = getattr(eng.comm, "peer_error", None) or "device-side exchange not set up (PLB_PEER_HALOS=0, or no IPC mapping)"
         rec["used"] = eng.use_transport("p2p")
@@ -395,8 +398,12 @@ def child_point(extra, timeout=600):
     prints, reduced to the keys a secondary point carries."""
     import subprocess
     cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1"] + extra + ["--no-cpu-baseline", "--no-secondary"]
+    # a child of one rank of an N > 1 run is a world of its own on that rank's GPU: the launcher's variables must not reach it
+    cenv = {k: v for k, v in os.environ.items()
+            if k not in ("RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "ROLE_WORLD_SIZE", "GROUP_WORLD_SIZE", "MASTER_ADDR",
+                         "MASTER_PORT", "PLB_BENCH_NOTE", "PLB_FORCE_SECONDARY") and not k.startswith("TORCHELASTIC")}
     try:
-        p = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, cwd=ROOT)
+        p = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, cwd=ROOT, env=cenv)
         line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
         if p.returncode != 0 or not line:
             return {"error": f"rc {p.returncode}: {p.stderr[-300:]}"}
@@ -501,6 +508,14 @@ class World:
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.ctl)
         return float(t.item())
 
+    def gather_objects(self, obj):
+        """[obj of rank 0, obj of rank 1, ...] on every rank (control plane)."""
+        if self.dist is None:
+            return [obj]
+        out = [None] * self.world
+        self.dist.all_gather_object(out, obj, group=self.ctl)
+        return out
+
     def sum_over_ranks(self, values):
         t = torch.tensor([float(v) for v in values], dtype=torch.float64)
         if self.dist is not None:
@@ -519,9 +534,18 @@ def timed_rollouts(Wd, env, state0, acts, repeats):
         env.set_state(state0, 666.0, False)
         Wd.barrier()
         t0 = time.perf_counter()
-        loss = rollout(env, acts)
+        err = None
+        try:
+            loss = rollout(env, acts)
+        except Exception as e:                                    # noqa: BLE001
+            err = e
         Wd.barrier()
-        times.append(Wd.max_over_ranks(time.perf_counter() - t0))
+        dt = Wd.max_over_ranks(time.perf_counter() - t0)
+        # a rank that failed alone still meets the others at the SAME collectives (barrier, max, agreement) and only then raises --
+        # on every rank: nobody is left in a barrier while another rank has moved on to a different collective
+        if not Wd.agree(err is None):
+            raise err if err is not None else RuntimeError("the rollout failed on another rank")
+        times.append(dt)
     return times, loss
 
 
@@ -541,8 +565,10 @@ def slab_point(Wd, base_args, pt, transport):
         # built so that BOTH forms of the device-side exchange can run on it (the fused grid kernels need every grid workgroup
         # resident: make_slab_env caps plmpm_config.grid_workgroups when it sees PLMPM_PEER_FUSED=1); timed with the default form
         os.environ["PLMPM_PEER_FUSED"] = "1"
-        env, parallelism = build_env(a, Wd.device, Wd.rank, Wd.world, slabs=True)
-        os.environ["PLMPM_PEER_FUSED"] = "0"
+        try:
+            env, parallelism = build_env(a, Wd.device, Wd.rank, Wd.world, slabs=True)
+        finally:
+            os.environ["PLMPM_PEER_FUSED"] = "0"
         eng = env.simulator.engine
         used = eng.use_transport(transport)               # what the headline's transport check settled on
         state0 = env.get_state()["state"]
@@ -553,11 +579,20 @@ def slab_point(Wd, base_args, pt, transport):
         ok = True
     except Exception as e:                                        # noqa: BLE001
         ok, err = False, f"{type(e).__name__}: {str(e)[:200]}"
+    def restore_fused():
+        if fused_before is None:
+            os.environ.pop("PLMPM_PEER_FUSED", None)
+        else:
+            os.environ["PLMPM_PEER_FUSED"] = fused_before
+
     if not Wd.agree(ok):
         rec["error"] = err or "failed on another rank"
-        os.environ["PLMPM_PEER_FUSED"] = fused_before or "0"
+        restore_fused()
         return rec, env
     rec["build_and_warmup_s"] = round(time.perf_counter() - t_build, 2)
+    # the persistent grid launches of THIS engine: capped for residency because the fused form is timed on it too (the library's
+    # default is 512 where the window has that many blocks); `value` of the default transport is measured with this cap
+    rec["grid_workgroups"] = int(getattr(env.simulator.engine, "grid_workgroups", 0) or 0)
     sim = env.simulator
     sub = sim.substeps
     try:
@@ -568,6 +603,7 @@ def slab_point(Wd, base_args, pt, transport):
         ok, err, times, loss, nodes = False, f"{type(e).__name__}: {str(e)[:200]}", [], None, 0
     if not Wd.agree(ok):
         rec["error"] = err or "failed on another rank"
+        restore_fused()
         return rec, env
     n_all, a_all = Wd.sum_over_ranks([sim.n_particles, nodes])     # halo nodes are active on both neighbours: swept twice, counted twice
     med = sorted(times)[len(times) // 2]
@@ -584,9 +620,11 @@ def slab_point(Wd, base_args, pt, transport):
     if ref and ref.get("value"):
         rec["n1_value"] = ref["value"]
         rec["n1_source"] = ref.get("source")
+        # what the single-GPU reference timed: "same rollout", or -- configs[4], whose 160 frames do not fit one GPU -- a window of it
+        rec["n1_schedule"] = ref.get("schedule", "same rollout")
         rec["strong_scaling_eff"] = rec["value"] / (Wd.world * ref["value"])
     else:
-        rec["n1_value"], rec["strong_scaling_eff"] = None, None
+        rec["n1_value"], rec["strong_scaling_eff"], rec["n1_schedule"] = None, None, None
     # BASELINE configs[4] asks for "halo-overlapped substeps": the same engine once more with the exchange FOLDED INTO the grid
     # kernels (PLMPM_PEER_FUSED=1: send | interior blocks | wait | blocks of the exchanged planes in one launch -- the interior hides
     # the arrival), timed and loss-checked like the default form.  Only on the device-side transport; its failure costs nothing else.
@@ -609,10 +647,7 @@ def slab_point(Wd, base_args, pt, transport):
                                       "speedup_vs_default": med / m2}
         else:
             rec["halo_overlapped"] = {"error": err or "failed on another rank"}
-    if fused_before is None:
-        os.environ.pop("PLMPM_PEER_FUSED", None)
-    else:
-        os.environ["PLMPM_PEER_FUSED"] = fused_before
+    restore_fused()
     return rec, env
 
 
@@ -705,7 +740,7 @@ def main():
         if agree(ok):
             try:
                 state0 = env.get_state()["state"]
-                tcheck = transport_check(env, state0, env.primitives.action_dim, agree)
+                tcheck = transport_check(env, state0, env.primitives.action_dim, agree, gather=Wd.gather_objects)
                 if tcheck.get("used") is None:
                     raise RuntimeError(tcheck.get("reason", "no usable halo transport"))
                 parallelism += ", " + slab_how(env)
@@ -882,8 +917,29 @@ def main():
         timer = threading.Timer(limit, give_up)
         timer.daemon = True
         timer.start()
+        # The N = 1 points of the strong-scaling series measured on THIS box, in this run: rank 0 alone, in child
+        # processes on its own GPU, times the headline and the configs[3]-size point on one GPU while the other ranks wait at the
+        # control-plane barrier (~25 s).  `strong_scaling_eff` divides by a number committed from another box (boxes differ by 3 %
+        # and more); `strong_scaling_eff_same_box` divides by these.
+        same_box = {}
+        if rank == 0 and os.environ.get("PLB_SAME_BOX_N1", "1") != "0":
+            hl = child_point(["--steps", str(K), "--warmup", str(W), "--repeats", "3", "--dtype", args.dtype, "--particles", str(args.particles),
+                              "--quality", repr(args.quality), "--side", repr(args.side), "--yield-stress", repr(args.yield_stress)])
+            same_box["headline"] = hl
+            same_box["configs[3]"] = secondary_point(args) if points else None
+        barrier()
+        phase_done("n1_same_box")
+        if rank == 0 and same_box:
+            hl = same_box["headline"]
+            out["n1_same_box"] = {k: (v if v is None or "error" in v else {q: v[q] for q in ("workload", "value", "value_min", "value_max", "steps", "repeats", "final_loss", "command")})
+                                  for k, v in same_box.items()}
+            out["strong_scaling_eff_same_box"] = value / (world * hl["value"]) if hl and "error" not in hl and hl.get("value") else None
         for pt in points:
             rec, penv = slab_point(Wd, args, pt, transport)
+            n1 = same_box.get("configs[3]") if pt is points[0] else None
+            if rank == 0 and "error" not in rec:
+                rec["strong_scaling_eff_same_box"] = (rec["value"] / (world * n1["value"])) if (n1 and "error" not in n1 and n1.get("value")) else None
+                rec["n1_same_box_value"] = n1["value"] if (n1 and "error" not in n1) else None
             out["secondary"].append(rec)
             if penv is not None:
                 close_env(penv)

@@ -103,9 +103,10 @@ typedef struct plmpm_config {
     int32_t contact_min_adjoint;
     int32_t minmax_tie;
     /* persistent workgroups of the grid kernels (grid_op, grid_op.grad; rounded down to a power of two, at most 512 and at most
-     * blocks / 4); 0 = 512.  Only ranks that SHARE a GPU need it: the fused exchange + grid kernels of the device-side halo
-     * exchange wait inside the launch for the neighbours, so every workgroup of every rank on a GPU must be resident at once
-     * (plmpm_peer_fused): at most 512 / ranks-per-GPU there. */
+     * blocks / 4); 0 = 512.  Slab engines that are to run the fused exchange + grid kernels of the device-side halo exchange
+     * (PLMPM_PEER_FUSED=1) must be created with 1 .. 256 here: those launches wait for the neighbours, so every grid workgroup of
+     * every rank on a GPU must be resident at once -- at most 256 / ranks-per-GPU; an engine created with 0 keeps the exchange
+     * kernels whatever the variable says (plmpm_peer_fused reports the form in use). */
     int32_t grid_workgroups;
 } plmpm_config;
 
@@ -293,9 +294,16 @@ int plmpm_peer_status(plmpm_handle h, int* status);
 int plmpm_halo_peer_reset(plmpm_handle h, int phase);
 /* 1: receive areas in uncached device memory (hipDeviceMallocUncached), 0: fine-grained (PLMPM_PEER_MEM=finegrained, or refused) */
 int plmpm_peer_memory_kind(plmpm_handle h, int* uncached);
+/* First contact with the neighbours, collective (every rank calls it with the same non-zero token and then meets the others
+ * at a host barrier): the token is stored through into a spare word of both neighbours' receive-area headers of `field` and
+ * theirs is polled for with system-scope loads -- the exchange's own hand-off on the real areas, before a halo depends on it.
+ * ok2[i] = 1: face i's token arrived within timeout_s; wait_us2[i]: how long the poll took.  Exchange counters untouched. */
+int plmpm_peer_ping(plmpm_handle h, int field, unsigned token, double timeout_s, int* ok2, double* wait_us2);
 /* 1: plmpm_slab_step / plmpm_slab_step_grad fold each exchange into the grid kernel that consumes it (send the owned blocks of
  * the exchanged planes | interior blocks | wait | blocks of the exchanged planes: one launch, the interior hides the arrival);
- * 0: exchange kernel + grid kernel (PLMPM_PEER_FUSED=0, or a build with -DPLB_PEER_FUSED_DEFAULT=0) */
+ * 0: exchange kernel + grid kernel (PLMPM_PEER_FUSED unset or 0 -- the build's default, -DPLB_PEER_FUSED_DEFAULT=0 -- or an engine
+ * that was not created for it: only engines with plmpm_config.grid_workgroups in 1 .. 256 take the fused form, because every
+ * grid workgroup of a fused launch waits for the neighbours and must be resident) */
 int plmpm_peer_fused(plmpm_handle h, int* fused);
 int plmpm_slab_step(plmpm_handle h, int first_frame, int n_substeps);         /* fk + n x (p2g | exchange | grid_op + g2p) */
 int plmpm_slab_step_grad(plmpm_handle h, int first_frame, int n_substeps);    /* n x (g2p.grad | exchange | grid_op.grad + p2g.grad), in reverse */

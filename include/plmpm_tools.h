@@ -51,6 +51,10 @@ int plmpm_debug_peer_spoil(plmpm_handle h, double factor);
 /* tuning aid: {error word, workgroups of the fused forward kernel that fell back to global atomics, workgroups on
  * the LDS-tile path, sum of their tile sizes in nodes} since the last call */
 int plmpm_debug_counters(plmpm_handle h, int* out4);
+/* test hook: the list of 4^3 blocks whose pose adjoints k_grid_op_grad left to the next k_p2g_grad launch.  seed >= 0 first
+ * overwrites the list with `seed` stale entries (block 0); *count = entries listed now.  A reverse substep must leave only its
+ * own entries behind, on a rank without particles too */
+int plmpm_debug_contact(plmpm_handle h, int seed, int* count);
 
 #ifdef __cplusplus
 }

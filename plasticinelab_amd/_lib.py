@@ -107,6 +107,7 @@ SYMBOLS = {
     "plmpm_halo_peer_reset": (_I, [_P, _I]),
     "plmpm_peer_fused": (_I, [_P, C.POINTER(_I)]),
     "plmpm_peer_memory_kind": (_I, [_P, C.POINTER(_I)]),
+    "plmpm_peer_ping": (_I, [_P, _I, C.c_uint, _D, C.POINTER(_I), C.POINTER(_D)]),
     "plmpm_debug_peer_spoil": (_I, [_P, _D]),
     "plmpm_slab_step": (_I, [_P, _I, _I]),
     "plmpm_slab_step_grad": (_I, [_P, _I, _I]),
@@ -134,6 +135,7 @@ SYMBOLS = {
     "plmpm_loss_backward_local": (_I, [_P, _I]),
     "plmpm_check_error": (_I, [_P, C.POINTER(_I)]),
     "plmpm_debug_counters": (_I, [_P, _P]),
+    "plmpm_debug_contact": (_I, [_P, _I, _P]),
     "plmpm_profile_enable": (_I, [_P, _I]),
     "plmpm_replay": (_I, [_P, _I, _I, _I, C.POINTER(C.c_double)]),
     "plmpm_replay_step": (_I, [_P, _I, _I, _I, _I, _I, C.POINTER(C.c_double)]),

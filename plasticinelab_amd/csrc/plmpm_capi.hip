@@ -1105,6 +1105,19 @@ int plmpm_debug_counters(plmpm_handle s, int* out4) {
     HIPCHK(hipMemsetAsync(s->err_d + 1, 0, 12, s->stream));
     return 0;
 }
+// test hook: the list of blocks whose pose adjoints are due (D.contact).  seed >= 0 first overwrites it with `seed` entries
+// naming block 0 (what a reverse substep that never reset the list would have left behind); *count = entries now listed
+int plmpm_debug_contact(plmpm_handle s, int seed, int* count) {
+    NEED_BOUND(s);
+    REQUIRE(count && seed <= s->nblk, "bad argument");
+    if (seed >= 0) {
+        HIPCHK(hipMemsetAsync(s->contact, 0, (size_t)(seed + 1) * 4, s->stream));
+        HIPCHK(hipMemcpyAsync(s->contact, &seed, 4, hipMemcpyHostToDevice, s->stream));
+    }
+    HIPCHK(hipMemcpyAsync(count, s->contact, 4, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    return 0;
+}
 #ifdef PLB_PHASE_TIMING
 extern "C" int plmpm_debug_trace(plmpm_handle s, unsigned long long* out, size_t n) {       // profiling builds only
     NEED_BOUND(s);

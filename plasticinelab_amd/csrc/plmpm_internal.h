@@ -234,8 +234,13 @@ static inline unsigned dyn_lds(int) { return 0; }
             DET_RESOLVE(s, D.gin[0], D.gin[1], D.gin[2], D.gin[3]);                                              \
         } else LAUNCH(s, K_G2P_P2G, (k_g2p_p2g<T>), dim3(nblocks_particles(s, f)), D, f, vprev);                   \
     } while (0)
+// (k_g2p_grad's workgroup 0 resets the contact list k_grid_op_grad(f) is about to fill.  A slab rank that holds no particles
+// launches nothing here, while its grid kernel still appends the blocks of the exchanged planes in which a NEIGHBOUR's mass
+// touches a manipulator: the list is then reset from the host side of the stream -- stale entries would be processed again by
+// the pose workgroups of every later reverse substep and could outgrow the list's nblk + 1 words)
 #define LAUNCH_G2P_GRAD(s, D, f, src, dst, vnext)                                                                \
     do {                                                                                                         \
+        if (nblocks_particles(s, f) == 0) (void)hipMemsetAsync((s)->contact, 0, sizeof(int), (s)->stream);       \
         if ((s)->det) {                                                                                          \
             LAUNCH(s, K_G2P_GRAD, (k_g2p_grad<T, true>), dim3(nblocks_particles(s, f)), D, f, src, dst, vnext);  \
             DET_RESOLVE(s, D.goa[0], D.goa[1], D.goa[2], (T*)nullptr);                                           \

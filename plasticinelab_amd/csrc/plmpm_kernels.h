@@ -414,8 +414,10 @@ __device__ __forceinline__ void xchg_wait_arrived(const PeerXchg& X) {
         const long long t0 = wall_clock64();
         while (__hip_atomic_load(X.done + 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != X.tag) {
             if (wall_clock64() - t0 > 2 * X.timeout_ticks) {
-                __hip_atomic_store(X.status, X.code | (0xff << 8), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                __hip_atomic_store(X.status_dev, X.code | (0xff << 8), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                // only if nobody has reported yet: the poller's code names the field AND the face that stayed silent
+                int none = 0;
+                if (__hip_atomic_compare_exchange_strong(X.status_dev, &none, X.code | (0xff << 8), __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                    __hip_atomic_store(X.status, X.code | (0xff << 8), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 break;
             }
             __builtin_amdgcn_s_sleep(1);

@@ -93,6 +93,33 @@ int peer_init(plmpm_sim* s) {
     return 0;
 }
 
+// First contact with a neighbour (plmpm_peer_ping): one lane per face stores a token THROUGH the caches into word 16 of the
+// neighbour's receive-area header (the arrival counter is word 0; the rest of the 256 B is otherwise unused) and polls word 16 of
+// its own header with system-scope loads until the neighbour's token shows up -- the exchange kernels' own hand-off pattern
+// (profiles/microbench/peer_xchg.hip) on the real areas, before any halo depends on it.  res[2 i] = last value seen on face i,
+// res[2 i + 1] = wait in 10 ns ticks (-1: timed out).
+__global__ void k_peer_ping(int n, unsigned* remote0, unsigned* remote1, unsigned* local0, unsigned* local1, unsigned token,
+                            long long timeout_ticks, long long* res) {
+    const int i = threadIdx.x;
+    if (i >= n) return;
+    unsigned* const theirs = i == 0 ? remote0 : remote1;
+    unsigned* const mine = i == 0 ? local0 : local1;
+    store_through(theirs + 16, token);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const long long t0 = wall_clock64();
+    unsigned got = 0;
+    long long waited = -1;
+    for (;;) {
+        got = __hip_atomic_load(mine + 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        const long long t = wall_clock64() - t0;
+        if (got == token) { waited = t; break; }
+        if (t > timeout_ticks) break;
+        __builtin_amdgcn_s_sleep(2);
+    }
+    res[2 * i] = (long long)got;
+    res[2 * i + 1] = waited;
+}
+
 double peer_timeout_seconds() {
     const char* e = getenv("PLMPM_PEER_TIMEOUT");
     const double v = e ? atof(e) : 20.0;
@@ -236,9 +263,15 @@ int plmpm_halo_peer_exchange(plmpm_handle s, int field, int frame) {
 // with plmpm_config.grid_workgroups = 256 (one rank per GPU) or 256 / ranks-per-GPU (ranks sharing a GPU: the tests).
 // Off by default: measured on a middle rank of 8 at config 3 (one block plane thick: no interior to hide anything behind) the
 // kernels sum to 86.7 us per fwd+bwd substep against 89.1 but the wall clock is 91.0 against 89.3 (profiles/r05_slab_host_cost.txt).
+// The request alone is not enough: an engine whose grid launches were not sized for residency at create time
+// (plmpm_config.grid_workgroups in 1 .. kFusedMaxWG; 0 = the library's 512, which fill a GPU with no margin) keeps the exchange
+// kernels -- every fused launch of such an engine would run into the bounded wait.  Ranks may end up on different
+// forms: both write the same receive areas and arrival counters, so they interoperate.
+constexpr int kFusedMaxWG = 256;
 static bool peer_fused(const plmpm_sim* s) {
     const char* e = getenv("PLMPM_PEER_FUSED");
-    return e ? e[0] != '0' : (PLB_PEER_FUSED_DEFAULT != 0);
+    const bool asked = e ? e[0] != '0' : (PLB_PEER_FUSED_DEFAULT != 0);
+    return asked && s->cfg.grid_workgroups > 0 && s->cfg.grid_workgroups <= kFusedMaxWG && s->gwg <= s->cfg.grid_workgroups;
 }
 int plmpm_peer_fused(plmpm_handle s, int* fused) {
     REQUIRE(s && fused, "null argument");
@@ -269,6 +302,28 @@ int plmpm_halo_peer_reset(plmpm_handle s, int phase) {
     HIPCHK(hipMemsetAsync(s->peer_done, 0, 256, s->stream));
     HIPCHK(hipStreamSynchronize(s->stream));
     *s->peer_status = 0;
+    return 0;
+}
+// Collective over the ranks of a slab run (every rank calls it with the same non-zero token, then meets at a host barrier):
+// token into both neighbours' headers of `field`, wait for theirs.  ok[i] = 1 when face i's token arrived within timeout_s,
+// wait_us[i] = how long the poll took.  A pre-flight for the first run on real neighbours (bench.py: transport_check.preflight);
+// the exchange counters are not touched.
+int plmpm_peer_ping(plmpm_handle s, int field, unsigned token, double timeout_s, int* ok2, double* wait_us2) {
+    NEED_BOUND(s);
+    REQUIRE(field >= 0 && field < 3 && token != 0 && ok2 && wait_us2 && timeout_s > 0, "peer_ping: bad argument");
+    const plmpm_sim::PeerField& F = s->peer[field];
+    ok2[0] = ok2[1] = 0; wait_us2[0] = wait_us2[1] = 0.0;
+    if (F.n == 0) return 0;
+    if (peer_init(s)) return -1;
+    long long* res = (long long*)(s->peer_done + 32);              // bytes 128 .. 159 of the 256-byte control block
+    HIPCHK(hipMemsetAsync(res, 0, 32, s->stream));
+    hipLaunchKernelGGL(k_peer_ping, dim3(1), dim3(64), 0, s->stream, F.n, (unsigned*)F.remote[0], (unsigned*)F.remote[1],
+                       (unsigned*)F.local[0], (unsigned*)F.local[1], token, (long long)(timeout_s * 1e8), res);
+    HIPCHK(hipGetLastError());
+    long long h[4];
+    HIPCHK(hipMemcpyAsync(h, res, 32, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    for (int i = 0; i < F.n; ++i) { ok2[i] = h[2 * i + 1] >= 0 ? 1 : 0; wait_us2[i] = h[2 * i + 1] >= 0 ? h[2 * i + 1] * 0.01 : -1.0; }
     return 0;
 }
 // test hook: scale what this rank sends through face 0 (1 = off).  A run with a spoiled halo must be NOTICED by whoever
@@ -305,7 +360,9 @@ int plmpm_slab_step(plmpm_handle s, int first, int n) {
         if (fused) {
             PeerXchg X;
             if (peer_prepare(s, PLMPM_HALO_GRID_IN, f, X)) return -1;
-            if (plmpm_grid_g2p_xchg(s, f, pending, &X)) return -1;
+            // (a refused call has published nothing: take the sequence number back, or this rank would stay one exchange ahead of
+            // its neighbours until the next collective reset)
+            if (plmpm_grid_g2p_xchg(s, f, pending, &X)) { if (X.n) --s->peer[PLMPM_HALO_GRID_IN].seq; return -1; }
         } else {
             if (plmpm_halo_peer_exchange(s, PLMPM_HALO_GRID_IN, f)) return -1;
             if (plmpm_grid_g2p(s, f, pending)) return -1;
@@ -324,7 +381,7 @@ int plmpm_slab_step_grad(plmpm_handle s, int first, int n) {
         if (fused) {
             PeerXchg X;
             if (peer_prepare(s, PLMPM_HALO_GRID_OUT_ADJ, f, X)) return -1;
-            if (plmpm_grad_gather_xchg(s, f, &X)) return -1;
+            if (plmpm_grad_gather_xchg(s, f, &X)) { if (X.n) --s->peer[PLMPM_HALO_GRID_OUT_ADJ].seq; return -1; }
         } else {
             if (plmpm_halo_peer_exchange(s, PLMPM_HALO_GRID_OUT_ADJ, f)) return -1;
             if (plmpm_grad_gather(s, f)) return -1;

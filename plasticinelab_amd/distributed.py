@@ -204,17 +204,37 @@ class HaloComm:
         faces = self.layout.faces(self.rank)
         fields = (engine.HALO_GRID_IN, engine.HALO_GRID_OUT_ADJ, engine.HALO_LOSS_MASS)
         mine, local, err = {}, {}, ""
+        # What the first run on real neighbours needs to know when something goes wrong (bench.py: transport_check.preflight): which
+        # device every rank sits on, whether the runtime lets this device reach the neighbours', what kind of memory the receive
+        # areas got, whether the IPC handles opened, and whether ONE hand-off of the exchange's own pattern crossed each face.
+        device = torch.cuda.current_device() if torch.cuda.is_available() else -1
+        pre = self.preflight = {"rank": self.rank, "gpu": list(gpu_identity()) + [device], "neighbours": {}, "alloc": None, "ipc_open": None, "ping": None}
         try:
             for field in fields:
                 for nbr, a, b in faces:
                     ptr, handle = engine.peer_alloc(field, a, b)
                     local[(field, nbr)] = ptr
                     mine[(field, nbr)] = (handle, a, b)
+            pre["alloc"] = engine.peer_memory_kind() if hasattr(engine, "peer_memory_kind") else "ok"
         except Exception as e:                                   # noqa: BLE001 -- e.g. no IPC in this environment
             err = f"{type(e).__name__}: {e}"
+            pre["alloc"] = "FAILED: " + err[:160]
         everyone = [None] * self.layout.world
-        dist.all_gather_object(everyone, {"rank": self.rank, "areas": mine, "err": err}, group=self.group)
+        dist.all_gather_object(everyone, {"rank": self.rank, "areas": mine, "err": err, "gpu": pre["gpu"]}, group=self.group)
         ok = not any(r["err"] for r in everyone)
+        for nbr, _a, _b in faces:
+            theirs = everyone[nbr]["gpu"]
+            same_host = theirs[0] == pre["gpu"][0]
+            if theirs[:2] == pre["gpu"][:2]:
+                access = "same device"
+            elif same_host and device >= 0 and theirs[2] >= 0:
+                try:
+                    access = bool(torch.cuda.can_device_access_peer(device, theirs[2]))      # hipDeviceCanAccessPeer
+                except Exception as e:                           # noqa: BLE001
+                    access = f"query failed: {type(e).__name__}"
+            else:
+                access = "other host" if not same_host else "no device"
+            pre["neighbours"][str(nbr)] = {"gpu": theirs, "can_access_peer": access}
         remote = {}
         if ok:
             try:
@@ -225,6 +245,7 @@ class HaloComm:
                         remote[(field, nbr)] = engine.peer_open(handle)
             except Exception as e:                               # noqa: BLE001
                 err = f"{type(e).__name__}: {e}"
+        pre["ipc_open"] = ("ok" if ok and not err else "FAILED: " + (err or "a receive area could not be allocated on another rank")[:160])
         flags = [None] * self.layout.world
         dist.all_gather_object(flags, err, group=self.group)
         if any(flags):
@@ -233,6 +254,15 @@ class HaloComm:
         for field in fields:
             engine.halo_peer_setup(field, [(a, b) for _n, a, b in faces], [local[(field, n)] for n, _a, _b in faces],
                                    [remote[(field, n)] for n, _a, _b in faces])
+        # one hand-off across every face, the exchange kernels' own pattern on the real areas (plmpm_peer_ping); a face that stays
+        # silent is reported, not fatal: bench.py's transport check decides what the halos travel on
+        if hasattr(engine, "peer_ping"):
+            try:
+                got = engine.peer_ping(engine.HALO_GRID_IN, 0x600D0001, float(os.environ.get("PLB_PEER_PING_TIMEOUT", "5")))
+                pre["ping"] = {str(nbr): {"arrived": got[i][0], "wait_us": round(got[i][1], 2)} for i, (nbr, _a, _b) in enumerate(faces)}
+            except Exception as e:                               # noqa: BLE001
+                pre["ping"] = "FAILED: " + f"{type(e).__name__}: {e}"[:160]
+            dist.barrier(group=self.group)                       # nobody resets or exchanges before every token has been seen
         spoil = os.environ.get("PLB_TEST_PEER_SPOIL", "")       # test hook "rank:factor": that rank sends wrong halos through face 0
         if spoil and int(spoil.split(":")[0]) == self.rank:
             engine.debug_peer_spoil(float(spoil.split(":")[1]))
@@ -650,6 +680,33 @@ def fused_grid_workgroups(fused: bool, world: int, ranks_per_gpu: int) -> int:
     return cap
 
 
+def ranks_sharing_my_gpu(group=None) -> int:
+    """How many processes of the torch.distributed world run on the GPU this process has selected -- from an all_gather of
+    (host name, device identity), not from a guess: `procs / device_count` says 1 when several ranks are bound to one device
+    while more devices are visible.  Collective over ``group`` when a process group exists; 1 otherwise (a
+    one-process emulation of a rank has the GPU to itself)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return 1
+    mine = gpu_identity()
+    everyone = [None] * dist.get_world_size(group)
+    dist.all_gather_object(everyone, mine, group=group)
+    return max(1, sum(1 for other in everyone if other == mine))
+
+
+def gpu_identity():
+    """(host, device) of this process's current GPU; the device by its UUID where the runtime reports one (two processes
+    may see the same physical GPU under different indices through HIP_VISIBLE_DEVICES), else by index."""
+    import socket
+    if not torch.cuda.is_available():
+        return (socket.gethostname(), "cpu")
+    idx = torch.cuda.current_device()
+    try:
+        dev = str(torch.cuda.get_device_properties(idx).uuid)
+    except Exception:
+        dev = f"index{idx}"
+    return (socket.gethostname(), dev)
+
+
 def make_slab_env(cfg, rank: int, world: int, *, halo: Optional[int] = None, compute_dtype=None, device=None, group=None,
                   target_fn: Optional[Callable] = None, particles: Optional[np.ndarray] = None,
                   layout: Optional[SlabLayout] = None, comm: Optional[HaloComm] = None,
@@ -698,11 +755,14 @@ def make_slab_env(cfg, rank: int, world: int, *, halo: Optional[int] = None, com
     # 256-thread workgroups per CU); ranks that share a GPU (tests, emulations) take half of a rank's share, as a power of two.
     # (processes of a torch.distributed world only: a one-process emulation of a rank -- profiles/tools/slab_host_cost.py -- has
     # the GPU to itself)
-    procs = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
-    per_gpu = -(-procs // max(torch.cuda.device_count(), 1)) if torch.cuda.is_available() else 1
+    # The cap is part of the ENGINE (plmpm_config.grid_workgroups): the library takes the fused form only on engines created
+    # with one (plmpm_peer_fused), so setting the variable after the build -- or building an Engine directly -- falls back to the
+    # exchange kernels instead of timing out.  An explicit cfg.SIMULATOR.grid_workgroups is kept when it is the smaller one.
+    per_gpu = ranks_sharing_my_gpu(group) if comm is None else 1
     cap = fused_grid_workgroups(os.environ.get("PLMPM_PEER_FUSED", "0") not in ("", "0"), world, per_gpu)
     if cap:
-        cfg.SIMULATOR["grid_workgroups"] = cap
+        asked = int(cfg.SIMULATOR.get("grid_workgroups", 0) or 0)
+        cfg.SIMULATOR["grid_workgroups"] = min(asked, cap) if asked > 0 else cap
     env.n_particles = len(mine)
     z0, z1 = layout.slab(rank)
     window = None

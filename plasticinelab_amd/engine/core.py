@@ -76,6 +76,7 @@ class Engine:
         # unverified Taichi autodiff semantics as switches (include/plmpm.h)
         cfg.contact_min_adjoint = {"add": 0, "argmin": 1}[contact_min_adjoint]
         cfg.minmax_tie = {"second": 0, "first": 1}[minmax_tie]
+        self.grid_workgroups = int(grid_workgroups)         # as asked for (0 = the library's default)
         cfg.grid_workgroups = int(grid_workgroups)          # 0: 512; ranks that share a GPU pass 512 / ranks-per-GPU or less (include/plmpm.h)
         self.deterministic = bool(deterministic)
         parr = (L.Primitive * max(len(primitives), 1))()
@@ -402,8 +403,20 @@ class Engine:
         L.check(self.lib.plmpm_peer_memory_kind(self.h, C.byref(k)))
         return "uncached" if k.value else "fine-grained"
 
+    def peer_ping(self, field, token, timeout_s=5.0):
+        """Collective first contact with the neighbours of ``field`` (plmpm_peer_ping): [(arrived, wait in us)] per face."""
+        ok, us = (C.c_int * 2)(), (C.c_double * 2)()
+        L.check(self.lib.plmpm_peer_ping(self.h, int(field), C.c_uint(int(token)), C.c_double(timeout_s), ok, us))
+        return [(bool(ok[i]), float(us[i])) for i in range(2)]
+
     def debug_peer_spoil(self, factor):
         L.check(self.lib.plmpm_debug_peer_spoil(self.h, C.c_double(factor)))
+
+    def debug_contact(self, seed=-1):
+        """Entries in the list of blocks whose pose adjoints are still due; ``seed`` >= 0 first plants that many stale ones (test hook)."""
+        k = C.c_int()
+        L.check(self.lib.plmpm_debug_contact(self.h, int(seed), C.byref(k)))
+        return k.value
 
     def slab_step(self, first, n):
         """fk + the forward substeps of one env step of a slab rank, exchanges included: enqueue only."""

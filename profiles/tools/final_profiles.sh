@@ -17,7 +17,7 @@ rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_AC
 cd $R
 python profiles/tools/pmc_summary.py --workload config3_cube128 --dtype f32 --steps 20 --warmup 5 --out $O/pmc.json $(find /tmp/p_fetch -name "*_results.db" | head -1) $(find /tmp/p_write -name "*_results.db" | head -1) $(find /tmp/p_sq -name "*_results.db" | head -1) > $O/pmc_summary.txt 2>&1
 tail -5 $O/pmc_summary.txt
-python profiles/tools/slab_host_cost.py --world 8 --peer --kernels > $O/slab_host_cost_fused.txt 2>&1
+PLMPM_PEER_FUSED=1 python profiles/tools/slab_host_cost.py --world 8 --peer --kernels > $O/slab_host_cost_fused.txt 2>&1
 PLMPM_PEER_FUSED=0 python profiles/tools/slab_host_cost.py --world 8 --peer --kernels > $O/slab_host_cost_unfused.txt 2>&1
 tail -3 $O/slab_host_cost_fused.txt $O/slab_host_cost_unfused.txt
 timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -8 > $O/pytest_gpu.txt

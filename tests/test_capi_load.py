@@ -34,7 +34,7 @@ def test_boundary_header_carries_no_scaffolding():
     # for the two introspection calls the engine object forwards to its callers
     allowed = {"plmpm_grid_stats", "plmpm_get_order", "plmpm_build_flags", "plmpm_profile_enable", "plmpm_profile_read",
                "plmpm_profile_kernel_count", "plmpm_profile_kernel_name", "plmpm_tile_boxes", "plmpm_debug_counters",
-               "plmpm_debug_peer_spoil", "plmpm_replay", "plmpm_replay_step", "plmpm_measure_hbm"}
+               "plmpm_debug_peer_spoil", "plmpm_debug_contact", "plmpm_replay", "plmpm_replay_step", "plmpm_measure_hbm"}
     assert tools == allowed
 
 

@@ -546,3 +546,29 @@ def test_a_migration_failure_on_one_rank_raises_on_every_rank():
     mp.spawn(_world_fail, args=(2, free_port(), out), nprocs=2, join=True)
     assert "rows leave at once" in out[1]
     assert "another rank failed in migrate_begin" in out[0]
+
+
+def _world_gpu_share(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from plasticinelab_amd import distributed as D
+        real = D.gpu_identity
+        out[("plain", rank)] = D.ranks_sharing_my_gpu()
+        # three ranks, two "devices" on one host: ranks 0 and 2 share one
+        D.gpu_identity = lambda: ("host", f"gpu{rank % 2}")
+        out[("mixed", rank)] = D.ranks_sharing_my_gpu()
+        D.gpu_identity = real
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_ranks_per_gpu_comes_from_an_all_gather_of_device_identities():
+    """`processes / visible devices` says one rank per GPU when several ranks are bound to ONE device while more are
+    visible; the residency cap of the fused exchange + grid kernels must count the ranks that really share this process's GPU."""
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_world_gpu_share, args=(3, free_port(), out), nprocs=3, join=True)
+    assert [out[("plain", r)] for r in range(3)] == [3, 3, 3]              # no GPU here: every rank reports (host, "cpu")
+    assert [out[("mixed", r)] for r in range(3)] == [2, 1, 2]

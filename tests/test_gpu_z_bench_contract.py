@@ -82,6 +82,25 @@ def test_bench_lines_single_gpu_and_two_slabs():
     ho = p["halo_overlapped"]
     assert "error" not in ho and ho["value"] > 0 and "folded into the grid kernels" in ho["halo_transport"], ho
     assert abs(ho["final_loss"] - s1["final_loss"]) < 1e-5 * abs(s1["final_loss"]) and set(ho["loss_check"]) >= {"n1_expected", "rel", "ok"}
+    # the N = 1 points of the series measured in the SAME run on the same box: rank 0's child processes time the
+    # headline and the configs[3]-size point on one GPU; the efficiencies against them stand beside the committed-reference ones
+    nb = two["n1_same_box"]
+    assert "error" not in nb["headline"] and nb["headline"]["workload"] == two["config"]["workload"] and nb["headline"]["steps"] == two["steps"]
+    assert abs(nb["headline"]["final_loss"] - two["final_loss"]) < 1e-5 * abs(two["final_loss"])
+    assert abs(two["strong_scaling_eff_same_box"] - two["value"] / (2 * nb["headline"]["value"])) < 1e-12
+    assert "error" not in nb["configs[3]"] and nb["configs[3]"]["workload"] == p["workload"]
+    assert abs(p["strong_scaling_eff_same_box"] - p["value"] / (2 * nb["configs[3]"]["value"])) < 1e-12 and p["n1_same_box_value"] == nb["configs[3]"]["value"]
+    assert "n1_schedule" in p and p["grid_workgroups"] > 0                       # (built for the fused form too: capped, and the record says so)
+    assert "n1_same_box" in two["phases_s"]
+    # first contact: one record per rank -- device, peer access towards the neighbour, kind of receive-area
+    # memory, IPC open, one hand-off of the exchange's own pattern across the face
+    pf = tc["preflight"]
+    assert len(pf) == 2 and [r["rank"] for r in pf] == [0, 1]
+    for r in pf:
+        nbr = str(1 - r["rank"])
+        assert r["alloc"] in ("uncached", "fine-grained") and r["ipc_open"] == "ok", r
+        assert r["neighbours"][nbr]["can_access_peer"] in ("same device", True, False), r
+        assert r["ping"][nbr]["arrived"] is True and r["ping"][nbr]["wait_us"] >= 0, r
 
 
 def test_a_spoiled_halo_flips_the_line():
