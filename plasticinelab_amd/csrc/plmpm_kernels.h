@@ -795,9 +795,7 @@ __global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_p2g(Dev<T> D, int f) 
             const int ex = tl.e[0], exy = tl.e[0] * tl.e[1];
             p2g_particle<T, double>(D.P, x, v, C, E, mu, lam, ys, En, b2, [&](int i, int j, int l, T mass, const T* mom) {
                 T a0 = mass, a1 = mom[0], a2 = mom[1], a3 = mom[2];
-                PLB_ABLATE_STOP(4, a0 + a1 + a2 + a3, tile);
                 seg_sum4(a0, a1, a2, a3, sg);
-                PLB_ABLATE_STOP(1, a0 + a1 + a2 + a3, tile);
                 if (emitter) {
                     if constexpr (DET) {          // node: 4 hi limbs, then 4 lo limbs
                         long long* q = reinterpret_cast<long long*>(tile) + 8 * ((oz + l) * exy + (oy + j) * ex + (ox + i));
@@ -830,7 +828,7 @@ __global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_p2g(Dev<T> D, int f) 
             for (int d = 0; d < 9; ++d) R1[(12 + d) * Np + p] = En[d];
         }
     }
-    if (tl.ok && !(PLB_ABLATE & 2)) {
+    if (tl.ok) {
         __syncthreads();
         const int ex = tl.e[0], exy = tl.e[0] * tl.e[1];
         for (int i = threadIdx.x; i < tn; i += kBlock) {
@@ -1040,7 +1038,6 @@ __global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_g2p_p2g(Dev<T> D, int
         for (int d = 0; d < 9; ++d) R1[(3 + d) * Np + p] = C[d];
     }
     PT_MARK(2);
-    PLB_PAD(x[0], D.err);
     // ---------------- p2g(f): scatter
     int base[3];
     for (int d = 0; d < 3; ++d) base[d] = (int)(x[d] * (double)D.P.inv_dx - 0.5);
@@ -1072,9 +1069,7 @@ __global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_g2p_p2g(Dev<T> D, int
             PT_MARK(4);
             p2g_emit<T>(w, K, [&](int i, int j, int l, T mass, const T* mom) {
                 T a0 = mass, a1 = mom[0], a2 = mom[1], a3 = mom[2];
-                PLB_ABLATE_STOP(4, a0 + a1 + a2 + a3, tile);
                 seg_sum4(a0, a1, a2, a3, sg);
-                PLB_ABLATE_STOP(1, a0 + a1 + a2 + a3, tile);
                 if (emitter) {
                     if constexpr (DET) {          // node: 4 hi limbs, then 4 lo limbs
                         long long* q = reinterpret_cast<long long*>(tile) + 8 * ((oz + l) * exy + (oy + j) * ex + (ox + i));
@@ -1108,7 +1103,7 @@ __global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_g2p_p2g(Dev<T> D, int
         }
     }
     PT_MARK(5);
-    if (tl.ok && !(PLB_ABLATE & 2)) {
+    if (tl.ok) {
         wg_barrier();
         const int ex = tl.e[0], exy = tl.e[0] * tl.e[1];
         for (int i = threadIdx.x; i < tn; i += kBlock) {

@@ -23,13 +23,14 @@ struct Rec { unsigned long long cyc, rt; unsigned hwid, xcc; };
 
 enum Kind {
     FMA_FWD1, FMA_2SRC, FMA_3SRC, FMAC, MUL, ADD, MAXF, FMAC_DPP, MOV_DPP, CVT_F64_F32, CVT_F32_I32, ADD_U32, LSHL_ADD, MAD_U24, MUL_LO, AND_B32,
-    CNDMASK, CMP_CND, RCP, RSQ, SQRT, MOV, PK_FMA, PK_MUL, FMA_F64, ADD_F64, MIX_FMA_MUL, MIX_PRODUCT, BANK_SAME, BANK_DIFF, FMA_1W_DEP, NKIND
+    CNDMASK, CMP_CND, LSHL_ADD_U64, ASHR_I32, MAD_U64_U32, BFE_U32, RCP, RSQ, SQRT, MOV, PK_FMA, PK_MUL, FMA_F64, ADD_F64, MIX_FMA_MUL, MIX_PRODUCT, BANK_SAME, BANK_DIFF, FMA_1W_DEP, NKIND
 };
 static const char* kname[NKIND] = {
     "v_fma_f32 d,d,m,m   ONE chain (result forwarded)", "v_fma_f32 d,d,m,m   (2 distinct VGPR sources)", "v_fma_f32 d,d,m,m2  (3 distinct VGPR sources)",
     "v_fmac_f32 d,m,m2   (2 sources + accumulator)", "v_mul_f32 d,d,m", "v_add_f32 d,d,m", "v_max_f32 d,d,m",
     "v_fmac_f32_dpp d,d,m row_shl:1 (product's reduce step)", "v_mov_b32_dpp d,d row_shl:1", "v_cvt_f64_f32", "v_cvt_f32_i32", "v_add_u32 d,d,m", "v_lshl_add_u32 d,d,2,m",
-    "v_mad_u32_u24 d,d,m,m2", "v_mul_lo_u32 d,d,m", "v_and_b32 d,d,m", "v_cndmask_b32 d,d,m,vcc", "v_cmp_lt_f32 + v_cndmask pair (per pair)",
+    "v_mad_u32_u24 d,d,m,m2", "v_mul_lo_u32 d,d,m", "v_and_b32 d,d,m", "v_cndmask_b32 d,d,m,vcc", "v_cmp_lt_f32 + v_cndmask pair (per pair)", "v_lshl_add_u64 d,d,2,m64 (64-bit address add)",
+    "v_ashrrev_i32 d,31,d (sign extension)", "v_mad_u64_u32", "v_bfe_u32 d,d,m,5",
     "v_rcp_f32", "v_rsq_f32", "v_sqrt_f32", "v_mov_b32 d,m", "v_pk_fma_f32 (two FMAs)", "v_pk_mul_f32 (two MULs)", "v_fma_f64", "v_add_f64",
     "mix: fma,mul,fma,add", "mix: product-like (10 fma, 4 mul, 2 add, 4 int, 2 cvt, 2 mov per 24)", "v_fma_f32, 3 sources in ONE VGPR bank (v8,v12,v16)",
     "v_fma_f32, 3 sources in 3 banks (v9,v14,v19)", "v_fma_f32 ONE chain, 1 wave/SIMD only (dependent-issue latency)"};
@@ -60,6 +61,10 @@ template <int KIND> __global__ __launch_bounds__(256) void k(Rec* rec, int iters
         if (KIND == AND_B32) { REP64(I4("v_and_b32", ", %4")) }
         if (KIND == CNDMASK) { REP64(asm volatile("v_cndmask_b32 %0, %0, %4, vcc\n v_cndmask_b32 %1, %1, %4, vcc\n v_cndmask_b32 %2, %2, %4, vcc\n v_cndmask_b32 %3, %3, %4, vcc\n" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(m) : "vcc");) }
         if (KIND == CMP_CND) { REP64(asm volatile("v_cmp_lt_f32 vcc, %0, %4\n v_cndmask_b32 %0, %0, %5, vcc\n v_cmp_lt_f32 vcc, %1, %4\n v_cndmask_b32 %1, %1, %5, vcc\n" : "+v"(a0), "+v"(a1) : "v"(m), "v"(m2) : "vcc");) }
+        if (KIND == LSHL_ADD_U64) { REP64(asm volatile("v_lshl_add_u64 %0, %0, 2, %4\n v_lshl_add_u64 %1, %1, 2, %4\n v_lshl_add_u64 %2, %2, 2, %4\n v_lshl_add_u64 %3, %3, 2, %4\n" : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3) : "v"(dm));) }
+        if (KIND == ASHR_I32) { REP64(asm volatile("v_ashrrev_i32 %0, 31, %4\n v_ashrrev_i32 %1, 31, %5\n v_ashrrev_i32 %2, 31, %4\n v_ashrrev_i32 %3, 31, %5\n" : "=v"(i0), "=v"(i1), "=v"(i2), "=v"(i3) : "v"(im), "v"(im2));) }
+        if (KIND == MAD_U64_U32) { REP64(asm volatile("v_mad_u64_u32 %0, vcc, %4, %5, %0\n v_mad_u64_u32 %1, vcc, %4, %5, %1\n v_mad_u64_u32 %2, vcc, %4, %5, %2\n v_mad_u64_u32 %3, vcc, %4, %5, %3\n" : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3) : "v"(im), "v"(im2) : "vcc");) }
+        if (KIND == BFE_U32) { REP64(I4("v_bfe_u32", ", %4, 5")) }
         if (KIND == RCP) { REP64(A4("v_rcp_f32", "")) }
         if (KIND == RSQ) { REP64(A4("v_rsq_f32", "")) }
         if (KIND == SQRT) { REP64(A4("v_sqrt_f32", "")) }

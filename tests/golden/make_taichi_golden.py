@@ -2,11 +2,26 @@
 """Generate Taichi-produced golden vectors for the hot path -- the missing pin of the oracle.
 
 THIS SCRIPT DOES NOT RUN IN THE BUILD CONTAINER OR ON THE GPU BOX: it needs the reference checkout and the Taichi it was
-written for (taichi 0.7.14, LLVM 10; plus yacs, gym, opencv-python, which plb imports).  Run it once, anywhere those are
-installed, and commit the three .npz files it writes next to this script:
+written for.  Run it once, anywhere with a network, and commit the three .npz files it writes next to this script.
 
-    pip install taichi==0.7.14 yacs gym==0.17 opencv-python
-    python tests/golden/make_taichi_golden.py /path/to/PlasticineLab            # CPU backend, float64
+The environment that reproduces the reference's own run -- cell 1 of plb/optimizer/long_term_gradient.ipynb prints
+"[Taichi] version 0.7.14, llvm 10.0.0, commit 58feee37, linux, python 3.7.3" -- in one go:
+
+    conda create -n plb-pin python=3.7 -y && conda activate plb-pin        # taichi 0.7.14 ships wheels for CPython 3.6 - 3.8
+    pip install taichi==0.7.14 "numpy<1.22" scipy pyyaml yacs "gym==0.17.3" opencv-python
+    #   (setup.py:3 of the reference lists scipy, numpy, torch, opencv-python, tqdm, taichi, gym, tensorboard, yacs, baselines,
+    #    all unpinned; `import plb` pulls in plb.envs only -- gym, yaml, yacs, numpy, and through plb.engine taichi, cv2 and
+    #    scipy; torch, tqdm, tensorboard and baselines are imported by plb/algorithms and the logger alone, which this script
+    #    never touches -- leave them out)
+    TI_ARCH=x64 python tests/golden/make_taichi_golden.py /path/to/PlasticineLab
+
+`TI_ARCH=x64` matters: plb/engine/taichi_env.py:6 runs `ti.init(arch=ti.gpu, debug=False, fast_math=True)` at import, and the
+pin is BASELINE configs[0]'s backend, the Taichi CPU backend (the variable overrides the arch argument in 0.7.x; without it
+and without a CUDA device Taichi falls back to x64 by itself and says so).  The simulator's fields are float64
+(mpm_simulator.py:8 `dtype = ti.f64`) whatever the arch.  `fast_math=True` stays as the reference sets it: it is part of what
+the reference computes (LLVM fast-math flags on the generated kernels; the oracle's tolerances of 1e-9 leave room for it).
+The three files together are < 2 MB.  If they disagree with the oracle on the Q10 semantics, the fix is a flag flip
+(`plmpm_config.contact_min_adjoint` / `minmax_tie`, `oracle/plb_oracle.py::SEMANTICS`) plus regenerated `rollout_*.npz`.
 
 It drives the reference through its OWN public surface only (plb.envs.make, TaichiEnv.set_state / step / compute_loss,
 ti.Tape, Primitives.get_grad, MPMSimulator.substep / substep_grad) -- nothing of the reference is copied here.
