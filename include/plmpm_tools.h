@@ -16,7 +16,8 @@ extern "C" {
 #endif
 
 /* what this build of the library was compiled with: bit 1 the elastic fast path (-DPLB_FAST=1), bit 2 the XCD-aware chunk map
- * (-DPLB_XCD_MAP=1); bit 0 (the experimental engine variants of rounds 3-4) is never set any more */
+ * (-DPLB_XCD_MAP=1), bit 3 particle arrays through buffer descriptors (-DPLB_BUFIO=1); bit 0 (the experimental engine variants of rounds 3-4)
+ * is never set any more */
 int plmpm_build_flags(void);
 
 /* number of grid nodes with mass > 0 and number of active 4^3 blocks after the last forward substep */

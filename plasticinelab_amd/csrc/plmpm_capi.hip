@@ -361,7 +361,7 @@ extern "C" {
 
 const char* plmpm_last_error(void) { return g_err.c_str(); }
 int plmpm_version(void) { return 1; }
-int plmpm_build_flags(void) { return (PLB_FAST ? 2 : 0) | (PLB_XCD_MAP ? 4 : 0); }
+int plmpm_build_flags(void) { return (PLB_FAST ? 2 : 0) | (PLB_XCD_MAP ? 4 : 0) | (PLB_BUFIO ? 8 : 0); }
 
 int plmpm_create(const plmpm_config* cfg, const plmpm_primitive* prims, plmpm_handle* out) {
     REQUIRE(cfg && out, "null argument");
@@ -397,6 +397,14 @@ int plmpm_create(const plmpm_config* cfg, const plmpm_primitive* prims, plmpm_ha
     s->N = cfg->n_particles;
     const int cap = std::max(cfg->particle_capacity, cfg->n_particles);
     s->Npad = (int)align_up(cap, kRowPad);
+#if PLB_BUFIO
+    // particle arrays are addressed through 32-bit buffer offsets (plmpm_kernels.h: Soa): the largest array set, an adjoint frame
+    // of 24 scalars per row, must stay below 4 GiB
+    if ((size_t)s->Npad * 24 * (cfg->dtype == PLMPM_F64 ? 8 : 4) >= ((size_t)1 << 32)) {
+        delete s;
+        return fail("particle capacity %d is too large for this build's 32-bit buffer addressing (-DPLB_BUFIO=1)", cap);
+    }
+#endif
     s->n = cfg->n_grid; s->Gfull = (size_t)s->n * s->n * s->n;
     // grid window: the box of 4^3 blocks that is allocated and swept (all-zero grid_lo / grid_hi = the whole grid)
     for (int d = 0; d < 3; ++d) {

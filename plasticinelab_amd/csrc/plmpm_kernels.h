@@ -114,6 +114,47 @@ template <class T> struct Dev {
     PrimStatic prim[kMaxPrim];
 };
 
+// Component c of row p of a particle SoA array set -- a frame's positions (3 doubles) or scalars (v, C, E: 21 T), an adjoint
+// frame (24 T), v[f+1] kept aside (3 T): element c * Np + p of `base`.
+// PLB_BUFIO = 1 goes through a buffer descriptor: wave-uniform base, the component's byte offset in an SGPR (scalar unit), the row
+// as one 32-bit byte offset per lane shared by every access of the kernel -- no 64-bit vector address arithmetic, which the
+// flat form pays with a sign extension and a v_lshl_add_u64 per access (~100-170 of a particle kernel's vector instructions).
+// An array set must then stay below 4 GiB (plmpm_create checks the capacity).
+#ifndef PLB_BUFIO
+#define PLB_BUFIO 0
+#endif
+template <class E> struct Soa {
+    const E* base;
+    int Np;
+#if PLB_BUFIO
+    __amdgpu_buffer_rsrc_t rsrc;
+    unsigned stride;                 // bytes between components
+    __device__ __forceinline__ Soa(const E* b, int np, int ncomp)
+        : base(b), Np(np), rsrc(__builtin_amdgcn_make_buffer_rsrc(const_cast<E*>(b), 0, (int)((unsigned)np * (unsigned)ncomp * (unsigned)sizeof(E)), 0x00020000)),
+          stride((unsigned)np * (unsigned)sizeof(E)) {}
+    __device__ __forceinline__ E ld(int c, int p) const {
+        if constexpr (sizeof(E) == 4) return __builtin_bit_cast(E, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (unsigned)p * 4u, (unsigned)c * stride, 0));
+        else return __builtin_bit_cast(E, __builtin_amdgcn_raw_buffer_load_b64(rsrc, (unsigned)p * 8u, (unsigned)c * stride, 0));
+    }
+    __device__ __forceinline__ void st(int c, int p, E v) const {
+        typedef unsigned u2 __attribute__((ext_vector_type(2)));
+        if constexpr (sizeof(E) == 4) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrc, (unsigned)p * 4u, (unsigned)c * stride, 0);
+        else __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2, v), rsrc, (unsigned)p * 8u, (unsigned)c * stride, 0);
+    }
+#else
+    __device__ __forceinline__ Soa(const E* b, int np, int) : base(b), Np(np) {}
+    __device__ __forceinline__ E ld(int c, int p) const { return base[c * Np + p]; }
+    __device__ __forceinline__ void st(int c, int p, E v) const { const_cast<E*>(base)[c * Np + p] = v; }
+#endif
+};
+template <class T> __device__ __forceinline__ Soa<double> frame_xs(const Dev<T>& D, int f) {
+    return Soa<double>(reinterpret_cast<const double*>(D.state + (size_t)f * D.frame_bytes), D.Npad, 3);
+}
+template <class T> __device__ __forceinline__ Soa<T> frame_rs(const Dev<T>& D, int f) {
+    return Soa<T>(reinterpret_cast<const T*>(D.state + (size_t)f * D.frame_bytes + (size_t)3 * 8 * D.Npad), D.Npad, 21);
+}
+template <class T> __device__ __forceinline__ Soa<T> adj_s(const Dev<T>& D, int which) { return Soa<T>(D.adj[which], D.Npad, 24); }
+
 template <class T> __device__ __forceinline__ void load_materials(const Dev<T>& D, int p, T& mu, T& lam, T& ys) {
     if (D.mats_uniform) { mu = D.mat_u[0]; lam = D.mat_u[1]; ys = D.mat_u[2]; }
     else { mu = D.mu[p]; lam = D.lam[p]; ys = D.ys[p]; }
@@ -702,12 +743,11 @@ template <class T> __device__ __forceinline__ Tile load_tile(const Dev<T>& D, in
 
 // Sorted particle load in two halves so that independent memory traffic can be issued in between.
 struct SortLoad { double x0[3]; long long key; };
-template <class T> __device__ __forceinline__ SortLoad sorted_begin(const Dev<T>& D, const double* X, int wg = blockIdx.x) {
-    const int Np = D.Npad;
+template <class T> __device__ __forceinline__ SortLoad sorted_begin(const Dev<T>& D, const Soa<double>& X, int wg = blockIdx.x) {
     const int p0 = wg * kBlock + threadIdx.x;
     SortLoad s;
     s.x0[0] = s.x0[1] = s.x0[2] = 0.5;
-    if (p0 < D.N) for (int d = 0; d < 3; ++d) s.x0[d] = X[d * Np + p0];
+    if (p0 < D.N) for (int d = 0; d < 3; ++d) s.x0[d] = X.ld(d, p0);
     return s;
 }
 template <class T>
@@ -733,14 +773,13 @@ __device__ __forceinline__ bool sorted_finish(const Dev<T>& D, SortLoad& s, int&
 // Load this lane's particle after the wave-local sort by stencil base: p = particle index, x = position,
 // base = stencil base.  Padding lanes (beyond N) sort to the end and return false.
 template <class T>
-__device__ __forceinline__ bool load_sorted_particle(const Dev<T>& D, const double* X, int& p, double* x, int* base, bool flag_err = false, int wg = blockIdx.x) {
-    const int Np = D.Npad;
+__device__ __forceinline__ bool load_sorted_particle(const Dev<T>& D, const Soa<double>& X, int& p, double* x, int* base, bool flag_err = false, int wg = blockIdx.x) {
     const int p0 = wg * kBlock + threadIdx.x;
     long long key = (1LL << 40);                                    // padding lanes last
     double x0[3] = {0.5, 0.5, 0.5};
     if (p0 < D.N) {
         int b[3];
-        for (int d = 0; d < 3; ++d) { x0[d] = X[d * Np + p0]; b[d] = (int)(x0[d] * (double)D.P.inv_dx - 0.5); }
+        for (int d = 0; d < 3; ++d) { x0[d] = X.ld(d, p0); b[d] = (int)(x0[d] * (double)D.P.inv_dx - 0.5); }
         key = ((long long)b[2] * D.P.n + b[1]) * D.P.n + b[0];
     }
     const int src = D.P.n <= 256 ? wave_sort_lanes32(p0 < D.N ? (unsigned)key : 0x3ffffffu) : wave_sort_lanes(key);
@@ -763,9 +802,8 @@ __global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_p2g(Dev<T> D, int f) 
     // accumulate in double: on gfx950 ds_add_f64 is ~5x cheaper per instruction than ds_add_f32
     // (profiles/microbench/lds_atomics.hip), and the node sums lose no precision
     __shared__ Vec4<double> tile[TileCap<T>::nodes];
-    const double* X = frame_x(D, f);
-    const T* R = frame_r(D, f);
-    const int Np = D.Npad;
+    const Soa<double> X = frame_xs(D, f);
+    const Soa<T> R = frame_rs(D, f);
     int p, base[3];
     double x[3];
     const int wgi = xcd_chunk((int)blockIdx.x, (int)gridDim.x);
@@ -783,8 +821,8 @@ __global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_p2g(Dev<T> D, int f) 
         for (int d = 0; d < 9; ++d) { C[d] = T(0); E[d] = T(0); }
         T mu = T(1), lam = T(1), ys = T(1);
         if (valid) {
-            for (int d = 0; d < 3; ++d) v[d] = R[d * Np + p];
-            for (int d = 0; d < 9; ++d) { C[d] = R[(3 + d) * Np + p]; E[d] = R[(12 + d) * Np + p]; }
+            for (int d = 0; d < 3; ++d) v[d] = R.ld(d, p);
+            for (int d = 0; d < 9; ++d) { C[d] = R.ld(3 + d, p); E[d] = R.ld(12 + d, p); }
             load_materials(D, p, mu, lam, ys);
         }
         const Seg<T> sg = wave_segments<T>(valid ? (base[2] * D.P.n + base[1]) * D.P.n + base[0] : -1);
@@ -824,8 +862,8 @@ __global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_p2g(Dev<T> D, int f) 
             });
         }
         if (WRITE_F && valid) {
-            T* R1 = frame_r(D, f + 1);
-            for (int d = 0; d < 9; ++d) R1[(12 + d) * Np + p] = En[d];
+            const Soa<T> R1 = frame_rs(D, f + 1);
+            for (int d = 0; d < 9; ++d) R1.st(12 + d, p, En[d]);
         }
     }
     if (tl.ok) {
@@ -932,11 +970,10 @@ __global__ __launch_bounds__(kBlock) void k_g2p(Dev<T> D, int f) {
     const int wgi = xcd_chunk((int)blockIdx.x, (int)gridDim.x);
     const int p = wgi * kBlock + threadIdx.x;
     const bool valid = p < D.N;
-    const double* X = frame_x(D, f);
-    const int Np = D.Npad;
+    const Soa<double> X = frame_xs(D, f);
     const Tile tl = load_tile(D, f, TileCap<T>::nodes, wgi);        // written by the scatter of this frame
     double x[3] = {0.5, 0.5, 0.5};
-    if (valid) { x[0] = X[p]; x[1] = X[Np + p]; x[2] = X[2 * Np + p]; }
+    if (valid) { x[0] = X.ld(0, p); x[1] = X.ld(1, p); x[2] = X.ld(2, p); }
     const int ex = tl.e[0], exy = tl.e[0] * tl.e[1], tn = exy * tl.e[2];
     if (tl.ok) {
         for (int i = threadIdx.x; i < tn; i += kBlock) {
@@ -964,10 +1001,10 @@ __global__ __launch_bounds__(kBlock) void k_g2p(Dev<T> D, int f) {
             gv[0] = a.x; gv[1] = a.y; gv[2] = a.z;
         });
     }
-    double* X1 = frame_x_w(D, f + 1);
-    T* R1 = frame_r(D, f + 1);
-    for (int d = 0; d < 3; ++d) { X1[d * Np + p] = xn[d]; R1[d * Np + p] = vn[d]; }
-    for (int d = 0; d < 9; ++d) R1[(3 + d) * Np + p] = Cn[d];
+    const Soa<double> X1 = frame_xs(D, f + 1);
+    const Soa<T> R1 = frame_rs(D, f + 1);
+    for (int d = 0; d < 3; ++d) { X1.st(d, p, xn[d]); R1.st(d, p, vn[d]); }
+    for (int d = 0; d < 9; ++d) R1.st(3 + d, p, Cn[d]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -980,11 +1017,10 @@ __global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_g2p_p2g(Dev<T> D, int
     __shared__ int sred[kSred];
     __shared__ Vec4<double> tile[TileCap<T>::nodes];
     Vec4<T>* tile_v = reinterpret_cast<Vec4<T>*>(tile);          // first use of the same LDS
-    const int Np = D.Npad;
     // ---------------- g2p(f-1): gather
     // lanes are sorted by the stencil base of frame f-1; particles move less than a cell per substep, so the
     // runs are (almost) the same for the scatter of frame f
-    const double* X0 = frame_x(D, f - 1);
+    const Soa<double> X0 = frame_xs(D, f - 1);
     int p, base0[3];
     double x0[3];
     PT_BEGIN();
@@ -1008,9 +1044,9 @@ __global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_g2p_p2g(Dev<T> D, int
     T E[9];
     for (int d = 0; d < 9; ++d) E[d] = T(0);
     T mu = T(1), lam = T(1), ys = T(1);
+    const Soa<T> R1 = frame_rs(D, f);                            // frame f: E is read, x / v / C are written
     if (valid) {
-        const T* R = frame_r(D, f);
-        for (int d = 0; d < 9; ++d) E[d] = R[(12 + d) * Np + p];
+        for (int d = 0; d < 9; ++d) E[d] = R1.ld(12 + d, p);
         load_materials(D, p, mu, lam, ys);
     }
     wg_barrier();                                               // tile_v complete
@@ -1032,10 +1068,9 @@ __global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_g2p_p2g(Dev<T> D, int
                 gv[0] = a.x; gv[1] = a.y; gv[2] = a.z;
             });
         }
-        double* X1 = frame_x_w(D, f);
-        T* R1 = frame_r(D, f);
-        for (int d = 0; d < 3; ++d) { X1[d * Np + p] = x[d]; R1[d * Np + p] = v[d]; }
-        for (int d = 0; d < 9; ++d) R1[(3 + d) * Np + p] = C[d];
+        const Soa<double> X1 = frame_xs(D, f);
+        for (int d = 0; d < 3; ++d) { X1.st(d, p, x[d]); R1.st(d, p, v[d]); }
+        for (int d = 0; d < 9; ++d) R1.st(3 + d, p, C[d]);
     }
     PT_MARK(2);
     // ---------------- p2g(f): scatter
@@ -1098,8 +1133,8 @@ __global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_g2p_p2g(Dev<T> D, int
             });
         }
         if (valid) {
-            T* R2 = frame_r(D, f + 1);
-            for (int d = 0; d < 9; ++d) R2[(12 + d) * Np + p] = En[d];
+            const Soa<T> R2 = frame_rs(D, f + 1);
+            for (int d = 0; d < 9; ++d) R2.st(12 + d, p, En[d]);
         }
     }
     PT_MARK(5);
@@ -1159,8 +1194,7 @@ __global__ __launch_bounds__(kBlock, sizeof(T) == 4 ? PLB_G2PG_WAVES : 1) void k
     constexpr int CAP = sizeof(T) == 4 ? PLB_G2PG_CAP : 480;
     __shared__ Vec4<T> tile[CAP];                    // v_out values
     __shared__ double tile_a[CAP * 3];               // v_out adjoint accumulation (f64, see k_p2g)
-    const double* X = frame_x(D, f);
-    const int Np = D.Npad;
+    const Soa<double> X = frame_xs(D, f);
     int p, base[3];
     double x[3];
     PT_BEGIN();
@@ -1199,13 +1233,13 @@ __global__ __launch_bounds__(kBlock, sizeof(T) == 4 ? PLB_G2PG_WAVES : 1) void k
     PT_MARK(1);
     {
         // v[f+1]: normally the stored frame; after a re-sort of frame f+1 the copy kept in this frame's particle order
-        const T* R1 = vnext ? vnext : frame_r(D, f + 1);
-        const T* A1 = D.adj[src];
+        const Soa<T> R1(vnext ? vnext : frame_r(D, f + 1), D.Npad, vnext ? 3 : 21);
+        const Soa<T> A1 = adj_s(D, src);
         T vn[3] = {T(0), T(0), T(0)}, xna[3] = {T(0), T(0), T(0)}, vna[3] = {T(0), T(0), T(0)}, Cna[9], xa[3];
         for (int d = 0; d < 9; ++d) Cna[d] = T(0);
         if (valid) {
-            for (int d = 0; d < 3; ++d) { vn[d] = R1[d * Np + p]; xna[d] = A1[d * Np + p]; vna[d] = A1[(3 + d) * Np + p]; }
-            for (int d = 0; d < 9; ++d) Cna[d] = A1[(6 + d) * Np + p];
+            for (int d = 0; d < 3; ++d) { vn[d] = R1.ld(d, p); xna[d] = A1.ld(d, p); vna[d] = A1.ld(3 + d, p); }
+            for (int d = 0; d < 9; ++d) Cna[d] = A1.ld(6 + d, p);
         }
         __syncthreads();                             // tile / tile_a complete (the loads above are in flight)
         PT_MARK(2);
@@ -1291,8 +1325,8 @@ __global__ __launch_bounds__(kBlock, sizeof(T) == 4 ? PLB_G2PG_WAVES : 1) void k
                 });
         }
         if (valid) {
-            T* A0 = D.adj[dst];
-            for (int d = 0; d < 3; ++d) A0[d * Np + p] = xa[d];
+            const Soa<T> A0 = adj_s(D, dst);
+            for (int d = 0; d < 3; ++d) A0.st(d, p, xa[d]);
         }
     }
     PT_MARK(3);
@@ -1500,13 +1534,12 @@ __global__ __launch_bounds__(kBlock, sizeof(T) == 4 ? PLB_P2G_GRAD_WAVES : 1) vo
     const int chunk = xcd_chunk((int)blockIdx.x - npose, (int)gridDim.x - npose);
     const int p = chunk * kBlock + threadIdx.x;
     const bool valid = p < D.N;
-    const double* X = frame_x(D, f);
-    const T* R = frame_r(D, f);
-    const int Np = D.Npad;
+    const Soa<double> X = frame_xs(D, f);
+    const Soa<T> R = frame_rs(D, f);
     PT_BEGIN();
     Tile tl = load_tile(D, f, TileCap<T>::nodes, chunk);   // stored by the scatter of this frame
     double x[3] = {0.5, 0.5, 0.5};
-    if (valid) { x[0] = X[p]; x[1] = X[Np + p]; x[2] = X[2 * Np + p]; }
+    if (valid) { x[0] = X.ld(0, p); x[1] = X.ld(1, p); x[2] = X.ld(2, p); }
     const int ex = tl.e[0], exy = tl.e[0] * tl.e[1], tn = exy * tl.e[2];
     if (tl.ok) {
         for (int i = threadIdx.x; i < tn; i += kBlock) {
@@ -1538,16 +1571,15 @@ __global__ __launch_bounds__(kBlock, sizeof(T) == 4 ? PLB_P2G_GRAD_WAVES : 1) vo
     }
     PT_MARK(2);
     T v[3], C[9], E[9], Ena[9], xa[3], va[3], Ca[9], Ea[9];
-    const T* A1 = D.adj[src];
-    T* A0 = D.adj[dst];
+    const Soa<T> A1 = adj_s(D, src), A0 = adj_s(D, dst);
     T mu, lam, ys;
-    for (int d = 0; d < 3; ++d) { v[d] = R[d * Np + p]; xa[d] = A0[d * Np + p]; }
-    for (int d = 0; d < 9; ++d) { C[d] = R[(3 + d) * Np + p]; E[d] = R[(12 + d) * Np + p]; Ena[d] = A1[(15 + d) * Np + p]; }
+    for (int d = 0; d < 3; ++d) { v[d] = R.ld(d, p); xa[d] = A0.ld(d, p); }
+    for (int d = 0; d < 9; ++d) { C[d] = R.ld(3 + d, p); E[d] = R.ld(12 + d, p); Ena[d] = A1.ld(15 + d, p); }
     load_materials(D, p, mu, lam, ys);
     p2g_finish_grad<T>(D.P, G, v, C, E, mu, lam, ys, Ena, xa, va, Ca, Ea);
     PT_MARK(3);
-    for (int d = 0; d < 3; ++d) { A0[d * Np + p] = xa[d]; A0[(3 + d) * Np + p] = va[d]; }
-    for (int d = 0; d < 9; ++d) { A0[(6 + d) * Np + p] = Ca[d]; A0[(15 + d) * Np + p] = Ea[d]; }
+    for (int d = 0; d < 3; ++d) { A0.st(d, p, xa[d]); A0.st(3 + d, p, va[d]); }
+    for (int d = 0; d < 9; ++d) { A0.st(6 + d, p, Ca[d]); A0.st(15 + d, p, Ea[d]); }
     PT_MARK(4);
     PT_END(D, 20);
 }
@@ -1558,7 +1590,7 @@ template <class T, bool DET = false>
 __global__ __launch_bounds__(kBlock) void k_grid_mass(Dev<T> D, int f, T* gm) {
     __shared__ int sred[kSred];
     __shared__ double tile[TileCap<T>::nodes * 4];
-    const double* X = frame_x(D, f);
+    const Soa<double> X = frame_xs(D, f);
     int p, base[3];
     double x[3];
     int base_true[3];
