@@ -975,6 +975,200 @@ PLB_HD void p2g_gather_grad(const SimP<typename Lane<T>::scalar>& P, const X* x,
     }
 }
 
+// ---- the same gather on packed fp32 pairs (fp32 engine, -DPLB_PK_GATHER=1) -------------------------------------------------------
+// v_pk_fma_f32 does two multiply-adds per instruction in about the issue time of one and a quarter plain ones, and either half of
+// a 64-bit source can be broadcast to both results by op_sel -- for free, IF the value already sits in a register pair (hipcc
+// folds a splat of an element of a pair into op_sel; a splat of a lone scalar costs a move, which is what sank round 2's attempt:
+// profiles/r02_notes.md).  So here every factor and every running sum lives in a pair from the start:
+//   node level   fetched {mv'_x, mv'_y | mv'_z, m'} x z-factor pairs (W, D), (ZW, ZD): 7 packed instead of 14 plain multiply-adds
+//   y level      14 packed + 2 plain instead of 30,        x level   22 packed + 7 plain instead of 51
+// = 381 packed + 39 plain instead of ~800 plain per particle.  Same sums in the same order per accumulator (each is still one
+// chain of 27 fused multiply-adds), so results agree with p2g_gather_grad to the last bit on the device; the host build (g++, no
+// vector extension) emulates the pairs for tests/test_host_emul.py.
+#ifndef PLB_PK_GATHER
+#define PLB_PK_GATHER 0          // bit 0: the p2g.grad gather, bit 1: the g2p gathers (k_g2p, k_g2p_p2g); off until measured
+#endif
+#if defined(__clang__)
+typedef float plb_f2 __attribute__((ext_vector_type(2)));
+PLB_HD plb_f2 pk_fma(plb_f2 a, plb_f2 b, plb_f2 c) { return __builtin_elementwise_fma(a, b, c); }
+#else
+struct plb_f2 { float x, y; };
+PLB_HD plb_f2 pk_fma(plb_f2 a, plb_f2 b, plb_f2 c) { plb_f2 r; r.x = fmaf(a.x, b.x, c.x); r.y = fmaf(a.y, b.y, c.y); return r; }
+#endif
+PLB_HD plb_f2 pk2(float a, float b) { plb_f2 r; r.x = a; r.y = b; return r; }
+PLB_HD plb_f2 pk_lo(plb_f2 v) { return pk2(v.x, v.x); }          // both halves = the low / the high element (op_sel on the device)
+PLB_HD plb_f2 pk_hi(plb_f2 v) { return pk2(v.y, v.y); }
+// Fetch(k0, k1, k2, axy, azw): axy = {grid_v_in.grad x, y}, azw = {grid_v_in.grad z, grid_m.grad}
+template <class X, class Fetch>
+PLB_HD void p2g_gather_grad_pk(const SimP<float>& P, const X* x, P2GGather<float>& G, Fetch&& fetch) {
+    int base[3];
+    float fx[3], w[3][3], dw[3][3];
+    stencil<float, X>(x, P.inv_dx, base, fx, w, dw);
+    // z factors of the three offsets as pairs: (W, D) and (ZW, ZD)
+    plb_f2 cz01[3], cz23[3];
+    for (int n = 0; n < 3; ++n) {
+        const float z = float(n) - fx[2];
+        cz01[n] = pk2(w[n][2], dw[n][2]);
+        cz23[n] = pk2(z * w[n][2], z * dw[n][2]);
+    }
+    const plb_f2 zero = pk2(0.f, 0.f);
+    // final sums.  (x, y) components of combination c: Fxy[c]  (c as in p2g_gather_grad: va | Aa0..2 | M00..M22 | s0..2).
+    // z components in the pairs the x level can produce with one instruction each:
+    //   Fz_0_13 = (c0, c13)  Fz_1_4 = (c1, c4)  Fz_14_5 = (c14, c5)  Fz_15_6 = (c15, c6)  Fz_2_7 = (c2, c7)  Fz_3_10 = (c3, c10); c8, c9, c11, c12 alone
+    plb_f2 Fxy[16];
+    for (int c = 0; c < 16; ++c) Fxy[c] = zero;
+    plb_f2 Fz_0_13 = zero, Fz_1_4 = zero, Fz_14_5 = zero, Fz_15_6 = zero, Fz_2_7 = zero, Fz_3_10 = zero;
+    float Fz8 = 0.f, Fz9 = 0.f, Fz11 = 0.f, Fz12 = 0.f, Fm0 = 0.f, Fm1 = 0.f, Fm2 = 0.f;
+    PLB_ROLL_GATH_I
+    for (int i = 0; i < 3; ++i) {
+        // sums over (j, l) for this i.  (x, y): Sxy[q], q = the (type on y, type on z) pair of p2g_gather_grad.  z components:
+        //   Sz01 = (q0, q1)  Sz34 = (q3, q4)  Sz67 = (q6, q7)  Sz25 = (q2, q5)  Sz8;   mass: Sm02 = (Sm0, Sm2), Sm1
+        plb_f2 Sxy[9];
+        for (int q = 0; q < 9; ++q) Sxy[q] = zero;
+        plb_f2 Sz01 = zero, Sz34 = zero, Sz67 = zero, Sz25 = zero, Sm02 = zero;
+        float Sz8 = 0.f, Sm1 = 0.f;
+        PLB_ROLL_GATH_J
+        for (int j = 0; j < 3; ++j) {
+            plb_f2 Rxy0 = zero, Rxy1 = zero, Rxy2 = zero, Rxy3 = zero;      // (x, y) x z type W, D, ZW, ZD
+            plb_f2 Rz01 = zero, Rz23 = zero, Rm01 = zero;                    // z component x (W, D), (ZW, ZD); mass x (W, D)
+            for (int l = 0; l < 3; ++l) {
+                plb_f2 axy, azw;
+                fetch(i, j, l, axy, azw);
+                Rxy0 = pk_fma(axy, pk_lo(cz01[l]), Rxy0);
+                Rxy1 = pk_fma(axy, pk_hi(cz01[l]), Rxy1);
+                Rxy2 = pk_fma(axy, pk_lo(cz23[l]), Rxy2);
+                Rxy3 = pk_fma(axy, pk_hi(cz23[l]), Rxy3);
+                Rz01 = pk_fma(cz01[l], pk_lo(azw), Rz01);
+                Rz23 = pk_fma(cz23[l], pk_lo(azw), Rz23);
+                Rm01 = pk_fma(cz01[l], pk_hi(azw), Rm01);
+            }
+            const float yw = sel3(j, w[0][1], w[1][1], w[2][1]), yd = sel3(j, dw[0][1], dw[1][1], dw[2][1]);
+            const float zy = float(j) - fx[1];
+            const plb_f2 cy01 = pk2(yw, yd), cy23 = pk2(zy * yw, zy * yd), cy02 = pk2(yw, zy * yw);
+            // (type on y, type on z) of q: (W,W) (D,W) (W,D) (ZW,W) (ZD,W) (ZW,D) (W,ZW) (D,ZW) (W,ZD)
+            Sxy[0] = pk_fma(Rxy0, pk_lo(cy01), Sxy[0]);
+            Sxy[1] = pk_fma(Rxy0, pk_hi(cy01), Sxy[1]);
+            Sxy[2] = pk_fma(Rxy1, pk_lo(cy01), Sxy[2]);
+            Sxy[3] = pk_fma(Rxy0, pk_lo(cy23), Sxy[3]);
+            Sxy[4] = pk_fma(Rxy0, pk_hi(cy23), Sxy[4]);
+            Sxy[5] = pk_fma(Rxy1, pk_lo(cy23), Sxy[5]);
+            Sxy[6] = pk_fma(Rxy2, pk_lo(cy01), Sxy[6]);
+            Sxy[7] = pk_fma(Rxy2, pk_hi(cy01), Sxy[7]);
+            Sxy[8] = pk_fma(Rxy3, pk_lo(cy01), Sxy[8]);
+            Sz01 = pk_fma(cy01, pk_lo(Rz01), Sz01);                          // q0 = yW zW, q1 = yD zW
+            Sz34 = pk_fma(cy23, pk_lo(Rz01), Sz34);                          // q3 = yZW zW, q4 = yZD zW
+            Sz67 = pk_fma(cy01, pk_lo(Rz23), Sz67);                          // q6 = yW zZW, q7 = yD zZW
+            Sz25 = pk_fma(cy02, pk_hi(Rz01), Sz25);                          // q2 = yW zD, q5 = yZW zD
+            Sz8 += yw * Rz23.y;                                              // q8 = yW zZD
+            Sm02 = pk_fma(Rm01, pk_lo(cy01), Sm02);                          // Sm0 = yW mW, Sm2 = yW mD
+            Sm1 += yd * Rm01.x;                                              // Sm1 = yD mW
+        }
+        const float xw = sel3(i, w[0][0], w[1][0], w[2][0]), xd = sel3(i, dw[0][0], dw[1][0], dw[2][0]);
+        const float zx = float(i) - fx[0];
+        const plb_f2 cx01 = pk2(xw, xd), cx23 = pk2(zx * xw, zx * xd), cx02 = pk2(xw, zx * xw);
+        //              c:  0   1   2  3   4   5   6  7  8  9  10 11 12 13 14 15
+        // type on x        W   ZW  W  W   ZD  ZW  ZW D  W  W  D  W  W  D  W  W
+        // pair q           0   0   3  6   0   1   2  3  4  5  6  7  8  0  1  2
+        Fxy[0] = pk_fma(Sxy[0], pk_lo(cx01), Fxy[0]);
+        Fxy[1] = pk_fma(Sxy[0], pk_lo(cx23), Fxy[1]);
+        Fxy[2] = pk_fma(Sxy[3], pk_lo(cx01), Fxy[2]);
+        Fxy[3] = pk_fma(Sxy[6], pk_lo(cx01), Fxy[3]);
+        Fxy[4] = pk_fma(Sxy[0], pk_hi(cx23), Fxy[4]);
+        Fxy[5] = pk_fma(Sxy[1], pk_lo(cx23), Fxy[5]);
+        Fxy[6] = pk_fma(Sxy[2], pk_lo(cx23), Fxy[6]);
+        Fxy[7] = pk_fma(Sxy[3], pk_hi(cx01), Fxy[7]);
+        Fxy[8] = pk_fma(Sxy[4], pk_lo(cx01), Fxy[8]);
+        Fxy[9] = pk_fma(Sxy[5], pk_lo(cx01), Fxy[9]);
+        Fxy[10] = pk_fma(Sxy[6], pk_hi(cx01), Fxy[10]);
+        Fxy[11] = pk_fma(Sxy[7], pk_lo(cx01), Fxy[11]);
+        Fxy[12] = pk_fma(Sxy[8], pk_lo(cx01), Fxy[12]);
+        Fxy[13] = pk_fma(Sxy[0], pk_hi(cx01), Fxy[13]);
+        Fxy[14] = pk_fma(Sxy[1], pk_lo(cx01), Fxy[14]);
+        Fxy[15] = pk_fma(Sxy[2], pk_lo(cx01), Fxy[15]);
+        Fz_0_13 = pk_fma(cx01, pk_lo(Sz01), Fz_0_13);                        // c0 = xW q0, c13 = xD q0
+        Fz_1_4 = pk_fma(cx23, pk_lo(Sz01), Fz_1_4);                          // c1 = xZW q0, c4 = xZD q0
+        Fz_14_5 = pk_fma(cx02, pk_hi(Sz01), Fz_14_5);                        // c14 = xW q1, c5 = xZW q1
+        Fz_15_6 = pk_fma(cx02, pk_lo(Sz25), Fz_15_6);                        // c15 = xW q2, c6 = xZW q2
+        Fz_2_7 = pk_fma(cx01, pk_lo(Sz34), Fz_2_7);                          // c2 = xW q3, c7 = xD q3
+        Fz_3_10 = pk_fma(cx01, pk_lo(Sz67), Fz_3_10);                        // c3 = xW q6, c10 = xD q6
+        Fz8 += xw * Sz34.y;                                                  // c8 = xW q4
+        Fz9 += xw * Sz25.y;                                                  // c9 = xW q5
+        Fz11 += xw * Sz67.y;                                                 // c11 = xW q7
+        Fz12 += xw * Sz8;                                                    // c12 = xW q8
+        Fm0 += xd * Sm02.x; Fm1 += xw * Sm1; Fm2 += xw * Sm02.y;
+    }
+    const float Fz[16] = {Fz_0_13.x, Fz_1_4.x, Fz_2_7.x, Fz_3_10.x, Fz_1_4.y, Fz_14_5.y, Fz_15_6.y, Fz_2_7.y,
+                          Fz8, Fz9, Fz_3_10.y, Fz11, Fz12, Fz_0_13.y, Fz_14_5.x, Fz_15_6.x};
+    for (int a = 0; a < 3; ++a) {
+        auto comp = [&](int c) { return a == 0 ? Fxy[c].x : (a == 1 ? Fxy[c].y : Fz[c]); };
+        G.va[a] = P.p_mass * comp(0);
+        for (int b = 0; b < 3; ++b) {
+            G.Aa[3 * a + b] = P.dx * comp(1 + b);
+            for (int d = 0; d < 3; ++d) G.M[9 * a + 3 * b + d] = P.dx * comp(4 + 3 * b + d);
+        }
+        for (int d = 0; d < 3; ++d) G.sv[3 * d + a] = comp(13 + d);
+    }
+    G.sm[0] = Fm0; G.sm[1] = Fm1; G.sm[2] = Fm2;
+}
+
+// g2p on packed pairs (fp32 engine, -DPLB_PK_GATHER=1): the gather of g2p_particle with every factor and running sum in a register
+// pair -- 132 packed + 15 plain multiply-adds instead of 279 plain.  Fetch(k0, k1, k2, axy, azw): axy = {v_out x, y}, azw.x = v_out z.
+template <class X, class Fetch>
+PLB_HD void g2p_particle_pk(const SimP<float>& P, const X* x, X* xn, float* vn, float* Cn, Fetch&& fetch) {
+    int base[3];
+    float fx[3], w[3][3];
+    stencil<float, X>(x, P.inv_dx, base, fx, w, nullptr);
+    plb_f2 cz[3];                                          // (w, z w) along z for the three offsets
+    for (int k = 0; k < 3; ++k) cz[k] = pk2(w[k][2], (float(k) - fx[2]) * w[k][2]);
+    const plb_f2 zero = pk2(0.f, 0.f);
+    // v' = sum w g;  C'[a][0] = sum (zx w) g_a, C'[a][1] = sum (zy w) g_a, C'[a][2] = sum (zz w) g_a
+    plb_f2 Vxy = zero, C0xy = zero, C1xy = zero, C2xy = zero;     // (a = 0, a = 1) of v', C'[a][0], C'[a][1], C'[a][2]
+    plb_f2 VC0z = zero;                                           // a = 2: (v'_z, C'[2][0])
+    float C1z = 0.f, C2z = 0.f;                                   // C'[2][1], C'[2][2]
+    PLB_ROLL_G2P_I
+    for (int i = 0; i < 3; ++i) {
+        plb_f2 Swwxy = zero, Szwxy = zero, Swzxy = zero, SwwSzw_z = zero;
+        float Swz_z = 0.f;
+        PLB_ROLL_G2P_J
+        for (int j = 0; j < 3; ++j) {
+            plb_f2 Rwxy = zero, Rzxy = zero, RwRz_z = zero;
+            for (int l = 0; l < 3; ++l) {
+                plb_f2 axy, azw;
+                fetch(i, j, l, axy, azw);
+                Rwxy = pk_fma(axy, pk_lo(cz[l]), Rwxy);
+                Rzxy = pk_fma(axy, pk_hi(cz[l]), Rzxy);
+                RwRz_z = pk_fma(cz[l], pk_lo(azw), RwRz_z);
+            }
+            const float wy = sel3(j, w[0][1], w[1][1], w[2][1]);
+            const plb_f2 cy = pk2(wy, (float(j) - fx[1]) * wy);
+            Swwxy = pk_fma(Rwxy, pk_lo(cy), Swwxy);
+            Szwxy = pk_fma(Rwxy, pk_hi(cy), Szwxy);
+            Swzxy = pk_fma(Rzxy, pk_lo(cy), Swzxy);
+            SwwSzw_z = pk_fma(cy, pk_lo(RwRz_z), SwwSzw_z);
+            Swz_z += wy * RwRz_z.y;
+        }
+        const float wi = sel3(i, w[0][0], w[1][0], w[2][0]);
+        const plb_f2 cx = pk2(wi, (float(i) - fx[0]) * wi);
+        Vxy = pk_fma(Swwxy, pk_lo(cx), Vxy);
+        C0xy = pk_fma(Swwxy, pk_hi(cx), C0xy);
+        C1xy = pk_fma(Szwxy, pk_lo(cx), C1xy);
+        C2xy = pk_fma(Swzxy, pk_lo(cx), C2xy);
+        VC0z = pk_fma(cx, pk_lo(SwwSzw_z), VC0z);
+        C1z += wi * SwwSzw_z.y;
+        C2z += wi * Swz_z;
+    }
+    const float c4 = 4.f * P.inv_dx;
+    vn[0] = Vxy.x; vn[1] = Vxy.y; vn[2] = VC0z.x;
+    Cn[0] = c4 * C0xy.x; Cn[1] = c4 * C1xy.x; Cn[2] = c4 * C2xy.x;
+    Cn[3] = c4 * C0xy.y; Cn[4] = c4 * C1xy.y; Cn[5] = c4 * C2xy.y;
+    Cn[6] = c4 * VC0z.y; Cn[7] = c4 * C1z; Cn[8] = c4 * C2z;
+    for (int d = 0; d < 3; ++d) {
+        X y = x[d] + cvt<X>(P.dt) * cvt<X>(vn[d]);
+        X hi = X(1) - X(3) / cvt<X>(P.n);
+        xn[d] = t_max(t_min(y, hi), X(0));
+    }
+}
+
 template <class T>
 PLB_HD void p2g_finish_grad(const SimP<typename Lane<T>::scalar>& P, const P2GGather<T>& G, const T* v, const T* C, const T* E, T mu, T lam, T ys,
                             const T* En_a, T* xa_io, T* va, T* Ca, T* Ea) {

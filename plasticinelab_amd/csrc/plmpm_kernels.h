@@ -989,6 +989,22 @@ __global__ __launch_bounds__(kBlock) void k_g2p(Dev<T> D, int f) {
     if (!valid) return;
     double xn[3];
     T vn[3], Cn[9];
+#if PLB_PK_GATHER & 2
+    if constexpr (sizeof(T) == 4) {                  // the gather on packed pairs (mpm_math.h: g2p_particle_pk)
+        if (tl.ok) {
+            const int ox = base[0] - tl.o[0], oy = base[1] - tl.o[1], oz = base[2] - tl.o[2];
+            g2p_particle_pk<double>(D.P, x, xn, vn, Cn, [&](int i, int j, int l, plb_f2& axy, plb_f2& azw) {
+                const Vec4<float> a = tile[(oz + l) * exy + (oy + j) * ex + (ox + i)];
+                axy = pk2(a.x, a.y); azw = pk2(a.z, a.w);
+            });
+        } else {
+            g2p_particle_pk<double>(D.P, x, xn, vn, Cn, [&](int i, int j, int l, plb_f2& axy, plb_f2& azw) {
+                const Vec4<float> a = D.grid_out[node_index(D, base[0] + i, base[1] + j, base[2] + l)];
+                axy = pk2(a.x, a.y); azw = pk2(a.z, a.w);
+            });
+        }
+    } else
+#endif
     if (tl.ok) {
         const int ox = base[0] - tl.o[0], oy = base[1] - tl.o[1], oz = base[2] - tl.o[2];
         g2p_particle<T, double>(D.P, x, xn, vn, Cn, [&](int i, int j, int l, T* gv) {
@@ -1055,6 +1071,23 @@ __global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_g2p_p2g(Dev<T> D, int
     T v[3] = {T(0), T(0), T(0)}, C[9];
     for (int d = 0; d < 9; ++d) C[d] = T(0);
     if (valid) {
+#if PLB_PK_GATHER & 2
+        if constexpr (sizeof(T) == 4) {              // the gather on packed pairs (mpm_math.h: g2p_particle_pk)
+            if (ta.ok) {
+                const int ex = ta.e[0], exy = ta.e[0] * ta.e[1];
+                const int ox = base0[0] - ta.o[0], oy = base0[1] - ta.o[1], oz = base0[2] - ta.o[2];
+                g2p_particle_pk<double>(D.P, x0, x, v, C, [&](int i, int j, int l, plb_f2& axy, plb_f2& azw) {
+                    const Vec4<float> a = tile_v[(oz + l) * exy + (oy + j) * ex + (ox + i)];
+                    axy = pk2(a.x, a.y); azw = pk2(a.z, a.w);
+                });
+            } else {
+                g2p_particle_pk<double>(D.P, x0, x, v, C, [&](int i, int j, int l, plb_f2& axy, plb_f2& azw) {
+                    const Vec4<float> a = vout_prev[node_index(D, base0[0] + i, base0[1] + j, base0[2] + l)];
+                    axy = pk2(a.x, a.y); azw = pk2(a.z, a.w);
+                });
+            }
+        } else
+#endif
         if (ta.ok) {
             const int ex = ta.e[0], exy = ta.e[0] * ta.e[1];
             const int ox = base0[0] - ta.o[0], oy = base0[1] - ta.o[1], oz = base0[2] - ta.o[2];
@@ -1557,6 +1590,23 @@ __global__ __launch_bounds__(kBlock, sizeof(T) == 4 ? PLB_P2G_GRAD_WAVES : 1) vo
     // the 27-node gather needs the position only: the other 42 words of particle state are fetched after it, so
     // that they are not live across the loop (the kernel then fits 3 waves per SIMD instead of 2)
     P2GGather<T> G;
+#if PLB_PK_GATHER & 1
+    // fp32 engine: the gather on packed pairs (mpm_math.h: p2g_gather_grad_pk) -- 381 v_pk_fma_f32 + 39 plain instead of ~800 plain
+    if constexpr (sizeof(T) == 4) {
+        if (tl.ok) {
+            const int ox = base[0] - tl.o[0], oy = base[1] - tl.o[1], oz = base[2] - tl.o[2];
+            p2g_gather_grad_pk<double>(D.P, x, G, [&](int i, int j, int l, plb_f2& axy, plb_f2& azw) {
+                const Vec4<float> a = tile[(oz + l) * exy + (oy + j) * ex + (ox + i)];
+                axy = pk2(a.x, a.y); azw = pk2(a.z, a.w);
+            });
+        } else {
+            p2g_gather_grad_pk<double>(D.P, x, G, [&](int i, int j, int l, plb_f2& axy, plb_f2& azw) {
+                const Vec4<float> a = D.grid_in_adj[node_index(D, base[0] + i, base[1] + j, base[2] + l)];
+                axy = pk2(a.x, a.y); azw = pk2(a.z, a.w);
+            });
+        }
+    } else
+#endif
     if (tl.ok) {
         const int ox = base[0] - tl.o[0], oy = base[1] - tl.o[1], oz = base[2] - tl.o[2];
         p2g_gather_grad<T, double>(D.P, x, G, [&](int i, int j, int l, T* g) {

@@ -164,3 +164,19 @@ def constitutive(Et, mu, lam, ys, GS, GF, clamp=1e-6, use_float=False, allow_fas
     lib().emul_constitutive(int(use_float), int(allow_fast), n, _p(a[0]), _p(a[1]), _p(a[2]), _p(a[3]), C.c_double(clamp),
                             _p(a[4]), _p(a[5]), _p(stress), _p(En), _p(Fta), _p(fast))
     return stress, En, Fta, fast.astype(bool)
+
+
+def gather_pk_check(n_grid, p_mass, x, g):
+    """Largest relative difference between the packed-pair and the plain form of the p2g.grad gather over the stencils (x[n,3], g[n,27,4])."""
+    L = lib()
+    L.emul_gather_pk_check.restype = C.c_double
+    x, g = np.ascontiguousarray(x, np.float64), np.ascontiguousarray(g, np.float64)
+    return float(L.emul_gather_pk_check(int(n_grid), C.c_double(p_mass), len(x), _p(x), _p(g)))
+
+
+def g2p_pk_check(n_grid, dt, x, gv):
+    """Largest relative difference between g2p_particle_pk and g2p_particle over the stencils (x[n,3], gv[n,27,3])."""
+    L = lib()
+    L.emul_g2p_pk_check.restype = C.c_double
+    x, gv = np.ascontiguousarray(x, np.float64), np.ascontiguousarray(gv, np.float64)
+    return float(L.emul_g2p_pk_check(int(n_grid), C.c_double(dt), len(x), _p(x), _p(gv)))

@@ -243,3 +243,60 @@ extern "C" void emul_constitutive(int use_float, int allow_fast, int n, const do
     if (use_float) constitutive_t<float>(allow_fast, n, Et, mu, lam, ys, clamp, GS, GF, stress, En, Fta, took_fast);
     else constitutive_t<double>(allow_fast, n, Et, mu, lam, ys, clamp, GS, GF, stress, En, Fta, took_fast);
 }
+
+
+// The packed-pair form of the p2g.grad gather (mpm_math.h: p2g_gather_grad_pk, the -DPLB_PK_GATHER=1 build of the fp32 engine) against
+// the plain form, on n random stencils: positions x[n][3] in (0.1, 0.9), nodal adjoints g[n][27][4] = {grid_m.grad, grid_v_in.grad[3]}.
+// Returns the largest difference of the 51 gathered sums relative to the largest sum of its particle.
+extern "C" double emul_gather_pk_check(int n_grid, double p_mass, int n, const double* x, const double* g) {
+    SimP<float> P{};
+    P.n = n_grid; P.dx = 1.0f / n_grid; P.inv_dx = (float)n_grid; P.p_mass = (float)p_mass;
+    double worst = 0.0;
+    for (int s = 0; s < n; ++s) {
+        double xp[3] = {x[3 * s], x[3 * s + 1], x[3 * s + 2]};
+        const double* gs = g + (size_t)s * 108;
+        P2GGather<float> A, B;
+        p2g_gather_grad<float, double>(P, xp, A, [&](int i, int j, int l, float* q) {
+            for (int a = 0; a < 4; ++a) q[a] = (float)gs[4 * (9 * i + 3 * j + l) + a];
+        });
+        p2g_gather_grad_pk<double>(P, xp, B, [&](int i, int j, int l, plb_f2& axy, plb_f2& azw) {
+            const double* q = gs + 4 * (9 * i + 3 * j + l);
+            axy = pk2((float)q[1], (float)q[2]); azw = pk2((float)q[3], (float)q[0]);
+        });
+        const float* a = reinterpret_cast<const float*>(&A);
+        const float* b = reinterpret_cast<const float*>(&B);
+        double scale = 0.0, diff = 0.0;
+        for (int k = 0; k < 51; ++k) { scale = std::max(scale, (double)std::fabs(a[k])); diff = std::max(diff, (double)std::fabs(a[k] - b[k])); }
+        worst = std::max(worst, diff / std::max(scale, 1e-30));          // (51 sums of different kinds: the largest sets the scale)
+    }
+    return worst;
+}
+
+// g2p_particle_pk against g2p_particle (fp32): n stencils, grid velocities gv[n][27][3]; largest difference of (v', C', x') relative
+// to the scale of the stencil's input.
+extern "C" double emul_g2p_pk_check(int n_grid, double dt, int n, const double* x, const double* gv) {
+    SimP<float> P{};
+    P.n = n_grid; P.dx = 1.0f / n_grid; P.inv_dx = (float)n_grid; P.dt = (float)dt;
+    double worst = 0.0;
+    for (int s = 0; s < n; ++s) {
+        double xp[3] = {x[3 * s], x[3 * s + 1], x[3 * s + 2]}, xa[3], xb[3];
+        const double* gs = gv + (size_t)s * 81;
+        float va[3], Ca[9], vb[3], Cb[9];
+        g2p_particle<float, double>(P, xp, xa, va, Ca, [&](int i, int j, int l, float* q) {
+            for (int a = 0; a < 3; ++a) q[a] = (float)gs[3 * (9 * i + 3 * j + l) + a];
+        });
+        g2p_particle_pk<double>(P, xp, xb, vb, Cb, [&](int i, int j, int l, plb_f2& axy, plb_f2& azw) {
+            const double* q = gs + 3 * (9 * i + 3 * j + l);
+            axy = pk2((float)q[0], (float)q[1]); azw = pk2((float)q[2], 0.f);
+        });
+        // scales of the INPUT (the weights sum to one, |z| <= 1.5 cells): sums of random-sign terms may cancel to nothing
+        double gmax = 0, diff = 0;
+        for (int k = 0; k < 81; ++k) gmax = std::max(gmax, std::fabs(gs[k]));
+        const double scale_v = gmax, scale_c = 4.0 * n_grid * gmax;
+        for (int k = 0; k < 3; ++k) diff = std::max(diff, std::fabs((double)va[k] - vb[k]) / std::max(scale_v, 1e-30));
+        for (int k = 0; k < 9; ++k) diff = std::max(diff, std::fabs((double)Ca[k] - Cb[k]) / std::max(scale_c, 1e-30));
+        for (int k = 0; k < 3; ++k) diff = std::max(diff, std::fabs(xa[k] - xb[k]));
+        worst = std::max(worst, diff);
+    }
+    return worst;
+}

@@ -321,3 +321,28 @@ def test_elastic_fast_path_matches_svd_path_and_oracle(use_float, tol):
     assert (err(g_s[f], g_o[f]) < 50 * tol).all()
     # particles the fast path refused: identical to the Jacobi path by construction
     assert np.array_equal(s_f[~f], s_s[~f]) and np.array_equal(g_f[~f], g_s[~f])
+
+
+def test_packed_pair_gather_equals_plain_gather():
+    """mpm_math.h: p2g_gather_grad_pk -- the p2g.grad gather on packed fp32 pairs (v_pk_fma_f32 on the device, the -DPLB_PK_GATHER=1
+    build) -- produces the same 51 sums as the plain sum-factorised gather: the pairing tables (which accumulators share an
+    instruction, which half of which factor pair is broadcast) are index bookkeeping that a typo breaks silently.  fp32 both ways; the
+    host build of the plain form does not fuse its multiply-adds, hence one rounding per term of slack."""
+    from tests import emul
+    rng = np.random.default_rng(5)
+    n = 3000
+    x = rng.uniform(0.05, 0.95, (n, 3))
+    g = rng.standard_normal((n, 27, 4)) * rng.uniform(0.1, 10.0, (n, 1, 1))
+    assert emul.gather_pk_check(64, 1.0e-4, x, g) < 2e-5
+    # one field at a time: a swapped pair shows up as an O(1) difference, not as round-off
+    for a in range(4):
+        ga = np.zeros_like(g)
+        ga[:, :, a] = g[:, :, a]
+        assert emul.gather_pk_check(128, 6.1e-5, x, ga) < 2e-5, a
+    # the forward gather of g2p on packed pairs (g2p_particle_pk): v', C' and the clamped x'
+    gv = rng.standard_normal((n, 27, 3)) * rng.uniform(0.01, 3.0, (n, 1, 1))
+    assert emul.g2p_pk_check(64, 1e-4, x, gv) < 2e-5
+    for a in range(3):
+        ga = np.zeros_like(gv)
+        ga[:, :, a] = gv[:, :, a]
+        assert emul.g2p_pk_check(128, 5e-5, x, ga) < 2e-5, a
