@@ -22,13 +22,13 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 struct Rec { unsigned long long cyc, rt; unsigned hwid, xcc; };
 
 enum Kind {
-    FMA_FWD1, FMA_2SRC, FMA_3SRC, FMAC, MUL, ADD, MAXF, FMAC_DPP, MOV_DPP, CVT_F64_F32, CVT_F32_I32, ADD_U32, LSHL_ADD, MAD_U24, MUL_LO, AND_B32,
+    FMA_FWD1, FMA_2SRC, FMA_3SRC, FMAC, MUL, ADD, MAXF, FMAC_DPP, MOV_DPP, ADD_DPP, AND_DPP, CVT_F64_F32, CVT_F32_I32, ADD_U32, LSHL_ADD, MAD_U24, MUL_LO, AND_B32,
     CNDMASK, CMP_CND, LSHL_ADD_U64, ASHR_I32, MAD_U64_U32, BFE_U32, RCP, RSQ, SQRT, MOV, PK_FMA, PK_MUL, FMA_F64, ADD_F64, MIX_FMA_MUL, MIX_PRODUCT, BANK_SAME, BANK_DIFF, FMA_1W_DEP, NKIND
 };
 static const char* kname[NKIND] = {
     "v_fma_f32 d,d,m,m   ONE chain (result forwarded)", "v_fma_f32 d,d,m,m   (2 distinct VGPR sources)", "v_fma_f32 d,d,m,m2  (3 distinct VGPR sources)",
     "v_fmac_f32 d,m,m2   (2 sources + accumulator)", "v_mul_f32 d,d,m", "v_add_f32 d,d,m", "v_max_f32 d,d,m",
-    "v_fmac_f32_dpp d,d,m row_shl:1 (product's reduce step)", "v_mov_b32_dpp d,d row_shl:1", "v_cvt_f64_f32", "v_cvt_f32_i32", "v_add_u32 d,d,m", "v_lshl_add_u32 d,d,2,m",
+    "v_fmac_f32_dpp d,d,m row_shl:1 (product's reduce step)", "v_mov_b32_dpp d,d row_shl:1", "v_add_f32_dpp d,d,m row_shl:1", "v_and_b32_dpp d,d,m row_shl:1", "v_cvt_f64_f32", "v_cvt_f32_i32", "v_add_u32 d,d,m", "v_lshl_add_u32 d,d,2,m",
     "v_mad_u32_u24 d,d,m,m2", "v_mul_lo_u32 d,d,m", "v_and_b32 d,d,m", "v_cndmask_b32 d,d,m,vcc", "v_cmp_lt_f32 + v_cndmask pair (per pair)", "v_lshl_add_u64 d,d,2,m64 (64-bit address add)",
     "v_ashrrev_i32 d,31,d (sign extension)", "v_mad_u64_u32", "v_bfe_u32 d,d,m,5",
     "v_rcp_f32", "v_rsq_f32", "v_sqrt_f32", "v_mov_b32 d,m", "v_pk_fma_f32 (two FMAs)", "v_pk_mul_f32 (two MULs)", "v_fma_f64", "v_add_f64",
@@ -51,6 +51,8 @@ template <int KIND> __global__ __launch_bounds__(256) void k(Rec* rec, int iters
         if (KIND == ADD) { REP64(A4("v_add_f32", ", %4")) }
         if (KIND == MAXF) { REP64(A4("v_max_f32", ", %4")) }
         if (KIND == FMAC_DPP) { REP64(A4("v_fmac_f32_dpp", ", %4 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1")) }
+        if (KIND == ADD_DPP) { REP64(A4("v_add_f32_dpp", ", %4 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1")) }
+        if (KIND == AND_DPP) { REP64(I4("v_and_b32_dpp", ", %4 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1")) }
         if (KIND == MOV_DPP) { REP64(A4("v_mov_b32_dpp", " row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1")) }
         if (KIND == CVT_F64_F32) { REP64(asm volatile("v_cvt_f64_f32 %0, %4\n v_cvt_f64_f32 %1, %5\n v_cvt_f64_f32 %2, %6\n v_cvt_f64_f32 %3, %7\n" : "=v"(d0), "=v"(d1), "=v"(d2), "=v"(d3) : "v"(a0), "v"(a1), "v"(a2), "v"(a3));) }
         if (KIND == CVT_F32_I32) { REP64(asm volatile("v_cvt_f32_i32 %0, %4\n v_cvt_f32_i32 %1, %5\n v_cvt_f32_i32 %2, %6\n v_cvt_f32_i32 %3, %7\n" : "=v"(a0), "=v"(a1), "=v"(a2), "=v"(a3) : "v"(i0), "v"(i1), "v"(i2), "v"(i3));) }
