@@ -81,6 +81,46 @@ def pmc_traffic(kernel, workload, dtype, steps, warmup):
         return None, None
 
 
+VALU_FILE = os.path.join(ROOT, "profiles", "r06_valu_calibration.json")
+
+
+def valu_roof(kernels, n_particles, workload, dtype, substeps_total):
+    """SURVEY 8(d)'s secondary check: the vector-ALU issue time of a fwd+bwd substep, next to the HBM roof.  From the committed
+    calibration (profiles/r06_valu_calibration.json, written by profiles/tools/valu_calibration.py): issue cycles per
+    wave-instruction of every instruction class at the REAL shader clock (profiles/microbench/valu_calibration.hip: s_memtime
+    against s_memrealtime) and the DYNAMIC instruction mix per wave of every hot kernel (rocprofv3 --pmc SQ_INSTS_VALU_* passes of
+    this command).  issue_us of a kernel = waves per SIMD x sum(class count x class cycles) / clock -- the time the four SIMDs of
+    every CU need to ISSUE the kernel's vector instructions if nothing else ever stalled; frac = that time over the measured
+    kernel time: 1.0 would be a kernel bound by vector issue alone.  None when the file is missing or was taken on another
+    workload / dtype."""
+    try:
+        with open(VALU_FILE) as f:
+            cal = json.load(f)
+    except (OSError, ValueError):
+        return None
+    if cal.get("workload") != workload or cal.get("dtype") != dtype:
+        return None
+    cyc, clock, simds = cal["cycles_per_wave_instruction"], float(cal["clock_ghz"]), int(cal.get("simds", 1024))
+    waves = -(-int(n_particles) // 64)
+    per, issue_total, time_total = {}, 0.0, 0.0
+    for name, k in kernels.items():
+        mix = cal["kernels"].get(name, {}).get("mix_per_wave")
+        if not mix:
+            continue
+        w = cal["kernels"][name].get("waves") or waves              # grid kernels: the waves the PMC pass counted
+        cycles = sum(float(n) * float(cyc.get(c, cyc["default"])) for c, n in mix.items())
+        issue_us = (w / simds) * cycles / (clock * 1e3)
+        per[name] = {"valu_per_wave": sum(mix.values()), "issue_cycles_per_wave": cycles, "issue_us": issue_us,
+                     "frac_of_kernel_time": issue_us / k["avg_us"] if k["avg_us"] > 0 else None}
+        issue_total += issue_us * k["launches"]
+        time_total += k["avg_us"] * k["launches"]
+    if not per:
+        return None
+    return {"issue_us_per_substep": issue_total / substeps_total, "frac": issue_total / time_total if time_total > 0 else None,
+            "clock_ghz": clock, "cycles_per_instr_source": "profiles/" + os.path.basename(VALU_FILE) + ": " + str(cal.get("source", "")),
+            "cycles_per_wave_instruction": cyc, "kernels": per}
+
+
 def mixed_yield(n):
     """BASELINE configs[4]: half the particles plastic (sigma_y = 50), half elastic (1e9), alternating in caller order."""
     return np.where(np.arange(n) % 2 == 0, 50.0, 1e9)
@@ -883,6 +923,8 @@ def main():
                            "job_alg_MB_per_substep": alg_unit * 1e-6,
                            "job_frac": alg_unit * value / (world * HBM_PEAK_GBS * 1e9),
                            "kernels": kernels}
+        # the secondary (vector-ALU) roof of SURVEY 8(d): null until a calibration of this workload is committed
+        out["roofline"]["valu"] = valu_roof(kernels, N, workload, out["dtype"], K * sub) if world == 1 else None
     headline = (args.workload, args.particles, args.quality, args.window, args.yield_stress, args.side, args.mixed_yield) == \
                ("config3_cube128", 500_000, 2, -1, 200.0, 0.31, False)
     # (PLB_FORCE_SECONDARY=1: the contract tests run the secondary points behind a reduced headline, with PLB_SECONDARY_SCALE)

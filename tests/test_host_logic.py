@@ -367,3 +367,29 @@ def test_grid_workgroups_of_engines_built_for_the_fused_exchange():
     for n in (2, 3, 4, 5, 8, 16):
         c = cap(True, n, n)
         assert c & (c - 1) == 0 and n * c <= 256
+
+
+def test_bench_valu_roof_arithmetic(tmp_path, monkeypatch):
+    """bench.py's secondary (vector-ALU) roof: issue time of a kernel = waves per SIMD x sum(class count x class cycles) / clock,
+    from a calibration file of the same workload and dtype; null otherwise."""
+    import json
+    import bench
+    cal = {"workload": "config3_cube128", "dtype": "f32", "clock_ghz": 2.0, "simds": 1024, "source": "synthetic",
+           "cycles_per_wave_instruction": {"fma_f32": 4.0, "mul_add_f32": 2.0, "default": 3.0},
+           "kernels": {"g2p_p2g": {"mix_per_wave": {"fma_f32": 1000, "mul_add_f32": 500, "other": 100}},
+                       "grid_op": {"mix_per_wave": {"fma_f32": 10}, "waves": 2048}}}
+    f = tmp_path / "cal.json"
+    f.write_text(json.dumps(cal))
+    monkeypatch.setattr(bench, "VALU_FILE", str(f))
+    kernels = {"g2p_p2g": {"avg_us": 50.0, "launches": 10}, "grid_op": {"avg_us": 7.0, "launches": 10}, "p2g_grad": {"avg_us": 45.0, "launches": 10}}
+    r = bench.valu_roof(kernels, 512_000, "config3_cube128", "f32", 10)
+    waves = 512_000 // 64
+    cyc = 1000 * 4.0 + 500 * 2.0 + 100 * 3.0
+    want = (waves / 1024) * cyc / 2.0e3
+    assert abs(r["kernels"]["g2p_p2g"]["issue_us"] - want) < 1e-9 and abs(r["kernels"]["g2p_p2g"]["frac_of_kernel_time"] - want / 50.0) < 1e-12
+    want_g = (2048 / 1024) * 40.0 / 2.0e3
+    assert abs(r["kernels"]["grid_op"]["issue_us"] - want_g) < 1e-12 and "p2g_grad" not in r["kernels"]
+    assert abs(r["issue_us_per_substep"] - (want + want_g)) < 1e-9 and abs(r["frac"] - (want + want_g) / 57.0) < 1e-12
+    assert bench.valu_roof(kernels, 512_000, "cube256_2000000p", "f32", 10) is None        # another workload: no stale constant
+    monkeypatch.setattr(bench, "VALU_FILE", str(tmp_path / "missing.json"))
+    assert bench.valu_roof(kernels, 512_000, "config3_cube128", "f32", 10) is None
