@@ -295,8 +295,11 @@ template <class T> PLB_HD void svd_finish(const T* Et, Svd3<T>& r) {
         for (int k = 0; k < 3; ++k)
             r.U[3 * k + i] = (V[3 * k + i] + Et[3 * k] * V[i] + Et[3 * k + 1] * V[3 + i] + Et[3 * k + 2] * V[6 + i]) * inv;
     }
-    // nearly singular F: rebuild the weakest column from the other two (constant indices only: a run-time
-    // index into U/sig would push the whole decomposition into scratch memory on the GPU)
+    // nearly singular F: rebuild the weakest column -- the FIRST one whose singular value is the smallest -- from the cross product
+    // of the other two.  Straight-line selects on purpose: written as a loop over the columns with a branch per column, hipcc
+    // turned the "which column" into a run-time index into a private array, i.e. scratch memory -- two scratch stores and four
+    // dependent scratch loads in EVERY wave of the scatter kernels for a branch that is never taken on a sane state, and a
+    // 7-word scratch frame (round 6, found in the device listing).
     T smin = t_min(r.sig[0], t_min(r.sig[1], r.sig[2]));
     typename Lane<T>::mask todo = smin < T(1e-3);
     if (any(todo)) {
@@ -304,18 +307,24 @@ template <class T> PLB_HD void svd_finish(const T* Et, Svd3<T>& r) {
         for (int i = 0; i < 9; ++i) Fm[i] = Et[i];
         Fm[0] += T(1); Fm[4] += T(1); Fm[8] += T(1);
         T sgn = sel(det3(Fm) < T(0), T(-1), T(1));
-        PLB_UNROLL
-        for (int k = 0; k < 3; ++k) {
-            const typename Lane<T>::mask hit = todo && (r.sig[k] == smin);        // the first such column only
-            if (any(hit)) {
-                const int a = (k + 1) % 3, b = (k + 2) % 3;
-                T ua[3] = {r.U[a], r.U[3 + a], r.U[6 + a]}, ub[3] = {r.U[b], r.U[3 + b], r.U[6 + b]}, uc[3];
-                cross3(ua, ub, uc);
-                T nrm = t_sqrt(dot3(uc, uc));
-                T sc = sel(nrm > T(0), sgn / nrm, T(0));
-                r.U[k] = sel(hit, uc[0] * sc, r.U[k]); r.U[3 + k] = sel(hit, uc[1] * sc, r.U[3 + k]); r.U[6 + k] = sel(hit, uc[2] * sc, r.U[6 + k]);
-                todo = todo && !hit;
-            }
+        const typename Lane<T>::mask hit0 = todo && (r.sig[0] == smin);
+        const typename Lane<T>::mask hit1 = todo && !hit0 && (r.sig[1] == smin);
+        const typename Lane<T>::mask hit2 = todo && !hit0 && !hit1 && (r.sig[2] == smin);
+        // column k is rebuilt from columns a = (k + 1) % 3 and b = (k + 2) % 3
+        T ua[3], ub[3], uc[3];
+        for (int row = 0; row < 3; ++row) {
+            const T c0 = r.U[3 * row], c1 = r.U[3 * row + 1], c2 = r.U[3 * row + 2];
+            ua[row] = sel(hit0, c1, sel(hit1, c2, c0));
+            ub[row] = sel(hit0, c2, sel(hit1, c0, c1));
+        }
+        cross3(ua, ub, uc);
+        T nrm = t_sqrt(dot3(uc, uc));
+        T sc = sel(nrm > T(0), sgn / nrm, T(0));
+        for (int row = 0; row < 3; ++row) {
+            const T v = uc[row] * sc;
+            r.U[3 * row] = sel(hit0, v, r.U[3 * row]);
+            r.U[3 * row + 1] = sel(hit1, v, r.U[3 * row + 1]);
+            r.U[3 * row + 2] = sel(hit2, v, r.U[3 * row + 2]);
         }
     }
 }

@@ -41,6 +41,11 @@ constexpr int kSred = (kBlock / 64) * 6 + 8;               // LDS ints of block_
 #ifndef PLB_P2G_GRAD_WAVES
 #define PLB_P2G_GRAD_WAVES 2
 #endif
+// the float64 instantiations of the two scatter kernels: 4 = the fp32 bound (128 VGPRs = 64 doubles: 350 B of scratch, ~200 scratch
+// operations per wave in the device listing), 2 = 256 VGPRs; which one is faster is for a measurement to say (round 6: not measured)
+#ifndef PLB_P2G_WAVES_F64
+#define PLB_P2G_WAVES_F64 PLB_P2G_WAVES
+#endif
 constexpr int kMaxPrim = 8;
 #ifndef PLB_GRID_WG
 #define PLB_GRID_WG 512
@@ -727,8 +732,12 @@ __device__ __forceinline__ Tile block_tile(const int* base, bool valid, int* sre
 // barrier -> fill.
 template <class T> __device__ __forceinline__ void store_tile(const Dev<T>& D, int f, const Tile& t, int wg = blockIdx.x) {
     if (threadIdx.x < 6) {
+        // (selects, not t.o[threadIdx.x]: a per-lane index into the struct sends all of it through scratch memory -- two scratch
+        // stores in every wave of every scatter launch and a dependent scratch load in front of this store)
+        const int i = threadIdx.x;
+        const int v = i == 0 ? t.o[0] : i == 1 ? t.o[1] : i == 2 ? t.o[2] : i == 3 ? t.e[0] : i == 4 ? t.e[1] : t.e[2];
         int* q = D.tiles + ((size_t)f * D.twg + wg) * 8;
-        q[threadIdx.x] = threadIdx.x < 3 ? t.o[threadIdx.x] : t.e[threadIdx.x - 3];
+        q[i] = v;
     }
 }
 template <class T> __device__ __forceinline__ Tile load_tile(const Dev<T>& D, int f, int cap, int wg = blockIdx.x) {
@@ -797,7 +806,7 @@ __device__ __forceinline__ bool load_sorted_particle(const Dev<T>& D, const Soa<
 // DET: deterministic mode -- the LDS tile and the global flush accumulate integer limbs (8 per node instead of 4
 // doubles: half the tile capacity), see det_add.
 template <class T, bool WRITE_F, bool DET = false>
-__global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_p2g(Dev<T> D, int f) {
+__global__ __launch_bounds__(kBlock, sizeof(T) == 4 ? PLB_P2G_WAVES : PLB_P2G_WAVES_F64) void k_p2g(Dev<T> D, int f) {
     __shared__ int sred[kSred];
     // accumulate in double: on gfx950 ds_add_f64 is ~5x cheaper per instruction than ds_add_f32
     // (profiles/microbench/lds_atomics.hip), and the node sums lose no precision
@@ -1029,7 +1038,7 @@ __global__ __launch_bounds__(kBlock) void k_g2p(Dev<T> D, int f) {
 // grid_v_out(f-1) tile, then -- after the gather -- is reused for the f64 accumulation tile of grid_in(f).
 // D is built for frame f (grid_in / flags of f); vout_prev is grid_v_out of substep f-1.
 template <class T, bool DET = false>
-__global__ __launch_bounds__(kBlock, PLB_P2G_WAVES) void k_g2p_p2g(Dev<T> D, int f, const Vec4<T>* vout_prev) {
+__global__ __launch_bounds__(kBlock, sizeof(T) == 4 ? PLB_P2G_WAVES : PLB_P2G_WAVES_F64) void k_g2p_p2g(Dev<T> D, int f, const Vec4<T>* vout_prev) {
     __shared__ int sred[kSred];
     __shared__ Vec4<double> tile[TileCap<T>::nodes];
     Vec4<T>* tile_v = reinterpret_cast<Vec4<T>*>(tile);          // first use of the same LDS

@@ -180,3 +180,14 @@ def g2p_pk_check(n_grid, dt, x, gv):
     L.emul_g2p_pk_check.restype = C.c_double
     x, gv = np.ascontiguousarray(x, np.float64), np.ascontiguousarray(gv, np.float64)
     return float(L.emul_g2p_pk_check(int(n_grid), C.c_double(dt), len(x), _p(x), _p(gv)))
+
+
+def svd_singular_check(Et, use_float):
+    """(largest difference between svd_finish and its pre-round-6 column-loop form over the matrices Et[n,3,3] = F - I, how many of
+    them took the nearly-singular branch)."""
+    L = lib()
+    L.emul_svd_singular_check.restype = C.c_double
+    Et = np.ascontiguousarray(Et, np.float64)
+    k = C.c_int(0)
+    d = float(L.emul_svd_singular_check(int(use_float), len(Et), _p(Et), C.byref(k)))
+    return d, k.value

@@ -300,3 +300,60 @@ extern "C" double emul_g2p_pk_check(int n_grid, double dt, int n, const double* 
     }
     return worst;
 }
+
+// svd_finish's rebuild of the weakest column of U for nearly singular F (sig_min < 1e-3), as it was written before round 6 -- a loop
+// over the columns with a branch per column -- kept HERE as the reference the straight-line form in mpm_math.h is checked against
+// (the two must agree exactly: same operations on the same values).
+template <class T> static void svd_finish_column_loop(const T* Et, Svd3<T>& r) {
+    const T* V = r.V;
+    for (int i = 0; i < 3; ++i) {
+        T sg = t_fsqrt(t_max(T(1) + r.lam[i], T(0)));
+        r.sig[i] = sg;
+        r.s[i] = r.lam[i] * t_rcp(T(1) + sg);
+    }
+    for (int i = 0; i < 3; ++i) {
+        T inv = t_rcp(t_max(r.sig[i], T(1e-30)));
+        for (int k = 0; k < 3; ++k)
+            r.U[3 * k + i] = (V[3 * k + i] + Et[3 * k] * V[i] + Et[3 * k + 1] * V[3 + i] + Et[3 * k + 2] * V[6 + i]) * inv;
+    }
+    T smin = t_min(r.sig[0], t_min(r.sig[1], r.sig[2]));
+    bool todo = smin < T(1e-3);
+    if (todo) {
+        T Fm[9];
+        for (int i = 0; i < 9; ++i) Fm[i] = Et[i];
+        Fm[0] += T(1); Fm[4] += T(1); Fm[8] += T(1);
+        T sgn = det3(Fm) < T(0) ? T(-1) : T(1);
+        for (int k = 0; k < 3; ++k) {
+            const bool hit = todo && (r.sig[k] == smin);
+            if (hit) {
+                const int a = (k + 1) % 3, b = (k + 2) % 3;
+                T ua[3] = {r.U[a], r.U[3 + a], r.U[6 + a]}, ub[3] = {r.U[b], r.U[3 + b], r.U[6 + b]}, uc[3];
+                cross3(ua, ub, uc);
+                T nrm = t_sqrt(dot3(uc, uc));
+                T sc = nrm > T(0) ? sgn / nrm : T(0);
+                r.U[k] = uc[0] * sc; r.U[3 + k] = uc[1] * sc; r.U[6 + k] = uc[2] * sc;
+                todo = false;
+            }
+        }
+    }
+}
+template <class T> static double svd_singular_check_t(int n, const double* Et, int* rebuilt) {
+    double worst = 0.0;
+    *rebuilt = 0;
+    for (int s = 0; s < n; ++s) {
+        T e[9];
+        for (int i = 0; i < 9; ++i) e[i] = (T)Et[9 * s + i];
+        Svd3<T> a, b;
+        svd_jacobi(e, a.lam, a.V);
+        b = a;
+        svd_finish(e, a);
+        svd_finish_column_loop(e, b);
+        if (std::min(a.sig[0], std::min(a.sig[1], a.sig[2])) < T(1e-3)) ++*rebuilt;
+        for (int i = 0; i < 9; ++i) worst = std::max(worst, (double)std::fabs(a.U[i] - b.U[i]));
+        for (int i = 0; i < 3; ++i) worst = std::max(worst, (double)std::fabs(a.sig[i] - b.sig[i]) + (double)std::fabs(a.s[i] - b.s[i]));
+    }
+    return worst;
+}
+extern "C" double emul_svd_singular_check(int use_float, int n, const double* Et, int* rebuilt) {
+    return use_float ? svd_singular_check_t<float>(n, Et, rebuilt) : svd_singular_check_t<double>(n, Et, rebuilt);
+}

@@ -346,3 +346,31 @@ def test_packed_pair_gather_equals_plain_gather():
         ga = np.zeros_like(gv)
         ga[:, :, a] = gv[:, :, a]
         assert emul.g2p_pk_check(128, 5e-5, x, ga) < 2e-5, a
+
+
+@pytest.mark.parametrize("use_float", [False, True])
+def test_nearly_singular_column_rebuild_is_unchanged(use_float):
+    """svd_finish rebuilds the weakest column of U by a cross product when sig_min < 1e-3 (crushed or flattened elements).  Round 6
+    rewrote that branch as straight-line selects (the column loop made hipcc index a private array at run time: scratch memory in
+    every wave of the scatter kernels); the result must be the old one exactly, whichever column is the weakest, ties included."""
+    from tests import emul
+    rng = np.random.default_rng(11)
+    mats = []
+    for k in range(600):
+        q1, _ = np.linalg.qr(rng.standard_normal((3, 3)))
+        q2, _ = np.linalg.qr(rng.standard_normal((3, 3)))
+        sig = rng.uniform(0.3, 1.5, 3)
+        kind = k % 6
+        if kind < 3:
+            sig[kind] = rng.choice([0.0, 1e-9, 1e-5, 5e-4])          # one weak direction, each position in turn
+        elif kind == 3:
+            sig[:2] = 1e-6                                           # two equally weak directions (a tie: the first one is rebuilt)
+        elif kind == 4:
+            sig[:] = 0.0                                             # F = 0
+        if k % 7 == 0:
+            q1[:, 0] *= -1                                           # inverted elements too
+        mats.append(q1 @ np.diag(sig) @ q2.T - np.eye(3))
+    mats.append(np.diag([-1.0, 0.2, -0.1]))                          # already diagonal: Jacobi is a no-op, column 0 is the weak one
+    mats.append(np.diag([0.1, -1.0, -1.0]))
+    d, rebuilt = emul.svd_singular_check(np.array(mats), use_float)
+    assert rebuilt >= 400 and d == 0.0, (d, rebuilt)

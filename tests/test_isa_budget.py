@@ -16,9 +16,9 @@ sys.path.insert(0, os.path.join(ROOT, "profiles", "tools"))
 
 # kernel (mangled-name fragment) -> (waves per SIMD the registers allow, most scratch bytes, most static vector instructions)
 BUDGET = {
-    "k_g2p_p2gIfLb0": (4, 56, 3200),
+    "k_g2p_p2gIfLb0": (4, 0, 3050),              # (round 6: no scratch at all any more -- two compiler-made private arrays removed)
     "k_g2p_gradIfLb0": (4, 0, 1620),
-    "k_p2g_gradIf": (2, 136, 11300),           # (the pose-adjoint workgroups share this kernel: fp64 collide adjoints, ~8k of the count)
+    "k_p2g_gradIf": (2, 128, 11200),           # (the pose-adjoint workgroups share this kernel: fp64 collide adjoints, ~8k of the count)
     "k_grid_opIfLb0": (4, 0, 1600),
     "k_grid_op_gradIf": (2, 0, 4700),
 }
