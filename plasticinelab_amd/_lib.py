@@ -160,14 +160,19 @@ def load():
         raise EngineError(
             f"{LIB_PATH} not found: the HIP engine is not built.  Run `python -c 'import __graft_entry__ as g; "
             f"g.build()'` at the repo root (needs hipcc).  There is no CPU implementation to fall back to.")
-    lib = C.CDLL(LIB_PATH)
+    _lib = bind(C.CDLL(LIB_PATH))
+    return _lib
+
+
+def bind(lib):
+    """Give every entry point of a loaded build of the library its ctypes signature (load() for the product build; the tests'
+    CPU interpreter of the device source, tests/emul_engine.py, binds its own build of the same sources)."""
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)          # AttributeError if the library lacks a declared symbol
         fn.restype, fn.argtypes = res, args
-    _lib = lib
     return lib
 
 
-def check(rc):
+def check(rc, lib=None):
     if rc != 0:
-        raise EngineError(load().plmpm_last_error().decode())
+        raise EngineError((lib or load()).plmpm_last_error().decode())

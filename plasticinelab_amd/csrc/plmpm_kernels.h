@@ -67,11 +67,23 @@ template <> struct TileCap<double> { static constexpr int nodes = 512; };
 #ifndef PLB_LDS_BAR
 #define PLB_LDS_BAR 1
 #endif
+// (the inline-assembly helpers -- this barrier, the counter waits, the write-through stores, the fused DPP steps of seg_sum -- are the
+// only device code a C++ compiler for the host cannot read: tests/host_emul/hipemu, the CPU interpreter the device source is
+// executed on in the GPU-less test tier, defines PLB_HOST_EMUL and brings its own)
+#ifndef PLB_HOST_EMUL
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+__device__ __forceinline__ void wait_lds() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }       // this wave's LDS traffic has landed
+__device__ __forceinline__ void wait_vmem() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }        // ... its global loads / stores are acknowledged
+#endif
 __device__ __forceinline__ void wg_barrier() {
     if (PLB_LDS_BAR) lds_barrier();
     else __syncthreads();
 }
+
+// a kernel's dynamic LDS as an array `name` of `type`
+#ifndef PLB_DYN_LDS
+#define PLB_DYN_LDS(type, name) extern __shared__ type name[]
+#endif
 
 template <class T> struct Vec4 { T x, y, z, w; };
 template <> struct __attribute__((aligned(16))) Vec4<float> { float x, y, z, w; };
@@ -250,7 +262,7 @@ template <class T, bool WAVE = false> __device__ __forceinline__ void load_prims
         for (int i = 0; i < 4; ++i) { p.rot[i] = c[i]; p.rot1[i] = d[i]; }
         sp[t] = p;
     }
-    if (WAVE) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (WAVE) wait_lds();
 }
 
 // one record per (frame, primitive): what load_prims assembles, kept in HBM for the fused-grid fills
@@ -363,10 +375,12 @@ struct PeerXchg {
 // neighbour -- another XCD, another process, another GPU -- reads it, and no L2 write-back is needed before the arrival
 // counter moves.  (A release fence at system scope writes back everything the PREVIOUS kernels left dirty in this XCD's L2
 // -- megabytes of particle state after a particle kernel: 11 us per exchange instead of 6; a system fence per thread: 25.)
+#ifndef PLB_HOST_EMUL
 __device__ __forceinline__ void store_through(float* p, float v) { asm volatile("global_store_dword %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory"); }
 __device__ __forceinline__ void store_through(double* p, double v) { asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory"); }
 __device__ __forceinline__ void store_through(int* p, int v) { asm volatile("global_store_dword %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory"); }
 __device__ __forceinline__ void store_through(unsigned* p, unsigned v) { asm volatile("global_store_dword %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory"); }
+#endif
 
 // the block `bl` of face i's planes (wave-uniform): validity word (lane 0), and -- if the block carries something -- its 64 nodes
 // per component, read from this rank's grid and stored through to the neighbour
@@ -389,7 +403,7 @@ template <class T> __device__ __forceinline__ void xchg_send_block(const PeerXch
 // counters.  Returns true in that workgroup (all threads).
 __device__ __forceinline__ bool xchg_publish(const PeerXchg& X) {
     __shared__ int s_last;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    wait_vmem();
     __syncthreads();
     if (threadIdx.x == 0) {
         const bool last = __hip_atomic_fetch_add(X.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
@@ -423,7 +437,7 @@ __device__ __forceinline__ void xchg_wait_lanes(const PeerXchg& X) {
             }
             __builtin_amdgcn_s_sleep(2);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        wait_vmem();
     }
 }
 // Folded into a persistent grid kernel (k_grid_op_x / k_grid_op_grad_x): workgroup g sends the blocks of the exchanged planes
@@ -670,6 +684,7 @@ template <class T> __device__ __forceinline__ void seg_sum4(T& a, T& b, T& c, T&
 template <class T> __device__ __forceinline__ void seg_sum3(T& a, T& b, T& c, const Seg<T>& s) {
     a = seg_sum(a, s); b = seg_sum(b, s); c = seg_sum(c, s);
 }
+#ifndef PLB_HOST_EMUL
 #define PLB_DPP_STEP(x, m, n) "v_fmac_f32_dpp " x ", " x ", " m " row_shl:" n " row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
 template <> __device__ __forceinline__ void seg_sum4<float>(float& a, float& b, float& c, float& d, const Seg<float>& s) {
     asm("s_nop 1\n"
@@ -693,6 +708,7 @@ template <> __device__ __forceinline__ void seg_sum3<float>(float& a, float& b, 
         : "+v"(a), "+v"(b), "+v"(c) : "v"(s.m1), "v"(s.m2), "v"(s.m4), "v"(s.m8));
 }
 #undef PLB_DPP_STEP
+#endif
 
 // all threads call; valid == false for padding lanes.  sred: LDS int[kSred], written once per kernel.
 // In two halves so that a kernel can put its own barrier between them: every wave publishes its box ...

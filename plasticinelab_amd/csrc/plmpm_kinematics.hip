@@ -52,7 +52,7 @@ constexpr int kChainFwdWords = 7, kChainBwdWords = 23;          // doubles stage
 constexpr size_t kChainMaxLds = 64 * 1024;                        // longer chains read global memory one frame ahead
 template <bool STAGED>
 __global__ __launch_bounds__(kChainThreads) void k_fk_chain(PrimChainArgs A, int first, int n, ChainBufs B) {
-    extern __shared__ double sm[];
+    PLB_DYN_LDS(double, sm);
     const int p = blockIdx.x;            // one workgroup per primitive: p is wave-uniform, A.*[p] are scalar loads
     if (STAGED) {
         for (int i = threadIdx.x; i < n; i += blockDim.x) {
@@ -102,7 +102,7 @@ __global__ __launch_bounds__(kChainThreads) void k_fk_chain(PrimChainArgs A, int
 // On entry X_a[frame] holds what the contact / loss kernels accumulated; on exit the complete adjoint.
 template <bool STAGED>
 __global__ __launch_bounds__(kChainThreads) void k_fk_chain_grad(PrimChainArgs A, int first, int n, int step, ChainBufs B) {
-    extern __shared__ double sm[];
+    PLB_DYN_LDS(double, sm);
     if (STAGED) {
         // frame s, primitive p: pos 0-2, v 3-5, w 6-8, own pos adjoint 9-11, rot 12-15, own rot adjoint 16-19, gap, gap_vel, own gap adjoint
         for (int i = threadIdx.x; i < n; i += blockDim.x) {

@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256) void k_halo_xchg(PeerXchg X) {
         }
     }
     // every wave waits for the acknowledgements of its own stores; the workgroup then counts itself done
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    wait_vmem();
     __syncthreads();
     __shared__ int last;
     if (threadIdx.x == 0) last = __hip_atomic_fetch_add(X.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
@@ -105,7 +105,7 @@ __global__ void k_peer_ping(int n, unsigned* remote0, unsigned* remote1, unsigne
     unsigned* const theirs = i == 0 ? remote0 : remote1;
     unsigned* const mine = i == 0 ? local0 : local1;
     store_through(theirs + 16, token);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    wait_vmem();
     const long long t0 = wall_clock64();
     unsigned got = 0;
     long long waited = -1;

@@ -1,0 +1,73 @@
+"""TEST INFRASTRUCTURE ONLY: the engine on the CPU interpreter of the device source.
+
+``tests/host_emul/libplmpm_emul.so`` is plasticinelab_amd/csrc compiled by g++ against ``tests/host_emul/hipemu`` (fibers for
+threads, lock-step 64-lane wave operations, the DPP lane maps of the ISA manual, plain-memory "HBM").  ``HostEngine`` is
+``plasticinelab_amd.engine.core.Engine`` with that library and host memory behind it, so that the CPU-only test tier can run the
+parity tests of the -m gpu tier on the kernels' own source -- tiling, sorting, segmented reductions, block flags, launch logic --
+where there is no GPU.  It is a checker (minutes for what the GPU does in milliseconds); nothing in plasticinelab_amd imports this
+module or that library, and the product Engine still refuses to start without a ROCm device.
+"""
+from __future__ import annotations
+
+import contextlib
+import ctypes as C
+import os
+import subprocess
+
+import torch
+
+from plasticinelab_amd import _lib as L
+from plasticinelab_amd.engine.core import Engine
+
+HERE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "host_emul")
+LIB_PATH = os.path.join(HERE, "libplmpm_emul.so")
+_lib = None
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-j", "6", "-C", HERE, "libplmpm_emul.so"])
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = L.bind(C.CDLL(LIB_PATH))
+    return _lib
+
+
+class HostEngine(Engine):
+    def _load_library(self):
+        return lib()
+
+    def _open_device(self, device):
+        return torch.device("cpu")
+
+    def _device_memory_bytes(self):
+        return 64 << 30
+
+    def _device_guard(self):
+        return contextlib.nullcontext()
+
+    def _allocate(self, nbytes):
+        raw = torch.full((nbytes + 256,), 0xff, dtype=torch.uint8)      # garbage, as torch.empty on a GPU is
+        off = (-raw.data_ptr()) % 256                                    # the library wants 256-byte aligned workspaces
+        return raw[off:off + nbytes]
+
+    def _stream_handle(self):
+        return 0
+
+    def synchronize(self):
+        pass
+
+
+def engine_for(sim, prims, dtype="float64", max_frames=64, svd_grad_clamp=1e-6, **engine_kw):
+    """tests.gpu_util.engine_for on the interpreter; a handful of persistent grid workgroups instead of 512 (every workgroup of a
+    launch costs 256 fiber start-ups here)."""
+    from tests import emul
+    plist = [dict(shape=p.shape, action_dim=p.action_dim, params=emul.prim_par(p), friction=p.friction,
+                  action_scale=p.action_scale, lower_bound=p.lower_bound, upper_bound=p.upper_bound) for p in prims]
+    engine_kw.setdefault("grid_workgroups", 8)
+    return HostEngine(n_grid=sim.n_grid, n_particles=sim.n_particles, max_frames=max_frames, substeps=sim.substeps,
+                      dt=sim.dt, p_vol=sim.p_vol, p_mass=sim.p_mass, gravity=sim.gravity,
+                      ground_friction=sim.ground_friction, primitives=plist, dtype=dtype, svd_grad_clamp=svd_grad_clamp, **engine_kw)

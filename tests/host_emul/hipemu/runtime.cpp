@@ -1,0 +1,221 @@
+// TEST INFRASTRUCTURE ONLY: the scheduler of the CPU interpreter described in hip/hip_runtime.h -- fibers, workgroup barrier,
+// wave-level gather, DPP lane maps, "device" memory -- plus host versions of the two rocPRIM entry points of plmpm_sort.hip.
+#include <hip/hip_runtime.h>
+#include <sys/mman.h>
+
+#include <numeric>
+#include <vector>
+
+extern "C" void hipemu_switch(void** save_sp, void* next_sp);
+// callee-saved registers on the old stack, swap stack pointers, restore from the new one (System V x86-64)
+asm(R"(
+.text
+.globl hipemu_switch
+.type hipemu_switch,@function
+hipemu_switch:
+    pushq %rbp
+    pushq %rbx
+    pushq %r12
+    pushq %r13
+    pushq %r14
+    pushq %r15
+    movq %rsp, (%rdi)
+    movq %rsi, %rsp
+    popq %r15
+    popq %r14
+    popq %r13
+    popq %r12
+    popq %rbx
+    popq %rbp
+    ret
+.size hipemu_switch,.-hipemu_switch
+)");
+
+namespace hipemu {
+
+Fiber* cur = nullptr;
+Idx g_block = {0, 0, 0}, g_bdim = {1, 1, 1}, g_gdim = {1, 1, 1};
+
+static constexpr int kMaxThreads = 1024;
+static constexpr size_t kStack = 256u << 10;
+static char* g_stacks = nullptr;
+static Fiber g_fib[kMaxThreads];
+static void* g_main_sp = nullptr;
+static unsigned long g_progress = 0;
+static void (*g_thunk)(void*) = nullptr;
+static void* g_ctx = nullptr;
+
+struct Wave {
+    int live, arrived;
+    unsigned gen;
+    uint64_t live_mask, snap[2];
+    uint64_t buf[2][64];
+    unsigned op[64];
+};
+static Wave g_wave[kMaxThreads / 64];
+static int g_blk_live, g_blk_arrived;
+static unsigned g_blk_gen;
+
+void* dyn_lds_arena() {
+    static double arena[8192];           // 64 KiB
+    return arena;
+}
+double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+void* device_alloc(size_t bytes) {
+    void* p = nullptr;
+    if (posix_memalign(&p, 256, bytes ? bytes : 256)) return nullptr;
+    memset(p, 0xff, bytes);              // hipMalloc returns garbage: nothing may rely on zeros (NaN as a float, -1 as an int)
+    return p;
+}
+void device_free(void* p) { free(p); }
+
+[[noreturn]] static void die(const char* what) {
+    fprintf(stderr, "hipemu: %s (workgroup %u of %u, thread %u, wave %d lane %d)\n", what, g_block.x, g_gdim.x, cur ? cur->tid.x : 0, cur ? cur->wave : -1,
+            cur ? cur->lane : -1);
+    fflush(stderr);
+    abort();
+}
+static inline void yield() { hipemu_switch(&cur->sp, g_main_sp); }
+
+static void wave_release(Wave& w) {
+    unsigned op = 0;
+    bool first = true;
+    for (int l = 0; l < 64; ++l) {
+        if (!((w.live_mask >> l) & 1)) continue;
+        if (first) { op = w.op[l]; first = false; }
+        else if (w.op[l] != op) {
+            fprintf(stderr, "hipemu: lanes of one wave reached different wave-level operations (lane %d: 0x%x, others 0x%x)\n", l, w.op[l], op);
+            die("divergent collective");
+        }
+    }
+    w.snap[w.gen & 1] = w.live_mask;
+    w.arrived = 0;
+    ++w.gen;
+}
+Gathered wave_gather(uint64_t mine, unsigned op) {
+    Wave& w = g_wave[cur->wave];
+    const unsigned g = w.gen;
+    w.buf[g & 1][cur->lane] = mine;
+    w.op[cur->lane] = op;
+    ++w.arrived;
+    ++g_progress;
+    if (w.arrived == w.live) wave_release(w);
+    while (w.gen == g) yield();
+    return Gathered{w.buf[g & 1], w.snap[g & 1]};
+}
+void block_barrier() {
+    const unsigned g = g_blk_gen;
+    ++g_blk_arrived;
+    ++g_progress;
+    if (g_blk_arrived == g_blk_live) { g_blk_arrived = 0; ++g_blk_gen; }
+    while (g_blk_gen == g) yield();
+}
+
+int dpp_source_lane(int lane, int ctrl) {
+    const int row = lane & ~15, r = lane & 15;
+    if (ctrl >= 0 && ctrl <= 0xff) return (lane & ~3) | ((ctrl >> (2 * (lane & 3))) & 3);                       // quad_perm
+    if (ctrl >= 0x101 && ctrl <= 0x10f) { const int s = r + (ctrl & 15); return s <= 15 ? row | s : -1; }       // row_shl
+    if (ctrl >= 0x111 && ctrl <= 0x11f) { const int s = r - (ctrl & 15); return s >= 0 ? row | s : -1; }        // row_shr
+    if (ctrl >= 0x121 && ctrl <= 0x12f) return row | ((r - (ctrl & 15)) & 15);                                  // row_ror
+    if (ctrl == 0x140) return row | (15 - r);                                                                   // row_mirror
+    if (ctrl == 0x141) return (lane & ~7) | (7 - (lane & 7));                                                   // row_half_mirror
+    if (ctrl == 0x142) return lane >= 16 ? row - 1 : -1;                                                        // row_bcast:15 (lane 15 of the row before)
+    if (ctrl == 0x143) return lane >= 32 ? 31 : -1;                                                             // row_bcast:31
+    fprintf(stderr, "hipemu: DPP control 0x%x\n", ctrl);
+    die("unsupported DPP control");
+}
+
+static void fiber_exit() {
+    Fiber* f = cur;
+    f->done = true;
+    ++g_progress;
+    Wave& w = g_wave[f->wave];
+    --w.live;
+    w.live_mask &= ~(1ULL << f->lane);
+    if (w.live > 0 && w.arrived == w.live) wave_release(w);
+    --g_blk_live;
+    if (g_blk_live > 0 && g_blk_arrived == g_blk_live) { g_blk_arrived = 0; ++g_blk_gen; }
+    hipemu_switch(&f->sp, g_main_sp);
+    die("a finished fiber was resumed");
+}
+static void fiber_entry() {
+    g_thunk(g_ctx);
+    fiber_exit();
+}
+
+void run_grid(dim3 grid, dim3 block, size_t lds, void (*thunk)(void*), void* ctx) {
+    const int nt = (int)(block.x * block.y * block.z);
+    if (nt <= 0 || nt > kMaxThreads) die("workgroup size");
+    if (lds > 8192 * sizeof(double)) die("dynamic LDS larger than the arena");
+    if (cur) die("nested launch");
+    if (!g_stacks) {
+        g_stacks = (char*)mmap(nullptr, kStack * kMaxThreads, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+        if (g_stacks == (char*)MAP_FAILED) die("mmap of the fiber stacks");
+    }
+    g_thunk = thunk; g_ctx = ctx;
+    g_bdim = {block.x, block.y, block.z};
+    g_gdim = {grid.x, grid.y, grid.z};
+    const int nw = (nt + 63) / 64;
+    for (unsigned bz = 0; bz < grid.z; ++bz)
+    for (unsigned by = 0; by < grid.y; ++by)
+    for (unsigned bx = 0; bx < grid.x; ++bx) {
+        g_block = {bx, by, bz};
+        for (int w = 0; w < nw; ++w) { g_wave[w].live = 0; g_wave[w].arrived = 0; g_wave[w].gen = 0; g_wave[w].live_mask = 0; }
+        g_blk_live = nt; g_blk_arrived = 0; g_blk_gen = 0;
+        for (int t = 0; t < nt; ++t) {
+            Fiber& f = g_fib[t];
+            f.tid = {(unsigned)t % block.x, ((unsigned)t / block.x) % block.y, (unsigned)t / (block.x * block.y)};
+            f.wave = t >> 6; f.lane = t & 63; f.done = false;
+            Wave& w = g_wave[f.wave];
+            ++w.live; w.live_mask |= 1ULL << f.lane;
+            // initial frame: six callee-saved registers, the entry point as the return address, a null return address above it
+            // (16-byte alignment of a freshly called function: rsp = 16 k + 8 at its first instruction)
+            uintptr_t top = ((uintptr_t)g_stacks + (size_t)(t + 1) * kStack) & ~(uintptr_t)15;
+            void** sp = (void**)top;
+            *--sp = nullptr;
+            *--sp = (void*)&fiber_entry;
+            for (int k = 0; k < 6; ++k) *--sp = nullptr;
+            f.sp = sp;
+        }
+        int alive = nt;
+        while (alive > 0) {
+            const unsigned long before = g_progress;
+            alive = 0;
+            for (int t = 0; t < nt; ++t) {
+                Fiber& f = g_fib[t];
+                if (f.done) continue;
+                cur = &f;
+                hipemu_switch(&g_main_sp, f.sp);
+                if (!f.done) ++alive;
+            }
+            if (alive > 0 && g_progress == before) {
+                for (int t = 0; t < nt; ++t) if (!g_fib[t].done) { cur = &g_fib[t]; break; }
+                die("deadlock: no thread of the workgroup can make progress (a barrier or wave operation not reached by all live threads, or a "
+                    "spin-wait on another workgroup -- workgroups run one after another here)");
+            }
+        }
+        cur = nullptr;
+    }
+}
+}  // namespace hipemu
+
+// ---- plmpm_sort.hip on the host (the device build calls rocPRIM; same contracts: stable pair sort on the low key bits, exclusive scan)
+extern "C" size_t plmpm_sort_temp_bytes(int) { return 256; }
+extern "C" size_t plmpm_scan_temp_bytes(size_t) { return 256; }
+extern "C" int plmpm_exclusive_scan(void*, size_t, const unsigned* in, unsigned* out, size_t n, void*) {
+    unsigned acc = 0;
+    for (size_t i = 0; i < n; ++i) { const unsigned v = in[i]; out[i] = acc; acc += v; }
+    return 0;
+}
+extern "C" int plmpm_sort_pairs(void*, size_t, const unsigned* kin, unsigned* kout, const int* vin, int* vout, int n, int key_bits, void*) {
+    std::vector<int> idx(n);
+    std::iota(idx.begin(), idx.end(), 0);
+    const unsigned mask = key_bits >= 32 ? 0xffffffffu : ((1u << key_bits) - 1u);
+    std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return (kin[a] & mask) < (kin[b] & mask); });
+    std::vector<unsigned> k(n);
+    std::vector<int> v(n);
+    for (int i = 0; i < n; ++i) { k[i] = kin[idx[i]]; v[i] = vin[idx[i]]; }
+    memcpy(kout, k.data(), sizeof(unsigned) * n);
+    memcpy(vout, v.data(), sizeof(int) * n);
+    return 0;
+}

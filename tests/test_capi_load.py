@@ -82,7 +82,9 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".h")):
                 src = open(os.path.join(dp, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+(oracle|tests)\b", src, flags=re.M), os.path.join(dp, f)
-                assert "host_emul" not in src or f in ("mpm_math.h", "mpm_grid.h"), os.path.join(dp, f)
+                # (the three headers whose host compilation the checkers rely on say so in a comment; nothing else knows of them)
+                assert "host_emul" not in src or f in ("mpm_math.h", "mpm_grid.h", "plmpm_kernels.h"), os.path.join(dp, f)
+                assert "libplmpm_emul" not in src and "HostEngine" not in src, os.path.join(dp, f)
 
 
 def test_integration_doc_structs_match_the_library_binding():
