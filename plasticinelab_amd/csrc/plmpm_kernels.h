@@ -154,7 +154,7 @@ template <class E> struct Soa {
         else return __builtin_bit_cast(E, __builtin_amdgcn_raw_buffer_load_b64(rsrc, (unsigned)p * 8u, (unsigned)c * stride, 0));
     }
     __device__ __forceinline__ void st(int c, int p, E v) const {
-        typedef unsigned u2 __attribute__((ext_vector_type(2)));
+        typedef unsigned u2 __attribute__((vector_size(8)));
         if constexpr (sizeof(E) == 4) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrc, (unsigned)p * 4u, (unsigned)c * stride, 0);
         else __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2, v), rsrc, (unsigned)p * 8u, (unsigned)c * stride, 0);
     }

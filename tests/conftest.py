@@ -8,15 +8,26 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+# PLMPM_TEST_INTERPRETER=1: run `-m gpu` tests on the CPU interpreter of the device source (tests/emul_engine.py) instead of a GPU --
+# what tests/test_emul_tier.py does, case by case, in the CPU-only tier.  A test-side switch only: the engines the tests build are
+# replaced here, in the test process; the package itself knows nothing of it.
+ON_INTERPRETER = os.environ.get("PLMPM_TEST_INTERPRETER") == "1"
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    if ON_INTERPRETER:
+        from tests import emul_engine, gpu_util
+        import plasticinelab_amd.engine.mpm_simulator as ms
+        gpu_util.engine_for = emul_engine.engine_for           # (before the test modules import the name)
+        ms.Engine = emul_engine.HostEngine
 
 
 def pytest_collection_modifyitems(config, items):
     """`-m gpu` tests are the parity tests proper and need a HIP device plus the in-tree libplmpm.so: without either
     they are skipped with the reason spelled out (a plain `pytest` on a CPU-only box is then green, not 40 errors).
     PLB_REQUIRE_GPU=1 (the GPU box) turns the skip into a failure, so a missing extension cannot pass silently."""
-    if not any("gpu" in it.keywords for it in items):
+    if ON_INTERPRETER or not any("gpu" in it.keywords for it in items):
         return
     reason = None
     try:

@@ -20,19 +20,33 @@ from plasticinelab_amd import _lib as L
 from plasticinelab_amd.engine.core import Engine
 
 HERE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "host_emul")
-LIB_PATH = os.path.join(HERE, "libplmpm_emul.so")
+# Compile-time variants of the device source that are not the default build (they wait for a timing on the GPU, profiles/r06_notes.md):
+# PLMPM_EMUL_VARIANT=<name> runs the tests on that variant's source, so that a variant is at least parity-green before it is timed.
+VARIANTS = {
+    "": "",
+    "bufio": "-DPLB_BUFIO=1",                            # particle arrays behind buffer descriptors
+    "pk": "-DPLB_PK_GATHER=3",                           # p2g.grad and g2p gathers on packed pairs
+    "pkbuf": "-DPLB_PK_GATHER=3 -DPLB_BUFIO=1",
+}
+VARIANT = os.environ.get("PLMPM_EMUL_VARIANT", "")
 _lib = None
 
 
-def build():
-    subprocess.check_call(["make", "-s", "-j", "6", "-C", HERE, "libplmpm_emul.so"])
+def lib_path(variant=VARIANT):
+    return os.path.join(HERE, f"libplmpm_emul{'_' + variant if variant else ''}.so")
+
+
+def build(variant=VARIANT):
+    tag = "_" + variant if variant else ""
+    subprocess.check_call(["make", "-s", "-j", "6", "-C", HERE, f"OBJDIR=build_emul{tag}", f"OUT=libplmpm_emul{tag}.so",
+                           f"EXTRA={VARIANTS[variant]}", f"libplmpm_emul{tag}.so"])
 
 
 def lib():
     global _lib
     if _lib is None:
         build()
-        _lib = L.bind(C.CDLL(LIB_PATH))
+        _lib = L.bind(C.CDLL(lib_path()))
     return _lib
 
 

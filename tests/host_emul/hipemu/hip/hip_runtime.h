@@ -220,6 +220,22 @@ HIPEMU_MINMAX(int) HIPEMU_MINMAX(unsigned) HIPEMU_MINMAX(long) HIPEMU_MINMAX(uns
 HIPEMU_MINMAX(unsigned long long) HIPEMU_MINMAX(float) HIPEMU_MINMAX(double)
 #undef HIPEMU_MINMAX
 
+// ---- buffer descriptors (PLB_BUFIO builds): base + byte range; raw loads / stores at voffset + soffset.  Stricter than the
+// hardware, which returns 0 / drops the store out of range: an access outside the descriptor's range aborts.
+struct hipemu_rsrc { char* base; unsigned bytes; };
+typedef hipemu_rsrc __amdgpu_buffer_rsrc_t;
+inline hipemu_rsrc hipemu_make_rsrc(void* p, int stride, int num, int) { (void)stride; return hipemu_rsrc{(char*)p, (unsigned)num}; }
+template <class W> inline W* hipemu_buf_addr(hipemu_rsrc r, unsigned voff, unsigned soff) {
+    if ((size_t)voff + soff + sizeof(W) > r.bytes) { fprintf(stderr, "hipemu: buffer access at %u + %u outside %u bytes\n", voff, soff, r.bytes); abort(); }
+    return reinterpret_cast<W*>(r.base + voff + soff);
+}
+typedef unsigned hipemu_u2 __attribute__((vector_size(8)));
+#define __builtin_amdgcn_make_buffer_rsrc(p, stride, num, flags) hipemu_make_rsrc((void*)(p), (stride), (num), (flags))
+#define __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, aux) (*hipemu_buf_addr<unsigned>((r), (voff), (soff)))
+#define __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, aux) (*hipemu_buf_addr<hipemu_u2>((r), (voff), (soff)))
+#define __builtin_amdgcn_raw_buffer_store_b32(v, r, voff, soff, aux) ((void)(*hipemu_buf_addr<unsigned>((r), (voff), (soff)) = (v)))
+#define __builtin_amdgcn_raw_buffer_store_b64(v, r, voff, soff, aux) ((void)(*hipemu_buf_addr<hipemu_u2>((r), (voff), (soff)) = (v)))
+
 // ---- host definitions of the inline-assembly helpers of plmpm_kernels.h (their device forms are guarded by PLB_HOST_EMUL)
 namespace plb {
 inline void lds_barrier() { hipemu::block_barrier(); }
