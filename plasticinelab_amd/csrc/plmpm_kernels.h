@@ -553,7 +553,7 @@ template <int CTRL, int ROWMASK> __device__ __forceinline__ double dpp_move_f64(
     long long b = __builtin_bit_cast(long long, v);
     int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffLL), CTRL, ROWMASK, 0xf, true);
     int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, ROWMASK, 0xf, true);
-    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+    return __builtin_bit_cast(double, ((unsigned long long)(unsigned int)hi << 32) | (unsigned int)lo);
 }
 __device__ __forceinline__ double wave_sum_to_lane63(double v) {
     v += dpp_move_f64<0x111, 0xf>(v);
@@ -664,7 +664,7 @@ template <int D> __device__ __forceinline__ double row_shl(double v) {
     int lo = (int)(b & 0xffffffffLL), hi = (int)(b >> 32);
     lo = __builtin_amdgcn_update_dpp(0, lo, 0x100 + D, 0xf, 0xf, true);
     hi = __builtin_amdgcn_update_dpp(0, hi, 0x100 + D, 0xf, 0xf, true);
-    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+    return __builtin_bit_cast(double, ((unsigned long long)(unsigned int)hi << 32) | (unsigned int)lo);
 }
 template <class T> __device__ __forceinline__ T seg_sum(T v, const Seg<T>& s) {
     v += row_shl<1>(v) * s.m1;
@@ -1288,6 +1288,11 @@ __global__ __launch_bounds__(kBlock, sizeof(T) == 4 ? PLB_G2PG_WAVES : 1) void k
         }
     PT_MARK(0);
     const bool valid = sorted_finish(D, sl, p, x, base, false, wg);
+    // padding lanes run the gather / scatter arithmetic on dummy data (the wave-level reductions need every lane): their stencil is
+    // parked on the tile's origin, so that what they read lies inside the tile (an LDS read outside the allocation returns zero on
+    // the hardware and nothing of it is kept -- but it is an out-of-bounds index all the same: found by the sanitizer run of the
+    // CPU interpreter, round 6)
+    if (!valid) { base[0] = tl.o[0]; base[1] = tl.o[1]; base[2] = tl.o[2]; }
     PT_MARK(1);
     {
         // v[f+1]: normally the stored frame; after a re-sort of frame f+1 the copy kept in this frame's particle order

@@ -27,6 +27,9 @@ VARIANTS = {
     "bufio": "-DPLB_BUFIO=1",                            # particle arrays behind buffer descriptors
     "pk": "-DPLB_PK_GATHER=3",                           # p2g.grad and g2p gathers on packed pairs
     "pkbuf": "-DPLB_PK_GATHER=3 -DPLB_BUFIO=1",
+    # the default source under AddressSanitizer + UndefinedBehaviorSanitizer (make SAN=1); the process that loads it needs
+    # LD_PRELOAD=$(gcc -print-file-name=libasan.so) and ASAN_OPTIONS=detect_leaks=0 (tests/test_emul_tier.py sets both)
+    "asan": "",
 }
 VARIANT = os.environ.get("PLMPM_EMUL_VARIANT", "")
 _lib = None
@@ -39,7 +42,7 @@ def lib_path(variant=VARIANT):
 def build(variant=VARIANT):
     tag = "_" + variant if variant else ""
     subprocess.check_call(["make", "-s", "-j", "6", "-C", HERE, f"OBJDIR=build_emul{tag}", f"OUT=libplmpm_emul{tag}.so",
-                           f"EXTRA={VARIANTS[variant]}", f"libplmpm_emul{tag}.so"])
+                           f"EXTRA={VARIANTS[variant]}", f"SAN={1 if variant == 'asan' else 0}", f"libplmpm_emul{tag}.so"])
 
 
 def lib():
@@ -51,6 +54,12 @@ def lib():
 
 
 class HostEngine(Engine):
+    def __init__(self, **kw):
+        # a handful of persistent grid workgroups instead of the GPU's 512: every workgroup of a launch is 256 fiber start-ups here
+        if not kw.get("grid_workgroups"):
+            kw["grid_workgroups"] = 8
+        super().__init__(**kw)
+
     def _load_library(self):
         return lib()
 
@@ -64,7 +73,12 @@ class HostEngine(Engine):
         return contextlib.nullcontext()
 
     def _allocate(self, nbytes):
-        raw = torch.full((nbytes + 256,), 0xff, dtype=torch.uint8)      # garbage, as torch.empty on a GPU is
+        # garbage, as torch.empty on a GPU is (NaN as a float, -1 as an int: nothing may rely on zeros) -- for workspaces up to 64 MiB;
+        # the per-frame grid stores of a 64-frame engine are ~1 GiB, and touching that for every engine of every test is what the
+        # tier's time would go into (untouched pages read as zero)
+        raw = torch.empty(nbytes + 256, dtype=torch.uint8)
+        if nbytes <= (64 << 20) or os.environ.get("PLMPM_EMUL_FILL") == "1":
+            raw.fill_(0xff)
         off = (-raw.data_ptr()) % 256                                    # the library wants 256-byte aligned workspaces
         return raw[off:off + nbytes]
 
@@ -76,12 +90,10 @@ class HostEngine(Engine):
 
 
 def engine_for(sim, prims, dtype="float64", max_frames=64, svd_grad_clamp=1e-6, **engine_kw):
-    """tests.gpu_util.engine_for on the interpreter; a handful of persistent grid workgroups instead of 512 (every workgroup of a
-    launch costs 256 fiber start-ups here)."""
+    """tests.gpu_util.engine_for on the interpreter."""
     from tests import emul
     plist = [dict(shape=p.shape, action_dim=p.action_dim, params=emul.prim_par(p), friction=p.friction,
                   action_scale=p.action_scale, lower_bound=p.lower_bound, upper_bound=p.upper_bound) for p in prims]
-    engine_kw.setdefault("grid_workgroups", 8)
     return HostEngine(n_grid=sim.n_grid, n_particles=sim.n_particles, max_frames=max_frames, substeps=sim.substeps,
                       dt=sim.dt, p_vol=sim.p_vol, p_mass=sim.p_mass, gravity=sim.gravity,
                       ground_friction=sim.ground_friction, primitives=plist, dtype=dtype, svd_grad_clamp=svd_grad_clamp, **engine_kw)

@@ -64,6 +64,7 @@ enum { hipDeviceMallocFinegrained = 1, hipDeviceMallocUncached = 3, hipHostMallo
 namespace hipemu {
 void* device_alloc(size_t bytes);
 void device_free(void* p);
+void device_memset(void* p, int v, size_t n);
 double now_ms();
 }
 inline const char* hipGetErrorString(hipError_t e) { return e == hipSuccess ? "success" : e == hipErrorNotSupported ? "not supported by the CPU interpreter" : "error"; }
@@ -76,8 +77,8 @@ inline hipError_t hipFree(void* p) { hipemu::device_free(p); return hipSuccess; 
 inline hipError_t hipHostFree(void* p) { hipemu::device_free(p); return hipSuccess; }
 inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t = nullptr) { if (n) memmove(d, s, n); return hipSuccess; }
 inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { if (n) memmove(d, s, n); return hipSuccess; }
-inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t = nullptr) { if (n) memset(d, v, n); return hipSuccess; }
-inline hipError_t hipMemset(void* d, int v, size_t n) { if (n) memset(d, v, n); return hipSuccess; }
+inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t = nullptr) { hipemu::device_memset(d, v, n); return hipSuccess; }
+inline hipError_t hipMemset(void* d, int v, size_t n) { hipemu::device_memset(d, v, n); return hipSuccess; }
 inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
 inline hipError_t hipEventCreate(hipEvent_t* e) { *e = new hipemu_event{0.0}; return hipSuccess; }
@@ -106,6 +107,7 @@ struct Fiber {
     Idx tid;                  // threadIdx
     int wave, lane;
     bool done;
+    void* asan_fake;          // AddressSanitizer builds: the fiber's fake-stack handle while it is switched out
 };
 extern Fiber* cur;            // the running fiber
 extern Idx g_block, g_bdim, g_gdim;

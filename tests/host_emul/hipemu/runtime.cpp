@@ -6,6 +6,17 @@
 #include <numeric>
 #include <vector>
 
+// AddressSanitizer has to be told about every stack switch (it keeps per-stack bookkeeping for use-after-return / stack redzones):
+// `make SAN=1` compiles the device source and this file with -fsanitize=address,undefined -- out-of-bounds LDS tiles, particle
+// rows and grid nodes, misaligned or overflowing index arithmetic in the kernels are then REPORTED instead of silently corrupting
+// a neighbour (the GPU has no such tool on this pool).
+#if defined(__SANITIZE_ADDRESS__)
+#include <sanitizer/common_interface_defs.h>
+#define HIPEMU_ASAN 1
+#else
+#define HIPEMU_ASAN 0
+#endif
+
 extern "C" void hipemu_switch(void** save_sp, void* next_sp);
 // callee-saved registers on the old stack, swap stack pointers, restore from the new one (System V x86-64)
 asm(R"(
@@ -68,6 +79,23 @@ void* device_alloc(size_t bytes) {
     return p;
 }
 void device_free(void* p) { free(p); }
+// Zeroing hundreds of megabytes (an engine clears its per-frame grid stores when its workspaces are bound) by touching every page is
+// most of a small test's time: whole pages of a large zero-fill are handed back to the kernel instead (MADV_DONTNEED on private
+// anonymous memory: they read as zero again, and only the pages a test really uses are ever faulted in).
+void device_memset(void* p, int v, size_t n) {
+    if (!n) return;
+    char* b = (char*)p;
+    if (v == 0 && n >= (4u << 20)) {
+        char* lo = (char*)(((uintptr_t)b + 4095) & ~(uintptr_t)4095);
+        char* hi = (char*)(((uintptr_t)b + n) & ~(uintptr_t)4095);
+        if (hi > lo && madvise(lo, (size_t)(hi - lo), MADV_DONTNEED) == 0) {
+            memset(b, 0, (size_t)(lo - b));
+            memset(hi, 0, (size_t)(b + n - hi));
+            return;
+        }
+    }
+    memset(p, v, n);
+}
 
 [[noreturn]] static void die(const char* what) {
     fprintf(stderr, "hipemu: %s (workgroup %u of %u, thread %u, wave %d lane %d)\n", what, g_block.x, g_gdim.x, cur ? cur->tid.x : 0, cur ? cur->wave : -1,
@@ -75,7 +103,32 @@ void device_free(void* p) { free(p); }
     fflush(stderr);
     abort();
 }
-static inline void yield() { hipemu_switch(&cur->sp, g_main_sp); }
+#if HIPEMU_ASAN
+static void* g_main_fake = nullptr;
+static const void* g_main_lo = nullptr;
+static size_t g_main_size = 0;
+#endif
+// fiber -> scheduler
+static inline void yield() {
+#if HIPEMU_ASAN
+    __sanitizer_start_switch_fiber(&cur->asan_fake, g_main_lo, g_main_size);
+#endif
+    hipemu_switch(&cur->sp, g_main_sp);
+#if HIPEMU_ASAN
+    __sanitizer_finish_switch_fiber(cur->asan_fake, nullptr, nullptr);
+#endif
+}
+// scheduler -> fiber t
+static inline void resume(Fiber& f, int t) {
+    cur = &f;
+#if HIPEMU_ASAN
+    __sanitizer_start_switch_fiber(&g_main_fake, g_stacks + (size_t)t * kStack, kStack);
+#endif
+    hipemu_switch(&g_main_sp, f.sp);
+#if HIPEMU_ASAN
+    __sanitizer_finish_switch_fiber(g_main_fake, nullptr, nullptr);
+#endif
+}
 
 static void wave_release(Wave& w) {
     unsigned op = 0;
@@ -135,10 +188,16 @@ static void fiber_exit() {
     if (w.live > 0 && w.arrived == w.live) wave_release(w);
     --g_blk_live;
     if (g_blk_live > 0 && g_blk_arrived == g_blk_live) { g_blk_arrived = 0; ++g_blk_gen; }
+#if HIPEMU_ASAN
+    __sanitizer_start_switch_fiber(nullptr, g_main_lo, g_main_size);        // (nullptr: this stack is never used again)
+#endif
     hipemu_switch(&f->sp, g_main_sp);
     die("a finished fiber was resumed");
 }
 static void fiber_entry() {
+#if HIPEMU_ASAN
+    __sanitizer_finish_switch_fiber(nullptr, &g_main_lo, &g_main_size);
+#endif
     g_thunk(g_ctx);
     fiber_exit();
 }
@@ -165,12 +224,13 @@ void run_grid(dim3 grid, dim3 block, size_t lds, void (*thunk)(void*), void* ctx
         for (int t = 0; t < nt; ++t) {
             Fiber& f = g_fib[t];
             f.tid = {(unsigned)t % block.x, ((unsigned)t / block.x) % block.y, (unsigned)t / (block.x * block.y)};
-            f.wave = t >> 6; f.lane = t & 63; f.done = false;
+            f.wave = t >> 6; f.lane = t & 63; f.done = false; f.asan_fake = nullptr;
             Wave& w = g_wave[f.wave];
             ++w.live; w.live_mask |= 1ULL << f.lane;
             // initial frame: six callee-saved registers, the entry point as the return address, a null return address above it
             // (16-byte alignment of a freshly called function: rsp = 16 k + 8 at its first instruction)
-            uintptr_t top = ((uintptr_t)g_stacks + (size_t)(t + 1) * kStack) & ~(uintptr_t)15;
+            // (the tops are staggered: 256 stacks at a power-of-two stride would put every fiber's hot frames into the same cache sets)
+            uintptr_t top = ((uintptr_t)g_stacks + (size_t)(t + 1) * kStack - (size_t)((t * 2368) & 0xffff)) & ~(uintptr_t)15;
             void** sp = (void**)top;
             *--sp = nullptr;
             *--sp = (void*)&fiber_entry;
@@ -184,8 +244,7 @@ void run_grid(dim3 grid, dim3 block, size_t lds, void (*thunk)(void*), void* ctx
             for (int t = 0; t < nt; ++t) {
                 Fiber& f = g_fib[t];
                 if (f.done) continue;
-                cur = &f;
-                hipemu_switch(&g_main_sp, f.sp);
+                resume(f, t);
                 if (!f.done) ++alive;
             }
             if (alive > 0 && g_progress == before) {

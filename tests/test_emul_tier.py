@@ -1,0 +1,65 @@
+"""CPU tier: a cross-section of the -m gpu parity tests, run on the DEVICE SOURCE through the CPU interpreter (tests/host_emul/hipemu,
+tests/emul_engine.py: plasticinelab_amd/csrc compiled by g++ against a HIP shim -- fibers for threads, lock-step wave operations, DPP
+lane maps) -- unchanged test bodies and tolerances, PLMPM_TEST_INTERPRETER=1 puts the interpreter's engine behind them
+(tests/conftest.py).  What this buys where there is no GPU: the kernels' tiling, in-wave sort, segmented reductions, block flags,
+contact lists, re-sorts and the launch logic of the C ABI are EXECUTED and compared with the oracle / the golden rollouts; compile-time
+variants that wait for a timing (packed gathers, buffer descriptors) are parity-checked before they ever reach a GPU; and the same
+source runs under AddressSanitizer + UndefinedBehaviorSanitizer, which the GPU pool does not offer.  Each case is a pytest run of its
+own (the interpreter's library is chosen per process); they run side by side.
+
+The whole -m gpu tier minus the full-size / multi-process modules passes this way (round 6: edge sizes 22, loss 4, semantics 6, shapes
+36, rollouts, ...: profiles/r06_notes.md); the selection below keeps the CPU tier at a few minutes."""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+import pytest
+
+from tests.util import ROOT
+
+# name -> (test file, -k expression or None, extra environment, least number of tests that must have passed)
+CASES = {
+    "edge_sizes": ("tests/test_gpu_edge_sizes.py", None, {}, 22),
+    "rollout_f64": ("tests/test_gpu_rollout.py", "test_small_rollout_matches_oracle and float64 and not soft", {}, 1),
+    "rollout_f32_soft": ("tests/test_gpu_rollout.py", "test_small_rollout_matches_oracle and float32 and soft", {}, 1),
+    "loss": ("tests/test_gpu_loss.py", "float32-True or float64-False", {}, 2),
+    "semantics": ("tests/test_gpu_semantics.py", "tie_routing", {}, 2),
+    "shapes": ("tests/test_gpu_shapes.py", "f32 and (chopsticks or scene_Rope or box_soft)", {}, 3),
+    "shapes_2": ("tests/test_gpu_shapes.py", "f32 and (rollingpin or torus_hard)", {}, 2),
+    "deterministic": ("tests/test_gpu_deterministic.py", "test_small_deterministic_rollout and float32", {}, 1),
+    # compile-time variants of the device source (tests/emul_engine.py: VARIANTS)
+    "variant_pkbuf": ("tests/test_emul_substep.py", None, {"PLMPM_EMUL_VARIANT": "pkbuf"}, 4),
+    # sanitizers over the device source: substep forward + adjoint, and the ragged / one-cell / wall cases (where an index would go wrong)
+    "asan_substep": ("tests/test_emul_substep.py", "float32", {"PLMPM_EMUL_VARIANT": "asan"}, 2),
+    "asan_edge_sizes": ("tests/test_gpu_edge_sizes.py", "float32 and (257 or 63 or one_cell or walls)", {"PLMPM_EMUL_VARIANT": "asan"}, 4),
+}
+
+
+def _run(name):
+    path, expr, extra, _ = CASES[name]
+    # (one torch thread per case: the cases run side by side, and the oracle's small tensors gain nothing from eight)
+    env = dict(os.environ, PLMPM_TEST_INTERPRETER="1", OMP_NUM_THREADS="1", MKL_NUM_THREADS="1", **extra)
+    if extra.get("PLMPM_EMUL_VARIANT") == "asan":
+        asan = subprocess.check_output(["gcc", "-print-file-name=libasan.so"]).decode().strip()
+        env.update(LD_PRELOAD=asan, ASAN_OPTIONS="detect_leaks=0")          # (the interpreter is not leak-checked: python itself "leaks")
+    cmd = [sys.executable, "-m", "pytest", path, "-q", "-x", "-p", "no:cacheprovider"] + (["-k", expr] if expr else [])
+    p = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=1500)
+    return p.returncode, p.stdout.decode(errors="replace")
+
+
+@pytest.fixture(scope="module")
+def results():
+    from tests import emul_engine
+    for variant in sorted({c[2].get("PLMPM_EMUL_VARIANT", "") for c in CASES.values()}):
+        emul_engine.build(variant)                       # (once, before the cases race for the same make)
+    with ThreadPoolExecutor(max_workers=min(6, os.cpu_count() or 2)) as pool:
+        return dict(zip(CASES, pool.map(_run, CASES)))
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_gpu_tier_case_on_the_interpreter(results, name):
+    import re
+    rc, log = results[name]
+    m = re.search(r"(\d+) passed", log)
+    assert rc == 0 and m and int(m.group(1)) >= CASES[name][3] and " failed" not in log and " skipped" not in log, log[-3000:]

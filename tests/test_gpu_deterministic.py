@@ -72,6 +72,22 @@ def test_deterministic_engine_matches_oracle(dtype):
     assert lerr < ltol and gerr < gtol
 
 
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_small_deterministic_rollout_repeats_and_matches_oracle(dtype):
+    """The 3-step / 2000-particle golden rollout on the integer-limb engine: the oracle's numbers (tolerances of test_gpu_rollout), and
+    the same bits when the rollout is run again.  (Small enough for the CPU interpreter of the device source, tests/test_emul_tier.py.)"""
+    from tests.test_gpu_rollout import make_env_sub
+    g = np.load(os.path.join(GOLDEN, "rollout_small.npz"))
+    env = make_env_sub("Move", int(g["n_particles"]), dtype, deterministic=True)
+    assert env.simulator.engine.deterministic
+    state0 = env.get_state()["state"]
+    a = rollout(env, g["actions"], state0)
+    b = rollout(env, g["actions"], state0)
+    assert same_bits(a, b)
+    ltol, gtol = (1e-10, 1e-7) if dtype == "float64" else (1e-5, 1e-4)
+    assert abs(a[0] - float(g["loss"])) / abs(float(g["loss"])) < ltol and relerr(a[1], g["grad"]) < gtol
+
+
 def test_large_cloud_is_bit_reproducible():
     """128^3, 200k particles, two manipulators pressing on the cube (the benchmark workload, smaller): every LDS-tile
     path of the normal engine is replaced by limb atomics here; two engines, identical bits."""

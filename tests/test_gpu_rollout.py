@@ -29,7 +29,7 @@ def make_env(scene, n_particles, dtype, soft_contact=False):
     return env
 
 
-def make_env_sub(scene, n_particles, dtype, soft_contact=False):
+def make_env_sub(scene, n_particles, dtype, soft_contact=False, deterministic=False):
     """TaichiEnv over a stride-subsampled particle cloud (keeps oracle runs short)."""
     from plasticinelab_amd.envs.scenes import load_scene
     from plasticinelab_amd.engine.taichi_env import TaichiEnv
@@ -43,6 +43,8 @@ def make_env_sub(scene, n_particles, dtype, soft_contact=False):
 
     cfg = load_scene(scene, 1)
     cfg.ENV.loss.target_path = ""
+    if deterministic:
+        cfg.SIMULATOR["deterministic"] = True
     orig = te.Shapes
     te.Shapes = SubShapes
     try:
