@@ -1727,7 +1727,11 @@ template <class T>
 __global__ __launch_bounds__(kBlock) void k_clear_active(Dev<T> D) {
     const int blk = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
     const int nblk = D.nbx * D.nby * D.nbz;
-    if (blk >= nblk || D.flags[flag_slot(D, blk)] == 0) return;
+    if (blk >= nblk) return;
+    // one flag per wave: taken through the scalar unit (a wave-uniform branch -- and a wave-level operation between the 64 lanes'
+    // reads of the flag and lane 0's write to it below, which the tests' CPU interpreter of this source needs: its lanes are not
+    // in lock-step between two such operations)
+    if (__builtin_amdgcn_readfirstlane(D.flags[flag_slot(D, blk)]) == 0) return;
     const int lane = threadIdx.x & 63;
     const int idx = (blk << 6) | lane;
     D.gin[0][idx] = T(0); D.gin[1][idx] = T(0); D.gin[2][idx] = T(0); D.gin[3][idx] = T(0);

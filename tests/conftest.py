@@ -18,9 +18,10 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     if ON_INTERPRETER:
         from tests import emul_engine, gpu_util
+        import plasticinelab_amd.engine.core as core
         import plasticinelab_amd.engine.mpm_simulator as ms
         gpu_util.engine_for = emul_engine.engine_for           # (before the test modules import the name)
-        ms.Engine = emul_engine.HostEngine
+        ms.Engine = core.Engine = emul_engine.HostEngine       # engines built by the simulator, and by tests that build their own
 
 
 def pytest_collection_modifyitems(config, items):

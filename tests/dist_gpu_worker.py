@@ -29,8 +29,17 @@ def main():
     overlap = os.environ.get("PLB_TEST_OVERLAP") == "1"      # interior grid blocks while the halos are in flight
     halo = int(os.environ["PLB_TEST_HALO"]) if os.environ.get("PLB_TEST_HALO") else None     # 2: thin slabs (one block plane)
     peer = os.environ.get("PLB_TEST_PEER") == "1"            # device-side halo exchange (peer writes through IPC-mapped areas)
+    # PLMPM_TEST_INTERPRETER=1 (tests/test_emul_tier.py): the ranks run the device source on the CPU interpreter instead of a GPU --
+    # same SlabEngine, same gloo exchange of host-staged halos, no ROCm device anywhere
+    interpreter = os.environ.get("PLMPM_TEST_INTERPRETER") == "1"
+    if interpreter:
+        from tests import emul_engine
+        import plasticinelab_amd.engine.mpm_simulator as ms
+        ms.Engine = emul_engine.HostEngine
+        assert backend == "gloo" and not peer, "the interpreter has host memory only: gloo, no peer writes"
     dev = rank % torch.cuda.device_count() if backend == "nccl" else 0
-    torch.cuda.set_device(dev)
+    if not interpreter:
+        torch.cuda.set_device(dev)
     if backend == "nccl":
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev))
     else:

@@ -57,7 +57,7 @@ class HostEngine(Engine):
     def __init__(self, **kw):
         # a handful of persistent grid workgroups instead of the GPU's 512: every workgroup of a launch is 256 fiber start-ups here
         if not kw.get("grid_workgroups"):
-            kw["grid_workgroups"] = 8
+            kw["grid_workgroups"] = int(os.environ.get("PLMPM_EMUL_GRID_WG", 8))
         super().__init__(**kw)
 
     def _load_library(self):

@@ -14,6 +14,10 @@
 //     each other, and read their partners' -- lock-step semantics of a 64-wide wavefront with the exec mask = lanes that have
 //     not returned.  Every live lane of the wave must reach the SAME operation (checked: a divergent collective aborts with a
 //     message instead of silently reading stale registers as the hardware would).
+// What is NOT reproduced: lock-step between two such points.  A lane runs ahead of its wave until the next wave-level operation or
+// barrier, so a kernel in which one lane overwrites what the other lanes of its wave read earlier in program order, with nothing
+// wave-wide in between, behaves differently here (k_clear_active did: lane 0 cleared the block flag the other 63 lanes were about
+// to test; it now takes the flag through v_readfirstlane).
 // DPP controls (quad_perm, row_shl / shr / ror, row_bcast15 / 31, row_mirror, row / bank masks, bound_ctrl) follow the CDNA3/4
 // ISA manual.  Atomics are plain read-modify-writes (one OS thread).  `__shared__` is storage shared by the fibers of the
 // running workgroup.  Inline assembly cannot be interpreted: the few asm helpers of plmpm_kernels.h have host definitions here
@@ -179,6 +183,11 @@ template <class T> inline T __shfl_down(T v, unsigned d) {
 #define __builtin_amdgcn_update_dpp(old, src, ctrl, row_mask, bank_mask, bound_ctrl) hipemu::update_dpp((int)(old), (int)(src), (ctrl), (row_mask), (bank_mask), (bound_ctrl))
 inline int hipemu_readlane(int v, int lane) { const hipemu::Gathered g = hipemu::wave_gather(hipemu::bits_of(v), hipemu::OP_READLANE); return hipemu::from_bits<int>(g.v[lane & 63]); }
 #define __builtin_amdgcn_readlane(v, lane) hipemu_readlane((v), (lane))
+inline int hipemu_readfirstlane(int v) {
+    const hipemu::Gathered g = hipemu::wave_gather(hipemu::bits_of(v), hipemu::OP_READLANE | 1u);
+    return hipemu::from_bits<int>(g.v[__builtin_ctzll(g.live)]);
+}
+#define __builtin_amdgcn_readfirstlane(v) hipemu_readfirstlane((v))
 #define __builtin_amdgcn_rcpf(x) (1.0f / (x))
 #define __builtin_amdgcn_rsqf(x) (1.0f / sqrtf(x))
 #define __builtin_amdgcn_sqrtf(x) sqrtf(x)

@@ -28,6 +28,9 @@ CASES = {
     "shapes": ("tests/test_gpu_shapes.py", "f32 and (chopsticks or scene_Rope or box_soft)", {}, 3),
     "shapes_2": ("tests/test_gpu_shapes.py", "f32 and (rollingpin or torus_hard)", {}, 2),
     "deterministic": ("tests/test_gpu_deterministic.py", "test_small_deterministic_rollout and float32", {}, 1),
+    "checkpointed": ("tests/test_gpu_rollout.py", "test_checkpointed_gradient_equals_tape_gradient and float32", {}, 1),
+    # z-slab ranks over gloo (one process per rank, host-staged halos, migration): the real kernels behind SlabEngine, against the golden rollout
+    "slab_ranks": ("tests/test_gpu_distributed.py", "(test_slab_ranks_match_golden_rollout or test_overlapped_exchange) and float32", {}, 2),
     # compile-time variants of the device source (tests/emul_engine.py: VARIANTS)
     "variant_pkbuf": ("tests/test_emul_substep.py", None, {"PLMPM_EMUL_VARIANT": "pkbuf"}, 4),
     # sanitizers over the device source: substep forward + adjoint, and the ragged / one-cell / wall cases (where an index would go wrong)
