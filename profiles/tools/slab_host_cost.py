@@ -31,7 +31,8 @@ class LoopbackComm(D.HaloComm):
         self.want_peer, self.peer_ready = bool(peer), False
         self.stage_host = False
         self.backend = "loopback"
-        self.scalar_device = torch.device("cuda", torch.cuda.current_device())
+        # (host tensors where there is no GPU: the tests run this communicator on the CPU interpreter of the device source too)
+        self.scalar_device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
         self._recv, self._ops = {}, {}
         self.down = rank - 1 if rank > 0 else None
         self.up = rank + 1 if rank < layout.world - 1 else None

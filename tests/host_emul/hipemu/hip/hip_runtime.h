@@ -68,6 +68,11 @@ enum { hipDeviceMallocFinegrained = 1, hipDeviceMallocUncached = 3, hipHostMallo
 namespace hipemu {
 void* device_alloc(size_t bytes);
 void device_free(void* p);
+void* shared_alloc(size_t bytes);
+bool shared_handle(void* p, char* handle64);
+void* shared_open(const char* handle64);
+void shared_close(void* p);
+void external_wait();
 void device_memset(void* p, int v, size_t n);
 double now_ms();
 }
@@ -75,7 +80,10 @@ inline const char* hipGetErrorString(hipError_t e) { return e == hipSuccess ? "s
 inline hipError_t hipGetLastError() { return hipSuccess; }
 inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
 template <class P> inline hipError_t hipMalloc(P** p, size_t bytes) { *p = (P*)hipemu::device_alloc(bytes); return *p ? hipSuccess : hipErrorOutOfMemory; }
-template <class P> inline hipError_t hipExtMallocWithFlags(P** p, size_t bytes, unsigned) { return hipMalloc(p, bytes); }
+// hipExtMallocWithFlags (the library asks for it only for memory a NEIGHBOUR RANK maps: the receive areas of the device-side halo
+// exchange) is POSIX shared memory here, and the IPC handle carries its name: ranks that are separate processes of one test exchange
+// halos through it exactly as ranks on one GPU do through hipIpc -- peer writes, arrival counters, bounded waits and all.
+template <class P> inline hipError_t hipExtMallocWithFlags(P** p, size_t bytes, unsigned) { *p = (P*)hipemu::shared_alloc(bytes); return *p ? hipSuccess : hipErrorOutOfMemory; }
 template <class P> inline hipError_t hipHostMalloc(P** p, size_t bytes, unsigned = 0) { return hipMalloc(p, bytes); }
 inline hipError_t hipFree(void* p) { hipemu::device_free(p); return hipSuccess; }
 inline hipError_t hipHostFree(void* p) { hipemu::device_free(p); return hipSuccess; }
@@ -97,10 +105,9 @@ inline hipError_t hipGraphInstantiate(hipGraphExec_t*, hipGraph_t, void*, void*,
 inline hipError_t hipGraphLaunch(hipGraphExec_t, hipStream_t) { return hipErrorNotSupported; }
 inline hipError_t hipGraphExecDestroy(hipGraphExec_t) { return hipSuccess; }
 inline hipError_t hipGraphDestroy(hipGraph_t) { return hipSuccess; }
-// "IPC" inside one process: the handle carries the pointer (several slab engines of ONE process can exchange through it)
-inline hipError_t hipIpcGetMemHandle(hipIpcMemHandle_t* h, void* p) { memset(h, 0, sizeof(*h)); memcpy(h->reserved, &p, sizeof(p)); return hipSuccess; }
-inline hipError_t hipIpcOpenMemHandle(void** p, hipIpcMemHandle_t h, unsigned) { memcpy(p, h.reserved, sizeof(*p)); return hipSuccess; }
-inline hipError_t hipIpcCloseMemHandle(void*) { return hipSuccess; }
+inline hipError_t hipIpcGetMemHandle(hipIpcMemHandle_t* h, void* p) { return hipemu::shared_handle(p, h->reserved) ? hipSuccess : hipErrorInvalidValue; }
+inline hipError_t hipIpcOpenMemHandle(void** p, hipIpcMemHandle_t h, unsigned) { *p = hipemu::shared_open(h.reserved); return *p ? hipSuccess : hipErrorInvalidValue; }
+inline hipError_t hipIpcCloseMemHandle(void* p) { hipemu::shared_close(p); return hipSuccess; }
 
 // ---------------------------------------------------------------------------------------------- the interpreter
 namespace hipemu {
@@ -191,7 +198,10 @@ inline int hipemu_readfirstlane(int v) {
 #define __builtin_amdgcn_rcpf(x) (1.0f / (x))
 #define __builtin_amdgcn_rsqf(x) (1.0f / sqrtf(x))
 #define __builtin_amdgcn_sqrtf(x) sqrtf(x)
-#define __builtin_amdgcn_s_sleep(n) ((void)0)
+// s_sleep is what a spin-wait on ANOTHER agent (a neighbour rank's arrival counter) does between two polls: the fiber lets the other
+// fibers -- and the other processes -- run, and the scheduler does not take the spinning for a deadlock (the waits are bounded by the
+// kernels' own wall-clock timeouts)
+#define __builtin_amdgcn_s_sleep(n) hipemu::external_wait()
 #define __builtin_amdgcn_s_getreg(x) 0
 inline int __ffsll(long long v) { return __builtin_ffsll(v); }
 inline int __ffs(int v) { return __builtin_ffs(v); }
@@ -219,11 +229,13 @@ template <class T> inline T atomicMin(T* p, T v) { T o = *p; if (v < o) *p = v; 
 #define __HIP_MEMORY_SCOPE_WORKGROUP 3
 #define __HIP_MEMORY_SCOPE_AGENT 4
 #define __HIP_MEMORY_SCOPE_SYSTEM 5
-#define __hip_atomic_load(p, order, scope) (*(p))
-#define __hip_atomic_store(p, v, order, scope) ((void)(*(p) = (v)))
-#define __hip_atomic_fetch_add(p, v, order, scope) hipemu_fetch_add((p), (v))
-template <class T> inline bool hipemu_cas(T* p, T* expected, T desired) { if (*p == *expected) { *p = desired; return true; } *expected = *p; return false; }
-#define __hip_atomic_compare_exchange_strong(p, e, d, o1, o2, scope) hipemu_cas((p), (e), (d))
+// the scoped atomics are what ranks in different processes talk through (shared-memory receive areas): real atomics
+template <class T> inline T hipemu_atomic_load(const T* p) { T v; __atomic_load(const_cast<T*>(p), &v, __ATOMIC_SEQ_CST); return v; }
+template <class T, class V> inline void hipemu_atomic_store(T* p, V v) { T w = (T)v; __atomic_store(p, &w, __ATOMIC_SEQ_CST); }
+#define __hip_atomic_load(p, order, scope) hipemu_atomic_load(p)
+#define __hip_atomic_store(p, v, order, scope) hipemu_atomic_store((p), (v))
+#define __hip_atomic_fetch_add(p, v, order, scope) __atomic_fetch_add((p), (v), __ATOMIC_SEQ_CST)
+#define __hip_atomic_compare_exchange_strong(p, e, d, o1, o2, scope) __atomic_compare_exchange_n((p), (e), (d), false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST)
 
 // HIP puts min / max of the arithmetic types in the global namespace
 #define HIPEMU_MINMAX(T) inline T min(T a, T b) { return b < a ? b : a; } inline T max(T a, T b) { return a < b ? b : a; }
@@ -252,5 +264,5 @@ namespace plb {
 inline void lds_barrier() { hipemu::block_barrier(); }
 inline void wait_lds() {}
 inline void wait_vmem() {}
-template <class P, class V> inline void store_through(P* p, V v) { *p = (P)v; }
+template <class P, class V> inline void store_through(P* p, V v) { hipemu_atomic_store(p, v); }
 }  // namespace plb

@@ -1,7 +1,14 @@
 // TEST INFRASTRUCTURE ONLY: the scheduler of the CPU interpreter described in hip/hip_runtime.h -- fibers, workgroup barrier,
 // wave-level gather, DPP lane maps, "device" memory -- plus host versions of the two rocPRIM entry points of plmpm_sort.hip.
 #include <hip/hip_runtime.h>
+#include <fcntl.h>
+#include <sched.h>
 #include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <map>
+#include <string>
 
 #include <numeric>
 #include <vector>
@@ -67,6 +74,56 @@ static Wave g_wave[kMaxThreads / 64];
 static int g_blk_live, g_blk_arrived;
 static unsigned g_blk_gen;
 
+// ---- memory another process can map (hipExtMallocWithFlags + hipIpc*): POSIX shared memory, the handle = its name and size
+struct Shared { std::string name; size_t bytes; bool mine; };
+static std::map<void*, Shared> g_shared;
+static void shared_cleanup() {
+    for (auto& kv : g_shared) if (kv.second.mine) shm_unlink(kv.second.name.c_str());
+}
+void* shared_alloc(size_t bytes) {
+    static int counter = 0;
+    static bool hooked = false;
+    if (!hooked) { hooked = true; atexit(shared_cleanup); }
+    char name[48];
+    snprintf(name, sizeof name, "/hipemu.%d.%d", (int)getpid(), counter++);
+    const int fd = shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600);
+    if (fd < 0) return nullptr;
+    void* p = ftruncate(fd, (off_t)bytes) == 0 ? mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0) : MAP_FAILED;
+    close(fd);
+    if (p == MAP_FAILED) { shm_unlink(name); return nullptr; }
+    memset(p, 0xff, bytes);
+    g_shared[p] = Shared{name, bytes, true};
+    return p;
+}
+bool shared_handle(void* p, char* handle64) {
+    auto it = g_shared.find(p);
+    if (it == g_shared.end() || !it->second.mine) return false;
+    memset(handle64, 0, 64);
+    const unsigned long long n = it->second.bytes;
+    memcpy(handle64, &n, 8);
+    snprintf(handle64 + 8, 56, "%s", it->second.name.c_str());
+    return true;
+}
+void* shared_open(const char* handle64) {
+    unsigned long long n = 0;
+    memcpy(&n, handle64, 8);
+    const std::string name(handle64 + 8, strnlen(handle64 + 8, 55));
+    for (auto& kv : g_shared) if (kv.second.mine && kv.second.name == name) return nullptr;      // (as HIP: a process cannot open its own handle)
+    const int fd = shm_open(name.c_str(), O_RDWR, 0600);
+    if (fd < 0) return nullptr;
+    void* p = mmap(nullptr, (size_t)n, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (p == MAP_FAILED) return nullptr;
+    g_shared[p] = Shared{name, (size_t)n, false};
+    return p;
+}
+void shared_close(void* p) {
+    auto it = g_shared.find(p);
+    if (it == g_shared.end() || it->second.mine) return;
+    munmap(p, it->second.bytes);
+    g_shared.erase(it);
+}
+
 void* dyn_lds_arena() {
     static double arena[8192];           // 64 KiB
     return arena;
@@ -78,7 +135,14 @@ void* device_alloc(size_t bytes) {
     memset(p, 0xff, bytes);              // hipMalloc returns garbage: nothing may rely on zeros (NaN as a float, -1 as an int)
     return p;
 }
-void device_free(void* p) { free(p); }
+void device_free(void* p) {
+    auto it = g_shared.find(p);
+    if (it != g_shared.end()) {
+        if (it->second.mine) { munmap(p, it->second.bytes); shm_unlink(it->second.name.c_str()); g_shared.erase(it); }
+        return;
+    }
+    free(p);
+}
 // Zeroing hundreds of megabytes (an engine clears its per-frame grid stores when its workspaces are bound) by touching every page is
 // most of a small test's time: whole pages of a large zero-fill are handed back to the kernel instead (MADV_DONTNEED on private
 // anonymous memory: they read as zero again, and only the pages a test really uses are ever faulted in).
@@ -128,6 +192,13 @@ static inline void resume(Fiber& f, int t) {
 #if HIPEMU_ASAN
     __sanitizer_finish_switch_fiber(g_main_fake, nullptr, nullptr);
 #endif
+}
+
+// between two polls of a spin-wait on another agent (s_sleep): not a deadlock, and the other fibers / processes get the core
+void external_wait() {
+    ++g_progress;
+    sched_yield();
+    yield();
 }
 
 static void wave_release(Wave& w) {

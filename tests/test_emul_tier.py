@@ -31,6 +31,11 @@ CASES = {
     "checkpointed": ("tests/test_gpu_rollout.py", "test_checkpointed_gradient_equals_tape_gradient and float32", {}, 1),
     # z-slab ranks over gloo (one process per rank, host-staged halos, migration): the real kernels behind SlabEngine, against the golden rollout
     "slab_ranks": ("tests/test_gpu_distributed.py", "(test_slab_ranks_match_golden_rollout or test_overlapped_exchange) and float32", {}, 2),
+    # the device-side halo exchange -- peer writes into IPC-mapped receive areas (POSIX shared memory behind the shim's hipIpc calls),
+    # arrival counters, native substep loops -- between ranks that are separate processes; a silent neighbour times out; a rank
+    # without a single particle steps and differentiates
+    "peer_writes": ("tests/test_gpu_distributed.py", "test_peer_write_halos_match_golden_rollout and False", {"PLMPM_PEER_TIMEOUT": "120"}, 2),
+    "peer_edge_cases": ("tests/test_gpu_distributed.py", "peer_exchange_wait_is_bounded or rank_without_particles or leaving_the_grid", {}, 4),
     # compile-time variants of the device source (tests/emul_engine.py: VARIANTS)
     "variant_pkbuf": ("tests/test_emul_substep.py", None, {"PLMPM_EMUL_VARIANT": "pkbuf"}, 4),
     # sanitizers over the device source: substep forward + adjoint, and the ragged / one-cell / wall cases (where an index would go wrong)

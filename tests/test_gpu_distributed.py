@@ -305,7 +305,8 @@ def test_peer_exchange_wait_is_bounded(monkeypatch):
     with pytest.raises(RuntimeError, match="timed out.*field 2"):
         env.set_state(env.get_state()["state"], 666.0, False)
     assert 0.25 < time.time() - t0 < 30
-    torch.cuda.synchronize()                                   # the GPU is still there
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()                               # the GPU is still there
     st = eng.peer_status()
     assert st & 1 and (st >> 16) == eng.HALO_LOSS_MASS
     with pytest.raises(RuntimeError, match="earlier arrival timed out"):       # and the engine refuses to go on exchanging
