@@ -286,9 +286,23 @@ void run_grid(dim3 grid, dim3 block, size_t lds, void (*thunk)(void*), void* ctx
     g_bdim = {block.x, block.y, block.z};
     g_gdim = {grid.x, grid.y, grid.z};
     const int nw = (nt + 63) / 64;
-    for (unsigned bz = 0; bz < grid.z; ++bz)
-    for (unsigned by = 0; by < grid.y; ++by)
-    for (unsigned bx = 0; bx < grid.x; ++bx) {
+    // PLMPM_EMUL_SHUFFLE=<seed>: the workgroups of every launch in a pseudo-random order, and the threads of a workgroup resumed in a
+    // pseudo-random rotation that changes with every scheduling round -- nothing in the kernels may depend on which workgroup's atomics
+    // arrive first or on which lane of a wave runs ahead (beyond the round-off of the floating-point sums)
+    static const long shuffle = getenv("PLMPM_EMUL_SHUFFLE") ? atol(getenv("PLMPM_EMUL_SHUFFLE")) + 1 : 0;
+    static unsigned long long rng = 0x9e3779b97f4a7c15ULL;
+    const size_t nwg = (size_t)grid.x * grid.y * grid.z;
+    std::vector<unsigned> order(nwg);
+    std::iota(order.begin(), order.end(), 0u);
+    if (shuffle) {
+        rng ^= (unsigned long long)shuffle * 0xbf58476d1ce4e5b9ULL;
+        for (size_t i = nwg; i > 1; --i) {
+            rng = rng * 6364136223846793005ULL + 1442695040888963407ULL;
+            std::swap(order[i - 1], order[(size_t)((rng >> 33) % i)]);
+        }
+    }
+    for (size_t wgi = 0; wgi < nwg; ++wgi) {
+        const unsigned lin = order[wgi], bx = lin % grid.x, by = (lin / grid.x) % grid.y, bz = lin / (grid.x * grid.y);
         g_block = {bx, by, bz};
         for (int w = 0; w < nw; ++w) { g_wave[w].live = 0; g_wave[w].arrived = 0; g_wave[w].gen = 0; g_wave[w].live_mask = 0; }
         g_blk_live = nt; g_blk_arrived = 0; g_blk_gen = 0;
@@ -312,7 +326,10 @@ void run_grid(dim3 grid, dim3 block, size_t lds, void (*thunk)(void*), void* ctx
         while (alive > 0) {
             const unsigned long before = g_progress;
             alive = 0;
-            for (int t = 0; t < nt; ++t) {
+            int t0 = 0;
+            if (shuffle) { rng = rng * 6364136223846793005ULL + 1442695040888963407ULL; t0 = (int)((rng >> 33) % (unsigned)nt); }
+            for (int k = 0; k < nt; ++k) {
+                const int t = shuffle ? (t0 + ((rng >> 20) & 1 ? k : nt - 1 - k) + nt) % nt : k;
                 Fiber& f = g_fib[t];
                 if (f.done) continue;
                 resume(f, t);

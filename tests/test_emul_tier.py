@@ -71,3 +71,28 @@ def test_gpu_tier_case_on_the_interpreter(results, name):
     rc, log = results[name]
     m = re.search(r"(\d+) passed", log)
     assert rc == 0 and m and int(m.group(1)) >= CASES[name][3] and " failed" not in log and " skipped" not in log, log[-3000:]
+
+
+def test_deterministic_engine_is_independent_of_the_execution_order():
+    """What cfg.deterministic promises -- the same BITS whatever order the workgroups' and lanes' contributions arrive in -- checked
+    where the order can be CHOSEN: the interpreter runs the workgroups of every launch, and the threads of every workgroup, in a
+    pseudo-random order (PLMPM_EMUL_SHUFFLE).  Three orders of the 3-step golden rollout, forward and reverse, on the integer-limb
+    engine: one digest.  The floating-point-atomics engine under two orders: two digests (the shuffle really reorders the sums)."""
+    import re
+
+    def digest(det, seed):
+        env = dict(os.environ, OMP_NUM_THREADS="1", PLMPM_EMUL_SHUFFLE=seed)
+        if not seed:
+            env.pop("PLMPM_EMUL_SHUFFLE")
+        p = subprocess.run([sys.executable, "-m", "tests.emul_determinism_probe", "float32", det], cwd=ROOT, env=env, stdout=subprocess.PIPE,
+                           stderr=subprocess.STDOUT, timeout=900)
+        m = re.search(r"DIGEST (\w+) loss_rel (\S+)", p.stdout.decode(errors="replace"))
+        assert p.returncode == 0 and m and float(m.group(2)) < 1e-5, p.stdout.decode(errors="replace")[-2000:]
+        return m.group(1)
+
+    from tests import emul_engine
+    emul_engine.build("")
+    with ThreadPoolExecutor(max_workers=5) as pool:
+        d = list(pool.map(lambda a: digest(*a), [("1", ""), ("1", "1"), ("1", "2"), ("0", ""), ("0", "1")]))
+    assert d[0] == d[1] == d[2], d
+    assert d[3] != d[4], "the shuffled order did not change the floating-point sums: is PLMPM_EMUL_SHUFFLE read?"
