@@ -96,3 +96,50 @@ def test_deterministic_engine_is_independent_of_the_execution_order():
         d = list(pool.map(lambda a: digest(*a), [("1", ""), ("1", "1"), ("1", "2"), ("0", ""), ("0", "1")]))
     assert d[0] == d[1] == d[2], d
     assert d[3] != d[4], "the shuffled order did not change the floating-point sums: is PLMPM_EMUL_SHUFFLE read?"
+
+
+def test_bench_py_runs_at_one_and_two_ranks():
+    """bench.py is what the driver runs unattended when the round ends; round 6 changed it (vector-ALU roof, same-box N = 1 references,
+    first-contact preflight) without a GPU to run it on.  Here its own control flow runs on the interpreter (tests/bench_on_interpreter.py:
+    the nine torch.cuda calls of its World patched, nothing else) at a size that takes seconds: `--gpus 1`, and `--gpus 2` exactly as the
+    driver launches it (torch.distributed.run, one process per rank; gloo + peer-write halos through shared memory).  Checked: ONE JSON
+    line each with the contract's keys, the two-slab run is the same workload ("strong") and ends with the single-rank loss, the transport
+    check compared the device-side exchange with the library transport, the preflight has one record per rank.  Not checked: any number."""
+    import json
+    import socket
+    from tests import emul_engine
+    emul_engine.build("")
+    common = ["--particles", "4000", "--quality", "1", "--steps", "1", "--warmup", "0", "--repeats", "2", "--no-cpu-baseline", "--no-secondary"]
+    wrapper = os.path.join(ROOT, "tests", "bench_on_interpreter.py")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmds = [[sys.executable, wrapper, "--gpus", "1"] + common,
+            [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+             wrapper, "--gpus", "2"] + common]
+    env = dict(os.environ, OMP_NUM_THREADS="1", PLB_DIST_BACKEND="gloo", PLB_PEER_HALOS="1", PLMPM_PEER_TIMEOUT="120")
+
+    def run(cmd):
+        p = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1200)
+        assert p.returncode == 0, p.stderr.decode(errors="replace")[-3000:]
+        lines = [ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")]
+        assert len(lines) == 1, "exactly one JSON line on stdout"
+        return json.loads(lines[0])
+
+    with ThreadPoolExecutor(max_workers=2) as pool:
+        one, two = pool.map(run, cmds)
+    keys = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+            "roofline", "phases_s", "repeats", "value_min", "value_max", "repeat_ms_per_step", "final_loss", "loss_check")
+    for d, n in ((one, 1), (two, 2)):
+        assert all(k in d for k in keys), [k for k in keys if k not in d]
+        assert d["n_gpus"] == n and d["steps"] == 1 and d["repeats"] == 2 and d["unit"] == "substeps/s" and d["scaling"] == "strong" and d["dtype"] == "f32"
+        r = d["roofline"]
+        assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and "valu" in r and "kernels" in r
+        assert abs(d["value"] - d["config"]["substeps_per_step"] / (1e-3 * d["ms_per_step"])) < 1e-6 * d["value"]
+    assert one["roofline"]["valu"] is None                        # no calibration of this workload is committed: null, not a stale number
+    assert "z-slabs" in two["config"]["parallelism"] and "FALLBACK" not in two["metric"]
+    tc = two["transport_check"]
+    assert two["halo_transport"].startswith("peer-write") and tc["checked"] and tc["agree"] and tc["rel_loss"] < 1e-5 and tc["rel_grad"] < 1e-4
+    assert [r["rank"] for r in tc["preflight"]] == [0, 1] and all(r["ipc_open"] == "ok" for r in tc["preflight"])
+    assert "halo_exchange" in two["roofline"]["kernels"]
+    assert abs(two["final_loss"] - one["final_loss"]) < 1e-5 * abs(one["final_loss"])
