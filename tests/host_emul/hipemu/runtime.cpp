@@ -1,8 +1,11 @@
 // TEST INFRASTRUCTURE ONLY: the scheduler of the CPU interpreter described in hip/hip_runtime.h -- fibers, workgroup barrier,
 // wave-level gather, DPP lane maps, "device" memory -- plus host versions of the two rocPRIM entry points of plmpm_sort.hip.
 #include <hip/hip_runtime.h>
+#include <dirent.h>
+#include <errno.h>
 #include <fcntl.h>
 #include <sched.h>
+#include <signal.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -80,10 +83,22 @@ static std::map<void*, Shared> g_shared;
 static void shared_cleanup() {
     for (auto& kv : g_shared) if (kv.second.mine) shm_unlink(kv.second.name.c_str());
 }
+// segments of processes that were killed (a test's timeout) never reach their atexit: every process that allocates first removes
+// what dead processes left behind -- /dev/shm is memory
+static void shared_gc() {
+    DIR* d = opendir("/dev/shm");
+    if (!d) return;
+    while (dirent* e = readdir(d)) {
+        int pid = 0, n = 0;
+        if (sscanf(e->d_name, "hipemu.%d.%d", &pid, &n) == 2 && pid > 0 && kill(pid, 0) != 0 && errno == ESRCH)
+            shm_unlink((std::string("/") + e->d_name).c_str());
+    }
+    closedir(d);
+}
 void* shared_alloc(size_t bytes) {
     static int counter = 0;
     static bool hooked = false;
-    if (!hooked) { hooked = true; atexit(shared_cleanup); }
+    if (!hooked) { hooked = true; atexit(shared_cleanup); shared_gc(); }
     char name[48];
     snprintf(name, sizeof name, "/hipemu.%d.%d", (int)getpid(), counter++);
     const int fd = shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600);
