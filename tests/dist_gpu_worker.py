@@ -37,8 +37,9 @@ def main():
         import plasticinelab_amd.engine.mpm_simulator as ms
         ms.Engine = emul_engine.HostEngine
         # (peer writes work here too: the receive areas are POSIX shared memory behind the shim's hipIpc calls; the exchange folded into
-        # the grid kernels does not -- its workgroups wait for each other, and the interpreter runs them one after another)
-        assert backend == "gloo" and os.environ.get("PLMPM_PEER_FUSED", "0") in ("", "0"), "the interpreter: gloo control plane, no fused exchange"
+        # the grid kernels needs its workgroups resident at once: PLMPM_EMUL_THREADS > 1, one OS thread per grid workgroup)
+        assert backend == "gloo", "the interpreter: gloo control plane"
+        assert os.environ.get("PLMPM_PEER_FUSED", "0") in ("", "0") or int(os.environ.get("PLMPM_EMUL_THREADS", "1")) > 1, "fused exchange: set PLMPM_EMUL_THREADS"
     dev = rank % torch.cuda.device_count() if backend == "nccl" else 0
     if not interpreter:
         torch.cuda.set_device(dev)

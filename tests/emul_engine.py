@@ -55,9 +55,11 @@ def lib():
 
 class HostEngine(Engine):
     def __init__(self, **kw):
-        # a handful of persistent grid workgroups instead of the GPU's 512: every workgroup of a launch is 256 fiber start-ups here
-        if not kw.get("grid_workgroups"):
-            kw["grid_workgroups"] = int(os.environ.get("PLMPM_EMUL_GRID_WG", 8))
+        # a handful of persistent grid workgroups instead of the GPU's 512 (every workgroup of a launch is 256 fiber start-ups here), and
+        # never more than the interpreter keeps resident at once (PLMPM_EMUL_THREADS: one OS thread per workgroup up to 16 -- the
+        # exchange folded into the grid kernels waits inside the launch for workgroups of the same launch)
+        cap = int(os.environ.get("PLMPM_EMUL_GRID_WG", 8))
+        kw["grid_workgroups"] = min(int(kw.get("grid_workgroups") or cap), cap)
         super().__init__(**kw)
 
     def _load_library(self):

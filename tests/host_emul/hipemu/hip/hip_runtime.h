@@ -7,8 +7,10 @@
 // tests/host_emul/libplmpm_emul.so); tests select that library explicitly (tests/emul_engine.py).  It is orders of magnitude
 // slower than the GPU and is not a fallback: plasticinelab_amd/_lib.py only ever loads the hipcc build.
 //
-// Execution model: a launch runs its workgroups one after another; the threads of a workgroup are fibers (one small stack
-// each) scheduled round-robin on the calling thread.  A fiber runs until it reaches a synchronisation point:
+// Execution model: a launch runs its workgroups one after another (PLMPM_EMUL_THREADS=n: on n OS threads at once, and ALL of them at
+// once -- one OS thread per workgroup -- when the launch has at most 16: kernels whose workgroups wait for each other, the halo
+// exchange folded into the grid kernels, need every workgroup resident); the threads of a workgroup are fibers (one small stack
+// each) scheduled round-robin on the workgroup's OS thread.  A fiber runs until it reaches a synchronisation point:
 //   * __syncthreads / s_barrier: waits for every thread of the workgroup that has not returned yet;
 //   * a wave-level operation (DPP move, shuffle, ballot, readlane): the 64 lanes of the wave deposit their operand, wait for
 //     each other, and read their partners' -- lock-step semantics of a 64-wide wavefront with the exec mask = lanes that have
@@ -19,8 +21,8 @@
 // wave-wide in between, behaves differently here (k_clear_active did: lane 0 cleared the block flag the other 63 lanes were about
 // to test; it now takes the flag through v_readfirstlane).
 // DPP controls (quad_perm, row_shl / shr / ror, row_bcast15 / 31, row_mirror, row / bank masks, bound_ctrl) follow the CDNA3/4
-// ISA manual.  Atomics are plain read-modify-writes (one OS thread).  `__shared__` is storage shared by the fibers of the
-// running workgroup.  Inline assembly cannot be interpreted: the few asm helpers of plmpm_kernels.h have host definitions here
+// ISA manual.  Atomics are real atomics (workgroups on several OS threads, ranks in several processes).  `__shared__` is storage
+// shared by the fibers of the running workgroup (per OS thread).  Inline assembly cannot be interpreted: the few asm helpers of plmpm_kernels.h have host definitions here
 // (PLB_HOST_EMUL), and the fused v_fmac_f32_dpp forms fall back to their generic C++ templates (same sums, mul + add).
 #pragma once
 #ifndef PLB_HOST_EMUL
@@ -40,7 +42,9 @@
 #define __device__
 #define __host__
 #define __forceinline__ inline
-#define __shared__ static
+// LDS: storage shared by the fibers of the running workgroup -- per OS thread, because with PLMPM_EMUL_THREADS the workgroups of a launch
+// run on several OS threads at once (each thread one workgroup at a time)
+#define __shared__ static thread_local
 #define __launch_bounds__(...)
 // dynamic LDS (plmpm_kernels.h: PLB_DYN_LDS): one static arena
 #define PLB_DYN_LDS(type, name) type* name = reinterpret_cast<type*>(hipemu::dyn_lds_arena())
@@ -120,8 +124,9 @@ struct Fiber {
     bool done;
     void* asan_fake;          // AddressSanitizer builds: the fiber's fake-stack handle while it is switched out
 };
-extern Fiber* cur;            // the running fiber
-extern Idx g_block, g_bdim, g_gdim;
+extern thread_local Fiber* cur;       // the running fiber (one OS thread runs one workgroup at a time)
+extern thread_local Idx g_block;
+extern Idx g_bdim, g_gdim;
 void* dyn_lds_arena();
 
 // what the 64 lanes of the calling wave passed to this operation, and which of them are still alive
@@ -213,17 +218,24 @@ inline float __expf(float x) { return expf(x); }
 inline long long wall_clock64() { return (long long)(hipemu::now_ms() * 1e5); }        // 100 MHz
 inline long long clock64() { return wall_clock64(); }
 
-// ---- atomics: one OS thread, fibers only switch at synchronisation points -> plain read-modify-write
-template <class T> inline T hipemu_fetch_add(T* p, T v) { T o = *p; *p = o + v; return o; }
-inline float atomicAdd(float* p, float v) { return hipemu_fetch_add(p, v); }
-inline double atomicAdd(double* p, double v) { return hipemu_fetch_add(p, v); }
-inline int atomicAdd(int* p, int v) { return hipemu_fetch_add(p, v); }
-inline unsigned atomicAdd(unsigned* p, unsigned v) { return hipemu_fetch_add(p, v); }
-inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v) { return hipemu_fetch_add(p, v); }
-inline int atomicOr(int* p, int v) { int o = *p; *p = o | v; return o; }
-inline unsigned atomicOr(unsigned* p, unsigned v) { unsigned o = *p; *p = o | v; return o; }
-template <class T> inline T atomicMax(T* p, T v) { T o = *p; if (v > o) *p = v; return o; }
-template <class T> inline T atomicMin(T* p, T v) { T o = *p; if (v < o) *p = v; return o; }
+// ---- atomics: real ones (workgroups may run on several OS threads, ranks in several processes)
+template <class T> inline T hipemu_fetch_op(T* p, T v, T (*op)(T, T)) {
+    T o;
+    __atomic_load(p, &o, __ATOMIC_RELAXED);
+    for (;;) {
+        T n = op(o, v);
+        if (__atomic_compare_exchange(p, &o, &n, false, __ATOMIC_SEQ_CST, __ATOMIC_RELAXED)) return o;
+    }
+}
+inline float atomicAdd(float* p, float v) { return hipemu_fetch_op<float>(p, v, [](float a, float b) { return a + b; }); }
+inline double atomicAdd(double* p, double v) { return hipemu_fetch_op<double>(p, v, [](double a, double b) { return a + b; }); }
+inline int atomicAdd(int* p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
+inline unsigned atomicAdd(unsigned* p, unsigned v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
+inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
+inline int atomicOr(int* p, int v) { return __atomic_fetch_or(p, v, __ATOMIC_SEQ_CST); }
+inline unsigned atomicOr(unsigned* p, unsigned v) { return __atomic_fetch_or(p, v, __ATOMIC_SEQ_CST); }
+template <class T> inline T atomicMax(T* p, T v) { return hipemu_fetch_op<T>(p, v, [](T a, T b) { return b > a ? b : a; }); }
+template <class T> inline T atomicMin(T* p, T v) { return hipemu_fetch_op<T>(p, v, [](T a, T b) { return b < a ? b : a; }); }
 #define __HIP_MEMORY_SCOPE_SINGLETHREAD 1
 #define __HIP_MEMORY_SCOPE_WAVEFRONT 2
 #define __HIP_MEMORY_SCOPE_WORKGROUP 3

@@ -10,8 +10,12 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <atomic>
+#include <condition_variable>
 #include <map>
+#include <mutex>
 #include <string>
+#include <thread>
 
 #include <numeric>
 #include <vector>
@@ -54,15 +58,17 @@ hipemu_switch:
 
 namespace hipemu {
 
-Fiber* cur = nullptr;
-Idx g_block = {0, 0, 0}, g_bdim = {1, 1, 1}, g_gdim = {1, 1, 1};
+thread_local Fiber* cur = nullptr;
+thread_local Idx g_block = {0, 0, 0};
+Idx g_bdim = {1, 1, 1}, g_gdim = {1, 1, 1};
 
 static constexpr int kMaxThreads = 1024;
 static constexpr size_t kStack = 256u << 10;
-static char* g_stacks = nullptr;
-static Fiber g_fib[kMaxThreads];
-static void* g_main_sp = nullptr;
-static unsigned long g_progress = 0;
+// scheduler state of the workgroup an OS thread is running
+static thread_local char* g_stacks = nullptr;
+static thread_local Fiber g_fib[kMaxThreads];
+static thread_local void* g_main_sp = nullptr;
+static thread_local unsigned long g_progress = 0;
 static void (*g_thunk)(void*) = nullptr;
 static void* g_ctx = nullptr;
 
@@ -73,9 +79,9 @@ struct Wave {
     uint64_t buf[2][64];
     unsigned op[64];
 };
-static Wave g_wave[kMaxThreads / 64];
-static int g_blk_live, g_blk_arrived;
-static unsigned g_blk_gen;
+static thread_local Wave g_wave[kMaxThreads / 64];
+static thread_local int g_blk_live, g_blk_arrived;
+static thread_local unsigned g_blk_gen;
 
 // ---- memory another process can map (hipExtMallocWithFlags + hipIpc*): POSIX shared memory, the handle = its name and size
 struct Shared { std::string name; size_t bytes; bool mine; };
@@ -140,7 +146,7 @@ void shared_close(void* p) {
 }
 
 void* dyn_lds_arena() {
-    static double arena[8192];           // 64 KiB
+    static thread_local double arena[8192];           // 64 KiB
     return arena;
 }
 double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
@@ -183,9 +189,9 @@ void device_memset(void* p, int v, size_t n) {
     abort();
 }
 #if HIPEMU_ASAN
-static void* g_main_fake = nullptr;
-static const void* g_main_lo = nullptr;
-static size_t g_main_size = 0;
+static thread_local void* g_main_fake = nullptr;
+static thread_local const void* g_main_lo = nullptr;
+static thread_local size_t g_main_size = 0;
 #endif
 // fiber -> scheduler
 static inline void yield() {
@@ -288,23 +294,107 @@ static void fiber_entry() {
     fiber_exit();
 }
 
+// one workgroup, start to finish, on the calling OS thread
+static void run_workgroup(unsigned lin, dim3 grid, dim3 block, int nt, long shuffle, unsigned long long& rng) {
+    if (!g_stacks) {
+        g_stacks = (char*)mmap(nullptr, kStack * kMaxThreads, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+        if (g_stacks == (char*)MAP_FAILED) die("mmap of the fiber stacks");
+    }
+    const int nw = (nt + 63) / 64;
+    g_block = {lin % grid.x, (lin / grid.x) % grid.y, lin / (grid.x * grid.y)};
+    for (int w = 0; w < nw; ++w) { g_wave[w].live = 0; g_wave[w].arrived = 0; g_wave[w].gen = 0; g_wave[w].live_mask = 0; }
+    g_blk_live = nt; g_blk_arrived = 0; g_blk_gen = 0;
+    for (int t = 0; t < nt; ++t) {
+        Fiber& f = g_fib[t];
+        f.tid = {(unsigned)t % block.x, ((unsigned)t / block.x) % block.y, (unsigned)t / (block.x * block.y)};
+        f.wave = t >> 6; f.lane = t & 63; f.done = false; f.asan_fake = nullptr;
+        Wave& w = g_wave[f.wave];
+        ++w.live; w.live_mask |= 1ULL << f.lane;
+        // initial frame: six callee-saved registers, the entry point as the return address, a null return address above it
+        // (16-byte alignment of a freshly called function: rsp = 16 k + 8 at its first instruction)
+        // (the tops are staggered: 256 stacks at a power-of-two stride would put every fiber's hot frames into the same cache sets)
+        uintptr_t top = ((uintptr_t)g_stacks + (size_t)(t + 1) * kStack - (size_t)((t * 2368) & 0xffff)) & ~(uintptr_t)15;
+        void** sp = (void**)top;
+        *--sp = nullptr;
+        *--sp = (void*)&fiber_entry;
+        for (int k = 0; k < 6; ++k) *--sp = nullptr;
+        f.sp = sp;
+    }
+    int alive = nt;
+    while (alive > 0) {
+        const unsigned long before = g_progress;
+        alive = 0;
+        int t0 = 0;
+        if (shuffle) { rng = rng * 6364136223846793005ULL + 1442695040888963407ULL; t0 = (int)((rng >> 33) % (unsigned)nt); }
+        for (int k = 0; k < nt; ++k) {
+            const int t = shuffle ? (t0 + ((rng >> 20) & 1 ? k : nt - 1 - k) + nt) % nt : k;
+            Fiber& f = g_fib[t];
+            if (f.done) continue;
+            resume(f, t);
+            if (!f.done) ++alive;
+        }
+        if (alive > 0 && g_progress == before) {
+            for (int t = 0; t < nt; ++t) if (!g_fib[t].done) { cur = &g_fib[t]; break; }
+            die("deadlock: no thread of the workgroup can make progress (a barrier or wave operation not reached by all live threads, or a "
+                "spin-wait without s_sleep on another workgroup)");
+        }
+    }
+    cur = nullptr;
+}
+
+// PLMPM_EMUL_THREADS=n: a pool of OS threads runs the workgroups of a launch, each thread one workgroup at a time (its own fibers,
+// its own LDS).  Launches of at most kResident workgroups get one thread PER workgroup: all of them are resident, as the kernels that
+// wait for other workgroups of their launch require.
+static constexpr size_t kResident = 16;
+struct Pool {
+    std::mutex m;
+    std::condition_variable cv_go, cv_done;
+    std::vector<std::thread> threads;
+    unsigned long generation = 0;
+    size_t want = 0, busy = 0;                 // threads that should take part in the current launch / that are still in it
+    std::atomic<size_t> next{0};
+    // the current launch
+    dim3 grid, block;
+    int nt = 0;
+    long shuffle = 0;
+    const unsigned* order = nullptr;
+    size_t nwg = 0;
+    bool stop = false;
+};
+static Pool* g_pool = nullptr;
+static void pool_worker(Pool* P, size_t index) {
+    unsigned long seen = 0;
+    unsigned long long rng = 0x9e3779b97f4a7c15ULL * (index + 2);
+    for (;;) {
+        {
+            std::unique_lock<std::mutex> lk(P->m);
+            P->cv_go.wait(lk, [&] { return P->stop || (P->generation != seen && index < P->want); });
+            if (P->stop) return;
+            seen = P->generation;
+        }
+        for (;;) {
+            const size_t i = P->next.fetch_add(1);
+            if (i >= P->nwg) break;
+            run_workgroup(P->order[i], P->grid, P->block, P->nt, P->shuffle, rng);
+        }
+        std::lock_guard<std::mutex> lk(P->m);
+        if (--P->busy == 0) P->cv_done.notify_all();
+    }
+}
+
 void run_grid(dim3 grid, dim3 block, size_t lds, void (*thunk)(void*), void* ctx) {
     const int nt = (int)(block.x * block.y * block.z);
     if (nt <= 0 || nt > kMaxThreads) die("workgroup size");
     if (lds > 8192 * sizeof(double)) die("dynamic LDS larger than the arena");
     if (cur) die("nested launch");
-    if (!g_stacks) {
-        g_stacks = (char*)mmap(nullptr, kStack * kMaxThreads, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
-        if (g_stacks == (char*)MAP_FAILED) die("mmap of the fiber stacks");
-    }
     g_thunk = thunk; g_ctx = ctx;
     g_bdim = {block.x, block.y, block.z};
     g_gdim = {grid.x, grid.y, grid.z};
-    const int nw = (nt + 63) / 64;
     // PLMPM_EMUL_SHUFFLE=<seed>: the workgroups of every launch in a pseudo-random order, and the threads of a workgroup resumed in a
     // pseudo-random rotation that changes with every scheduling round -- nothing in the kernels may depend on which workgroup's atomics
     // arrive first or on which lane of a wave runs ahead (beyond the round-off of the floating-point sums)
     static const long shuffle = getenv("PLMPM_EMUL_SHUFFLE") ? atol(getenv("PLMPM_EMUL_SHUFFLE")) + 1 : 0;
+    static const long nthreads = getenv("PLMPM_EMUL_THREADS") ? atol(getenv("PLMPM_EMUL_THREADS")) : 1;
     static unsigned long long rng = 0x9e3779b97f4a7c15ULL;
     const size_t nwg = (size_t)grid.x * grid.y * grid.z;
     std::vector<unsigned> order(nwg);
@@ -316,48 +406,21 @@ void run_grid(dim3 grid, dim3 block, size_t lds, void (*thunk)(void*), void* ctx
             std::swap(order[i - 1], order[(size_t)((rng >> 33) % i)]);
         }
     }
-    for (size_t wgi = 0; wgi < nwg; ++wgi) {
-        const unsigned lin = order[wgi], bx = lin % grid.x, by = (lin / grid.x) % grid.y, bz = lin / (grid.x * grid.y);
-        g_block = {bx, by, bz};
-        for (int w = 0; w < nw; ++w) { g_wave[w].live = 0; g_wave[w].arrived = 0; g_wave[w].gen = 0; g_wave[w].live_mask = 0; }
-        g_blk_live = nt; g_blk_arrived = 0; g_blk_gen = 0;
-        for (int t = 0; t < nt; ++t) {
-            Fiber& f = g_fib[t];
-            f.tid = {(unsigned)t % block.x, ((unsigned)t / block.x) % block.y, (unsigned)t / (block.x * block.y)};
-            f.wave = t >> 6; f.lane = t & 63; f.done = false; f.asan_fake = nullptr;
-            Wave& w = g_wave[f.wave];
-            ++w.live; w.live_mask |= 1ULL << f.lane;
-            // initial frame: six callee-saved registers, the entry point as the return address, a null return address above it
-            // (16-byte alignment of a freshly called function: rsp = 16 k + 8 at its first instruction)
-            // (the tops are staggered: 256 stacks at a power-of-two stride would put every fiber's hot frames into the same cache sets)
-            uintptr_t top = ((uintptr_t)g_stacks + (size_t)(t + 1) * kStack - (size_t)((t * 2368) & 0xffff)) & ~(uintptr_t)15;
-            void** sp = (void**)top;
-            *--sp = nullptr;
-            *--sp = (void*)&fiber_entry;
-            for (int k = 0; k < 6; ++k) *--sp = nullptr;
-            f.sp = sp;
-        }
-        int alive = nt;
-        while (alive > 0) {
-            const unsigned long before = g_progress;
-            alive = 0;
-            int t0 = 0;
-            if (shuffle) { rng = rng * 6364136223846793005ULL + 1442695040888963407ULL; t0 = (int)((rng >> 33) % (unsigned)nt); }
-            for (int k = 0; k < nt; ++k) {
-                const int t = shuffle ? (t0 + ((rng >> 20) & 1 ? k : nt - 1 - k) + nt) % nt : k;
-                Fiber& f = g_fib[t];
-                if (f.done) continue;
-                resume(f, t);
-                if (!f.done) ++alive;
-            }
-            if (alive > 0 && g_progress == before) {
-                for (int t = 0; t < nt; ++t) if (!g_fib[t].done) { cur = &g_fib[t]; break; }
-                die("deadlock: no thread of the workgroup can make progress (a barrier or wave operation not reached by all live threads, or a "
-                    "spin-wait on another workgroup -- workgroups run one after another here)");
-            }
-        }
-        cur = nullptr;
+    if (nthreads <= 1 || nwg <= 1) {
+        for (size_t i = 0; i < nwg; ++i) run_workgroup(order[i], grid, block, nt, shuffle, rng);
+        return;
     }
+    if (!g_pool) g_pool = new Pool;             // (never destroyed: its threads sleep until the process ends)
+    Pool* P = g_pool;
+    const size_t want = nwg <= kResident ? nwg : std::min<size_t>((size_t)nthreads, nwg);
+    std::unique_lock<std::mutex> lk(P->m);
+    while (P->threads.size() < want) { const size_t idx = P->threads.size(); P->threads.emplace_back(pool_worker, P, idx); }
+    P->grid = grid; P->block = block; P->nt = nt; P->shuffle = shuffle; P->order = order.data(); P->nwg = nwg;
+    P->next.store(0);
+    P->want = want; P->busy = want;
+    ++P->generation;
+    P->cv_go.notify_all();
+    P->cv_done.wait(lk, [&] { return P->busy == 0; });
 }
 }  // namespace hipemu
 

@@ -36,6 +36,10 @@ CASES = {
     # without a single particle steps and differentiates
     "peer_writes": ("tests/test_gpu_distributed.py", "test_peer_write_halos_match_golden_rollout and False", {"PLMPM_PEER_TIMEOUT": "120"}, 2),
     "peer_edge_cases": ("tests/test_gpu_distributed.py", "peer_exchange_wait_is_bounded or rank_without_particles or leaving_the_grid", {}, 4),
+    # ... and the exchange FOLDED INTO the grid kernels (PLMPM_PEER_FUSED=1: send | interior blocks | wait inside the launch | exchanged
+    # planes): its workgroups wait for each other, so the interpreter runs them on OS threads of their own (PLMPM_EMUL_THREADS)
+    "fused_exchange": ("tests/test_gpu_distributed.py", "(test_peer_write_halos_match_golden_rollout and True and float32) or test_fused_exchange_wait_is_bounded_too",
+                       {"PLMPM_EMUL_THREADS": "4", "PLMPM_PEER_TIMEOUT": "120"}, 2),
     # compile-time variants of the device source (tests/emul_engine.py: VARIANTS)
     "variant_pkbuf": ("tests/test_emul_substep.py", None, {"PLMPM_EMUL_VARIANT": "pkbuf"}, 4),
     # sanitizers over the device source: substep forward + adjoint, and the ragged / one-cell / wall cases (where an index would go wrong)

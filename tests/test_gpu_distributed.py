@@ -351,7 +351,8 @@ def test_fused_exchange_wait_is_bounded_too(monkeypatch):
         env.step(bench.seeded_actions(1, 6)[0])
         eng._check()
     assert 0.25 < time.time() - t0 < 30                              # one timeout, not one per substep
-    torch.cuda.synchronize()                                          # the GPU is still there
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()                                      # the GPU is still there
     st = eng.peer_status()
     assert st & 1 and (st >> 16) == eng.HALO_GRID_IN
 
