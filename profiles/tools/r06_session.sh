@@ -49,6 +49,9 @@ for k in sorted(out, key=lambda k: -out[k].get("SQ_WAVE_CYCLES", 0) * out[k]["ca
     print(k, json.dumps({c: round(x, 1) for c, x in out[k].items()}))
 PY
 cat $O/stall_summary.txt
+# the file bench.py's roofline.valu reads: the table of step 1 x the instruction mix just collected (copy it to profiles/ to commit it)
+python profiles/tools/valu_calibration.py $O/valu_calibration.txt $O/stall_pmc.json --workload config3_cube128 --dtype f32 --out $O/r06_valu_calibration.json > $O/valu_calibration_summary.txt 2>&1
+cat $O/valu_calibration_summary.txt
 tail -3 $O/s1.err $O/s2.err $O/s3.err $O/s4.err $O/s5.err
 # ---- kernel A/B of the prepared variants on bit-identical inputs, then the headline, then parity of the variants
 cd $R

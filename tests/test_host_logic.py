@@ -393,3 +393,42 @@ def test_bench_valu_roof_arithmetic(tmp_path, monkeypatch):
     assert bench.valu_roof(kernels, 512_000, "cube256_2000000p", "f32", 10) is None        # another workload: no stale constant
     monkeypatch.setattr(bench, "VALU_FILE", str(tmp_path / "missing.json"))
     assert bench.valu_roof(kernels, 512_000, "config3_cube128", "f32", 10) is None
+
+
+def test_valu_calibration_tool_feeds_the_bench_line(tmp_path, monkeypatch):
+    """profiles/tools/valu_calibration.py: the microbenchmark's table + the per-kernel SQ_INSTS_VALU_* counters -> the JSON bench.py's
+    roofline.valu reads.  Synthetic inputs in the formats the GPU session writes (profiles/tools/r06_session.sh): the parse, the
+    class -> stream pricing, the per-wave mix, the kernel-name mapping and the hand-off to bench.valu_roof."""
+    import json
+    import os
+    import sys
+    from tests.util import ROOT
+    sys.path.insert(0, os.path.join(ROOT, "profiles", "tools"))
+    import bench
+    import valu_calibration as vc
+
+    def row(name, *cyc):
+        return f"{name:<58s}" + "".join(f"  W={w}: {c:5.2f} cyc @{1.93:4.2f} GHz" for w, c in zip((1, 2, 4, 8), cyc)) + "\n"
+
+    names = [s for _c, streams in vc.CLASSES.values() for s in streams] + vc.DEFAULT_STREAMS
+    text = "# gfx950, 256 CUs; header line\n" + "".join(row(n, 5.7, 4.2, 4.0 if "fma_f32" in n else 2.0, 4.0) for n in dict.fromkeys(names))
+    table = vc.parse_table(text)
+    assert len(table) == len(set(names)) and table["v_mul_f32 d,d,m"][4] == (2.0, 1.93) and table["v_rcp_f32"][1] == (5.7, 1.93)
+    waves = 7813.0
+    pmc = {"k_g2p_p2g<float, false>": {"calls": 10, "SQ_WAVES": waves, "SQ_INSTS_VALU": 3000 * waves, "SQ_INSTS_VALU_FMA_F32": 1000 * waves,
+                                        "SQ_INSTS_VALU_MUL_F32": 400 * waves, "SQ_INSTS_VALU_INT32": 600 * waves, "SQ_INSTS_VALU_CVT": 70 * waves},
+           "k_g2p_p2g<double, false>": {"calls": 10, "SQ_WAVES": waves, "SQ_INSTS_VALU": 1.0},
+           "k_grid_op<float, false>": {"calls": 10, "SQ_WAVES": 2048.0, "SQ_INSTS_VALU": 2048.0 * 900, "SQ_INSTS_VALU_FMA_F64": 2048.0 * 500},
+           "__amd_rocclr_copyBuffer": {"calls": 3, "SQ_WAVES": 10.0, "SQ_INSTS_VALU": 100.0}}
+    cal = vc.build(table, pmc, "config3_cube128", "f32", 4, "synthetic")
+    assert set(cal["kernels"]) == {"g2p_p2g", "grid_op"} and abs(cal["clock_ghz"] - 1.93) < 1e-12
+    mix = cal["kernels"]["g2p_p2g"]["mix_per_wave"]
+    assert abs(mix["fma_f32"] - 1000) < 1e-9 and abs(mix["other"] - (3000 - 1000 - 400 - 600 - 70)) < 1e-9
+    assert cal["cycles_per_wave_instruction"]["fma_f32"] == 4.0 and cal["cycles_per_wave_instruction"]["mul_f32"] == 2.0
+    f = tmp_path / "cal.json"
+    f.write_text(json.dumps(cal))
+    monkeypatch.setattr(bench, "VALU_FILE", str(f))
+    r = bench.valu_roof({"g2p_p2g": {"avg_us": 50.0, "launches": 38}, "grid_op": {"avg_us": 7.0, "launches": 39}}, 500_000, "config3_cube128", "f32", 39)
+    cycles = 1000 * 4.0 + (3000 - 1000) * 2.0                   # every other class and the default are 2.0 in the synthetic table
+    want = (waves / 1024) * cycles / (1.93e3)
+    assert abs(r["kernels"]["g2p_p2g"]["issue_us"] - want) < 1e-9 and 0 < r["frac"] < 1
