@@ -25,16 +25,15 @@ CASES = {
     "rollout_f32_soft": ("tests/test_gpu_rollout.py", "test_small_rollout_matches_oracle and float32 and soft", {}, 1),
     "loss": ("tests/test_gpu_loss.py", "float32-True or float64-False", {}, 2),
     "semantics": ("tests/test_gpu_semantics.py", "tie_routing", {}, 2),
-    "shapes": ("tests/test_gpu_shapes.py", "f32 and (chopsticks or scene_Rope or box_soft)", {}, 3),
-    "shapes_2": ("tests/test_gpu_shapes.py", "f32 and (rollingpin or torus_hard)", {}, 2),
+    "shapes": ("tests/test_gpu_shapes.py", "f32 and (chopsticks or scene_Rope or torus_hard)", {}, 3),
     "deterministic": ("tests/test_gpu_deterministic.py", "test_small_deterministic_rollout and float32", {}, 1),
     "checkpointed": ("tests/test_gpu_rollout.py", "test_checkpointed_gradient_equals_tape_gradient and float32", {}, 1),
     # z-slab ranks over gloo (one process per rank, host-staged halos, migration): the real kernels behind SlabEngine, against the golden rollout
-    "slab_ranks": ("tests/test_gpu_distributed.py", "(test_slab_ranks_match_golden_rollout or test_overlapped_exchange) and float32", {}, 2),
+    "slab_ranks": ("tests/test_gpu_distributed.py", "(test_slab_ranks_match_golden_rollout or test_overlapped_exchange) and float32", {"PLMPM_EMUL_THREADS": "2"}, 2),
     # the device-side halo exchange -- peer writes into IPC-mapped receive areas (POSIX shared memory behind the shim's hipIpc calls),
     # arrival counters, native substep loops -- between ranks that are separate processes; a silent neighbour times out; a rank
     # without a single particle steps and differentiates
-    "peer_writes": ("tests/test_gpu_distributed.py", "test_peer_write_halos_match_golden_rollout and False", {"PLMPM_PEER_TIMEOUT": "120"}, 2),
+    "peer_writes": ("tests/test_gpu_distributed.py", "test_peer_write_halos_match_golden_rollout and False and float64", {"PLMPM_PEER_TIMEOUT": "120"}, 1),
     "peer_edge_cases": ("tests/test_gpu_distributed.py", "peer_exchange_wait_is_bounded or rank_without_particles or leaving_the_grid", {}, 4),
     # ... and the exchange FOLDED INTO the grid kernels (PLMPM_PEER_FUSED=1: send | interior blocks | wait inside the launch | exchanged
     # planes): its workgroups wait for each other, so the interpreter runs them on OS threads of their own (PLMPM_EMUL_THREADS)
@@ -65,8 +64,20 @@ def results():
     from tests import emul_engine
     for variant in sorted({c[2].get("PLMPM_EMUL_VARIANT", "") for c in CASES.values()}):
         emul_engine.build(variant)                       # (once, before the cases race for the same make)
-    with ThreadPoolExecutor(max_workers=min(6, os.cpu_count() or 2)) as pool:
-        return dict(zip(CASES, pool.map(_run, CASES)))
+    with ThreadPoolExecutor(max_workers=min(7, os.cpu_count() or 2)) as pool:
+        # (the two jobs that are not pytest runs -- bench.py at one and two ranks, the digests of the deterministic engine -- side by
+        # side with the cases: they are what the tier would otherwise wait for at the end)
+        extra = {"bench": pool.submit(_guard, _bench_lines), "digests": pool.submit(_guard, _digests)}
+        out = dict(zip(CASES, pool.map(_run, CASES)))
+        out.update({k: f.result() for k, f in extra.items()})
+        return out
+
+
+def _guard(fn):
+    try:
+        return fn()
+    except BaseException as e:          # noqa: BLE001 -- reported by the test that reads the result
+        return e
 
 
 @pytest.mark.parametrize("name", list(CASES))
@@ -77,11 +88,7 @@ def test_gpu_tier_case_on_the_interpreter(results, name):
     assert rc == 0 and m and int(m.group(1)) >= CASES[name][3] and " failed" not in log and " skipped" not in log, log[-3000:]
 
 
-def test_deterministic_engine_is_independent_of_the_execution_order():
-    """What cfg.deterministic promises -- the same BITS whatever order the workgroups' and lanes' contributions arrive in -- checked
-    where the order can be CHOSEN: the interpreter runs the workgroups of every launch, and the threads of every workgroup, in a
-    pseudo-random order (PLMPM_EMUL_SHUFFLE).  Three orders of the 3-step golden rollout, forward and reverse, on the integer-limb
-    engine: one digest.  The floating-point-atomics engine under two orders: two digests (the shuffle really reorders the sums)."""
+def _digests():
     import re
 
     def digest(det, seed):
@@ -94,25 +101,25 @@ def test_deterministic_engine_is_independent_of_the_execution_order():
         assert p.returncode == 0 and m and float(m.group(2)) < 1e-5, p.stdout.decode(errors="replace")[-2000:]
         return m.group(1)
 
-    from tests import emul_engine
-    emul_engine.build("")
-    with ThreadPoolExecutor(max_workers=5) as pool:
-        d = list(pool.map(lambda a: digest(*a), [("1", ""), ("1", "1"), ("1", "2"), ("0", ""), ("0", "1")]))
+    with ThreadPoolExecutor(max_workers=3) as pool:
+        return list(pool.map(lambda a: digest(*a), [("1", ""), ("1", "1"), ("1", "2"), ("0", ""), ("0", "1")]))
+
+
+def test_deterministic_engine_is_independent_of_the_execution_order(results):
+    """What cfg.deterministic promises -- the same BITS whatever order the workgroups' and lanes' contributions arrive in -- checked
+    where the order can be CHOSEN: the interpreter runs the workgroups of every launch, and the threads of every workgroup, in a
+    pseudo-random order (PLMPM_EMUL_SHUFFLE).  Three orders of the 3-step golden rollout, forward and reverse, on the integer-limb
+    engine: one digest.  The floating-point-atomics engine under two orders: two digests (the shuffle really reorders the sums)."""
+    d = results["digests"]
+    if isinstance(d, BaseException):
+        raise d
     assert d[0] == d[1] == d[2], d
     assert d[3] != d[4], "the shuffled order did not change the floating-point sums: is PLMPM_EMUL_SHUFFLE read?"
 
 
-def test_bench_py_runs_at_one_and_two_ranks():
-    """bench.py is what the driver runs unattended when the round ends; round 6 changed it (vector-ALU roof, same-box N = 1 references,
-    first-contact preflight) without a GPU to run it on.  Here its own control flow runs on the interpreter (tests/bench_on_interpreter.py:
-    the nine torch.cuda calls of its World patched, nothing else) at a size that takes seconds: `--gpus 1`, and `--gpus 2` exactly as the
-    driver launches it (torch.distributed.run, one process per rank; gloo + peer-write halos through shared memory).  Checked: ONE JSON
-    line each with the contract's keys, the two-slab run is the same workload ("strong") and ends with the single-rank loss, the transport
-    check compared the device-side exchange with the library transport, the preflight has one record per rank.  Not checked: any number."""
+def _bench_lines():
     import json
     import socket
-    from tests import emul_engine
-    emul_engine.build("")
     common = ["--particles", "4000", "--quality", "1", "--steps", "1", "--warmup", "0", "--repeats", "2", "--no-cpu-baseline", "--no-secondary"]
     wrapper = os.path.join(ROOT, "tests", "bench_on_interpreter.py")
     with socket.socket() as sk:
@@ -131,7 +138,19 @@ def test_bench_py_runs_at_one_and_two_ranks():
         return json.loads(lines[0])
 
     with ThreadPoolExecutor(max_workers=2) as pool:
-        one, two = pool.map(run, cmds)
+        return list(pool.map(run, cmds))
+
+
+def test_bench_py_runs_at_one_and_two_ranks(results):
+    """bench.py is what the driver runs unattended when the round ends; round 6 changed it (vector-ALU roof, same-box N = 1 references,
+    first-contact preflight) without a GPU to run it on.  Here its own control flow runs on the interpreter (tests/bench_on_interpreter.py:
+    the nine torch.cuda calls of its World patched, nothing else) at a size that takes seconds: `--gpus 1`, and `--gpus 2` exactly as the
+    driver launches it (torch.distributed.run, one process per rank; gloo + peer-write halos through shared memory).  Checked: ONE JSON
+    line each with the contract's keys, the two-slab run is the same workload ("strong") and ends with the single-rank loss, the transport
+    check compared the device-side exchange with the library transport, the preflight has one record per rank.  Not checked: any number."""
+    if isinstance(results["bench"], BaseException):
+        raise results["bench"]
+    one, two = results["bench"]
     keys = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
             "roofline", "phases_s", "repeats", "value_min", "value_max", "repeat_ms_per_step", "final_loss", "loss_check")
     for d, n in ((one, 1), (two, 2)):
