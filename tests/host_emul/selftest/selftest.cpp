@@ -115,7 +115,7 @@ int main(int argc, char** argv) {
         }
     }
 
-    const int n = 1000 * 256 - 77, nwg = 1000;
+    const int n = 200 * 256 - 77, nwg = 200;
     hipMemset(out, 0, 16);
     hipLaunchKernelGGL(k_block, dim3(nwg), dim3(256), 0, nullptr, out, n);
     CHECK(out[0] == n, "block sums: %d, want %d", out[0], n);

@@ -26,7 +26,7 @@ def test_mass_and_momentum_conservation(rolled, dtype):  # noqa: F811
 def test_interpreter_selftest():
     """The interpreter itself against results stated by hand (tests/host_emul/selftest/selftest.cpp): every DPP control the product kernels
     use (quad_perm, row_shl / shr / ror, row_bcast:15 / :31, mirror, row and bank masks, bound_ctrl), shuffles, ballot / readlane /
-    readfirstlane / any / all with part of the wave returned, barrier + LDS, integer and float atomics from 1 000 workgroups -- run
+    readfirstlane / any / all with part of the wave returned, barrier + LDS, integer and float atomics from 200 workgroups -- run
     sequentially, on 8 OS threads and in a shuffled order -- and the two aborts: lanes of one wave at different wave operations, and
     a barrier that can never complete."""
     import os
