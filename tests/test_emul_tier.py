@@ -56,7 +56,13 @@ def _run(name):
         env.update(LD_PRELOAD=asan, ASAN_OPTIONS="detect_leaks=0")          # (the interpreter is not leak-checked: python itself "leaks")
     cmd = [sys.executable, "-m", "pytest", path, "-q", "-x", "-p", "no:cacheprovider"] + (["-k", expr] if expr else [])
     p = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=1500)
-    return p.returncode, p.stdout.decode(errors="replace")
+    log = p.stdout.decode(errors="replace")
+    if p.returncode != 0 and "test_gpu_distributed" in path:
+        # the multi-process cases depend on the machine (a rendezvous port taken between the probe and the bind, ranks starved of a core
+        # past a wait's limit): one more try before the case counts as failed -- a real defect fails twice, and both logs are shown
+        p = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=1500)
+        log = "=== first attempt ===\n" + log[-1500:] + "\n=== second attempt ===\n" + p.stdout.decode(errors="replace")
+    return p.returncode, log
 
 
 @pytest.fixture(scope="module")
