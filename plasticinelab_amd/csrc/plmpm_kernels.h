@@ -237,6 +237,13 @@ template <class T> __device__ __forceinline__ int node_index(const Dev<T>& D, in
 template <class T> __device__ __forceinline__ int flag_slot(const Dev<T>& D, int blk) {
     return (blk & ((1 << D.fgl) - 1)) * D.fs + (blk >> D.fgl);
 }
+// A scatter marks the blocks it touches.  Several workgroups of one launch may mark the same block: plain stores of the same value, a
+// race by design (nobody reads a flag in the launch that sets it).  One function, so that the tests' CPU interpreter -- which runs the
+// workgroups on OS threads under ThreadSanitizer -- can make exactly these stores relaxed atomics and report every OTHER conflict.
+#ifndef PLB_HOST_EMUL
+__device__ __forceinline__ void store_flag(int* p, int v) { *p = v; }
+#endif
+template <class T> __device__ __forceinline__ void mark_block(const Dev<T>& D, int blk) { store_flag(&D.flags[flag_slot(D, blk)], 1); }
 // block index inside the window -> node coordinates of lane `lane` of the wave that owns the block
 template <class T> __device__ __forceinline__ void block_nodes(const Dev<T>& D, int blk, int lane, int* I) {
     const int bx = blk % D.nbx, by = (blk / D.nbx) % D.nby, bz = blk / (D.nbx * D.nby);
@@ -882,7 +889,7 @@ __global__ __launch_bounds__(kBlock, sizeof(T) == 4 ? PLB_P2G_WAVES : PLB_P2G_WA
                         atomicAdd(&D.gin[0][idx], a0); atomicAdd(&D.gin[1][idx], a1);
                         atomicAdd(&D.gin[2][idx], a2); atomicAdd(&D.gin[3][idx], a3);
                     }
-                    D.flags[flag_slot(D, idx >> 6)] = 1;
+                    mark_block(D, idx >> 6);
                 }
             });
         }
@@ -907,7 +914,7 @@ __global__ __launch_bounds__(kBlock, sizeof(T) == 4 ? PLB_P2G_WAVES : PLB_P2G_WA
                     tile_coords(i, ex, exy, lz, ly, lx);
                     int idx = node_index(D, tl.o[0] + lx, tl.o[1] + ly, tl.o[2] + lz);
                     for (int c = 0; c < 4; ++c) det_flush_node(D, c, idx, q[c], q[4 + c]);
-                    D.flags[flag_slot(D, idx >> 6)] = 1;
+                    mark_block(D, idx >> 6);
                 }
                 continue;
             }
@@ -918,7 +925,7 @@ __global__ __launch_bounds__(kBlock, sizeof(T) == 4 ? PLB_P2G_WAVES : PLB_P2G_WA
                 int idx = node_index(D, tl.o[0] + lx, tl.o[1] + ly, tl.o[2] + lz);
                 atomicAdd(&D.gin[0][idx], (T)a.x); atomicAdd(&D.gin[1][idx], (T)a.y);
                 atomicAdd(&D.gin[2][idx], (T)a.z); atomicAdd(&D.gin[3][idx], (T)a.w);
-                D.flags[flag_slot(D, idx >> 6)] = 1;
+                mark_block(D, idx >> 6);
             }
         }
     }
@@ -1186,7 +1193,7 @@ __global__ __launch_bounds__(kBlock, sizeof(T) == 4 ? PLB_P2G_WAVES : PLB_P2G_WA
                         atomicAdd(&D.gin[0][idx], a0); atomicAdd(&D.gin[1][idx], a1);
                         atomicAdd(&D.gin[2][idx], a2); atomicAdd(&D.gin[3][idx], a3);
                     }
-                    D.flags[flag_slot(D, idx >> 6)] = 1;
+                    mark_block(D, idx >> 6);
                 }
             });
         }
@@ -1212,7 +1219,7 @@ __global__ __launch_bounds__(kBlock, sizeof(T) == 4 ? PLB_P2G_WAVES : PLB_P2G_WA
                     tile_coords(i, ex, exy, lz, ly, lx);
                     int idx = node_index(D, tl.o[0] + lx, tl.o[1] + ly, tl.o[2] + lz);
                     for (int c = 0; c < 4; ++c) det_flush_node(D, c, idx, q[c], q[4 + c]);
-                    D.flags[flag_slot(D, idx >> 6)] = 1;
+                    mark_block(D, idx >> 6);
                 }
                 continue;
             }
@@ -1223,7 +1230,7 @@ __global__ __launch_bounds__(kBlock, sizeof(T) == 4 ? PLB_P2G_WAVES : PLB_P2G_WA
                 int idx = node_index(D, tl.o[0] + lx, tl.o[1] + ly, tl.o[2] + lz);
                 atomicAdd(&D.gin[0][idx], (T)a.x); atomicAdd(&D.gin[1][idx], (T)a.y);
                 atomicAdd(&D.gin[2][idx], (T)a.z); atomicAdd(&D.gin[3][idx], (T)a.w);
-                D.flags[flag_slot(D, idx >> 6)] = 1;
+                mark_block(D, idx >> 6);
             }
         }
     }

@@ -30,6 +30,8 @@ VARIANTS = {
     # the default source under AddressSanitizer + UndefinedBehaviorSanitizer (make SAN=1); the process that loads it needs
     # LD_PRELOAD=$(gcc -print-file-name=libasan.so) and ASAN_OPTIONS=detect_leaks=0 (tests/test_emul_tier.py sets both)
     "asan": "",
+    # ThreadSanitizer (make SAN=thread; LD_PRELOAD=$(gcc -print-file-name=libtsan.so), PLMPM_EMUL_THREADS > 1): races between workgroups
+    "tsan": "",
 }
 VARIANT = os.environ.get("PLMPM_EMUL_VARIANT", "")
 _lib = None
@@ -42,7 +44,7 @@ def lib_path(variant=VARIANT):
 def build(variant=VARIANT):
     tag = "_" + variant if variant else ""
     subprocess.check_call(["make", "-s", "-j", "6", "-C", HERE, f"OBJDIR=build_emul{tag}", f"OUT=libplmpm_emul{tag}.so",
-                           f"EXTRA={VARIANTS[variant]}", f"SAN={1 if variant == 'asan' else 0}", f"libplmpm_emul{tag}.so"])
+                           f"EXTRA={VARIANTS[variant]}", f"SAN={1 if variant == 'asan' else 'thread' if variant == 'tsan' else 0}", f"libplmpm_emul{tag}.so"])
 
 
 def lib():

@@ -37,6 +37,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 
 #define __global__
 #define __device__
@@ -123,6 +124,7 @@ struct Fiber {
     int wave, lane;
     bool done;
     void* asan_fake;          // AddressSanitizer builds: the fiber's fake-stack handle while it is switched out
+    void* tsan_fiber;         // ThreadSanitizer builds: the fiber's own TSan context (every thread of a workgroup is a thread to TSan)
 };
 extern thread_local Fiber* cur;       // the running fiber (one OS thread runs one workgroup at a time)
 extern thread_local Idx g_block;
@@ -220,11 +222,18 @@ inline long long clock64() { return wall_clock64(); }
 
 // ---- atomics: real ones (workgroups may run on several OS threads, ranks in several processes)
 template <class T> inline T hipemu_fetch_op(T* p, T v, T (*op)(T, T)) {
-    T o;
-    __atomic_load(p, &o, __ATOMIC_RELAXED);
+    // compare-and-swap on the word's integer image (integer atomics are what the sanitizers understand)
+    typedef typename std::conditional<sizeof(T) == 4, uint32_t, uint64_t>::type W;
+    static_assert(sizeof(T) == sizeof(W), "4- or 8-byte operands");
+    W* q = reinterpret_cast<W*>(p);
+    W o = __atomic_load_n(q, __ATOMIC_RELAXED);
     for (;;) {
-        T n = op(o, v);
-        if (__atomic_compare_exchange(p, &o, &n, false, __ATOMIC_SEQ_CST, __ATOMIC_RELAXED)) return o;
+        T ov;
+        memcpy(&ov, &o, sizeof(T));
+        const T nv = op(ov, v);
+        W n;
+        memcpy(&n, &nv, sizeof(T));
+        if (__atomic_compare_exchange_n(q, &o, n, false, __ATOMIC_SEQ_CST, __ATOMIC_RELAXED)) return ov;
     }
 }
 inline float atomicAdd(float* p, float v) { return hipemu_fetch_op<float>(p, v, [](float a, float b) { return a + b; }); }
@@ -274,6 +283,7 @@ typedef unsigned hipemu_u2 __attribute__((vector_size(8)));
 // ---- host definitions of the inline-assembly helpers of plmpm_kernels.h (their device forms are guarded by PLB_HOST_EMUL)
 namespace plb {
 inline void lds_barrier() { hipemu::block_barrier(); }
+inline void store_flag(int* p, int v) { __atomic_store_n(p, v, __ATOMIC_RELAXED); }      // (the same-value block marks of the scatters: see plmpm_kernels.h)
 inline void wait_lds() {}
 inline void wait_vmem() {}
 template <class P, class V> inline void store_through(P* p, V v) { hipemu_atomic_store(p, v); }

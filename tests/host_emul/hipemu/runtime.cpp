@@ -30,6 +30,20 @@
 #else
 #define HIPEMU_ASAN 0
 #endif
+// ThreadSanitizer (`make SAN=thread`): every fiber is a thread of its own to TSan (its fiber API), the barrier and the wave-level
+// operations are the happens-before edges between them -- so two threads of a workgroup that touch the same LDS or global word
+// without a barrier or wave operation in between, one of them writing, are REPORTED: the missing-__syncthreads detector the GPU pool
+// has no tool for.  (Workgroups on different OS threads, PLMPM_EMUL_THREADS, add the conflicts between workgroups.)
+// (this file itself is compiled WITHOUT -fsanitize=thread in such a build -- the scheduler's own bookkeeping is not what is being
+// checked -- and only calls TSan's interface: -DHIPEMU_TSAN=1, tests/host_emul/Makefile)
+#ifndef HIPEMU_TSAN
+#define HIPEMU_TSAN 0
+#endif
+#if HIPEMU_TSAN
+#include <sanitizer/tsan_interface.h>
+static char g_tsan_done;                       // happens-before: every thread of a launch -> the host behind the launch
+static thread_local char g_tsan_chain;         // ... and workgroup -> next workgroup on the same OS thread (they reuse its LDS storage)
+#endif
 
 extern "C" void hipemu_switch(void** save_sp, void* next_sp);
 // callee-saved registers on the old stack, swap stack pointers, restore from the new one (System V x86-64)
@@ -63,7 +77,11 @@ thread_local Idx g_block = {0, 0, 0};
 Idx g_bdim = {1, 1, 1}, g_gdim = {1, 1, 1};
 
 static constexpr int kMaxThreads = 1024;
+#if HIPEMU_TSAN || defined(__SANITIZE_ADDRESS__)
+static constexpr size_t kStack = 1024u << 10;          // instrumented frames are several times larger
+#else
 static constexpr size_t kStack = 256u << 10;
+#endif
 // scheduler state of the workgroup an OS thread is running
 static thread_local char* g_stacks = nullptr;
 static thread_local Fiber g_fib[kMaxThreads];
@@ -194,9 +212,15 @@ static thread_local const void* g_main_lo = nullptr;
 static thread_local size_t g_main_size = 0;
 #endif
 // fiber -> scheduler
+#if HIPEMU_TSAN
+static thread_local void* g_main_tsan = nullptr;
+#endif
 static inline void yield() {
 #if HIPEMU_ASAN
     __sanitizer_start_switch_fiber(&cur->asan_fake, g_main_lo, g_main_size);
+#endif
+#if HIPEMU_TSAN
+    __tsan_switch_to_fiber(g_main_tsan, 1);              // (1 = no synchronisation implied by the switch itself)
 #endif
     hipemu_switch(&cur->sp, g_main_sp);
 #if HIPEMU_ASAN
@@ -208,6 +232,9 @@ static inline void resume(Fiber& f, int t) {
     cur = &f;
 #if HIPEMU_ASAN
     __sanitizer_start_switch_fiber(&g_main_fake, g_stacks + (size_t)t * kStack, kStack);
+#endif
+#if HIPEMU_TSAN
+    __tsan_switch_to_fiber(f.tsan_fiber, 1);
 #endif
     hipemu_switch(&g_main_sp, f.sp);
 #if HIPEMU_ASAN
@@ -244,16 +271,28 @@ Gathered wave_gather(uint64_t mine, unsigned op) {
     w.op[cur->lane] = op;
     ++w.arrived;
     ++g_progress;
+#if HIPEMU_TSAN
+    __tsan_release(&w);                                  // what this lane did before the operation ...
+#endif
     if (w.arrived == w.live) wave_release(w);
     while (w.gen == g) yield();
+#if HIPEMU_TSAN
+    __tsan_acquire(&w);                                  // ... is visible to every lane behind it
+#endif
     return Gathered{w.buf[g & 1], w.snap[g & 1]};
 }
 void block_barrier() {
     const unsigned g = g_blk_gen;
     ++g_blk_arrived;
     ++g_progress;
+#if HIPEMU_TSAN
+    __tsan_release(&g_blk_gen);
+#endif
     if (g_blk_arrived == g_blk_live) { g_blk_arrived = 0; ++g_blk_gen; }
     while (g_blk_gen == g) yield();
+#if HIPEMU_TSAN
+    __tsan_acquire(&g_blk_gen);
+#endif
 }
 
 int dpp_source_lane(int lane, int ctrl) {
@@ -283,6 +322,11 @@ static void fiber_exit() {
 #if HIPEMU_ASAN
     __sanitizer_start_switch_fiber(nullptr, g_main_lo, g_main_size);        // (nullptr: this stack is never used again)
 #endif
+#if HIPEMU_TSAN
+    __tsan_release(&g_tsan_done);
+    __tsan_release(&g_tsan_chain);
+    __tsan_switch_to_fiber(g_main_tsan, 1);
+#endif
     hipemu_switch(&f->sp, g_main_sp);
     die("a finished fiber was resumed");
 }
@@ -290,6 +334,8 @@ static void fiber_entry() {
 #if HIPEMU_ASAN
     __sanitizer_finish_switch_fiber(nullptr, &g_main_lo, &g_main_size);
 #endif
+    // (ThreadSanitizer: a fiber inherits the happens-before state of the context that CREATES it -- the workgroup's OS thread, behind the
+    // host's launch and behind the previous workgroup it ran -- and nothing from its sibling threads)
     g_thunk(g_ctx);
     fiber_exit();
 }
@@ -308,6 +354,9 @@ static void run_workgroup(unsigned lin, dim3 grid, dim3 block, int nt, long shuf
         Fiber& f = g_fib[t];
         f.tid = {(unsigned)t % block.x, ((unsigned)t / block.x) % block.y, (unsigned)t / (block.x * block.y)};
         f.wave = t >> 6; f.lane = t & 63; f.done = false; f.asan_fake = nullptr;
+#if HIPEMU_TSAN
+        f.tsan_fiber = __tsan_create_fiber(0);
+#endif
         Wave& w = g_wave[f.wave];
         ++w.live; w.live_mask |= 1ULL << f.lane;
         // initial frame: six callee-saved registers, the entry point as the return address, a null return address above it
@@ -320,6 +369,9 @@ static void run_workgroup(unsigned lin, dim3 grid, dim3 block, int nt, long shuf
         for (int k = 0; k < 6; ++k) *--sp = nullptr;
         f.sp = sp;
     }
+#if HIPEMU_TSAN
+    g_main_tsan = __tsan_get_current_fiber();
+#endif
     int alive = nt;
     while (alive > 0) {
         const unsigned long before = g_progress;
@@ -340,6 +392,10 @@ static void run_workgroup(unsigned lin, dim3 grid, dim3 block, int nt, long shuf
         }
     }
     cur = nullptr;
+#if HIPEMU_TSAN
+    __tsan_acquire(&g_tsan_chain);                       // the next workgroup on this OS thread (same LDS storage) comes after this one
+    for (int t = 0; t < nt; ++t) __tsan_destroy_fiber(g_fib[t].tsan_fiber);
+#endif
 }
 
 // PLMPM_EMUL_THREADS=n: a pool of OS threads runs the workgroups of a launch, each thread one workgroup at a time (its own fibers,
@@ -408,6 +464,9 @@ void run_grid(dim3 grid, dim3 block, size_t lds, void (*thunk)(void*), void* ctx
     }
     if (nthreads <= 1 || nwg <= 1) {
         for (size_t i = 0; i < nwg; ++i) run_workgroup(order[i], grid, block, nt, shuffle, rng);
+#if HIPEMU_TSAN
+        __tsan_acquire(&g_tsan_done);
+#endif
         return;
     }
     if (!g_pool) g_pool = new Pool;             // (never destroyed: its threads sleep until the process ends)
@@ -421,6 +480,9 @@ void run_grid(dim3 grid, dim3 block, size_t lds, void (*thunk)(void*), void* ctx
     ++P->generation;
     P->cv_go.notify_all();
     P->cv_done.wait(lk, [&] { return P->busy == 0; });
+#if HIPEMU_TSAN
+    __tsan_acquire(&g_tsan_done);
+#endif
 }
 }  // namespace hipemu
 

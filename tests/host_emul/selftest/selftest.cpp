@@ -74,9 +74,17 @@ __global__ void k_deadlock(int* out) {
     out[0] = 1;
 }
 
+// (for the ThreadSanitizer build: a forgotten barrier -- thread t + 1 reads what thread t wrote into LDS with nothing in between)
+__global__ void k_race(int* out) {
+    __shared__ int x[256];
+    x[threadIdx.x] = threadIdx.x;
+    out[threadIdx.x] = x[(threadIdx.x + 1) & 255];
+}
+
 int main(int argc, char** argv) {
     int* out = nullptr;
     hipMalloc(&out, 64 * 64 * sizeof(int));
+    if (argc > 1 && !strcmp(argv[1], "race")) { hipLaunchKernelGGL(k_race, dim3(1), dim3(256), 0, nullptr, out); printf("ran\n"); return 0; }
     if (argc > 1 && !strcmp(argv[1], "diverge")) { hipLaunchKernelGGL(k_diverge, dim3(1), dim3(64), 0, nullptr, out); return 0; }
     if (argc > 1 && !strcmp(argv[1], "deadlock")) { hipLaunchKernelGGL(k_deadlock, dim3(1), dim3(256), 0, nullptr, out); return 0; }
 
